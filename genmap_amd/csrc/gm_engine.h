@@ -1,0 +1,189 @@
+// gm_engine.h -- the search engine of one lane: node encoding, step planning, child generation.
+//
+// What it replaces: the recursion of the reference,
+//   _optimalSearchSchemeGM / ...ChildrenGM / ...ExactGM   /root/reference/src/find2_index_approx.hpp:223-457
+//   extend / approxSearch / extendExact                   /root/reference/src/algo.hpp:26-218
+// re-organised for a 64-wide wavefront: there is no recursion and no per-function control flow.  A search
+// NODE is 16 bytes (two SA range starts, the width, 32 bits of position/phase), and EVERY node advances
+// by the same step -- "extend the matched interval [a,bx) by one character in the node's direction":
+// two aligned rank-block reads (range lo / range hi), from which all sigma children follow.  Whether the
+// node is inside an OSS block or in the extension phase only changes a few integer fields, so lanes in
+// different phases of different k-mer blocks execute one instruction stream without divergence.
+//
+// Phases (mode):  OSS    inside block `t` of search s of the common infix        (find2_index_approx.hpp)
+//                 EXT_R  extending right until bx == t                           (algo.hpp:90-126, Rev)
+//                 EXT_L  extending left  until a  == t                           (algo.hpp:127-163, Fwd)
+//                 SPLIT  matched interval complete for this level; becomes EXT_R + (pushed) EXT_L with
+//                        the halving targets of algo.hpp:53-56,68-71 / :196-211 -- or a LEAF when
+//                        bx - a == K (algo.hpp:38-49, :180-193): width is added to the k-mer's counter.
+// Coordinates are those of the reference's `needles` window (algo.hpp:256): a = first matched index,
+// bx = one past the last matched index (the reference's b + 1), 0 <= a <= bx <= K + n - 1.
+#pragma once
+#include "gm_common.h"
+#include "gm_rank.h"
+#include "gm_oss.h"
+
+namespace gm {
+
+enum : uint32_t { M_OSS = 0, M_EXT_R = 1, M_EXT_L = 2, M_SPLIT = 3 };
+
+struct Node { uint32_t flo, rlo, w, meta; };   // meta: a | bx<<8 | t<<16 | errs<<24 | mode<<27
+
+GM_HD uint32_t meta_pack(uint32_t a, uint32_t bx, uint32_t t, uint32_t errs, uint32_t mode)
+{
+    return a | bx << 8 | t << 16 | errs << 24 | mode << 27;
+}
+GM_HD uint32_t meta_a(uint32_t m) { return m & 0xFFu; }
+GM_HD uint32_t meta_bx(uint32_t m) { return (m >> 8) & 0xFFu; }
+GM_HD uint32_t meta_t(uint32_t m) { return (m >> 16) & 0xFFu; }
+GM_HD uint32_t meta_errs(uint32_t m) { return (m >> 24) & 7u; }
+GM_HD uint32_t meta_mode(uint32_t m) { return (m >> 27) & 3u; }
+
+// the root a lane is currently working on: one (k-mer block, strand, search) triple
+struct Root {
+    uint32_t win;      // slice-relative text offset of the block's window = position of its first k-mer
+    uint32_t n;        // k-mers in the block; window length W = K + n - 1; common infix = [n-1, K)
+    uint32_t strand;   // 1: the window is read reverse-complemented (algo.hpp:286-287)
+    OssRecord rec;
+};
+
+GM_HD Node root_node(const Root& rt, uint32_t nRows)
+{
+    // _optimalSearchSchemeGM(..., s.startPos, s.startPos + 1, 0, s, 0, Rev()) find2_index_approx.hpp:441
+    uint32_t a = (rt.n - 1u) + oss_start(rt.rec);
+    Node nd; nd.flo = 0; nd.rlo = 0; nd.w = nRows; nd.meta = meta_pack(a, a, 0, 0, M_OSS);
+    return nd;
+}
+
+// SPLIT -> (EXT_R kept, EXT_L returned through `left`).  algo.hpp:53-56 and :68-71 (same in :196-211).
+GM_HD void split_node(Node& nd, Node& left, uint32_t K)
+{
+    uint32_t m = nd.meta, a = meta_a(m), bx = meta_bx(m), errs = meta_errs(m);
+    uint32_t alm = bx - K;                                 // b + 1 - length  (>= 0)
+    uint32_t bx_new = bx + ((a + K - bx + 1u) >> 1);       // b + ceil((a + K - 1 - b) / 2), exclusive
+    uint32_t a_new = alm + ((a - alm - 1u) >> 1);          // a > alm whenever the interval is not full
+    left = nd;
+    left.meta = meta_pack(a, bx, a_new, errs, M_EXT_L);
+    nd.meta = meta_pack(a, bx, bx_new, errs, M_EXT_R);
+}
+
+struct Plan {
+    uint32_t right;      // 1: append text[bx] (reverse-index BWT, SeqAn's Rev); 0: prepend text[a-1] (Fwd)
+    uint32_t exact;      // only the needle character may be taken (no error budget in this segment)
+    uint32_t minErr;     // OSS lower bound still to be met inside the current block
+    uint32_t charsLeft;  // OSS: characters left in the current block, including this one
+    uint32_t pos;        // window coordinate of the character to compare with
+};
+
+GM_HD Plan make_plan(uint32_t meta, const OssRecord& rec, uint32_t E)
+{
+    Plan p;
+    uint32_t a = meta_a(meta), bx = meta_bx(meta), t = meta_t(meta), errs = meta_errs(meta), mode = meta_mode(meta);
+    if (mode == M_OSS) {
+        uint32_t u = oss_u(rec, t), l = oss_l(rec, t);
+        p.right = oss_right(rec, t);
+        p.exact = (u == errs);                        // maxErrorsLeftInBlock == 0  (find2:388,397)
+        p.minErr = l > errs ? l - errs : 0u;          // find2:389
+        p.charsLeft = oss_bl(rec, t) - (bx - a);      // find2:247
+    } else {
+        p.right = (mode == M_EXT_R);
+        p.exact = (errs == E);                        // errorsLeft == 0  (algo.hpp:106,117,143,154,175)
+        p.minErr = 0; p.charsLeft = 0;
+    }
+    p.pos = p.right ? bx : a - 1u;
+    return p;
+}
+
+// structural outcome of taking one character (identical for every child of the node)
+struct Post { uint32_t meta0; uint32_t leaf; uint32_t kmer; };   // meta0 has errs = 0; children OR their errs in
+
+GM_HD Post make_post(uint32_t meta, const Plan& pl, const OssRecord& rec, uint32_t K)
+{
+    uint32_t a = meta_a(meta), bx = meta_bx(meta), t = meta_t(meta), mode = meta_mode(meta);
+    if (pl.right) bx += 1u; else a -= 1u;
+    bool done;
+    if (mode == M_OSS) {
+        done = false;
+        if (bx - a == oss_bl(rec, t)) {               // block complete (find2:263, :335-344, :358-367)
+            t += 1u;
+            done = (t == oss_nb(rec));                // "Done": delegate -> extend  (find2:392-395, algo.hpp:262-298)
+        }
+    } else {
+        done = pl.right ? (bx == t) : (a == t);       // algo.hpp:101-105,138-142
+    }
+    Post ps; ps.leaf = 0; ps.kmer = a;
+    if (done) {
+        if (bx - a == K) { ps.leaf = 1; mode = M_SPLIT; }   // algo.hpp:38,180
+        else mode = M_SPLIT;
+        t = 0;
+    }
+    ps.meta0 = meta_pack(a, bx, t, 0, mode);
+    return ps;
+}
+
+// One step of one lane.  Env supplies memory:
+//   void rank2(uint32_t right, uint32_t lo, uint32_t hi, uint32_t rl[5], uint32_t rh[5])
+//   uint32_t text_char(const Root&, uint32_t pos)     (already complemented for strand 1)
+//   void push(const Node&)                            (lane-private LIFO)
+//   void add_hit(const Root&, uint32_t kmer, uint32_t count)
+//   uint32_t C(uint32_t c)                            (first row of letter c)
+// On return `have` tells whether nd holds a node to continue with.
+template <class Env>
+GM_HD void lane_step(Node& nd, bool& have, const Root& rt, uint32_t K, uint32_t E, Env& env)
+{
+    const Plan pl = make_plan(nd.meta, rt.rec, E);
+    const uint32_t plo = pl.right ? nd.rlo : nd.flo;
+    uint32_t rl[NLET], rh[NLET];
+    env.rank2(pl.right, plo, plo + nd.w, rl, rh);
+    const uint32_t tc = env.text_char(rt, pl.pos);
+    const Post ps = make_post(nd.meta, pl, rt.rec, K);
+    const uint32_t errs = meta_errs(nd.meta);
+    const uint32_t olo = pl.right ? nd.flo : nd.rlo;
+
+    uint32_t cnt[NLET], sm[NLET], tot = 0;
+#pragma unroll
+    for (int x = 0; x < (int)NLET; ++x) { cnt[x] = rh[x] - rl[x]; tot += cnt[x]; }
+    uint32_t run = nd.w - tot;   // sentinels in BWT[lo,hi) sort before every letter
+#pragma unroll
+    for (int x = 0; x < (int)NLET; ++x) { sm[x] = run; run += cnt[x]; }
+
+    Node keep; keep.flo = keep.rlo = keep.w = keep.meta = 0;
+    bool haveKeep = false;
+    uint32_t leafSum = 0;
+    // order: the matching child first (it ends up deepest in the LIFO), mismatching children after it;
+    // the lane continues with the last one.  This bounds the stack by 4*E + log2(n) + c.
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int x = 0; x < (int)NLET; ++x) {
+            const bool isMatch = ((uint32_t)x == tc);        // tc == N never "matches" (delta = 1 below)
+            if (pass == 0 ? !isMatch : isMatch) continue;
+            if (cnt[x] == 0) continue;
+            const uint32_t delta = (!isMatch || tc == SYM_N) ? 1u : 0u;   // find2:250, algo.hpp:111-112,148-149
+            if (pl.exact && delta) continue;                  // exact segment: pattern N or another letter fails
+            if (pl.minErr > 0 && pl.charsLeft + delta < pl.minErr + 1u) continue;   // find2:254-258
+            if (ps.leaf) { leafSum += cnt[x]; continue; }
+            Node ch;
+            const uint32_t pnew = env.C((uint32_t)x) + rl[x];
+            const uint32_t onew = olo + sm[x];
+            ch.flo = pl.right ? onew : pnew;
+            ch.rlo = pl.right ? pnew : onew;
+            ch.w = cnt[x];
+            ch.meta = ps.meta0 | ((errs + delta) << 24);
+            if (haveKeep) env.push(keep);
+            keep = ch; haveKeep = true;
+        }
+    }
+    if (leafSum) env.add_hit(rt, ps.kmer, leafSum);
+    nd = keep; have = haveKeep;
+}
+
+// upper bound of simultaneously stacked nodes of one lane (DESIGN.md "stack bound")
+inline uint32_t stack_bound(uint32_t E, uint32_t stepSize)
+{
+    uint32_t lg = 0;
+    while ((1u << lg) < stepSize) ++lg;
+    return 4u * E + lg + 8u;
+}
+
+}  // namespace gm

@@ -1,0 +1,92 @@
+// gm_host.h -- host-side planning of one computeMappability call (no device code).
+//
+// Mirrors the scheduling half of /root/reference/src/algo.hpp:405-476 and the option arithmetic of
+// /root/reference/src/mappability.hpp:519-543: which k-mer blocks exist, how many k-mers each holds,
+// and the OSS block-length record of every block shape.  Used by the C-ABI implementation and by the
+// CPU logic harness in tests/emu (which runs the same lane code without a GPU).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <utility>
+#include <vector>
+#include <algorithm>
+#include "gm_oss.h"
+
+namespace gm {
+
+// SearchParams.overlap after mappability.hpp:519-543, i.e. the length of the common infix.
+// xo < 0: option not given.  Returns 0 on error (explicit xo too large -> PARSE_ERROR in the reference).
+inline uint32_t default_infix_length(uint32_t K, uint32_t E, int32_t xo)
+{
+    unsigned overlap;
+    if (xo >= 0) overlap = (unsigned)xo;
+    else if (E == 0) overlap = (unsigned)(K * 0.7);
+    else {
+        unsigned mm = std::min(std::max(K, 30u), 100u);
+        overlap = (unsigned)((K * mm) * std::pow((double)0.7f, (double)E) / 100.0);
+    }
+    uint64_t maxPossibleOverlap = std::min(K - 1u, K - E - 2u);   // unsigned wrap as in the reference
+    if (overlap > maxPossibleOverlap) {
+        if (xo >= 0) return 0;
+        overlap = (unsigned)maxPossibleOverlap;
+    }
+    return K - overlap;
+}
+
+struct MapPlan {
+    uint32_t K = 0, E = 0, infix = 0, stepSize = 0, nSearches = 0, nStrands = 0;
+    uint64_t textLen = 0, numKmers = 0;
+    bool useList = false;
+    std::vector<std::pair<uint32_t, uint32_t>> blocks;   // (first k-mer position, k-mers) when useList
+    uint64_t numBlocks = 0;
+    std::vector<OssRecord> table;                        // [(n-1)*8 + s], n = 1..stepSize
+    uint64_t numRoots() const { return numBlocks * nSearches * nStrands; }
+};
+
+enum PlanError { PLAN_OK = 0, PLAN_BAD_E = -2, PLAN_BAD_K = -6, PLAN_BAD_OVERLAP = -5, PLAN_TOO_LONG = -7 };
+
+// intervals: half-open (begin,end) pairs in slice coordinates (mappability.hpp:334-357); overlapping
+// intervals are merged (the reference skips already-filled positions, algo.hpp:236-242; the value of a
+// position does not depend on which block computes it).
+inline int make_map_plan(uint32_t K, uint32_t E, uint32_t infix, int revcompl, uint64_t textLen,
+                         const uint64_t* intervals, uint64_t nIntervals, MapPlan* out)
+{
+    MapPlan& p = *out;
+    if (E > MAX_ERRORS) return PLAN_BAD_E;
+    if (K < 1 || K > 128) return PLAN_BAD_K;
+    if (infix < 1 || infix > K) return PLAN_BAD_OVERLAP;
+    if (textLen >= 0xFFFFFFFFull) return PLAN_TOO_LONG;
+    p.K = K; p.E = E; p.infix = infix; p.stepSize = K - infix + 1;   // algo.hpp:416
+    p.nSearches = oss_scheme(E).ns; p.nStrands = revcompl ? 2 : 1;
+    p.textLen = textLen;
+    p.numKmers = textLen >= K ? textLen - K + 1 : 0;                 // algo.hpp:414 underflows for textLen < K
+    p.table.assign((size_t)p.stepSize * 8, OssRecord{0, 0, 0, 0});
+    for (uint32_t n = 1; n <= p.stepSize; ++n)
+        for (uint32_t s = 0; s < p.nSearches; ++s)
+            if (!oss_make_record(E, s, K - n + 1, &p.table[(size_t)(n - 1) * 8 + s])) return PLAN_BAD_OVERLAP;
+    p.blocks.clear();
+    if (nIntervals == 0) {
+        p.useList = false;
+        p.numBlocks = (p.numKmers + p.stepSize - 1) / p.stepSize;   // algo.hpp:435
+    } else {
+        p.useList = true;
+        std::vector<std::pair<uint64_t, uint64_t>> iv;
+        for (uint64_t k = 0; k < nIntervals; ++k) {
+            uint64_t b = intervals[2 * k], e = std::min(intervals[2 * k + 1], p.numKmers);   // algo.hpp:231-233
+            if (b < e) iv.emplace_back(b, e);
+        }
+        std::sort(iv.begin(), iv.end());
+        std::vector<std::pair<uint64_t, uint64_t>> mg;
+        for (auto& x : iv) {
+            if (!mg.empty() && x.first <= mg.back().second) mg.back().second = std::max(mg.back().second, x.second);
+            else mg.push_back(x);
+        }
+        for (auto& x : mg)
+            for (uint64_t i = x.first; i < x.second; i += p.stepSize)                          // algo.hpp:448-451
+                p.blocks.emplace_back((uint32_t)i, (uint32_t)std::min<uint64_t>(p.stepSize, x.second - i));
+        p.numBlocks = p.blocks.size();
+    }
+    return PLAN_OK;
+}
+
+}  // namespace gm

@@ -1,0 +1,92 @@
+// gm_oss.h -- Optimum Search Schemes (Hamming) as data, plus the per-block-shape length table.
+//
+// Scheme constants are those of /root/reference/src/find2_index_approx.hpp:67-134 (pi = block order,
+// l/u = cumulative lower/upper error bounds).  Block lengths follow
+// _optimalSearchSchemeComputeFixedBlocklengthGM / SetBlockLengthGM / InitGM (:139-176).
+// The reference recomputes lengths per block on the CPU (std::vector, src/algo.hpp:248-249); here the
+// host tabulates one 16-byte record per (k-mers-in-block n, search s) and a lane keeps the record of
+// its current root in four VGPRs.
+#pragma once
+#include "gm_common.h"
+
+namespace gm {
+
+constexpr int OSS_MAXB = 6;
+constexpr int OSS_MAXS = 7;   // table stride per n is 8 records
+
+struct OssSearch { uint8_t nb; uint8_t pi[OSS_MAXB], l[OSS_MAXB], u[OSS_MAXB]; };
+struct OssScheme { uint8_t ns; OssSearch s[OSS_MAXS]; };
+
+inline const OssScheme& oss_scheme(uint32_t E)   // host only: lanes read packed OssRecords
+{
+    static const OssScheme S[5] = {
+        {1, {{1, {1}, {0}, {0}}}},
+        {2, {{2, {1, 2}, {0, 0}, {0, 1}},
+             {2, {2, 1}, {0, 1}, {0, 1}}}},
+        {3, {{4, {1, 2, 3, 4}, {0, 0, 1, 1}, {0, 0, 2, 2}},
+             {4, {3, 2, 1, 4}, {0, 0, 0, 0}, {0, 1, 1, 2}},
+             {4, {4, 3, 2, 1}, {0, 0, 0, 2}, {0, 1, 2, 2}}}},
+        {4, {{5, {1, 2, 3, 4, 5}, {0, 0, 0, 0, 3}, {0, 1, 2, 3, 3}},
+             {5, {2, 3, 4, 5, 1}, {0, 0, 0, 2, 2}, {0, 1, 2, 2, 3}},
+             {5, {3, 4, 5, 2, 1}, {0, 0, 1, 1, 1}, {0, 1, 1, 3, 3}},
+             {5, {5, 4, 3, 2, 1}, {0, 0, 0, 0, 0}, {0, 0, 3, 3, 3}}}},
+        {7, {{6, {1, 2, 3, 4, 5, 6}, {0, 0, 0, 0, 0, 4}, {0, 2, 3, 3, 4, 4}},
+             {6, {3, 4, 5, 6, 2, 1}, {0, 0, 0, 1, 4, 4}, {0, 0, 1, 1, 4, 4}},
+             {6, {2, 3, 4, 5, 6, 1}, {0, 0, 0, 0, 0, 0}, {0, 2, 2, 3, 3, 4}},
+             {6, {3, 2, 4, 5, 6, 1}, {0, 1, 1, 1, 1, 1}, {0, 1, 2, 3, 3, 4}},
+             {6, {4, 3, 2, 5, 6, 1}, {0, 0, 2, 2, 2, 2}, {0, 0, 2, 3, 3, 4}},
+             {6, {4, 3, 2, 5, 6, 1}, {0, 1, 2, 2, 2, 2}, {0, 1, 2, 3, 3, 4}},
+             {6, {6, 5, 4, 3, 2, 1}, {0, 0, 0, 0, 3, 3}, {0, 0, 4, 4, 4, 4}}}},
+    };
+    return S[E];
+}
+
+// One search of one block shape, packed:
+//   x: cumulative block lengths bl[0..3] (8 bit each, search order)
+//   y: bl[4] | bl[5]<<8 | startPos<<16 | nb<<24
+//   z: l[0..5] 3 bit each (bits 0..17) | goRight[0..5] (bits 18..23; block bi is searched left-to-right)
+//   w: u[0..5] 3 bit each
+struct OssRecord { uint32_t x, y, z, w; };
+
+GM_HD uint32_t oss_bl(const OssRecord& r, uint32_t bi)
+{
+    uint32_t lo = bi < 4 ? r.x : r.y;
+    return (lo >> (8u * (bi & 3u))) & 0xFFu;
+}
+GM_HD uint32_t oss_start(const OssRecord& r) { return (r.y >> 16) & 0xFFu; }
+GM_HD uint32_t oss_nb(const OssRecord& r) { return r.y >> 24; }
+GM_HD uint32_t oss_l(const OssRecord& r, uint32_t bi) { return (r.z >> (3u * bi)) & 7u; }
+GM_HD uint32_t oss_u(const OssRecord& r, uint32_t bi) { return (r.w >> (3u * bi)) & 7u; }
+GM_HD uint32_t oss_right(const OssRecord& r, uint32_t bi) { return (r.z >> (18u + bi)) & 1u; }
+
+// infixLen = length of the common infix of the block's k-mers (the reference's local `overlap`,
+// src/algo.hpp:246).  Returns false if the infix is shorter than the number of scheme blocks.
+inline bool oss_make_record(uint32_t E, uint32_t s, uint32_t infixLen, OssRecord* out)
+{
+    const OssSearch& S = oss_scheme(E).s[s];
+    uint32_t blocks = S.nb;
+    if (infixLen < blocks || infixLen > 255u) return false;
+    uint32_t base = infixLen / blocks, rest = infixLen - blocks * base;   // :167-172
+    uint32_t bl[OSS_MAXB] = {0, 0, 0, 0, 0, 0}, cum = 0, start = 0;
+    for (uint32_t i = 0; i < blocks; ++i) {
+        uint32_t len = base + ((uint32_t)(S.pi[i] - 1) < rest ? 1u : 0u);   // :145 blocklength[pi[i]-1]
+        cum += len;
+        bl[i] = cum;
+        if (S.pi[i] < S.pi[0]) start += len;                               // :158-160
+    }
+    OssRecord r;
+    r.x = bl[0] | bl[1] << 8 | bl[2] << 16 | bl[3] << 24;
+    r.y = bl[4] | bl[5] << 8 | start << 16 | blocks << 24;
+    r.z = 0; r.w = 0;
+    for (uint32_t i = 0; i < blocks; ++i) {
+        r.z |= (uint32_t)S.l[i] << (3u * i);
+        r.w |= (uint32_t)S.u[i] << (3u * i);
+        // direction of block i: the first block always goes right (:441); later ones by pi order (:274,:321)
+        uint32_t right = (i == 0) ? 1u : (S.pi[i] > S.pi[i - 1] ? 1u : 0u);
+        r.z |= right << (18u + i);
+    }
+    *out = r;
+    return true;
+}
+
+}  // namespace gm

@@ -1,0 +1,127 @@
+// gm_emu.cpp -- CPU LOGIC HARNESS for the device engine (test infrastructure only).
+//
+// Runs the very same lane code the HIP kernel runs (genmap_amd/csrc/gm_engine.h, gm_rank.h, gm_oss.h,
+// gm_host.h) one lane at a time on the host, so that the search logic can be checked against the oracle
+// in a container without a GPU.  It is NOT a product path: libgenmap_amd.so never contains or calls it,
+// and the GPU parity tests (-m gpu) go through the C ABI only.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include "../../genmap_amd/csrc/gm_engine.h"
+#include "../../genmap_amd/csrc/gm_host.h"
+
+using namespace gm;
+
+template <int WPP> struct HostIndex {
+    std::vector<uint32_t> blk[2];
+    uint32_t C[NLET + 1];
+    uint64_t n;
+    void build(const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nseq)
+    {
+        n = rows;
+        const uint8_t* b[2] = {bf, br};
+        constexpr uint32_t SPB = BlockGeom<WPP>::SPB, WPB = BlockGeom<WPP>::WPB;
+        for (int d = 0; d < 2; ++d) {
+            uint64_t nb = num_blocks<WPP>(rows);
+            blk[d].assign(nb * WPB, 0);
+            uint32_t run[NLET] = {0, 0, 0, 0, 0};
+            for (uint64_t q = 0; q < nb; ++q) {
+                uint32_t* p = &blk[d][q * WPB];
+                for (int c = 0; c < (int)NLET; ++c) p[c] = run[c];
+                pack_planes<WPP>(b[d], rows, q, p);
+                for (uint32_t t = 0; t < SPB; ++t) { uint64_t i = q * SPB + t; if (i < rows && b[d][i] < NLET) run[b[d][i]]++; }
+            }
+            if (d == 0) { uint32_t acc = nseq; for (int c = 0; c < (int)NLET; ++c) { C[c] = acc; acc += run[c]; } C[NLET] = acc; }
+        }
+    }
+};
+
+template <int WPP> struct EmuEnv {
+    const HostIndex<WPP>* ix;
+    const uint8_t* text;
+    uint32_t K;
+    std::vector<Node> stack;
+    std::vector<uint32_t>* acc;
+    size_t maxDepth = 0;
+    uint64_t steps = 0;
+    void rank2(uint32_t right, uint32_t lo, uint32_t hi, uint32_t rl[NLET], uint32_t rh[NLET])
+    {
+        constexpr uint32_t SPB = BlockGeom<WPP>::SPB, WPB = BlockGeom<WPP>::WPB;
+        const uint32_t* base = ix->blk[right].data();
+        block_rank<WPP>(base + (size_t)(lo / SPB) * WPB, lo % SPB, rl);
+        block_rank<WPP>(base + (size_t)(hi / SPB) * WPB, hi % SPB, rh);
+        ++steps;
+    }
+    uint32_t text_char(const Root& rt, uint32_t pos) const
+    {
+        uint32_t W = K + rt.n - 1;
+        return rt.strand ? complement(text[rt.win + (W - 1 - pos)]) : text[rt.win + pos];
+    }
+    void push(const Node& nd) { stack.push_back(nd); if (stack.size() > maxDepth) maxDepth = stack.size(); }
+    void add_hit(const Root& rt, uint32_t kmer, uint32_t count)
+    {
+        uint32_t pos = rt.win + (rt.strand ? rt.n - 1 - kmer : kmer);
+        uint32_t add = count < 0xFFFFu ? count : 0xFFFFu;
+        uint64_t v = (uint64_t)(*acc)[pos] + add;
+        (*acc)[pos] = v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v;
+    }
+    uint32_t C(uint32_t c) const { return ix->C[c]; }
+};
+
+template <int WPP>
+static int run(const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nseqTotal, const uint8_t* text, uint64_t textLen,
+               const uint64_t* seqCum, uint32_t nseqLocal, uint32_t K, uint32_t E, uint32_t infix, int revcompl, int valueBits,
+               const uint64_t* intervals, uint64_t nIntervals, void* out, uint64_t* stats)
+{
+    MapPlan plan;
+    int rc = make_map_plan(K, E, infix, revcompl, textLen, intervals, nIntervals, &plan);
+    if (rc) return rc;
+    HostIndex<WPP> ix; ix.build(bf, br, rows, nseqTotal);
+    std::vector<uint32_t> acc(textLen ? textLen : 1, 0);
+    EmuEnv<WPP> env; env.ix = &ix; env.text = text; env.K = K; env.acc = &acc;
+    uint32_t bound = stack_bound(E, plan.stepSize);
+    uint64_t roots = plan.numRoots();
+    uint32_t rpb = plan.nSearches * plan.nStrands;
+    for (uint64_t id = 0; id < roots; ++id) {
+        uint64_t b = id / rpb; uint32_t r = (uint32_t)(id % rpb);
+        Root rt;
+        if (plan.useList) { rt.win = plan.blocks[b].first; rt.n = plan.blocks[b].second; }
+        else { rt.win = (uint32_t)(b * plan.stepSize); rt.n = (uint32_t)std::min<uint64_t>(plan.stepSize, plan.numKmers - rt.win); }
+        rt.strand = r / plan.nSearches;
+        rt.rec = plan.table[(size_t)(rt.n - 1) * 8 + (r % plan.nSearches)];
+        Node nd = root_node(rt, (uint32_t)rows);
+        bool have = true;
+        for (;;) {
+            if (!have) { if (env.stack.empty()) break; nd = env.stack.back(); env.stack.pop_back(); have = true; }
+            if (meta_mode(nd.meta) == M_SPLIT) { Node left; split_node(nd, left, K); env.push(left); }
+            lane_step(nd, have, rt, K, E, env);
+        }
+    }
+    uint32_t maxv = valueBits == 8 ? 255u : 65535u;
+    for (uint64_t j = 0; j < textLen; ++j) {
+        uint32_t v = acc[j] < maxv ? acc[j] : maxv;
+        if (valueBits == 8) ((uint8_t*)out)[j] = (uint8_t)v; else ((uint16_t*)out)[j] = (uint16_t)v;
+    }
+    for (uint32_t s = 1; s <= nseqLocal; ++s) {   // resetLimits, algo.hpp:10-22
+        uint64_t lim = std::min<uint64_t>(K, seqCum[s] - seqCum[s - 1] + 1);
+        for (uint64_t j = 1; j < lim; ++j) { if (valueBits == 8) ((uint8_t*)out)[seqCum[s] - j] = 0; else ((uint16_t*)out)[seqCum[s] - j] = 0; }
+    }
+    if (stats) { stats[0] = env.maxDepth; stats[1] = bound; stats[2] = env.steps; }
+    return 0;
+}
+
+extern "C" int gm_emu_map(int wpp, const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nseqTotal, const uint8_t* text,
+                          uint64_t textLen, const uint64_t* seqCum, uint32_t nseqLocal, uint32_t K, uint32_t E, int32_t xo,
+                          int32_t infixOverride, int revcompl, int valueBits, const uint64_t* intervals, uint64_t nIntervals,
+                          void* out, uint64_t* stats)
+{
+    uint32_t infix = infixOverride > 0 ? (uint32_t)infixOverride : default_infix_length(K, E, xo);
+    if (infix == 0) return PLAN_BAD_OVERLAP;
+    memset(out, 0, textLen * (valueBits / 8));
+    switch (wpp) {
+        case 1: return run<1>(bf, br, rows, nseqTotal, text, textLen, seqCum, nseqLocal, K, E, infix, revcompl, valueBits, intervals, nIntervals, out, stats);
+        case 3: return run<3>(bf, br, rows, nseqTotal, text, textLen, seqCum, nseqLocal, K, E, infix, revcompl, valueBits, intervals, nIntervals, out, stats);
+        case 9: return run<9>(bf, br, rows, nseqTotal, text, textLen, seqCum, nseqLocal, K, E, infix, revcompl, valueBits, intervals, nIntervals, out, stats);
+    }
+    return -100;
+}

@@ -1,0 +1,107 @@
+"""CPU check of the DEVICE engine's logic: tests/emu compiles the very headers the HIP kernel is built
+from (gm_engine.h, gm_rank.h, gm_oss.h, gm_host.h) and runs them lane by lane on the host.  Compared
+bit-exactly with the oracle.  This is not a product path (the product fails without a GPU); it exists so
+that logic errors are found here and GPU minutes are spent on GPU questions."""
+import ctypes as C
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+_emu = None
+
+
+def emu():
+    global _emu
+    if _emu is None:
+        subprocess.check_call(["make", "-s", "-C", str(H.ROOT / "tests" / "emu")])
+        _emu = C.CDLL(str(H.ROOT / "tests" / "emu" / "libgmemu.so"))
+        _emu.gm_emu_map.restype = C.c_int
+        _emu.gm_emu_map.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64,
+                                    C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    return _emu
+
+
+def emu_map(ix, wpp, K, E, first_seq=0, n_seq=None, xo=None, infix=0, revcompl=True, value_bits=16, intervals=None):
+    if n_seq is None:
+        n_seq = len(ix.seq_len) - first_seq
+    tb = int(ix.cum[first_seq])
+    tl = int(ix.cum[first_seq + n_seq]) - tb
+    bf, br = ix.bwt(0), ix.bwt(1)
+    text = np.ascontiguousarray(ix.codes[tb:tb + tl])
+    cum = np.ascontiguousarray(ix.cum[first_seq:first_seq + n_seq + 1] - ix.cum[first_seq]).astype(np.uint64)
+    out = np.zeros(tl, dtype=np.uint8 if value_bits == 8 else np.uint16)
+    iv = None
+    if intervals:
+        iv = np.ascontiguousarray(np.asarray(intervals, dtype=np.uint64).reshape(-1))
+    stats = np.zeros(3, dtype=np.uint64)
+    rc = emu().gm_emu_map(wpp, H._ptr(bf), H._ptr(br), ix.n, len(ix.seq_len), H._ptr(text), tl, H._ptr(cum), n_seq, K, E,
+                          -1 if xo is None else xo, infix, int(revcompl), value_bits, H._ptr(iv),
+                          0 if iv is None else len(iv) // 2, H._ptr(out), H._ptr(stats))
+    assert rc == 0, rc
+    return out, stats
+
+
+@pytest.mark.parametrize("case", sorted(H.CASES))
+def test_engine_logic_on_reference_fixtures(case):
+    d = H.CASES_DIR / f"case_{case}"
+    g, directory, fl, bed = H.load_case(case)
+    if fl.get("ep"):
+        pytest.skip("--exclude-pseudo goes through the locate path")
+    ix = H.OracleIndex(g.codes, g.seq_len, keep_sa=False)
+    for xo in H.xo_variants(case):
+        for wpp in (1, 3, 9):
+            for name, first, nseq, tb, tl in g.file_slices():
+                iv = None
+                if bed is not None:
+                    iv = H.slice_intervals(g, first, nseq, bed)
+                    if not iv:
+                        continue
+                out, _ = emu_map(ix, wpp, fl["K"], fl["E"], first, nseq, xo=xo, revcompl=not fl.get("nc", False), intervals=iv)
+                exp = np.fromfile(d / "raw_freq16" / (name.rsplit(".", 1)[0] + ".genmap.freq16"), dtype=np.uint16)
+                assert np.array_equal(out, exp), (case, xo, wpp, name, out.tolist(), exp.tolist())
+
+
+@pytest.mark.parametrize("dna5", [False, True])
+@pytest.mark.parametrize("E", [0, 1, 2, 3, 4])
+def test_engine_logic_gtest_matrix(E, dna5):
+    rng = np.random.default_rng(2000 + 10 * E + dna5)
+    nseq, ln = 3, (1000 if E < 3 else 300)
+    codes = rng.integers(0, 5 if dna5 else 4, size=nseq * ln, dtype=np.uint8)
+    ix = H.OracleIndex(codes, [ln] * nseq, keep_sa=False)
+    minK = E + 1 + (E >= 2)
+    nblocks = [1, 2, 4, 5, 6][E]
+    for K in range(minK, 9 if E < 4 else 8):
+        rc = bool(rng.integers(0, 2))
+        triv = ix.trivial(K, E, revcompl=rc, value_bits=8)
+        for infix in range(max(minK, nblocks), K + 1):
+            out, st = emu_map(ix, 3, K, E, infix=infix, revcompl=rc, value_bits=8)
+            assert np.array_equal(out, triv), (E, dna5, K, infix)
+            assert st[0] <= st[1], ("stack bound violated", st)
+
+
+@pytest.mark.parametrize("K,E", [(30, 0), (30, 1), (30, 2), (100, 1), (24, 1), (50, 3), (36, 4), (128, 0)])
+def test_engine_logic_baseline_settings(K, E):
+    rng = np.random.default_rng(K * 10 + E)
+    lens = [1500, 700, K - 1, 900, 3]
+    n = sum(lens)
+    codes = rng.integers(0, 4, size=n, dtype=np.uint8)
+    fam = rng.integers(0, 4, size=200, dtype=np.uint8)
+    for s in (50, 400, 1600, 2300, 2900):
+        cp = fam.copy()
+        mut = rng.random(200) < 0.03
+        cp[mut] = rng.integers(0, 4, size=int(mut.sum()), dtype=np.uint8)
+        codes[s:s + 200] = cp
+    codes[700:760] = 4
+    codes[1234] = 4
+    codes[1000:1100] = 0  # poly-A
+    ix = H.OracleIndex(codes, lens, keep_sa=False)
+    for bits in (8, 16):
+        exp = ix.mappability(K, E, value_bits=bits, threads=4)
+        for wpp in (1, 3, 9):
+            out, st = emu_map(ix, wpp, K, E, value_bits=bits)
+            assert np.array_equal(out, exp), (K, E, bits, wpp)
+            assert st[0] <= st[1], ("stack bound violated", st)
