@@ -1,0 +1,191 @@
+"""ctypes binding of include/genmap_amd.h (one class per opaque handle, same names and argument meaning).
+
+No fallback: if libgenmap_amd.so is missing this module raises, and every compute call needs a HIP device
+(the library returns GM_ERR_NO_DEVICE otherwise, surfaced as GenmapError)."""
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_ROOT = Path(__file__).resolve().parent
+_LIB = None
+_LIB_NAME = None
+
+
+class GenmapError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__(f"genmap_amd error {status}: {text}")
+        self.status = status
+
+
+class MapParams(C.Structure):
+    """struct gm_map_params"""
+    _fields_ = [("K", C.c_uint32), ("E", C.c_uint32), ("overlap", C.c_int32), ("infix", C.c_int32),
+                ("revcompl", C.c_int32), ("value_bits", C.c_int32), ("exclude_pseudo", C.c_int32),
+                ("reserved0", C.c_int32), ("kmer_begin", C.c_uint64), ("kmer_end", C.c_uint64)]
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("n_rows", C.c_uint64), ("text_len", C.c_uint64), ("n_seq", C.c_uint32), ("sampling", C.c_uint32),
+                ("alphabet_size", C.c_uint32), ("block_bytes", C.c_uint32), ("device_bytes", C.c_uint64),
+                ("device", C.c_int32)]
+
+
+class MapStats(C.Structure):
+    _fields_ = [("kmers", C.c_uint64), ("roots", C.c_uint64), ("node_steps", C.c_uint64), ("rank_lines", C.c_uint64),
+                ("search_ms", C.c_double), ("total_ms", C.c_double)]
+
+
+EXPORTS = ["gm_status_string", "gm_last_error", "gm_device_count", "gm_index_build", "gm_index_import",
+           "gm_index_export_bwt", "gm_index_get_info", "gm_index_free", "gm_map", "gm_map_device",
+           "gm_last_map_stats", "gm_default_infix_length"]
+
+
+def lib_path(profiling=False):
+    name = "libgenmap_amd_prof.so" if profiling else "libgenmap_amd.so"
+    return _ROOT / "lib" / name
+
+
+def load_library(profiling=False):
+    """Load the in-tree HIP library.  Raises if it has not been built (python __graft_entry__.py build)."""
+    global _LIB, _LIB_NAME
+    path = lib_path(profiling)
+    if _LIB is not None and _LIB_NAME == str(path):
+        return _LIB
+    if not path.exists():
+        raise GenmapError(-1, f"{path} not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(str(path))
+    vp = C.c_void_p
+    lib.gm_status_string.restype = C.c_char_p
+    lib.gm_status_string.argtypes = [C.c_int]
+    lib.gm_last_error.restype = C.c_char_p
+    lib.gm_device_count.restype = C.c_int
+    lib.gm_index_build.restype = C.c_int
+    lib.gm_index_build.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)]
+    lib.gm_index_import.restype = C.c_int
+    lib.gm_index_import.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)]
+    lib.gm_index_export_bwt.restype = C.c_int
+    lib.gm_index_export_bwt.argtypes = [vp, vp, vp]
+    lib.gm_index_get_info.restype = C.c_int
+    lib.gm_index_get_info.argtypes = [vp, C.POINTER(IndexInfo)]
+    lib.gm_index_free.argtypes = [vp]
+    lib.gm_map.restype = C.c_int
+    lib.gm_map.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(MapParams), vp, C.c_uint64, vp, vp]
+    lib.gm_map_device.restype = C.c_int
+    lib.gm_map_device.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(MapParams), vp, C.c_uint64, vp, vp, vp]
+    lib.gm_last_map_stats.restype = C.c_int
+    lib.gm_last_map_stats.argtypes = [vp, C.POINTER(MapStats)]
+    lib.gm_default_infix_length.restype = C.c_uint32
+    lib.gm_default_infix_length.argtypes = [C.c_uint32, C.c_uint32, C.c_int32]
+    _LIB, _LIB_NAME = lib, str(path)
+    return lib
+
+
+def _check(lib, rc):
+    if rc != 0:
+        detail = lib.gm_last_error().decode() or lib.gm_status_string(rc).decode()
+        raise GenmapError(rc, f"{lib.gm_status_string(rc).decode()} [{detail}]")
+
+
+def device_count():
+    return int(load_library().gm_device_count())
+
+
+def default_infix_length(K, E, xo=None):
+    return int(load_library().gm_default_infix_length(K, E, -1 if xo is None else xo))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Index:
+    """gm_index handle: the bidirectional FM index resident in one GPU's HBM."""
+
+    def __init__(self, handle, lib, codes, seq_len):
+        self._h, self._lib = handle, lib
+        self.seq_len = np.ascontiguousarray(seq_len, dtype=np.uint64)
+        self.cum = np.concatenate([[0], np.cumsum(self.seq_len)]).astype(np.uint64)
+        self.text_len = int(self.cum[-1])
+
+    @classmethod
+    def build(cls, codes, seq_len, sampling=0, block_bytes=0, device=0, profiling=False):
+        """gm_index_build: suffix-sort and pack both indexes on the GPU."""
+        lib = load_library(profiling)
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        sl = np.ascontiguousarray(seq_len, dtype=np.uint64)
+        h = C.c_void_p()
+        _check(lib, lib.gm_index_build(_ptr(codes), _ptr(sl), len(sl), sampling, block_bytes, device, C.byref(h)))
+        return cls(h, lib, codes, sl)
+
+    @classmethod
+    def from_bwt(cls, bwt_fwd, bwt_rev, codes, seq_len, sa_fwd=None, sampling=0, block_bytes=0, device=0, profiling=False):
+        """gm_index_import"""
+        lib = load_library(profiling)
+        bf = np.ascontiguousarray(bwt_fwd, dtype=np.uint8)
+        br = np.ascontiguousarray(bwt_rev, dtype=np.uint8)
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        sl = np.ascontiguousarray(seq_len, dtype=np.uint64)
+        sa = None if sa_fwd is None else np.ascontiguousarray(sa_fwd, dtype=np.uint32)
+        h = C.c_void_p()
+        _check(lib, lib.gm_index_import(_ptr(bf), _ptr(br), _ptr(sa), _ptr(codes), _ptr(sl), len(sl), sampling, block_bytes, device, C.byref(h)))
+        return cls(h, lib, codes, sl)
+
+    def close(self):
+        if self._h:
+            self._lib.gm_index_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        i = IndexInfo()
+        _check(self._lib, self._lib.gm_index_get_info(self._h, C.byref(i)))
+        return {k: getattr(i, k) for k, _ in IndexInfo._fields_}
+
+    def export_bwt(self):
+        n = self.info()["n_rows"]
+        bf, br = np.empty(n, np.uint8), np.empty(n, np.uint8)
+        _check(self._lib, self._lib.gm_index_export_bwt(self._h, _ptr(bf), _ptr(br)))
+        return bf, br
+
+    def _params(self, K, E, overlap, infix, revcompl, value_bits, exclude_pseudo, kmer_range):
+        kb, ke = kmer_range if kmer_range else (0, 0)
+        return MapParams(K, E, -1 if overlap is None else overlap, infix, int(revcompl), value_bits, int(exclude_pseudo), 0, kb, ke)
+
+    def _slice(self, first_seq, n_seq):
+        if n_seq is None:
+            n_seq = len(self.seq_len) - first_seq
+        tb = int(self.cum[first_seq])
+        return n_seq, tb, int(self.cum[first_seq + n_seq]) - tb
+
+    def map(self, K, E, first_seq=0, n_seq=None, overlap=None, infix=0, revcompl=True, value_bits=16,
+            exclude_pseudo=False, intervals=None, seq_file_id=None, kmer_range=None):
+        """gm_map: computeMappability for the fasta slice made of sequences [first_seq, first_seq+n_seq); host result."""
+        n_seq, tb, tl = self._slice(first_seq, n_seq)
+        p = self._params(K, E, overlap, infix, revcompl, value_bits, exclude_pseudo, kmer_range)
+        out = np.zeros(tl, dtype=np.uint8 if value_bits == 8 else np.uint16)
+        iv = None if not intervals else np.ascontiguousarray(np.asarray(intervals, dtype=np.uint64).reshape(-1))
+        sf = None if seq_file_id is None else np.ascontiguousarray(seq_file_id, dtype=np.uint32)
+        _check(self._lib, self._lib.gm_map(self._h, tb, tl, first_seq, n_seq, C.byref(p), _ptr(iv), 0 if iv is None else len(iv) // 2, _ptr(sf), _ptr(out)))
+        return out
+
+    def map_device(self, out_ptr, K, E, first_seq=0, n_seq=None, overlap=None, infix=0, revcompl=True, value_bits=16,
+                   exclude_pseudo=False, intervals=None, seq_file_id=None, kmer_range=None, stream=None):
+        """gm_map_device: result written to device memory at out_ptr (e.g. a torch tensor's data_ptr())."""
+        n_seq, tb, tl = self._slice(first_seq, n_seq)
+        p = self._params(K, E, overlap, infix, revcompl, value_bits, exclude_pseudo, kmer_range)
+        iv = None if not intervals else np.ascontiguousarray(np.asarray(intervals, dtype=np.uint64).reshape(-1))
+        sf = None if seq_file_id is None else np.ascontiguousarray(seq_file_id, dtype=np.uint32)
+        _check(self._lib, self._lib.gm_map_device(self._h, tb, tl, first_seq, n_seq, C.byref(p), _ptr(iv), 0 if iv is None else len(iv) // 2,
+                                                  _ptr(sf), C.c_void_p(out_ptr), C.c_void_p(stream or 0)))
+
+    def last_stats(self):
+        s = MapStats()
+        _check(self._lib, self._lib.gm_last_map_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in MapStats._fields_}

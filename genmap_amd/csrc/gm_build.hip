@@ -1,0 +1,150 @@
+// gm_build.hip -- GPU construction of the bidirectional FM index (gfx950).
+//
+// Replaces the CPU index construction of the reference (genmap index):
+//   /root/reference/src/indexing.hpp:73-148        fwd index, reverse(text), rev index
+//   /root/reference/src/seqan_libdivsufsort.h:36-240  SA (libdivsufsort) -> BWT, sentinels, SA samples
+// with an MI355X-first design: the whole suffix array lives in HBM (288 GB: 32 B per text symbol is
+// affordable even for 3.1 Gbp) and is sorted by PREFIX DOUBLING, every round being one rocPRIM
+// device-wide radix sort of (rank[i], rank[i+h]) pairs plus streaming kernels.  Conventions kept from the
+// reference because locate results depend on them: one sentinel after every sequence, sentinels smaller
+// than every letter and ordered by position (seqan_libdivsufsort.h:80-91,121-123); the reverse index is
+// built on each sequence reversed, same sequence order (indexing.hpp:130).
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <vector>
+#include <cstdio>
+#include "gm_internal.h"
+
+namespace gm {
+
+// ---- sentinel text -------------------------------------------------------------------------------------
+// sym[p] (codes 0..5) and key[p] (sentinel s -> s, letter c -> nSeq + c) for the forward or reversed text.
+__global__ __launch_bounds__(256) void make_symbols_kernel(const uint8_t* __restrict__ codes, const uint64_t* __restrict__ cum,
+                                                           uint32_t nSeq, uint64_t textLen, int rev,
+                                                           uint8_t* __restrict__ sym, uint32_t* __restrict__ key, uint32_t* __restrict__ sa)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // sentinel-free position, or textLen + s for sentinels
+    if (i < textLen) {
+        uint32_t lo = 0, hi = nSeq;   // sequence containing i: last s with cum[s] <= i
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cum[mid] <= i) lo = mid; else hi = mid; }
+        const uint64_t b = cum[lo], e = cum[lo + 1];
+        const uint64_t p = (rev ? (b + (e - 1 - i)) : i) + lo;
+        const uint32_t c = codes[i];
+        sym[p] = (uint8_t)c; key[p] = nSeq + c; sa[p] = (uint32_t)p;
+    } else if (i < textLen + nSeq) {
+        const uint32_t s = (uint32_t)(i - textLen);
+        const uint64_t p = cum[s + 1] + s;
+        sym[p] = (uint8_t)SYM_SENT; key[p] = s; sa[p] = (uint32_t)p;
+    }
+}
+
+__global__ __launch_bounds__(256) void head_flags32_kernel(const uint32_t* __restrict__ keys, uint32_t* __restrict__ flag, uint64_t n)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) flag[j] = (j > 0 && keys[j] != keys[j - 1]) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void head_flags64_kernel(const uint64_t* __restrict__ keys, uint32_t* __restrict__ flag, uint64_t n)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) flag[j] = (j > 0 && keys[j] != keys[j - 1]) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void scatter_rank_kernel(const uint32_t* __restrict__ sa, const uint32_t* __restrict__ dense, uint32_t* __restrict__ rank, uint64_t n)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) rank[sa[j]] = dense[j];
+}
+__global__ __launch_bounds__(256) void make_keys_kernel(const uint32_t* __restrict__ sa, const uint32_t* __restrict__ rank, uint64_t* __restrict__ keys,
+                                                        uint64_t n, uint64_t h)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) {
+        const uint64_t p = sa[j];
+        const uint64_t r1 = rank[p];
+        // a suffix shorter than h ends in a (unique) sentinel and already has a unique rank: second key irrelevant
+        const uint64_t r2 = (p + h < n) ? rank[p + h] : 0ull;
+        keys[j] = r1 << 32 | r2;
+    }
+}
+__global__ __launch_bounds__(256) void bwt_kernel(const uint32_t* __restrict__ sa, const uint8_t* __restrict__ sym, uint8_t* __restrict__ bwt, uint64_t n)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) { const uint32_t p = sa[j]; bwt[j] = p ? sym[p - 1] : sym[n - 1]; }
+}
+
+static inline unsigned grid_for(uint64_t n, unsigned bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+
+// Suffix array of the sentinel text (forward or reversed) in d_sa_out (n x u32), its BWT in d_bwt (n x u8).
+// Both are caller-provided device buffers; everything else is allocated and freed here.
+int build_sa_bwt(const uint8_t* d_codes, const uint64_t* d_cum, uint32_t nSeq, uint64_t textLen, int rev,
+                 uint32_t* d_sa_out, uint8_t* d_bwt, int* roundsOut)
+{
+    const uint64_t n = textLen + nSeq;
+    uint8_t* d_sym = nullptr;
+    uint32_t *d_key32 = nullptr, *d_key32b = nullptr, *d_own = nullptr, *d_rank = nullptr, *d_flag = nullptr, *d_dense = nullptr;
+    uint64_t *d_k64 = nullptr, *d_k64b = nullptr;
+    void* d_tmp = nullptr;
+    size_t tmpBytes = 0;
+    int rc = GM_OK;
+#define HC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); rc = (e_ == hipErrorOutOfMemory ? GM_ERR_OOM : GM_ERR_HIP); goto done; } } while (0)
+    {
+        uint32_t* cur = d_sa_out;   // holds the current order
+        uint32_t* alt = nullptr;    // sort output
+        HC(hipMalloc(&d_sym, n));
+        HC(hipMalloc(&d_own, n * 4)); HC(hipMalloc(&d_rank, n * 4));
+        HC(hipMalloc(&d_flag, n * 4)); HC(hipMalloc(&d_dense, n * 4));
+        HC(hipMalloc(&d_k64, n * 8)); HC(hipMalloc(&d_k64b, n * 8));
+        d_key32 = reinterpret_cast<uint32_t*>(d_k64);    // round 0 keys alias the 64-bit key buffers
+        d_key32b = reinterpret_cast<uint32_t*>(d_k64b);
+        alt = d_own;
+        hipLaunchKernelGGL(make_symbols_kernel, dim3(grid_for(n)), dim3(256), 0, 0, d_codes, d_cum, nSeq, textLen, rev, d_sym, d_key32, cur);
+        HC(hipGetLastError());
+
+        size_t t1 = 0, t2 = 0, t3 = 0;
+        unsigned keyBits = 1; while ((1ull << keyBits) < (uint64_t)nSeq + NLET) ++keyBits;
+        unsigned rbits = 1; while ((1ull << rbits) < n) ++rbits;
+        HC(rocprim::radix_sort_pairs(nullptr, t1, d_key32, d_key32b, cur, alt, n, 0, keyBits));
+        HC(rocprim::radix_sort_pairs(nullptr, t2, d_k64, d_k64b, cur, alt, n, 0, 32 + rbits));
+        HC(rocprim::inclusive_scan(nullptr, t3, d_flag, d_dense, n, rocprim::plus<uint32_t>()));
+        tmpBytes = std::max(t1, std::max(t2, t3));
+        HC(hipMalloc(&d_tmp, tmpBytes ? tmpBytes : 16));
+
+        // round 0: order by first symbol (sentinels are unique symbols ordered by sequence number)
+        size_t tb = tmpBytes;
+        HC(rocprim::radix_sort_pairs(d_tmp, tb, d_key32, d_key32b, cur, alt, n, 0, keyBits));
+        std::swap(cur, alt);
+        hipLaunchKernelGGL(head_flags32_kernel, dim3(grid_for(n)), dim3(256), 0, 0, d_key32b, d_flag, n);
+        tb = tmpBytes;
+        HC(rocprim::inclusive_scan(d_tmp, tb, d_flag, d_dense, n, rocprim::plus<uint32_t>()));
+        hipLaunchKernelGGL(scatter_rank_kernel, dim3(grid_for(n)), dim3(256), 0, 0, cur, d_dense, d_rank, n);
+        uint32_t maxRank = 0;
+        HC(hipMemcpy(&maxRank, d_dense + (n - 1), 4, hipMemcpyDeviceToHost));
+        int rounds = 0;
+        for (uint64_t h = 1; maxRank != (uint32_t)(n - 1); h <<= 1) {
+            if (h >= n) { set_error("prefix doubling did not converge"); rc = GM_ERR_INTERNAL; goto done; }
+            hipLaunchKernelGGL(make_keys_kernel, dim3(grid_for(n)), dim3(256), 0, 0, cur, d_rank, d_k64, n, h);
+            tb = tmpBytes;
+            HC(rocprim::radix_sort_pairs(d_tmp, tb, d_k64, d_k64b, cur, alt, n, 0, 32 + rbits));
+            std::swap(cur, alt);
+            hipLaunchKernelGGL(head_flags64_kernel, dim3(grid_for(n)), dim3(256), 0, 0, d_k64b, d_flag, n);
+            tb = tmpBytes;
+            HC(rocprim::inclusive_scan(d_tmp, tb, d_flag, d_dense, n, rocprim::plus<uint32_t>()));
+            hipLaunchKernelGGL(scatter_rank_kernel, dim3(grid_for(n)), dim3(256), 0, 0, cur, d_dense, d_rank, n);
+            HC(hipMemcpy(&maxRank, d_dense + (n - 1), 4, hipMemcpyDeviceToHost));
+            ++rounds;
+        }
+        if (roundsOut) *roundsOut = rounds;
+        if (cur != d_sa_out) HC(hipMemcpy(d_sa_out, cur, n * 4, hipMemcpyDeviceToDevice));
+        hipLaunchKernelGGL(bwt_kernel, dim3(grid_for(n)), dim3(256), 0, 0, d_sa_out, d_sym, d_bwt, n);
+        HC(hipGetLastError());
+        HC(hipDeviceSynchronize());
+    }
+done:
+    hipFree(d_sym); hipFree(d_own); hipFree(d_rank); hipFree(d_flag); hipFree(d_dense);
+    hipFree(d_k64); hipFree(d_k64b); hipFree(d_tmp);
+#undef HC
+    return rc;
+}
+
+}  // namespace gm

@@ -1,0 +1,43 @@
+// gm_internal.h -- private declarations shared by the translation units of libgenmap_amd.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdarg>
+#include <vector>
+#include "../../include/genmap_amd.h"
+#include "gm_common.h"
+
+namespace gm {
+
+void set_error(const char* fmt, ...);
+
+// gm_build.hip
+int build_sa_bwt(const uint8_t* d_codes, const uint64_t* d_cum, uint32_t nSeq, uint64_t textLen, int rev,
+                 uint32_t* d_sa_out, uint8_t* d_bwt, int* roundsOut);
+
+}  // namespace gm
+
+struct gm_index {
+    int device = 0;
+    uint32_t wpp = 3;                 // words per plane of the rank blocks (1, 3, 9)
+    uint64_t nRows = 0, textLen = 0;
+    uint32_t nSeq = 0, sampling = 0, alphabet = 4;
+    uint32_t* d_blk[2] = {nullptr, nullptr};
+    uint64_t blkBytes = 0;            // per direction
+    uint32_t C[gm::NLET + 1] = {0, 0, 0, 0, 0, 0};
+    uint8_t* d_text = nullptr;        // sentinel-free codes, one byte each
+    std::vector<uint64_t> cum;        // nSeq + 1
+    uint64_t* d_cum = nullptr;
+    int numCU = 0;
+    // ---- workspace of gm_map*, grown on demand, reused across calls ----
+    uint32_t* d_acc = nullptr; uint64_t accCap = 0;
+    uint4* d_stack = nullptr; uint64_t stackCap = 0;       // in uint4 units
+    void* d_small = nullptr;                               // counter(8) | error(4) | pad | counters(16)
+    uint4* d_table = nullptr; uint64_t tableCap = 0;
+    uint2* d_blocks = nullptr; uint64_t blocksCap = 0;
+    uint64_t* d_cumLocal = nullptr; uint64_t cumLocalCap = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool evValid = false;
+    gm_map_stats stats{};
+    int buildRounds[2] = {0, 0};
+};

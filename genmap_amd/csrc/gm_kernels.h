@@ -1,0 +1,192 @@
+// gm_kernels.h -- device kernels of the mappability hot path (HIP, gfx950 only).
+//
+//   search_kernel<WPP>   persistent wavefronts; every lane owns one search node at a time and advances it
+//                        with gm::lane_step (gm_engine.h).  Work items are (k-mer block, strand, OSS search)
+//                        roots drawn from a global counter in chunks, handed out inside the wavefront with
+//                        a ballot/mbcnt rank -- the "warp-ballot work queue" of the search tree.  Lanes keep
+//                        their pending nodes in a lane-private LIFO in HBM/L2 (16-byte nodes, one
+//                        global_store_dwordx4 / global_load_dwordx4 each).
+//   finalize_kernel      acc (u32, saturating-safe) -> c[] as uint8/uint16:  min(total, MAX)
+//                        (std::min(count + hits, max_val), /root/reference/src/algo.hpp:36,48,191)
+//   reset_limits_kernel  resetLimits, /root/reference/src/algo.hpp:10-22
+//
+// Roofline: integer/pointer chasing, bound by random HBM line reads; no MFMA anywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gm_engine.h"
+
+namespace gm {
+
+struct SearchArgs {
+    const uint32_t* blk[2];     // rank blocks: [0] forward BWT (extend left), [1] reverse BWT (extend right)
+    uint32_t C[NLET + 1];
+    uint32_t nRows;
+    const uint8_t* text;        // slice base, one code per byte
+    uint32_t* acc;              // per slice position, zeroed by the caller
+    uint32_t K, E;
+    uint32_t stepSize, nSearches, rootsPerBlock;
+    uint32_t numKmers;
+    uint64_t blockBegin;        // first block of this shard
+    uint64_t numRoots;          // roots of this shard
+    const uint2* blockList;     // (first k-mer, count) per block, or nullptr for the arithmetic partition
+    const uint4* table;         // OssRecord[(n-1)*8 + s]
+    uint4* stack;               // lane-private LIFOs: stack[lane * stackDepth + i]
+    uint32_t stackDepth;
+    unsigned long long* workCounter;
+    uint32_t* errorFlag;
+    unsigned long long* counters;   // [0] node steps, [1] distinct rank lines (only with GM_COUNTERS)
+};
+
+constexpr uint32_t WORK_CHUNK = 256;   // roots taken from the global counter per atomic
+
+template <int WPP> struct DevEnv {
+    const SearchArgs& A;
+    uint4* stk;
+    uint32_t sp;
+    uint32_t K;
+#ifdef GM_COUNTERS
+    uint32_t steps = 0, lines = 0;
+#endif
+    __device__ __forceinline__ DevEnv(const SearchArgs& a, uint4* s, uint32_t k) : A(a), stk(s), sp(0), K(k) {}
+
+    __device__ __forceinline__ void rank2(uint32_t right, uint32_t lo, uint32_t hi, uint32_t rl[NLET], uint32_t rh[NLET])
+    {
+        constexpr uint32_t SPB = BlockGeom<WPP>::SPB, WPB = BlockGeom<WPP>::WPB;
+        constexpr int NV = (5 + 3 * WPP + 3) / 4;   // uint4 loads that cover header + planes
+        const uint32_t* base = right ? A.blk[1] : A.blk[0];
+        const uint32_t bl = lo / SPB, bh = hi / SPB;
+        const uint4* pl = reinterpret_cast<const uint4*>(base + (size_t)bl * WPB);
+        const uint4* ph = reinterpret_cast<const uint4*>(base + (size_t)bh * WPB);
+        uint32_t wl[NV * 4], wh[NV * 4];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { uint4 v = pl[j]; wl[4 * j] = v.x; wl[4 * j + 1] = v.y; wl[4 * j + 2] = v.z; wl[4 * j + 3] = v.w; }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { uint4 v = ph[j]; wh[4 * j] = v.x; wh[4 * j + 1] = v.y; wh[4 * j + 2] = v.z; wh[4 * j + 3] = v.w; }
+        block_rank<WPP>(wl, lo - bl * SPB, rl);
+        block_rank<WPP>(wh, hi - bh * SPB, rh);
+#ifdef GM_COUNTERS
+        steps += 1; lines += 1 + (bl != bh);
+#endif
+    }
+    __device__ __forceinline__ uint32_t text_char(const Root& rt, uint32_t pos) const
+    {
+        const uint32_t W = K + rt.n - 1u;
+        const uint32_t idx = rt.strand ? (W - 1u - pos) : pos;
+        const uint32_t c = A.text[(size_t)rt.win + idx];
+        return rt.strand ? complement(c) : c;
+    }
+    __device__ __forceinline__ void push(const Node& nd)
+    {
+        if (sp < A.stackDepth) { stk[sp] = make_uint4(nd.flo, nd.rlo, nd.w, nd.meta); ++sp; }
+        else *A.errorFlag = 1u;   // never expected: depth = stack_bound(E, stepSize)
+    }
+    __device__ __forceinline__ void add_hit(const Root& rt, uint32_t kmer, uint32_t count)
+    {
+        const uint32_t pos = rt.win + (rt.strand ? rt.n - 1u - kmer : kmer);
+        const uint32_t add = count < 0xFFFFu ? count : 0xFFFFu;   // every add is <= MAX of the widest value type
+        const uint32_t old = atomicAdd(&A.acc[pos], add);
+        if (old > 0xFFFFFFFFu - add) atomicOr(&A.acc[pos], 0x80000000u);   // sticky saturation on (theoretical) wrap
+    }
+    __device__ __forceinline__ uint32_t C(uint32_t c) const { return A.C[c]; }
+};
+
+template <int WPP>
+__global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const size_t gl = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    DevEnv<WPP> env(A, A.stack + gl * A.stackDepth, A.K);
+    Node nd; nd.flo = nd.rlo = nd.w = nd.meta = 0;
+    Root rt; rt.win = 0; rt.n = 1; rt.strand = 0; rt.rec = OssRecord{0, 0, 0, 0};
+    bool have = false, exhausted = false;
+    unsigned long long poolCur = 0, poolEnd = 0;   // wave-uniform
+    bool globalDone = false;                        // wave-uniform
+
+    for (;;) {
+        if (!have && env.sp > 0) {
+            const uint4 v = env.stk[--env.sp];
+            nd.flo = v.x; nd.rlo = v.y; nd.w = v.z; nd.meta = v.w;
+            have = true;
+        }
+        // ---- wavefront work queue: lanes without a node draw roots, ranked by ballot ----
+#pragma unroll 1
+        for (int round = 0; round < 2; ++round) {
+            const bool need = !have && !exhausted;
+            const unsigned long long m = __ballot(need);
+            if (m == 0ull) break;
+            if (poolCur == poolEnd && !globalDone) {
+                unsigned long long base = 0;
+                const int leader = __ffsll((long long)m) - 1;
+                if ((int)lane == leader) base = atomicAdd(A.workCounter, (unsigned long long)WORK_CHUNK);
+                base = __shfl(base, leader);
+                if (base >= A.numRoots) globalDone = true;
+                else { poolCur = base; poolEnd = base + WORK_CHUNK < A.numRoots ? base + WORK_CHUNK : A.numRoots; }
+            }
+            const uint32_t avail = (uint32_t)(poolEnd - poolCur);
+            const uint32_t want = (uint32_t)__popcll(m);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (need) {
+                if (rank < avail) {
+                    const unsigned long long id = poolCur + rank;
+                    const unsigned long long b = id / A.rootsPerBlock;
+                    const uint32_t r = (uint32_t)(id - b * A.rootsPerBlock);
+                    const unsigned long long gb = A.blockBegin + b;
+                    if (A.blockList) { const uint2 e = A.blockList[gb]; rt.win = e.x; rt.n = e.y; }
+                    else {
+                        rt.win = (uint32_t)(gb * A.stepSize);
+                        const uint32_t left = A.numKmers - rt.win;
+                        rt.n = left < A.stepSize ? left : A.stepSize;
+                    }
+                    rt.strand = r / A.nSearches;
+                    const uint4 q = A.table[(size_t)(rt.n - 1u) * 8u + (r - rt.strand * A.nSearches)];
+                    rt.rec.x = q.x; rt.rec.y = q.y; rt.rec.z = q.z; rt.rec.w = q.w;
+                    nd = root_node(rt, A.nRows);
+                    have = true;
+                } else if (globalDone && avail == 0u) {
+                    exhausted = true;
+                }
+            }
+            poolCur += want < avail ? want : avail;
+        }
+        if (__ballot(have) == 0ull) break;   // nothing in flight in this wavefront, nothing left to draw
+
+        if (have) {
+            if (meta_mode(nd.meta) == M_SPLIT) { Node left; split_node(nd, left, A.K); env.push(left); }
+            lane_step(nd, have, rt, A.K, A.E, env);
+        }
+    }
+#ifdef GM_COUNTERS
+    atomicAdd(&A.counters[0], (unsigned long long)env.steps);
+    atomicAdd(&A.counters[1], (unsigned long long)env.lines);
+#endif
+}
+
+// acc -> c[]  (4 positions per thread)
+template <typename TValue>
+__global__ __launch_bounds__(256) void finalize_kernel(const uint32_t* __restrict__ acc, TValue* __restrict__ out, uint64_t n, uint32_t maxVal)
+{
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4ull;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(out + i)) & (sizeof(TValue) * 4 - 1)) == 0;
+    if (i + 4 <= n && aligned) {
+        const uint4 v = *reinterpret_cast<const uint4*>(acc + i);
+        TValue r[4] = {(TValue)(v.x < maxVal ? v.x : maxVal), (TValue)(v.y < maxVal ? v.y : maxVal),
+                       (TValue)(v.z < maxVal ? v.z : maxVal), (TValue)(v.w < maxVal ? v.w : maxVal)};
+        if (sizeof(TValue) == 1) *reinterpret_cast<uint32_t*>(out + i) = *reinterpret_cast<uint32_t*>(r);
+        else *reinterpret_cast<uint2*>(out + i) = *reinterpret_cast<uint2*>(r);
+    } else {
+        for (uint64_t j = i; j < n && j < i + 4; ++j) { const uint32_t v = acc[j]; out[j] = (TValue)(v < maxVal ? v : maxVal); }
+    }
+}
+
+// resetLimits (algo.hpp:10-22): zero the last K-1 positions of every sequence of the slice.
+template <typename TValue>
+__global__ void reset_limits_kernel(TValue* out, const uint64_t* cumLocal, uint32_t nSeq, uint32_t K)
+{
+    const uint32_t s = blockIdx.x + 1u;
+    if (s > nSeq) return;
+    const uint64_t len = cumLocal[s] - cumLocal[s - 1];
+    const uint64_t lim = (uint64_t)K < len + 1 ? (uint64_t)K : len + 1;
+    for (uint64_t j = 1 + threadIdx.x; j < lim; j += blockDim.x) out[cumLocal[s] - j] = (TValue)0;
+}
+
+}  // namespace gm

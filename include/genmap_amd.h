@@ -1,0 +1,132 @@
+/*
+ * genmap_amd.h -- C ABI of the MI355X-native (k,e)-mappability engine (libgenmap_amd.so).
+ *
+ * The reference (cpockrandt/genmap) has no plugin/FFI interface; its de-facto boundary for the hot path
+ * is the function
+ *     computeMappability<errors>(index, text, c, params, directory, chromLengths, chromCumLengths,
+ *                                locations, mappingSeqIdFile, intervals, completeSameKmers, ...)
+ *     /root/reference/src/algo.hpp:405-410      callers: src/mappability.hpp:177-185, tests/tests.cpp:192-193
+ * plus the index it is handed (built by src/indexing.hpp:73-148, opened by src/genmap_helper.hpp:72-98).
+ * Every entry point below names the reference interface it replaces.  Plain pointers and sizes only;
+ * no C++/torch types.  All functions return 0 (GM_OK) or a negative gm_status and never exit().
+ * The library needs a HIP device: without one every compute entry point returns GM_ERR_NO_DEVICE
+ * (there is no CPU fallback).
+ *
+ * Symbol codes in every buffer: A=0 C=1 G=2 T=3 N=4 (non-ACGTU characters are N, src/indexing.hpp:13-20);
+ * BWT buffers additionally use 5 for the per-sequence sentinel.
+ */
+#ifndef GENMAP_AMD_H
+#define GENMAP_AMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gm_status {
+    GM_OK = 0,
+    GM_ERR_NO_DEVICE = -1,     /* no usable HIP device / HIP runtime error at start-up */
+    GM_ERR_BAD_ERRORS = -2,    /* E > 4: "E > 4 not yet supported." src/mappability.hpp:187 */
+    GM_ERR_BAD_VALUE_BITS = -3,/* value_bits must be 8 (-fs) or 16 (-fl, mappability) src/mappability.hpp:388-394 */
+    GM_ERR_NEED_LOCATE = -4,   /* csv / --exclude-pseudo requested on an index without SA samples */
+    GM_ERR_BAD_OVERLAP = -5,   /* -xo larger than min(K-1, K-E-2), src/mappability.hpp:528-540; or infix < #blocks */
+    GM_ERR_BAD_K = -6,         /* K < 1 or K > 128 (this build's node encoding) */
+    GM_ERR_TOO_LONG = -7,      /* total index length >= 2^32 - 1 (32-bit BWT positions, src/indexing.hpp:159-162) */
+    GM_ERR_BAD_ARG = -8,
+    GM_ERR_HIP = -9,           /* a HIP call failed; gm_last_error() has the text */
+    GM_ERR_IO = -10,
+    GM_ERR_OOM = -11,
+    GM_ERR_INTERNAL = -12      /* a device-side invariant was violated (e.g. lane stack bound) */
+} gm_status;
+
+const char *gm_status_string(int status);
+const char *gm_last_error(void);          /* thread-local text of the last failing call */
+int gm_device_count(void);                /* number of HIP devices visible, 0 if none */
+
+/* ------------------------------------------------------------------------------------------------
+ * Index  (replaces Index<StringSet, BidirectionalIndex<FMIndex>>: src/common.hpp:38-52;
+ *         construction src/indexing.hpp:73-148 + src/seqan_libdivsufsort.h:36-240;
+ *         open() src/genmap_helper.hpp:72-98)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct gm_index gm_index;
+
+typedef struct gm_index_info {
+    uint64_t n_rows;          /* text symbols + one sentinel per sequence */
+    uint64_t text_len;        /* sum of sequence lengths */
+    uint32_t n_seq;
+    uint32_t sampling;        /* SA sampling rate (0 = no samples, counts only) */
+    uint32_t alphabet_size;   /* 4 or 5 (index.info "alphabet_size", src/indexing.hpp:102) */
+    uint32_t block_bytes;     /* rank block size of this index: 32, 64 or 128 */
+    uint64_t device_bytes;    /* HBM held by the index */
+    int32_t  device;
+} gm_index_info;
+
+/* Build both FM indexes ON THE GPU from host sequences (concatenated codes, no sentinels).
+ * block_bytes: 32, 64 or 128 (0 = library default).  sampling: keep SA[i] where the in-sequence offset
+ * is a multiple of `sampling` (src/seqan_libdivsufsort.h:129-143); 0 = none. */
+int gm_index_build(const uint8_t *codes, const uint64_t *seq_len, uint32_t n_seq,
+                   uint32_t sampling, uint32_t block_bytes, int device, gm_index **out);
+
+/* Adopt BWTs that already exist on the host (an index file read from disk, or another builder):
+ * uploads them and packs the rank blocks on the GPU.  sa_fwd may be NULL (no locate). */
+int gm_index_import(const uint8_t *bwt_fwd, const uint8_t *bwt_rev, const uint32_t *sa_fwd,
+                    const uint8_t *codes, const uint64_t *seq_len, uint32_t n_seq,
+                    uint32_t sampling, uint32_t block_bytes, int device, gm_index **out);
+
+/* Copy the BWTs (codes 0..5, n_rows bytes each) back to the host: index files, parity tests. */
+int gm_index_export_bwt(const gm_index *idx, uint8_t *bwt_fwd, uint8_t *bwt_rev);
+
+int gm_index_get_info(const gm_index *idx, gm_index_info *info);
+void gm_index_free(gm_index *idx);
+
+/* ------------------------------------------------------------------------------------------------
+ * computeMappability  (src/algo.hpp:405-483, for ONE fasta file's slice of the concatenated text:
+ * the loop body of src/mappability.hpp:289-365)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct gm_map_params {
+    uint32_t K;               /* -K  SearchParams.length */
+    uint32_t E;               /* -E  0..4 */
+    int32_t  overlap;         /* hidden -xo; < 0 = reference default (src/mappability.hpp:519-525) */
+    int32_t  infix;           /* > 0: set the common-infix length (SearchParams.overlap) directly, as
+                                 tests/tests.cpp:179-181 does; overrides `overlap` */
+    int32_t  revcompl;        /* 0 with -nc */
+    int32_t  value_bits;      /* 8 or 16 */
+    int32_t  exclude_pseudo;  /* -ep: count distinct fasta files (needs SA samples) */
+    int32_t  reserved0;
+    uint64_t kmer_begin;      /* shard: compute only k-mer start positions in [kmer_begin, kmer_end) of   */
+    uint64_t kmer_end;        /*        the slice; both 0 = everything.  Other positions are left zero.   */
+} gm_map_params;
+
+/* text_begin/text_len: the slice in sentinel-free global coordinates (src/mappability.hpp:312);
+ * first_seq/n_seq: its sequences (for resetLimits, src/algo.hpp:10-22);
+ * intervals: n_intervals half-open pairs in slice coordinates or NULL (-S, src/mappability.hpp:334-357);
+ * seq_file_id: fasta id per GLOBAL sequence (only read with exclude_pseudo, src/mappability.hpp:230-248);
+ * out: text_len values of value_bits width, caller-owned HOST memory (gm_map) or DEVICE memory on the
+ * index's device (gm_map_device; stream = hipStream_t or NULL).  Values are bit-identical to the
+ * reference's c[] after resetLimits and the selection reset of src/mappability.hpp:83-99. */
+int gm_map(gm_index *idx, uint64_t text_begin, uint64_t text_len, uint32_t first_seq, uint32_t n_seq,
+           const gm_map_params *params, const uint64_t *intervals, uint64_t n_intervals,
+           const uint32_t *seq_file_id, void *out_host);
+
+int gm_map_device(gm_index *idx, uint64_t text_begin, uint64_t text_len, uint32_t first_seq, uint32_t n_seq,
+                  const gm_map_params *params, const uint64_t *intervals, uint64_t n_intervals,
+                  const uint32_t *seq_file_id, void *out_device, void *stream);
+
+/* counters of the most recent gm_map* call on this index (for the roofline numerator) */
+typedef struct gm_map_stats {
+    uint64_t kmers;           /* k-mer positions searched */
+    uint64_t roots;           /* (block, strand, search) work items */
+    uint64_t node_steps;      /* bidirectional extensions evaluated (0 unless the library was built with GM_COUNTERS) */
+    uint64_t rank_lines;      /* distinct rank blocks those steps read (same) */
+    double   search_ms;       /* HIP-event time of the search kernel alone */
+    double   total_ms;        /* memset + search + finalize, HIP events on the call's stream */
+} gm_map_stats;
+int gm_last_map_stats(const gm_index *idx, gm_map_stats *stats);
+
+/* reference default of SearchParams.overlap (common-infix length) for (K,E,-xo): src/mappability.hpp:519-543.
+ * Returns 0 if -xo is too large. */
+uint32_t gm_default_infix_length(uint32_t K, uint32_t E, int32_t xo);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,56 @@
+"""CPU-side checks of the boundary: the C-ABI library loads, exports every symbol include/genmap_amd.h
+declares, and fails loudly (no CPU fallback) when there is no GPU."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _declared_symbols():
+    txt = (ROOT / "include" / "genmap_amd.h").read_text()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(gm_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    import genmap_amd as g
+    lib = g.load_library()
+    names = _declared_symbols()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(lib, n), n
+    assert set(names) == set(g.capi.EXPORTS)
+
+
+def test_no_cpu_fallback_without_device():
+    import genmap_amd as g
+    if g.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(g.GenmapError) as e:
+        g.Index.build(np.zeros(100, np.uint8), [100])
+    assert e.value.status == -1
+
+
+def test_default_infix_matches_oracle_rule():
+    import genmap_amd as g
+    import helpers as H
+    for K in (3, 4, 8, 24, 30, 36, 50, 100, 101, 128):
+        for E in range(5):
+            for xo in (None, 0, 1, 2, 5):
+                a = g.default_infix_length(K, E, xo)
+                b = H.default_infix_length(K, E, xo)
+                assert a == (0 if b < 0 else b), (K, E, xo, a, b)
+
+
+def test_product_does_not_reference_oracle():
+    """The shipped sources never include, link or load anything under oracle/ or tests/."""
+    for p in list((ROOT / "genmap_amd").rglob("*")) + [ROOT / "include" / "genmap_amd.h"]:
+        if p.is_file() and p.suffix in (".py", ".h", ".hip", ".cpp", ".hpp") or p.name == "Makefile":
+            if not p.is_file():
+                continue
+            t = p.read_text(errors="ignore")
+            assert "gm_oracle" not in t and "libgmoracle" not in t and "libgmemu" not in t, p

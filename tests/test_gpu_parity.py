@@ -1,0 +1,174 @@
+"""GPU parity tests (run with -m gpu on an MI355X): everything goes through the C ABI of libgenmap_amd.so
+(genmap_amd.capi) and is compared bit-exactly with the CPU oracle / the reference's golden files.
+The GPU box has no /root/reference: only tests/golden and the oracle are used."""
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+BLOCK_BYTES = (32, 64, 128)
+
+
+def _gm():
+    import genmap_amd as g
+    if g.device_count() < 1:
+        pytest.fail("no HIP device: the GPU tests must run on the MI355X box")
+    return g
+
+
+def _repeat_text(rng, n, dna5):
+    codes = rng.integers(0, 4, size=n, dtype=np.uint8)
+    fam = rng.integers(0, 4, size=300, dtype=np.uint8)
+    for s in rng.integers(0, max(1, n - 300), size=max(2, n // 3000)):
+        cp = fam.copy()
+        mut = rng.random(300) < 0.05
+        cp[mut] = rng.integers(0, 4, size=int(mut.sum()), dtype=np.uint8)
+        codes[s:s + 300] = cp[:max(0, min(300, n - s))]
+    if dna5:
+        a = n // 3
+        codes[a:a + max(1, n // 50)] = 4
+        codes[rng.integers(0, n, size=max(1, n // 5000))] = 4
+    if n > 2000:
+        codes[n // 2:n // 2 + 150] = 0  # poly-A
+    return codes
+
+
+@pytest.mark.parametrize("dna5", [False, True])
+def test_gpu_builder_matches_oracle_bwt(dna5):
+    g = _gm()
+    rng = np.random.default_rng(11 + dna5)
+    lens = [70000, 1, 33, 50000, 2, 12345]
+    codes = _repeat_text(rng, sum(lens), dna5)
+    ora = H.OracleIndex(codes, lens, keep_sa=False)
+    for bb in BLOCK_BYTES:
+        ix = g.Index.build(codes, lens, block_bytes=bb)
+        bf, br = ix.export_bwt()
+        assert np.array_equal(bf, ora.bwt(0)), bb
+        assert np.array_equal(br, ora.bwt(1)), bb
+        info = ix.info()
+        assert info["alphabet_size"] == (5 if dna5 else 4) and info["block_bytes"] == bb
+        ix.close()
+
+
+@pytest.mark.parametrize("case", sorted(H.CASES))
+def test_gpu_reference_fixture_cases(case):
+    g = _gm()
+    d = H.CASES_DIR / f"case_{case}"
+    gen, directory, fl, bed = H.load_case(case)
+    if fl.get("ep"):
+        pytest.skip("--exclude-pseudo goes through the locate path")
+    for bb in BLOCK_BYTES:
+        ix = g.Index.build(gen.codes, gen.seq_len, block_bytes=bb)
+        for xo in H.xo_variants(case):
+            for name, first, nseq, tb, tl in gen.file_slices():
+                iv = None
+                if bed is not None:
+                    iv = H.slice_intervals(gen, first, nseq, bed)
+                    if not iv:
+                        continue
+                for bits, sub, ext, dt in ((16, "raw_freq16", "freq16", np.uint16), (8, "raw_freq8", "freq8", np.uint8)):
+                    out = ix.map(fl["K"], fl["E"], first_seq=first, n_seq=nseq, overlap=xo, revcompl=not fl.get("nc", False),
+                                 value_bits=bits, intervals=iv)
+                    exp = np.fromfile(d / sub / (name.rsplit(".", 1)[0] + ".genmap." + ext), dtype=dt)
+                    assert np.array_equal(out, exp), (case, bb, xo, bits, name, out.tolist(), exp.tolist())
+        ix.close()
+
+
+@pytest.mark.parametrize("dna5", [False, True])
+@pytest.mark.parametrize("E", [0, 1, 2, 3, 4])
+def test_gpu_gtest_matrix(E, dna5):
+    """tests/tests.cpp:133-260 with a portable PRNG: every K, every infix length, vs trivial backtracking."""
+    g = _gm()
+    rng = np.random.default_rng(3000 + 10 * E + dna5)
+    nseq, ln = 3, (1000 if E < 3 else 300)
+    codes = rng.integers(0, 5 if dna5 else 4, size=nseq * ln, dtype=np.uint8)
+    ora = H.OracleIndex(codes, [ln] * nseq, keep_sa=False)
+    ix = g.Index.build(codes, [ln] * nseq)
+    minK = E + 1 + (E >= 2)
+    nblocks = [1, 2, 4, 5, 6][E]
+    for K in range(minK, 9 if E < 4 else 8):
+        rc = bool(rng.integers(0, 2))
+        triv = ora.trivial(K, E, revcompl=rc, value_bits=8)
+        for infix in range(max(minK, nblocks), K + 1):
+            out = ix.map(K, E, infix=infix, revcompl=rc, value_bits=8)
+            assert np.array_equal(out, triv), (E, dna5, K, infix)
+    ix.close()
+
+
+@pytest.mark.parametrize("K,E", [(30, 0), (30, 1), (30, 2), (100, 1), (24, 1), (50, 3), (36, 4), (128, 0)])
+def test_gpu_baseline_settings_small(K, E):
+    g = _gm()
+    rng = np.random.default_rng(K * 10 + E)
+    lens = [60000, 700, K - 1, 30000, 3]
+    codes = _repeat_text(rng, sum(lens), True)
+    ora = H.OracleIndex(codes, lens, keep_sa=False)
+    for bb in BLOCK_BYTES:
+        ix = g.Index.build(codes, lens, block_bytes=bb)
+        for bits in (8, 16):
+            exp = ora.mappability(K, E, value_bits=bits, threads=8)
+            out = ix.map(K, E, value_bits=bits)
+            assert np.array_equal(out, exp), (K, E, bits, bb)
+        ix.close()
+
+
+def test_gpu_shards_and_device_output():
+    """kmer_begin/kmer_end shards written into a torch device buffer add up to the unsharded result."""
+    g = _gm()
+    import torch
+    rng = np.random.default_rng(5)
+    lens = [200000, 150000]
+    codes = _repeat_text(rng, sum(lens), True)
+    ix = g.Index.build(codes, lens)
+    K, E = 30, 1
+    full = ix.map(K, E, value_bits=8)
+    step = 30 - g.default_infix_length(K, E) + 1
+    nk = sum(lens) - K + 1
+    cuts = [0, (nk // 3 // step) * step, (2 * nk // 3 // step) * step, nk]
+    acc = torch.zeros(sum(lens), dtype=torch.uint8, device="cuda:0")
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        part = torch.zeros(sum(lens), dtype=torch.uint8, device="cuda:0")
+        ix.map_device(part.data_ptr(), K, E, value_bits=8, kmer_range=(a, b), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        acc |= part
+    got = acc.cpu().numpy()
+    # positions zeroed by resetLimits are zero in every shard; other positions are non-zero in exactly one
+    assert np.array_equal(got, full)
+    ix.close()
+
+
+def test_gpu_midsize_vs_oracle_and_properties():
+    """4 Mbp chr1-like text: GPU-built index; oracle adopts the exported BWTs (its own suffix sort is the slow
+    part) and checks e=0 everywhere and e=1/2 on selected intervals; plus size-independent properties."""
+    g = _gm()
+    from genmap_amd import synth
+    codes, lens, _ = synth.workload("chr1", 0.016)
+    ix = g.Index.build(codes, lens)
+    bf, br = ix.export_bwt()
+    n = len(codes) + len(lens)
+    # BWT is a permutation of the sentinel text
+    cnt_text = np.bincount(codes, minlength=6); cnt_text[5] = len(lens)
+    assert np.array_equal(np.bincount(bf, minlength=6), cnt_text)
+    assert np.array_equal(np.bincount(br, minlength=6), cnt_text)
+    ora = H.OracleIndex(codes, lens, keep_sa=False, bwt=(bf, br))
+    out0 = ix.map(30, 0, value_bits=8)
+    exp0 = ora.mappability(30, 0, value_bits=8, threads=8)
+    assert np.array_equal(out0, exp0)
+    # properties: every N-free k-mer inside the sequence occurs at least once; last K-1 positions are zero
+    assert (out0[-29:] == 0).all()
+    win = np.convolve((codes == 4).astype(np.int32), np.ones(30, dtype=np.int32))[29:len(codes)]
+    ok = win[:len(codes) - 29] == 0
+    assert (out0[:len(codes) - 29][ok] >= 1).all() and (out0[:len(codes) - 29][~ok] == 0).all()
+    iv = [(1000, 9000), (len(codes) // 2 - 4000, len(codes) // 2 + 4000), (len(codes) - 20000, len(codes) - 12000)]
+    for K, E in ((30, 1), (30, 2), (100, 1)):
+        out = ix.map(K, E, value_bits=16, intervals=iv)
+        exp = ora.mappability(K, E, value_bits=16, threads=8, intervals=iv)
+        assert np.array_equal(out, exp), (K, E)
+        # monotone in E on the computed positions
+        sel = np.zeros(len(codes), bool)
+        for a, b in iv:
+            sel[a:b] = True
+        base = ix.map(K, 0, value_bits=16, intervals=iv)
+        assert (out[sel] >= base[sel]).all()
+    ix.close()
