@@ -80,6 +80,14 @@ int main(int argc, char** argv)
     hipLaunchKernelGGL(fill_kernel, dim3(cus * 8), dim3(256), 0, 0, tab, maxBytes / 16);
     CK(hipDeviceSynchronize());
     const int iters = 400;
+    if (argc > 2) {   // sweep: where does the random-read rate fall off with the footprint (TLB reach, MALL)?
+        for (uint64_t sz = 128ull << 20; sz <= maxBytes; sz <<= 1) {
+            run<2, 2>(tab, sz, cus * 8, iters, d_out, "sweep");
+            run<4, 2>(tab, sz, cus * 8, iters, d_out, "sweep");
+            run<8, 2>(tab, sz, cus * 4, iters, d_out, "sweep");
+        }
+        return 0;
+    }
     uint64_t sizes[] = {64ull << 20, 2ull << 30, maxBytes};
     for (uint64_t sz : sizes) {
         if (sz > maxBytes) continue;
