@@ -37,7 +37,13 @@ class MapStats(C.Structure):
                 ("search_ms", C.c_double), ("total_ms", C.c_double)]
 
 
-EXPORTS = ["gm_status_string", "gm_last_error", "gm_device_count", "gm_index_build", "gm_index_import",
+class Locations(C.Structure):
+    """struct gm_locations"""
+    _fields_ = [("pos_begin", C.c_uint64), ("n_positions", C.c_uint64), ("plus_off", C.POINTER(C.c_uint64)),
+                ("minus_off", C.POINTER(C.c_uint64)), ("plus", C.POINTER(C.c_uint64)), ("minus", C.POINTER(C.c_uint64))]
+
+
+EXPORTS = ["gm_locate", "gm_locations_free", "gm_status_string", "gm_last_error", "gm_device_count", "gm_index_build", "gm_index_import",
            "gm_index_export_bwt", "gm_index_get_info", "gm_index_free", "gm_map", "gm_map_device",
            "gm_last_map_stats", "gm_default_infix_length"]
 
@@ -74,6 +80,9 @@ def load_library(profiling=False):
     lib.gm_map.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(MapParams), vp, C.c_uint64, vp, vp]
     lib.gm_map_device.restype = C.c_int
     lib.gm_map_device.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(MapParams), vp, C.c_uint64, vp, vp, vp]
+    lib.gm_locate.restype = C.c_int
+    lib.gm_locate.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(MapParams), vp, C.c_uint64, C.POINTER(C.POINTER(Locations))]
+    lib.gm_locations_free.argtypes = [C.POINTER(Locations)]
     lib.gm_last_map_stats.restype = C.c_int
     lib.gm_last_map_stats.argtypes = [vp, C.POINTER(MapStats)]
     lib.gm_default_infix_length.restype = C.c_uint32
@@ -184,6 +193,25 @@ class Index:
         sf = None if seq_file_id is None else np.ascontiguousarray(seq_file_id, dtype=np.uint32)
         _check(self._lib, self._lib.gm_map_device(self._h, tb, tl, first_seq, n_seq, C.byref(p), _ptr(iv), 0 if iv is None else len(iv) // 2,
                                                   _ptr(sf), C.c_void_p(out_ptr), C.c_void_p(stream or 0)))
+
+    def locate(self, K, E, first_seq=0, n_seq=None, overlap=None, infix=0, revcompl=True, intervals=None, kmer_range=None):
+        """gm_locate: (pos_begin, plus_off, plus, minus_off, minus) -- occurrence lists per slice position,
+        occurrences packed as seqNo << 32 | seqPos (global sequence numbers), each list sorted."""
+        n_seq, tb, tl = self._slice(first_seq, n_seq)
+        p = self._params(K, E, overlap, infix, revcompl, 16, False, kmer_range)
+        iv = None if not intervals else np.ascontiguousarray(np.asarray(intervals, dtype=np.uint64).reshape(-1))
+        L = C.POINTER(Locations)()
+        _check(self._lib, self._lib.gm_locate(self._h, tb, tl, first_seq, n_seq, C.byref(p), _ptr(iv), 0 if iv is None else len(iv) // 2, C.byref(L)))
+        try:
+            c = L.contents
+            n = int(c.n_positions)
+            po = np.ctypeslib.as_array(c.plus_off, shape=(n + 1,)).copy()
+            mo = np.ctypeslib.as_array(c.minus_off, shape=(n + 1,)).copy()
+            pl = np.ctypeslib.as_array(c.plus, shape=(max(int(po[-1]), 1),))[:int(po[-1])].copy()
+            mi = np.ctypeslib.as_array(c.minus, shape=(max(int(mo[-1]), 1),))[:int(mo[-1])].copy()
+            return int(c.pos_begin), po, pl, mo, mi
+        finally:
+            self._lib.gm_locations_free(L)
 
     def last_stats(self):
         s = MapStats()

@@ -3,6 +3,7 @@
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -121,7 +122,7 @@ static uint32_t wpp_of_block_bytes(uint32_t bb)
 {
     if (bb == 0) {
         const char* e = getenv("GM_BLOCK_BYTES");
-        bb = e ? (uint32_t)atoi(e) : 64u;
+        bb = e ? (uint32_t)atoi(e) : 32u;   // measured: 32-B blocks sustain the highest random-read rate (profiles/r01_gather_*)
     }
     return bb == 32 ? 1u : bb == 64 ? 3u : bb == 128 ? 9u : 0u;
 }
@@ -129,6 +130,7 @@ static uint32_t wpp_of_block_bytes(uint32_t bb)
 static int index_common_setup(gm_index* ix, const uint8_t* codes, const uint64_t* seq_len, uint32_t n_seq, uint32_t sampling, uint32_t block_bytes, int device)
 {
     ix->device = device; ix->nSeq = n_seq; ix->sampling = sampling;
+    if (sampling > 1) { set_error("this build keeps the full suffix array in HBM (sampling 1) or none (0); sampled SA + LF walk is not implemented"); return GM_ERR_BAD_ARG; }
     ix->wpp = wpp_of_block_bytes(block_bytes);
     if (!ix->wpp) { set_error("block_bytes must be 32, 64 or 128"); return GM_ERR_BAD_ARG; }
     ix->cum.assign((size_t)n_seq + 1, 0);
@@ -191,7 +193,7 @@ void gm_index_free(gm_index* ix)
 {
     if (!ix) return;
     hipSetDevice(ix->device);
-    hipFree(ix->d_blk[0]); hipFree(ix->d_blk[1]); hipFree(ix->d_text); hipFree(ix->d_cum);
+    hipFree(ix->d_blk[0]); hipFree(ix->d_blk[1]); hipFree(ix->d_text); hipFree(ix->d_cum); hipFree(ix->d_sa); hipFree(ix->d_seqFile); hipFree(ix->d_bits);
     hipFree(ix->d_acc); hipFree(ix->d_stack); hipFree(ix->d_small); hipFree(ix->d_table); hipFree(ix->d_blocks); hipFree(ix->d_cumLocal);
     for (int i = 0; i < 4; ++i) if (ix->ev[i]) hipEventDestroy(ix->ev[i]);
     delete ix;
@@ -211,6 +213,10 @@ int gm_index_build(const uint8_t* codes, const uint64_t* seq_len, uint32_t n_seq
     for (int d = 0; d < 2 && !rc; ++d) {
         rc = build_sa_bwt(ix->d_text, ix->d_cum, n_seq, ix->textLen, d, d_sa, d_bwt, &ix->buildRounds[d]);
         if (!rc) rc = pack_dispatch(ix, d, d_bwt);
+        if (!rc && d == 0 && sampling == 1) {   // the forward SA stays resident: 4 B/row of 288 GB buys locate without LF walks
+            ix->d_sa = d_sa; d_sa = nullptr;
+            if (hipMalloc(&d_sa, ix->nRows * 4) != hipSuccess) rc = GM_ERR_OOM;
+        }
     }
     hipFree(d_sa); hipFree(d_bwt);
     if (rc) { gm_index_free(ix); return rc; }
@@ -221,7 +227,6 @@ int gm_index_build(const uint8_t* codes, const uint64_t* seq_len, uint32_t n_seq
 int gm_index_import(const uint8_t* bwt_fwd, const uint8_t* bwt_rev, const uint32_t* sa_fwd, const uint8_t* codes, const uint64_t* seq_len,
                     uint32_t n_seq, uint32_t sampling, uint32_t block_bytes, int device, gm_index** out)
 {
-    (void)sa_fwd;
     if (!bwt_fwd || !bwt_rev || !codes || !seq_len || !n_seq || !out) { set_error("null argument"); return GM_ERR_BAD_ARG; }
     int rc = select_device(device);
     if (rc) return rc;
@@ -235,6 +240,10 @@ int gm_index_import(const uint8_t* bwt_fwd, const uint8_t* bwt_rev, const uint32
         rc = pack_dispatch(ix, d, d_bwt);
     }
     hipFree(d_bwt);
+    if (!rc && sa_fwd && sampling == 1) {
+        if (hipMalloc(&ix->d_sa, ix->nRows * 4) != hipSuccess) rc = GM_ERR_OOM;
+        else if (hipMemcpy(ix->d_sa, sa_fwd, ix->nRows * 4, hipMemcpyHostToDevice) != hipSuccess) rc = GM_ERR_HIP;
+    }
     if (rc) { gm_index_free(ix); return rc; }
     *out = ix;
     return GM_OK;
@@ -264,7 +273,8 @@ int gm_index_get_info(const gm_index* ix, gm_index_info* info)
     info->n_rows = ix->nRows; info->text_len = ix->textLen; info->n_seq = ix->nSeq; info->sampling = ix->sampling;
     info->alphabet_size = ix->alphabet;
     info->block_bytes = ix->wpp == 1 ? 32 : ix->wpp == 3 ? 64 : 128;
-    info->device_bytes = 2 * ix->blkBytes + ix->textLen + (ix->nSeq + 1) * 8ull;
+    info->device_bytes = 2 * ix->blkBytes + ix->textLen + (ix->nSeq + 1) * 8ull + (ix->d_sa ? ix->nRows * 4ull : 0ull);
+    if (!ix->d_sa) info->sampling = 0;
     info->device = ix->device;
     return GM_OK;
 }
@@ -284,29 +294,57 @@ template <typename T> static int grow(T** p, uint64_t* cap, uint64_t need)
     return GM_OK;
 }
 
-template <int WPP>
-static int launch_search(gm_index* ix, const SearchArgs& A, unsigned blocks, hipStream_t st)
+enum LeafMode { LEAF_COUNT = 0, LEAF_FILESET = 1, LEAF_OCC_COUNT = 2, LEAF_OCC_EMIT = 3 };
+
+template <int WPP, class EnvT>
+static int launch_one(const SearchArgs& A, unsigned blocks, hipStream_t st)
 {
-    hipLaunchKernelGGL(search_kernel<WPP>, dim3(blocks), dim3(256), 0, st, A);
+    hipLaunchKernelGGL((search_kernel<WPP, EnvT>), dim3(blocks), dim3(256), 0, st, A);
     GM_HIP(hipGetLastError());
     return GM_OK;
+}
+template <int WPP>
+static int launch_mode(int mode, const SearchArgs& A, unsigned blocks, hipStream_t st)
+{
+    switch (mode) {
+        case LEAF_COUNT: return launch_one<WPP, CountEnv<WPP>>(A, blocks, st);
+        case LEAF_FILESET: return launch_one<WPP, FileSetEnv<WPP>>(A, blocks, st);
+        case LEAF_OCC_COUNT: return launch_one<WPP, OccCountEnv<WPP>>(A, blocks, st);
+        default: return launch_one<WPP, OccEmitEnv<WPP>>(A, blocks, st);
+    }
+}
+static int launch_search(const gm_index* ix, int mode, const SearchArgs& A, unsigned blocks, hipStream_t st)
+{
+    switch (ix->wpp) {
+        case 1: return launch_mode<1>(mode, A, blocks, st);
+        case 3: return launch_mode<3>(mode, A, blocks, st);
+        default: return launch_mode<9>(mode, A, blocks, st);
+    }
 }
 
 template <int WPP> static int occupancy_blocks(int* out)
 {
     int nb = 0;
-    GM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, search_kernel<WPP>, 256, 0));
+    GM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (search_kernel<WPP, CountEnv<WPP>>), 256, 0));
     *out = nb;
     return GM_OK;
 }
 
-static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t first_seq, uint32_t n_seq, const gm_map_params* p,
-                    const uint64_t* intervals, uint64_t n_intervals, const uint32_t* seq_file_id, void* d_out, hipStream_t st)
+static int check_device_error(gm_index* ix);
+
+struct SearchSetup {
+    MapPlan plan;
+    uint64_t blockBegin = 0, blockEnd = 0, numRoots = 0, kmers = 0;
+    unsigned blocks = 1;
+    uint32_t posBase = 0, posEnd = 0;   // slice positions covered by the selected blocks: [posBase, posEnd)
+};
+
+// validation, planning, workspace, uploads; fills every SearchArgs field that does not depend on the leaf policy
+static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t first_seq, uint32_t n_seq, const gm_map_params* p,
+                          const uint64_t* intervals, uint64_t n_intervals, hipStream_t st, SearchSetup* S, SearchArgs* Aout)
 {
-    (void)seq_file_id;
-    if (!ix || !p || !d_out) { set_error("null argument"); return GM_ERR_BAD_ARG; }
+    if (!ix || !p) { set_error("null argument"); return GM_ERR_BAD_ARG; }
     if (p->value_bits != 8 && p->value_bits != 16) return GM_ERR_BAD_VALUE_BITS;
-    if (p->exclude_pseudo) { set_error("--exclude-pseudo needs the locate path"); return GM_ERR_NEED_LOCATE; }
     if (text_begin + text_len > ix->textLen || (uint64_t)first_seq + n_seq > ix->nSeq || n_seq == 0) { set_error("slice outside the index"); return GM_ERR_BAD_ARG; }
     if (ix->cum[first_seq] != text_begin || ix->cum[first_seq + n_seq] != text_begin + text_len) { set_error("slice does not match its sequences"); return GM_ERR_BAD_ARG; }
     if (p->E > MAX_ERRORS) return GM_ERR_BAD_ERRORS;
@@ -314,7 +352,7 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
 
     const uint32_t infix = p->infix > 0 ? (uint32_t)p->infix : default_infix_length(p->K, p->E, p->overlap);
     if (infix == 0) return GM_ERR_BAD_OVERLAP;
-    MapPlan plan;
+    MapPlan& plan = S->plan;
     int rc = make_map_plan(p->K, p->E, infix, p->revcompl, text_len, intervals, n_intervals, &plan);
     if (rc) return rc;   // PlanError values coincide with gm_status
 
@@ -332,22 +370,34 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
         if (blockEnd < blockBegin) blockEnd = blockBegin;
     }
     const uint32_t rpb = plan.nSearches * plan.nStrands;
-    const uint64_t numRoots = (blockEnd - blockBegin) * rpb;
+    S->blockBegin = blockBegin; S->blockEnd = blockEnd; S->numRoots = (blockEnd - blockBegin) * rpb;
+    uint64_t kmers = 0;
+    S->posBase = S->posEnd = 0;
+    if (blockEnd > blockBegin) {
+        if (plan.useList) {
+            for (uint64_t b = blockBegin; b < blockEnd; ++b) kmers += plan.blocks[b].second;
+            S->posBase = plan.blocks[blockBegin].first; S->posEnd = plan.blocks[blockEnd - 1].first + plan.blocks[blockEnd - 1].second;
+        } else {
+            S->posBase = (uint32_t)(blockBegin * plan.stepSize); S->posEnd = (uint32_t)std::min<uint64_t>(blockEnd * plan.stepSize, plan.numKmers);
+            kmers = S->posEnd - S->posBase;
+        }
+    }
+    S->kmers = kmers;
 
     // ---- workspace ----
-    rc = grow(&ix->d_acc, &ix->accCap, text_len + 4); if (rc) return rc;
     rc = grow(&ix->d_table, &ix->tableCap, (uint64_t)plan.table.size()); if (rc) return rc;
     rc = grow(&ix->d_cumLocal, &ix->cumLocalCap, (uint64_t)n_seq + 1); if (rc) return rc;
     if (plan.useList) { rc = grow(&ix->d_blocks, &ix->blocksCap, std::max<uint64_t>(plan.blocks.size(), 1)); if (rc) return rc; }
-
     int perCU = 0;
     switch (ix->wpp) { case 1: rc = occupancy_blocks<1>(&perCU); break; case 3: rc = occupancy_blocks<3>(&perCU); break; default: rc = occupancy_blocks<9>(&perCU); break; }
     if (rc) return rc;
-    if (const char* e = getenv("GM_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0) perCU = std::min(perCU, v); }
-    if (perCU < 1) perCU = 1;
+    int wantPerCU = 4;   // measured (profiles/r01a): 16 waves/CU beat full occupancy (less cache/TLB pressure)
+    if (const char* e = getenv("GM_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0) wantPerCU = v; }
+    perCU = std::max(1, std::min(perCU, wantPerCU));
     uint64_t blocks = (uint64_t)ix->numCU * perCU;
-    const uint64_t useful = (numRoots + 255) / 256;
+    const uint64_t useful = (S->numRoots + 255) / 256;
     if (blocks > useful) blocks = std::max<uint64_t>(useful, 1);
+    S->blocks = (unsigned)blocks;
     const uint32_t depth = stack_bound(p->E, plan.stepSize);
     rc = grow(&ix->d_stack, &ix->stackCap, blocks * 256ull * depth); if (rc) return rc;
 
@@ -359,55 +409,150 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
     GM_HIP(hipMemcpyAsync(ix->d_cumLocal, cumLocal.data(), cumLocal.size() * 8, hipMemcpyHostToDevice, st));
     GM_HIP(hipStreamSynchronize(st));   // host staging buffers go out of scope; also keeps the timed region device-only
 
-    GM_HIP(hipEventRecord(ix->ev[0], st));
-    GM_HIP(hipMemsetAsync(ix->d_acc, 0, (text_len + 4) * sizeof(uint32_t), st));
-    GM_HIP(hipMemsetAsync(ix->d_small, 0, 64, st));
-
-    SearchArgs A;
+    SearchArgs A; memset(&A, 0, sizeof(A));
     A.blk[0] = ix->d_blk[0]; A.blk[1] = ix->d_blk[1];
     for (uint32_t c = 0; c <= NLET; ++c) A.C[c] = ix->C[c];
     A.nRows = (uint32_t)ix->nRows;
     A.text = ix->d_text + text_begin;
-    A.acc = ix->d_acc;
     A.K = p->K; A.E = p->E;
     A.stepSize = plan.stepSize; A.nSearches = plan.nSearches; A.rootsPerBlock = rpb;
     A.numKmers = (uint32_t)plan.numKmers;
-    A.blockBegin = blockBegin; A.numRoots = numRoots;
+    A.blockBegin = blockBegin; A.numRoots = S->numRoots;
     A.blockList = plan.useList ? ix->d_blocks : nullptr;
     A.table = ix->d_table;
     A.stack = ix->d_stack; A.stackDepth = depth;
     A.workCounter = reinterpret_cast<unsigned long long*>(ix->d_small);
     A.errorFlag = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ix->d_small) + 8);
     A.counters = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ix->d_small) + 16);
+    A.sa = ix->d_sa; A.cumGlobal = ix->d_cum; A.nSeqGlobal = ix->nSeq;
+    A.posBase = S->posBase; A.windowLen = S->posEnd - S->posBase;
+    *Aout = A;
+    return GM_OK;
+}
+
+template <typename TValue>
+static int launch_reset_limits(gm_index* ix, TValue* d_out, uint32_t n_seq, uint32_t K, hipStream_t st)
+{
+    hipLaunchKernelGGL(reset_limits_kernel<TValue>, dim3(n_seq), dim3(64), 0, st, d_out, ix->d_cumLocal, n_seq, K);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+}
+
+static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t first_seq, uint32_t n_seq, const gm_map_params* p,
+                    const uint64_t* intervals, uint64_t n_intervals, const uint32_t* seq_file_id, void* d_out, hipStream_t st)
+{
+    if (!d_out) { set_error("null output"); return GM_ERR_BAD_ARG; }
+    SearchSetup S; SearchArgs A;
+    int rc = prepare_search(ix, text_begin, text_len, first_seq, n_seq, p, intervals, n_intervals, st, &S, &A);
+    if (rc) return rc;
+    const bool ep = p->exclude_pseudo != 0;
+    uint32_t wordsPerKmer = 0;
+    if (ep) {
+        if (!ix->d_sa) { set_error("--exclude-pseudo needs an index built with sampling 1"); return GM_ERR_NEED_LOCATE; }
+        if (!seq_file_id) { set_error("--exclude-pseudo needs seq_file_id"); return GM_ERR_BAD_ARG; }
+        uint32_t nFiles = 0;
+        for (uint32_t s = 0; s < ix->nSeq; ++s) nFiles = std::max(nFiles, seq_file_id[s] + 1);
+        wordsPerKmer = (nFiles + 31) / 32;
+        rc = grow(&ix->d_seqFile, &ix->seqFileCap, (uint64_t)ix->nSeq); if (rc) return rc;
+        GM_HIP(hipMemcpyAsync(ix->d_seqFile, seq_file_id, (size_t)ix->nSeq * 4, hipMemcpyHostToDevice, st));
+        rc = grow(&ix->d_bits, &ix->bitsCap, (text_len + 1) * wordsPerKmer); if (rc) return rc;
+        GM_HIP(hipStreamSynchronize(st));
+    } else {
+        rc = grow(&ix->d_acc, &ix->accCap, text_len + 4); if (rc) return rc;
+    }
+
+    GM_HIP(hipEventRecord(ix->ev[0], st));
+    if (ep) GM_HIP(hipMemsetAsync(ix->d_bits, 0, (text_len + 1) * wordsPerKmer * sizeof(uint32_t), st));
+    else GM_HIP(hipMemsetAsync(ix->d_acc, 0, (text_len + 4) * sizeof(uint32_t), st));
+    GM_HIP(hipMemsetAsync(ix->d_small, 0, 64, st));
+    A.acc = ix->d_acc; A.fileBits = ix->d_bits; A.wordsPerKmer = wordsPerKmer; A.seqFile = ix->d_seqFile;
 
     GM_HIP(hipEventRecord(ix->ev[1], st));
-    if (numRoots > 0) {
-        switch (ix->wpp) {
-            case 1: rc = launch_search<1>(ix, A, (unsigned)blocks, st); break;
-            case 3: rc = launch_search<3>(ix, A, (unsigned)blocks, st); break;
-            default: rc = launch_search<9>(ix, A, (unsigned)blocks, st); break;
-        }
-        if (rc) return rc;
-    }
+    if (S.numRoots > 0) { rc = launch_search(ix, ep ? LEAF_FILESET : LEAF_COUNT, A, S.blocks, st); if (rc) return rc; }
     GM_HIP(hipEventRecord(ix->ev[2], st));
     if (text_len > 0) {
+        const unsigned g4 = grid_for((text_len + 3) / 4), g1 = grid_for(text_len);
         if (p->value_bits == 8) {
-            hipLaunchKernelGGL(finalize_kernel<uint8_t>, dim3(grid_for((text_len + 3) / 4)), dim3(256), 0, st, ix->d_acc, (uint8_t*)d_out, text_len, 255u);
-            hipLaunchKernelGGL(reset_limits_kernel<uint8_t>, dim3(n_seq), dim3(64), 0, st, (uint8_t*)d_out, ix->d_cumLocal, n_seq, p->K);
+            if (ep) hipLaunchKernelGGL(finalize_fileset_kernel<uint8_t>, dim3(g1), dim3(256), 0, st, ix->d_bits, wordsPerKmer, (uint8_t*)d_out, text_len);
+            else hipLaunchKernelGGL(finalize_kernel<uint8_t>, dim3(g4), dim3(256), 0, st, ix->d_acc, (uint8_t*)d_out, text_len, 255u);
+            rc = launch_reset_limits(ix, (uint8_t*)d_out, n_seq, p->K, st);
         } else {
-            hipLaunchKernelGGL(finalize_kernel<uint16_t>, dim3(grid_for((text_len + 3) / 4)), dim3(256), 0, st, ix->d_acc, (uint16_t*)d_out, text_len, 65535u);
-            hipLaunchKernelGGL(reset_limits_kernel<uint16_t>, dim3(n_seq), dim3(64), 0, st, (uint16_t*)d_out, ix->d_cumLocal, n_seq, p->K);
+            if (ep) hipLaunchKernelGGL(finalize_fileset_kernel<uint16_t>, dim3(g1), dim3(256), 0, st, ix->d_bits, wordsPerKmer, (uint16_t*)d_out, text_len);
+            else hipLaunchKernelGGL(finalize_kernel<uint16_t>, dim3(g4), dim3(256), 0, st, ix->d_acc, (uint16_t*)d_out, text_len, 65535u);
+            rc = launch_reset_limits(ix, (uint16_t*)d_out, n_seq, p->K, st);
         }
-        GM_HIP(hipGetLastError());
+        if (rc) return rc;
     }
     GM_HIP(hipEventRecord(ix->ev[3], st));
     ix->evValid = true;
     ix->stats = gm_map_stats{};
-    uint64_t kmers = 0;
-    if (plan.useList) { for (uint64_t b = blockBegin; b < blockEnd; ++b) kmers += plan.blocks[b].second; }
-    else if (blockEnd > blockBegin) kmers = std::min<uint64_t>(blockEnd * plan.stepSize, plan.numKmers) - blockBegin * plan.stepSize;
-    ix->stats.kmers = kmers; ix->stats.roots = numRoots;
+    ix->stats.kmers = S.kmers; ix->stats.roots = S.numRoots;
     return GM_OK;
+}
+
+// ---- gm_locate: per-position occurrence lists for csv (algo.hpp:311-348) -------------------------------------
+static int locate_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t first_seq, uint32_t n_seq, const gm_map_params* p,
+                       const uint64_t* intervals, uint64_t n_intervals, gm_locations* L)
+{
+    hipStream_t st = nullptr;
+    SearchSetup S; SearchArgs A;
+    int rc = prepare_search(ix, text_begin, text_len, first_seq, n_seq, p, intervals, n_intervals, st, &S, &A);
+    if (rc) return rc;
+    if (!ix->d_sa) { set_error("csv output needs an index built with sampling 1"); return GM_ERR_NEED_LOCATE; }
+    const uint64_t W = S.posEnd - S.posBase;
+    L->pos_begin = S.posBase; L->n_positions = W;
+    L->plus_off = (uint64_t*)calloc(W + 1, 8); L->minus_off = (uint64_t*)calloc(W + 1, 8);
+    L->plus = nullptr; L->minus = nullptr;
+    if (!L->plus_off || !L->minus_off) return GM_ERR_OOM;
+    if (W == 0 || S.numRoots == 0) return GM_OK;
+
+    uint32_t* d_cnt = nullptr; uint64_t* d_offs = nullptr; uint64_t *d_emit = nullptr, *d_sorted = nullptr; void* d_tmp = nullptr;
+    uint32_t *d_segB = nullptr, *d_segE = nullptr;
+    size_t tmpBytes = 0;
+    const uint64_t slots = 2 * W;
+#define LC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); rc = (e_ == hipErrorOutOfMemory) ? GM_ERR_OOM : GM_ERR_HIP; goto done; } } while (0)
+    {
+        LC(hipMalloc(&d_cnt, (slots + 1) * 4)); LC(hipMalloc(&d_offs, (slots + 1) * 8));
+        LC(hipMemset(d_cnt, 0, (slots + 1) * 4)); LC(hipMemset(ix->d_small, 0, 64));
+        A.cnt2 = d_cnt;
+        rc = launch_search(ix, LEAF_OCC_COUNT, A, S.blocks, st); if (rc) goto done;
+        LC(rocprim::exclusive_scan(nullptr, tmpBytes, d_cnt, d_offs, (uint64_t)0, slots + 1, rocprim::plus<uint64_t>()));
+        LC(hipMalloc(&d_tmp, tmpBytes ? tmpBytes : 16));
+        { size_t tb = tmpBytes; LC(rocprim::exclusive_scan(d_tmp, tb, d_cnt, d_offs, (uint64_t)0, slots + 1, rocprim::plus<uint64_t>())); }
+        std::vector<uint64_t> offs(slots + 1);
+        LC(hipMemcpy(offs.data(), d_offs, (slots + 1) * 8, hipMemcpyDeviceToHost));
+        const uint64_t total = offs[slots];
+        if (total >= (1ull << 31)) { set_error("%llu occurrences in one gm_locate window; use a smaller k-mer range", (unsigned long long)total); rc = GM_ERR_TOO_LONG; goto done; }
+        for (uint64_t j = 0; j <= W; ++j) { L->plus_off[j] = offs[j]; L->minus_off[j] = offs[W + j] - offs[W]; }
+        // slot W (end of the plus strand) == start of the minus strand
+        L->plus_off[W] = offs[W];
+        L->plus = (uint64_t*)malloc((offs[W] + 1) * 8); L->minus = (uint64_t*)malloc((total - offs[W] + 1) * 8);
+        if (!L->plus || !L->minus) { rc = GM_ERR_OOM; goto done; }
+        if (total > 0) {
+            LC(hipMalloc(&d_emit, total * 8)); LC(hipMalloc(&d_sorted, total * 8));
+            LC(hipMemset(d_cnt, 0, (slots + 1) * 4)); LC(hipMemset(ix->d_small, 0, 64));
+            A.offs = d_offs; A.emit = d_emit;
+            rc = launch_search(ix, LEAF_OCC_EMIT, A, S.blocks, st); if (rc) goto done;
+            // std::sort of every list (algo.hpp:336,348): segmented radix sort, segments = (position, strand) slots
+            LC(hipMalloc(&d_segB, (slots + 1) * 4));
+            std::vector<uint32_t> seg(slots + 1);
+            for (uint64_t j = 0; j <= slots; ++j) seg[j] = (uint32_t)offs[j];
+            LC(hipMemcpy(d_segB, seg.data(), (slots + 1) * 4, hipMemcpyHostToDevice));
+            d_segE = d_segB + 1;
+            size_t sb = 0;
+            LC(rocprim::segmented_radix_sort_keys(nullptr, sb, d_emit, d_sorted, (unsigned int)total, (unsigned int)slots, d_segB, d_segE, 0, 64));
+            if (sb > tmpBytes) { hipFree(d_tmp); d_tmp = nullptr; LC(hipMalloc(&d_tmp, sb)); tmpBytes = sb; }
+            { size_t tb = tmpBytes; LC(rocprim::segmented_radix_sort_keys(d_tmp, tb, d_emit, d_sorted, (unsigned int)total, (unsigned int)slots, d_segB, d_segE, 0, 64)); }
+            LC(hipMemcpy(L->plus, d_sorted, offs[W] * 8, hipMemcpyDeviceToHost));
+            LC(hipMemcpy(L->minus, d_sorted + offs[W], (total - offs[W]) * 8, hipMemcpyDeviceToHost));
+        }
+        LC(hipDeviceSynchronize());
+    }
+done:
+#undef LC
+    hipFree(d_cnt); hipFree(d_offs); hipFree(d_emit); hipFree(d_sorted); hipFree(d_tmp); hipFree(d_segB);
+    if (!rc) rc = check_device_error(ix);
+    return rc;
 }
 
 static int check_device_error(gm_index* ix)
@@ -442,6 +587,24 @@ int gm_map(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t first_
     if (!rc) rc = check_device_error(ix);
     hipFree(d_out);
     return rc;
+}
+
+int gm_locate(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t first_seq, uint32_t n_seq, const gm_map_params* p,
+              const uint64_t* intervals, uint64_t n_intervals, gm_locations** out)
+{
+    if (!out) { set_error("null argument"); return GM_ERR_BAD_ARG; }
+    gm_locations* L = (gm_locations*)calloc(1, sizeof(gm_locations));
+    if (!L) return GM_ERR_OOM;
+    int rc = locate_impl(ix, text_begin, text_len, first_seq, n_seq, p, intervals, n_intervals, L);
+    if (rc) { gm_locations_free(L); return rc; }
+    *out = L;
+    return GM_OK;
+}
+
+void gm_locations_free(gm_locations* L)
+{
+    if (!L) return;
+    free(L->plus_off); free(L->minus_off); free(L->plus); free(L->minus); free(L);
 }
 
 int gm_last_map_stats(const gm_index* cix, gm_map_stats* out)

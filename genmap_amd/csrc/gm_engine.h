@@ -125,7 +125,10 @@ GM_HD Post make_post(uint32_t meta, const Plan& pl, const OssRecord& rec, uint32
 //   void rank2(uint32_t right, uint32_t lo, uint32_t hi, uint32_t rl[5], uint32_t rh[5])
 //   uint32_t text_char(const Root&, uint32_t pos)     (already complemented for strand 1)
 //   void push(const Node&)                            (lane-private LIFO)
-//   void add_hit(const Root&, uint32_t kmer, uint32_t count)
+//   void leaf(const Root&, uint32_t kmer, uint32_t flo, uint32_t w)   one matching string of k-mer `kmer`:
+//                                                     rows [flo, flo+w) of the forward SA (countOccurrences /
+//                                                     itAll.push_back, algo.hpp:42-48,185-191)
+//   void leaf_flush(const Root&, uint32_t kmer)       after the last leaf() of a step
 //   uint32_t C(uint32_t c)                            (first row of letter c)
 // On return `have` tells whether nd holds a node to continue with.
 template <class Env>
@@ -149,7 +152,6 @@ GM_HD void lane_step(Node& nd, bool& have, const Root& rt, uint32_t K, uint32_t 
 
     Node keep; keep.flo = keep.rlo = keep.w = keep.meta = 0;
     bool haveKeep = false;
-    uint32_t leafSum = 0;
     // order: the matching child first (it ends up deepest in the LIFO), mismatching children after it;
     // the lane continues with the last one.  This bounds the stack by 4*E + log2(n) + c.
 #pragma unroll
@@ -162,10 +164,10 @@ GM_HD void lane_step(Node& nd, bool& have, const Root& rt, uint32_t K, uint32_t 
             const uint32_t delta = (!isMatch || tc == SYM_N) ? 1u : 0u;   // find2:250, algo.hpp:111-112,148-149
             if (pl.exact && delta) continue;                  // exact segment: pattern N or another letter fails
             if (pl.minErr > 0 && pl.charsLeft + delta < pl.minErr + 1u) continue;   // find2:254-258
-            if (ps.leaf) { leafSum += cnt[x]; continue; }
-            Node ch;
             const uint32_t pnew = env.C((uint32_t)x) + rl[x];
             const uint32_t onew = olo + sm[x];
+            if (ps.leaf) { env.leaf(rt, ps.kmer, pl.right ? onew : pnew, cnt[x]); continue; }
+            Node ch;
             ch.flo = pl.right ? onew : pnew;
             ch.rlo = pl.right ? pnew : onew;
             ch.w = cnt[x];
@@ -174,7 +176,7 @@ GM_HD void lane_step(Node& nd, bool& have, const Root& rt, uint32_t K, uint32_t 
             keep = ch; haveKeep = true;
         }
     }
-    if (leafSum) env.add_hit(rt, ps.kmer, leafSum);
+    if (ps.leaf) env.leaf_flush(rt, ps.kmer);
     nd = keep; have = haveKeep;
 }
 

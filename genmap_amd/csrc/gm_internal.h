@@ -28,6 +28,9 @@ struct gm_index {
     uint8_t* d_text = nullptr;        // sentinel-free codes, one byte each
     std::vector<uint64_t> cum;        // nSeq + 1
     uint64_t* d_cum = nullptr;
+    uint32_t* d_sa = nullptr;         // forward suffix array (kept when sampling == 1): locate = one HBM read
+    uint32_t* d_seqFile = nullptr; uint64_t seqFileCap = 0;
+    uint32_t* d_bits = nullptr; uint64_t bitsCap = 0;
     int numCU = 0;
     // ---- workspace of gm_map*, grown on demand, reused across calls ----
     uint32_t* d_acc = nullptr; uint64_t accCap = 0;

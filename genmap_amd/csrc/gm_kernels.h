@@ -35,11 +35,31 @@ struct SearchArgs {
     unsigned long long* workCounter;
     uint32_t* errorFlag;
     unsigned long long* counters;   // [0] node steps, [1] distinct rank lines (only with GM_COUNTERS)
+    // ---- locate path (csv, --exclude-pseudo; /root/reference/src/algo.hpp:311-387) ----
+    const uint32_t* sa;             // forward suffix array (sentinel-text positions), sampling rate 1
+    const uint64_t* cumGlobal;      // sentinel-free cumulative sequence lengths of the WHOLE index, nSeqGlobal + 1
+    uint32_t nSeqGlobal;
+    const uint32_t* seqFile;        // fasta id per global sequence (mappingSeqIdFile, src/mappability.hpp:230-248)
+    uint32_t* fileBits;             // [pos * wordsPerKmer + w]: set of fasta ids seen for the k-mer at pos
+    uint32_t wordsPerKmer;
+    uint32_t posBase;               // window origin of cnt2 / offs / emit arrays (slice position)
+    uint32_t windowLen;
+    uint32_t* cnt2;                 // [strand * windowLen + pos - posBase]: occurrences (pass 1) / cursor (pass 2)
+    const uint64_t* offs;           // exclusive scan of cnt2 (pass 2)
+    uint64_t* emit;                 // packed (seqNo << 32 | seqPos) per occurrence
 };
+
+// sentinel-text position -> (seqNo, seqPos); sequence s starts at cum[s] + s
+__device__ __forceinline__ uint2 locate_position(const uint64_t* __restrict__ cum, uint32_t nSeq, uint32_t p)
+{
+    uint32_t lo = 0, hi = nSeq;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cum[mid] + mid <= (uint64_t)p) lo = mid; else hi = mid; }
+    return make_uint2(lo, (uint32_t)(p - (cum[lo] + lo)));
+}
 
 constexpr uint32_t WORK_CHUNK = 256;   // roots taken from the global counter per atomic
 
-template <int WPP> struct DevEnv {
+template <int WPP> struct EnvBase {
     const SearchArgs& A;
     uint4* stk;
     uint32_t sp;
@@ -47,7 +67,8 @@ template <int WPP> struct DevEnv {
 #ifdef GM_COUNTERS
     uint32_t steps = 0, lines = 0;
 #endif
-    __device__ __forceinline__ DevEnv(const SearchArgs& a, uint4* s, uint32_t k) : A(a), stk(s), sp(0), K(k) {}
+    __device__ __forceinline__ EnvBase(const SearchArgs& a, uint4* s, uint32_t k) : A(a), stk(s), sp(0), K(k) {}
+    __device__ __forceinline__ uint32_t slice_pos(const Root& rt, uint32_t kmer) const { return rt.win + (rt.strand ? rt.n - 1u - kmer : kmer); }
 
     __device__ __forceinline__ void rank2(uint32_t right, uint32_t lo, uint32_t hi, uint32_t rl[NLET], uint32_t rh[NLET])
     {
@@ -60,8 +81,14 @@ template <int WPP> struct DevEnv {
         uint32_t wl[NV * 4], wh[NV * 4];
 #pragma unroll
         for (int j = 0; j < NV; ++j) { uint4 v = pl[j]; wl[4 * j] = v.x; wl[4 * j + 1] = v.y; wl[4 * j + 2] = v.z; wl[4 * j + 3] = v.w; }
+        // range lo and range hi usually share a block once the range is narrow: one request instead of two
+        const bool other = (bh != bl);
 #pragma unroll
-        for (int j = 0; j < NV; ++j) { uint4 v = ph[j]; wh[4 * j] = v.x; wh[4 * j + 1] = v.y; wh[4 * j + 2] = v.z; wh[4 * j + 3] = v.w; }
+        for (int j = 0; j < NV; ++j) {
+            uint4 v = make_uint4(wl[4 * j], wl[4 * j + 1], wl[4 * j + 2], wl[4 * j + 3]);
+            if (other) v = ph[j];
+            wh[4 * j] = v.x; wh[4 * j + 1] = v.y; wh[4 * j + 2] = v.z; wh[4 * j + 3] = v.w;
+        }
         block_rank<WPP>(wl, lo - bl * SPB, rl);
         block_rank<WPP>(wh, hi - bh * SPB, rh);
 #ifdef GM_COUNTERS
@@ -80,22 +107,75 @@ template <int WPP> struct DevEnv {
         if (sp < A.stackDepth) { stk[sp] = make_uint4(nd.flo, nd.rlo, nd.w, nd.meta); ++sp; }
         else *A.errorFlag = 1u;   // never expected: depth = stack_bound(E, stepSize)
     }
-    __device__ __forceinline__ void add_hit(const Root& rt, uint32_t kmer, uint32_t count)
+    __device__ __forceinline__ uint32_t C(uint32_t c) const { return A.C[c]; }
+};
+
+// leaf policy 1: frequency only -- hits[a-ab] = min(countOccurrences(it) + hits[a-ab], max) (algo.hpp:48,191)
+template <int WPP> struct CountEnv : EnvBase<WPP> {
+    using EnvBase<WPP>::A;
+    uint32_t leafSum = 0;
+    __device__ __forceinline__ CountEnv(const SearchArgs& a, uint4* s, uint32_t k) : EnvBase<WPP>(a, s, k) {}
+    __device__ __forceinline__ void leaf(const Root&, uint32_t, uint32_t, uint32_t w) { leafSum += w; }
+    __device__ __forceinline__ void leaf_flush(const Root& rt, uint32_t kmer)
     {
-        const uint32_t pos = rt.win + (rt.strand ? rt.n - 1u - kmer : kmer);
+        const uint32_t count = leafSum; leafSum = 0;
+        if (!count) return;
+        const uint32_t pos = this->slice_pos(rt, kmer);
         const uint32_t add = count < 0xFFFFu ? count : 0xFFFFu;   // every add is <= MAX of the widest value type
         const uint32_t old = atomicAdd(&A.acc[pos], add);
         if (old > 0xFFFFFFFFu - add) atomicOr(&A.acc[pos], 0x80000000u);   // sticky saturation on (theoretical) wrap
     }
-    __device__ __forceinline__ uint32_t C(uint32_t c) const { return A.C[c]; }
 };
 
-template <int WPP>
+// leaf policy 2: --exclude-pseudo -- the set of fasta files that contain the k-mer (algo.hpp:351-364)
+template <int WPP> struct FileSetEnv : EnvBase<WPP> {
+    using EnvBase<WPP>::A;
+    __device__ __forceinline__ FileSetEnv(const SearchArgs& a, uint4* s, uint32_t k) : EnvBase<WPP>(a, s, k) {}
+    __device__ __forceinline__ void leaf(const Root& rt, uint32_t kmer, uint32_t flo, uint32_t w)
+    {
+        uint32_t* bits = A.fileBits + (size_t)this->slice_pos(rt, kmer) * A.wordsPerKmer;
+        for (uint32_t r = 0; r < w; ++r) {
+            const uint2 sp = locate_position(A.cumGlobal, A.nSeqGlobal, A.sa[flo + r]);
+            const uint32_t f = A.seqFile[sp.x];
+            atomicOr(&bits[f >> 5], 1u << (f & 31u));
+        }
+    }
+    __device__ __forceinline__ void leaf_flush(const Root&, uint32_t) {}
+};
+
+// leaf policy 3: csv pass 1 -- occurrences per (k-mer, strand)
+template <int WPP> struct OccCountEnv : EnvBase<WPP> {
+    using EnvBase<WPP>::A;
+    __device__ __forceinline__ OccCountEnv(const SearchArgs& a, uint4* s, uint32_t k) : EnvBase<WPP>(a, s, k) {}
+    __device__ __forceinline__ void leaf(const Root& rt, uint32_t kmer, uint32_t, uint32_t w)
+    {
+        atomicAdd(&A.cnt2[(size_t)rt.strand * A.windowLen + (this->slice_pos(rt, kmer) - A.posBase)], w);
+    }
+    __device__ __forceinline__ void leaf_flush(const Root&, uint32_t) {}
+};
+
+// leaf policy 4: csv pass 2 -- getOccurrences(iterator) of every leaf (algo.hpp:328-345), unsorted
+template <int WPP> struct OccEmitEnv : EnvBase<WPP> {
+    using EnvBase<WPP>::A;
+    __device__ __forceinline__ OccEmitEnv(const SearchArgs& a, uint4* s, uint32_t k) : EnvBase<WPP>(a, s, k) {}
+    __device__ __forceinline__ void leaf(const Root& rt, uint32_t kmer, uint32_t flo, uint32_t w)
+    {
+        const size_t slot = (size_t)rt.strand * A.windowLen + (this->slice_pos(rt, kmer) - A.posBase);
+        const uint64_t base = A.offs[slot] + atomicAdd(&A.cnt2[slot], w);
+        for (uint32_t r = 0; r < w; ++r) {
+            const uint2 sp = locate_position(A.cumGlobal, A.nSeqGlobal, A.sa[flo + r]);
+            A.emit[base + r] = (uint64_t)sp.x << 32 | sp.y;
+        }
+    }
+    __device__ __forceinline__ void leaf_flush(const Root&, uint32_t) {}
+};
+
+template <int WPP, class EnvT>
 __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const size_t gl = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    DevEnv<WPP> env(A, A.stack + gl * A.stackDepth, A.K);
+    EnvT env(A, A.stack + gl * A.stackDepth, A.K);
     Node nd; nd.flo = nd.rlo = nd.w = nd.meta = 0;
     Root rt; rt.win = 0; rt.n = 1; rt.strand = 0; rt.rec = OssRecord{0, 0, 0, 0};
     bool have = false, exhausted = false;
@@ -176,6 +256,17 @@ __global__ __launch_bounds__(256) void finalize_kernel(const uint32_t* __restric
     } else {
         for (uint64_t j = i; j < n && j < i + 4; ++j) { const uint32_t v = acc[j]; out[j] = (TValue)(v < maxVal ? v : maxVal); }
     }
+}
+
+// --exclude-pseudo: hits[j] = distinct_sequences.size(), a narrowing store without saturation (algo.hpp:360)
+template <typename TValue>
+__global__ __launch_bounds__(256) void finalize_fileset_kernel(const uint32_t* __restrict__ bits, uint32_t wordsPerKmer, TValue* __restrict__ out, uint64_t n)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint32_t c = 0;
+    for (uint32_t w = 0; w < wordsPerKmer; ++w) c += (uint32_t)__popc(bits[j * wordsPerKmer + w]);
+    out[j] = (TValue)c;
 }
 
 // resetLimits (algo.hpp:10-22): zero the last K-1 positions of every sequence of the slice.

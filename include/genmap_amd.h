@@ -111,6 +111,26 @@ int gm_map_device(gm_index *idx, uint64_t text_begin, uint64_t text_len, uint32_
                   const gm_map_params *params, const uint64_t *intervals, uint64_t n_intervals,
                   const uint32_t *seq_file_id, void *out_device, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Locations for csv output  (the `locations` map filled by src/algo.hpp:311-387 and consumed by
+ * saveCsv, src/output.hpp:189-288).  For every slice position j in [pos_begin, pos_begin + n_positions):
+ * the sorted occurrences of the k-mer at j on the + strand, plus[plus_off[j']..plus_off[j'+1]), and of its
+ * reverse complement, minus[...], j' = j - pos_begin.  An occurrence is (seqNo << 32 | seqPos) with the
+ * GLOBAL sequence number of the index.  Positions that were not computed (outside the selection / shard)
+ * have empty lists.  Needs an index with sampling 1.  The window is params->kmer_begin/kmer_end rounded
+ * to whole k-mer blocks (both 0 = the whole slice); windows holding >= 2^31 occurrences are refused with
+ * GM_ERR_TOO_LONG -- split the range.  Host arrays are owned by the library: gm_locations_free().
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct gm_locations {
+    uint64_t pos_begin, n_positions;
+    uint64_t *plus_off, *minus_off;   /* n_positions + 1 each */
+    uint64_t *plus, *minus;
+} gm_locations;
+
+int gm_locate(gm_index *idx, uint64_t text_begin, uint64_t text_len, uint32_t first_seq, uint32_t n_seq,
+              const gm_map_params *params, const uint64_t *intervals, uint64_t n_intervals, gm_locations **out);
+void gm_locations_free(gm_locations *loc);
+
 /* counters of the most recent gm_map* call on this index (for the roofline numerator) */
 typedef struct gm_map_stats {
     uint64_t kmers;           /* k-mer positions searched */

@@ -58,8 +58,12 @@ template <int WPP> struct EmuEnv {
         return rt.strand ? complement(text[rt.win + (W - 1 - pos)]) : text[rt.win + pos];
     }
     void push(const Node& nd) { stack.push_back(nd); if (stack.size() > maxDepth) maxDepth = stack.size(); }
-    void add_hit(const Root& rt, uint32_t kmer, uint32_t count)
+    uint32_t leafSum = 0;
+    void leaf(const Root&, uint32_t, uint32_t, uint32_t w) { leafSum += w; }
+    void leaf_flush(const Root& rt, uint32_t kmer)
     {
+        uint32_t count = leafSum; leafSum = 0;
+        if (!count) return;
         uint32_t pos = rt.win + (rt.strand ? rt.n - 1 - kmer : kmer);
         uint32_t add = count < 0xFFFFu ? count : 0xFFFFu;
         uint64_t v = (uint64_t)(*acc)[pos] + add;

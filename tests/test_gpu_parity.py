@@ -57,10 +57,8 @@ def test_gpu_reference_fixture_cases(case):
     g = _gm()
     d = H.CASES_DIR / f"case_{case}"
     gen, directory, fl, bed = H.load_case(case)
-    if fl.get("ep"):
-        pytest.skip("--exclude-pseudo goes through the locate path")
     for bb in BLOCK_BYTES:
-        ix = g.Index.build(gen.codes, gen.seq_len, block_bytes=bb)
+        ix = g.Index.build(gen.codes, gen.seq_len, sampling=1, block_bytes=bb)
         for xo in H.xo_variants(case):
             for name, first, nseq, tb, tl in gen.file_slices():
                 iv = None
@@ -70,10 +68,70 @@ def test_gpu_reference_fixture_cases(case):
                         continue
                 for bits, sub, ext, dt in ((16, "raw_freq16", "freq16", np.uint16), (8, "raw_freq8", "freq8", np.uint8)):
                     out = ix.map(fl["K"], fl["E"], first_seq=first, n_seq=nseq, overlap=xo, revcompl=not fl.get("nc", False),
-                                 value_bits=bits, intervals=iv)
+                                 value_bits=bits, intervals=iv, exclude_pseudo=fl.get("ep", False), seq_file_id=gen.seq_file)
                     exp = np.fromfile(d / sub / (name.rsplit(".", 1)[0] + ".genmap." + ext), dtype=dt)
                     assert np.array_equal(out, exp), (case, bb, xo, bits, name, out.tolist(), exp.tolist())
         ix.close()
+
+
+def _csv_entries(gen, first, nseq, K, loc):
+    """csv rows from gm_locate lists: positions with at least one hit whose k-mer lies inside its sequence
+    (src/algo.hpp:366-386), keyed by (sequence number within the fasta file, position)."""
+    pos_begin, po, pl, mo, mi = loc
+    base = int(gen.cum[first])
+    ent = []
+    for jj in range(len(po) - 1):
+        plus = [(int(v >> 32), int(v & 0xFFFFFFFF)) for v in pl[po[jj]:po[jj + 1]]]
+        minus = [(int(v >> 32), int(v & 0xFFFFFFFF)) for v in mi[mo[jj]:mo[jj + 1]]]
+        if not plus and not minus:
+            continue
+        j = pos_begin + jj + base
+        s = int(np.searchsorted(gen.cum, j, side="right") - 1)
+        off = j - int(gen.cum[s])
+        if off <= int(gen.seq_len[s]) - K:
+            ent.append(((s - first, off), plus, minus))
+    return ent
+
+
+@pytest.mark.parametrize("case", sorted(H.CASES))
+def test_gpu_csv_locations_match_reference_fixtures(case):
+    g = _gm()
+    d = H.CASES_DIR / f"case_{case}"
+    gen, directory, fl, bed = H.load_case(case)
+    ix = g.Index.build(gen.codes, gen.seq_len, sampling=1)
+    rc = not fl.get("nc", False)
+    for xo in H.xo_variants(case):
+        for name, first, nseq, tb, tl in gen.file_slices():
+            iv = civ = None
+            if bed is not None:
+                iv = H.slice_intervals(gen, first, nseq, bed)
+                if not iv:
+                    continue
+                civ = sorted((s - first, b, e) for s in range(first, first + nseq) for b, e in bed.get(gen.seq_names[s], []))
+            loc = ix.locate(fl["K"], fl["E"], first_seq=first, n_seq=nseq, overlap=xo, revcompl=rc, intervals=iv)
+            txt = H.format_csv(gen, _csv_entries(gen, first, nseq, fl["K"], loc), rc, civ)
+            exp = (d / "csv" / (name.rsplit(".", 1)[0] + ".genmap.csv")).read_text()
+            assert txt == exp, (case, xo, name)
+    ix.close()
+
+
+def test_gpu_exclude_pseudo_and_locations_vs_oracle():
+    """BASELINE configs[4] shape (5 related genomes, K=24 E=1, -ep, csv) at test size."""
+    g = _gm()
+    from genmap_amd import synth
+    files = synth.bacteria5(0.004)
+    gen = H.Genome(files)
+    ora = H.OracleIndex(gen.codes, gen.seq_len, keep_sa=True)
+    ix = g.Index.build(gen.codes, gen.seq_len, sampling=1)
+    K, E = 24, 1
+    for name, first, nseq, tb, tl in gen.file_slices():
+        exp, _, locs = ora.mappability(K, E, first_seq=first, n_seq=nseq, text_begin=tb, text_len=tl, value_bits=16, directory=True,
+                                       exclude_pseudo=True, csv=True, seq_file_id=gen.seq_file, threads=8)
+        out = ix.map(K, E, first_seq=first, n_seq=nseq, value_bits=16, exclude_pseudo=True, seq_file_id=gen.seq_file)
+        assert np.array_equal(out, exp), name
+        ent = _csv_entries(gen, first, nseq, K, ix.locate(K, E, first_seq=first, n_seq=nseq))
+        assert ent == locs, name
+    ix.close()
 
 
 @pytest.mark.parametrize("dna5", [False, True])
