@@ -43,7 +43,7 @@ class Locations(C.Structure):
                 ("minus_off", C.POINTER(C.c_uint64)), ("plus", C.POINTER(C.c_uint64)), ("minus", C.POINTER(C.c_uint64))]
 
 
-EXPORTS = ["gm_locate", "gm_locations_free", "gm_status_string", "gm_last_error", "gm_device_count", "gm_index_build", "gm_index_import",
+EXPORTS = ["gm_index_export_sa", "gm_locate", "gm_locations_free", "gm_status_string", "gm_last_error", "gm_device_count", "gm_index_build", "gm_index_import",
            "gm_index_export_bwt", "gm_index_get_info", "gm_index_free", "gm_map", "gm_map_device",
            "gm_last_map_stats", "gm_default_infix_length"]
 
@@ -73,6 +73,8 @@ def load_library(profiling=False):
     lib.gm_index_import.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)]
     lib.gm_index_export_bwt.restype = C.c_int
     lib.gm_index_export_bwt.argtypes = [vp, vp, vp]
+    lib.gm_index_export_sa.restype = C.c_int
+    lib.gm_index_export_sa.argtypes = [vp, vp]
     lib.gm_index_get_info.restype = C.c_int
     lib.gm_index_get_info.argtypes = [vp, C.POINTER(IndexInfo)]
     lib.gm_index_free.argtypes = [vp]
@@ -162,6 +164,11 @@ class Index:
         bf, br = np.empty(n, np.uint8), np.empty(n, np.uint8)
         _check(self._lib, self._lib.gm_index_export_bwt(self._h, _ptr(bf), _ptr(br)))
         return bf, br
+
+    def export_sa(self):
+        sa = np.empty(self.info()["n_rows"], np.uint32)
+        _check(self._lib, self._lib.gm_index_export_sa(self._h, _ptr(sa)))
+        return sa
 
     def _params(self, K, E, overlap, infix, revcompl, value_bits, exclude_pseudo, kmer_range):
         kb, ke = kmer_range if kmer_range else (0, 0)

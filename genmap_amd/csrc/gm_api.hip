@@ -267,6 +267,15 @@ int gm_index_export_bwt(const gm_index* ix, uint8_t* bwt_fwd, uint8_t* bwt_rev)
     return GM_OK;
 }
 
+int gm_index_export_sa(const gm_index* ix, uint32_t* sa)
+{
+    if (!ix || !sa) return GM_ERR_BAD_ARG;
+    if (!ix->d_sa) { set_error("index holds no suffix array (built with sampling 0)"); return GM_ERR_NEED_LOCATE; }
+    GM_HIP(hipSetDevice(ix->device));
+    GM_HIP(hipMemcpy(sa, ix->d_sa, ix->nRows * 4, hipMemcpyDeviceToHost));
+    return GM_OK;
+}
+
 int gm_index_get_info(const gm_index* ix, gm_index_info* info)
 {
     if (!ix || !info) return GM_ERR_BAD_ARG;

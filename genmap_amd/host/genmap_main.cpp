@@ -1,0 +1,316 @@
+// genmap_main.cpp -- the `genmap` host program of the MI355X build: `genmap index` and `genmap map`.
+//
+// Command line, messages, exit codes and output files follow the reference
+//   main / sub-command dispatch   /root/reference/src/genmap.cpp:16-94
+//   genmap map                    /root/reference/src/mappability.hpp:409-642 (options :417-466), per-fasta loop :271-365
+//   genmap index                  /root/reference/src/indexing.hpp:277-510
+// but every computation goes through the C ABI of libgenmap_amd.so (include/genmap_amd.h): the index is
+// suffix-sorted on the GPU, computeMappability runs as HIP kernels.  There is no CPU compute path.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <map>
+#include <string>
+#include <sys/stat.h>
+#include <sys/time.h>
+#include <unistd.h>
+#include <cmath>
+#include <vector>
+#include "../../include/genmap_amd.h"
+#include "gm_hostlib.h"
+
+namespace {
+
+const char* kVersion = "1.3.0-mi355x";
+
+double wall() { timeval t; gettimeofday(&t, nullptr); return t.tv_sec + t.tv_usec * 1e-6; }
+
+struct OptSpec { const char* s; const char* l; bool value; };
+
+// minimal re-statement of the SeqAn ArgumentParser behaviour the reference relies on: -x / --long, values as next token
+struct Args {
+    std::map<std::string, std::string> val;
+    std::map<std::string, bool> flag;
+    bool parse(int argc, const char** argv, const std::vector<OptSpec>& specs, std::string& err)
+    {
+        for (int i = 1; i < argc; ++i) {
+            std::string a = argv[i];
+            const OptSpec* sp = nullptr;
+            for (auto& o : specs)
+                if ((a.size() > 1 && a[0] == '-' && a[1] != '-' && a.substr(1) == o.s) || (a.size() > 2 && a.compare(0, 2, "--") == 0 && a.substr(2) == o.l)) { sp = &o; break; }
+            if (!sp) { err = "Unknown option: " + a; return false; }
+            if (sp->value) {
+                if (i + 1 >= argc) { err = std::string("Option ") + a + " needs a value"; return false; }
+                val[sp->l] = argv[++i];
+            } else flag[sp->l] = true;
+        }
+        return true;
+    }
+    bool has(const char* l) const { return val.count(l) || flag.count(l); }
+    std::string get(const char* l, const std::string& d = "") const { auto it = val.find(l); return it == val.end() ? d : it->second; }
+};
+
+bool is_dir(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode); }
+bool exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+
+int fail_gm(const char* what, int rc)
+{
+    std::cerr << "ERROR: " << what << ": " << gm_status_string(rc) << " (" << gm_last_error() << ")\n";
+    return 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+int index_main(int argc, const char** argv)
+{
+    const std::vector<OptSpec> specs = {{"F", "fasta-file", true}, {"FD", "fasta-directory", true}, {"I", "index", true}, {"A", "algorithm", true},
+                                        {"S", "sampling", true}, {"v", "verbose", false}, {"xa", "seqno", true}, {"xb", "seqpos", true}, {"xc", "bwtlen", true},
+                                        {"B", "block-bytes", true}, {"D", "device", true}};
+    Args a; std::string err;
+    if (!a.parse(argc, argv, specs, err)) { std::cerr << "genmap index: " << err << "\n"; return 1; }
+    if (!a.has("index")) { std::cerr << "genmap index: option -I/--index is required\n"; return 1; }
+    const bool isFile = a.has("fasta-file"), isDir = a.has("fasta-directory");
+    if (isFile && isDir) { std::cerr << "ERROR: You can only use eiher --fasta-file or --fasta-directory, not both.\n"; return 1; }
+    if (!isFile && !isDir) { std::cerr << "ERROR: You forgot to specify --fasta-file or --fasta-directory.\n"; return 1; }
+    const std::string algo = a.get("algorithm", "divsufsort");
+    if (algo != "divsufsort" && algo != "skew") { std::cerr << "genmap index: the value '" << algo << "' of option -A is not one of [divsufsort, skew]\n"; return 1; }
+    const int sampling = std::atoi(a.get("sampling", "10").c_str());
+    if (sampling < 1 || sampling > 64) { std::cerr << "genmap index: the value of -S must be in [1, 64]\n"; return 1; }
+    const bool verbose = a.has("verbose");
+    std::string fastaPath = isDir ? a.get("fasta-directory") : a.get("fasta-file");
+    if (isDir && !is_dir(fastaPath)) { std::cerr << "ERROR: The fasta directory does not exist!\n"; return 1; }
+    if (isFile && !exists(fastaPath)) { std::cerr << "ERROR: The fasta file does not exist!\n"; return 1; }
+    std::string indexPath = a.get("index");
+    if (exists(indexPath)) { std::cerr << "ERROR: The directory for the index already exists at " << indexPath << "\n       Please remove it, or choose a different location.\n"; return 1; }
+    if (mkdir(indexPath.c_str(), 0755)) { std::cerr << "ERROR: Cannot create directory at " << indexPath << '\n'; return 1; }
+
+    gmh::IndexMeta meta; meta.directory = isDir;
+    std::vector<uint8_t> text; std::vector<uint64_t> seqLen;
+    auto ingest = [&](const std::string& full, const std::string& name) {
+        std::vector<gmh::FastaRecord> recs;
+        if (!gmh::read_fasta(full, recs, err)) { std::cerr << "ERROR: " << err << "\n"; return false; }
+        if (recs.empty()) { std::cerr << "WARNING: The fasta file " << full << " seems to be empty. Excluded from indexing.\n"; return true; }
+        for (auto& r : recs) {
+            meta.ids.push_back({name, (uint64_t)r.codes.size(), r.id});
+            seqLen.push_back(r.codes.size());
+            text.insert(text.end(), r.codes.begin(), r.codes.end());
+        }
+        return true;
+    };
+    if (isDir) {
+        std::vector<std::pair<std::string, std::string>> files;
+        if (!gmh::list_fasta_directory(fastaPath, files, err)) { rmdir(indexPath.c_str()); std::cerr << err; return 1; }
+        for (auto& f : files) if (!ingest(f.first + f.second, f.second)) return 1;
+        if (seqLen.empty()) { rmdir(indexPath.c_str()); std::cerr << "ERROR: No (non-empty) fasta file found!\n"; return 1; }
+        std::cout << files.size() << " fasta files have been loaded (run with --verbose to list the files):\n";
+        if (verbose) for (auto& f : files) std::cout << f.first << f.second << '\n';
+    } else {
+        size_t sl = fastaPath.find_last_of('/');
+        if (!ingest(fastaPath, sl == std::string::npos ? fastaPath : fastaPath.substr(sl + 1))) return 1;
+    }
+    if (seqLen.empty()) { rmdir(indexPath.c_str()); std::cerr << "ERROR: There is no non-empty sequence in the fasta file(s).\n"; return 1; }
+
+    // alphabet and index dimensions (src/indexing.hpp:459-470,152-170)
+    const bool dna5 = std::find(text.begin(), text.end(), (uint8_t)4) != text.end();
+    uint64_t maxLen = 0, total = seqLen.size();
+    for (uint64_t l : seqLen) { total += l; maxLen = std::max(maxLen, l); }
+    meta.alphabetSize = dna5 ? 5 : 4;
+    if (seqLen.size() <= 0xFFFFull && maxLen <= 0xFFFFFFFFull) { meta.seqNoBits = 16; meta.seqPosBits = 32; meta.bwtBits = total <= 0xFFFFFFFFull ? 32 : 64; }
+    else if (seqLen.size() <= 0xFFFFFFFFull && maxLen <= 0xFFFFull) { meta.seqNoBits = 32; meta.seqPosBits = 16; meta.bwtBits = 64; }
+    else { meta.seqNoBits = 64; meta.seqPosBits = 64; meta.bwtBits = 64; }
+    meta.sampling = 1;   // this build keeps the whole suffix array (HBM is large); -S is accepted for compatibility
+    if (verbose)
+        std::cout << "Index will be constructed using " << (dna5 ? "dna5/rna5" : "dna4/rna4") << " alphabet.\n"
+                  << "- The BWT is represented by " << meta.bwtBits << " bit values.\n"
+                  << "- The suffix array is kept unsampled (requested sampling rate " << sampling << ") as pairs of " << meta.seqNoBits << " and " << meta.seqPosBits << " bit values.\n";
+    std::cout << "Suffix sorting runs on the GPU (prefix doubling, algorithm option '" << algo << "' is accepted for compatibility).\n" << std::flush;
+
+    const double t0 = wall();
+    gm_index* ix = nullptr;
+    std::cout << "Create fwd Index ... Create bwd Index ... " << std::flush;
+    int rc = gm_index_build(text.data(), seqLen.data(), (uint32_t)seqLen.size(), 1, (uint32_t)std::atoi(a.get("block-bytes", "0").c_str()),
+                            std::atoi(a.get("device", "0").c_str()), &ix);
+    if (rc) { rmdir(indexPath.c_str()); return fail_gm("index construction failed", rc); }
+    std::cout << "done!\n";
+    gm_index_info info; gm_index_get_info(ix, &info);
+    std::vector<uint8_t> bf(info.n_rows), br(info.n_rows); std::vector<uint32_t> sa(info.n_rows);
+    rc = gm_index_export_bwt(ix, bf.data(), br.data());
+    if (!rc) rc = gm_index_export_sa(ix, sa.data());
+    gm_index_free(ix);
+    if (rc) return fail_gm("index export failed", rc);
+    if (!gmh::write_index_dir(indexPath, meta, text, bf, br, sa.data(), err)) { std::cerr << "ERROR: " << err << "\n"; return 1; }
+    if (verbose) std::cout << "Index of " << info.n_rows << " rows built and written in " << (wall() - t0) << " seconds\n";
+    std::cout << "Index created successfully.\n";
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+int map_main(int argc, const char** argv)
+{
+    const std::vector<OptSpec> specs = {
+        {"I", "index", true}, {"O", "output", true}, {"E", "errors", true}, {"K", "length", true}, {"S", "selection", true},
+        {"nc", "no-reverse-complement", false}, {"ep", "exclude-pseudo", false}, {"fs", "frequency-small", false}, {"fl", "frequency-large", false},
+        {"r", "raw", false}, {"t", "txt", false}, {"w", "wig", false}, {"bg", "bedgraph", false}, {"b", "bed", false}, {"d", "csv", false},
+        {"m", "memory-mapping", false}, {"T", "threads", true}, {"v", "verbose", false}, {"xo", "overlap", true}, {"D", "device", true}, {"B", "block-bytes", true}};
+    Args a; std::string err;
+    if (!a.parse(argc, argv, specs, err)) { std::cerr << "genmap map: " << err << "\n"; return 1; }
+    for (const char* req : {"index", "output", "length"})
+        if (!a.has(req)) { std::cerr << "genmap map: option --" << req << " is required\n"; return 1; }
+    const bool wig = a.has("wig"), bg = a.has("bedgraph"), bed = a.has("bed"), raw = a.has("raw"), txt = a.has("txt"), csv = a.has("csv"), verbose = a.has("verbose");
+    if (!wig && !bg && !bed && !raw && !txt && !csv) {
+        std::cerr << "ERROR: Please choose at least one output format (i.e., --wig, --bedgraph, --bed, --raw, --txt, --csv).\n"; return 1; }
+    const bool fs = a.has("frequency-small"), fl = a.has("frequency-large");
+    if (fs && fl) { std::cerr << "ERROR: Cannot use both --frequency-small and --frequency-large. Please choose one.\n"; return 1; }
+    const gmh::ValueKind kind = fs ? gmh::ValueKind::Freq8 : fl ? gmh::ValueKind::Freq16 : gmh::ValueKind::Mappability;
+    const bool mappability = kind == gmh::ValueKind::Mappability;
+    const uint32_t K = (uint32_t)std::atoi(a.get("length").c_str());
+    const uint32_t E = (uint32_t)std::atoi(a.get("errors", "0").c_str());   // the reference leaves -E uninitialised when absent; 0 here
+    const bool revCompl = !a.has("no-reverse-complement"), ep = a.has("exclude-pseudo");
+    if (E > 4) { std::cerr << "E > 4 not yet supported.\n"; return 1; }
+    const int32_t xo = a.has("overlap") ? std::atoi(a.get("overlap").c_str()) : -1;
+    const uint32_t infix = gmh::default_infix_length(K, E, xo);
+    if (infix == 0) { std::cerr << "ERROR: overlap cannot be larger than min(K - 1, K - E - 2) = " << std::min(K - 1u, K - E - 2u) << ".\n"; return 1; }
+
+    std::string indexPath = a.get("index");
+    gmh::IndexMeta meta; std::vector<uint8_t> text, bf, br; std::vector<uint32_t> sa;
+    if (!gmh::read_index_dir(indexPath, meta, text, bf, br, sa, err)) { std::cout << err << (err.empty() || err.back() != '\n' ? "\n" : ""); return 1; }
+
+    // output path: directory, or a file name for single-fasta indices (src/mappability.hpp:562-619)
+    std::string outputPath = a.get("output");
+    bool outputIncludesFilename = false;
+    if (is_dir(outputPath)) { if (outputPath.back() != '/') outputPath += '/'; }
+    else if (!meta.directory) {
+        if (outputPath.back() == '.') outputPath += '/';
+        else {
+            size_t sl = outputPath.find_last_of('/');
+            std::string parent = sl == std::string::npos ? "." : outputPath.substr(0, sl);
+            outputIncludesFilename = true;
+            if (!is_dir(parent)) {
+                std::cerr << "ERROR: The output cannot be written to the file " << outputPath << ".\n       It seems the directory " << parent << " does not exist.\n";
+                return 1;
+            }
+        }
+    } else {
+        std::cerr << "ERROR: The output directory " << outputPath << " does not exist.\n"
+                  << "       A filename can only be specified for single indexed fasta files (not for indexed fasta directories).\n"
+                  << "       Please create it, or choose a different location.\n";
+        return 1;
+    }
+    if (verbose) {
+        std::cout << "Index was loaded (dna" << meta.alphabetSize << " alphabet, sampling rate of " << meta.sampling << ").\n"
+                  << "- The BWT is represented by " << meta.bwtBits << " bit values.\n"
+                  << "- The sampled suffix array is represented by pairs of " << meta.seqNoBits << " and " << meta.seqPosBits << " bit values.\n";
+        std::cout << (meta.directory ? "- Index was built on an entire directory.\n" : "- Index was built on a single fasta file.\n") << std::flush;
+    }
+
+    // selection (src/mappability.hpp:253-269): BED3 rows keyed by sequence name
+    std::map<std::string, std::vector<std::pair<uint64_t, uint64_t>>> selection;
+    const bool haveSelection = a.has("selection");
+    if (haveSelection) {
+        FILE* f = fopen(a.get("selection").c_str(), "r");
+        if (!f) { std::cerr << "ERROR: cannot open " << a.get("selection") << "\n"; return 1; }
+        char name[4096]; unsigned long long b, e; char line[8192];
+        while (fgets(line, sizeof line, f))
+            if (sscanf(line, "%4095s %llu %llu", name, &b, &e) == 3) selection[name].push_back({b, e});
+        fclose(f);
+    }
+
+    // sequences and files of the index (src/mappability.hpp:225-250)
+    std::vector<uint64_t> seqLen; std::vector<uint32_t> seqFile; std::vector<std::string> fileNames; std::vector<uint64_t> seqsPerFile;
+    for (auto& r : meta.ids) {
+        if (fileNames.empty() || fileNames.back() != r.file) { fileNames.push_back(r.file); seqsPerFile.push_back(0); }
+        seqLen.push_back(r.length); seqFile.push_back((uint32_t)fileNames.size() - 1); seqsPerFile.back()++;
+    }
+    gm_index* ix = nullptr;
+    int rc = gm_index_import(bf.data(), br.data(), sa.empty() ? nullptr : sa.data(), text.data(), seqLen.data(), (uint32_t)seqLen.size(), sa.empty() ? 0 : 1,
+                             (uint32_t)std::atoi(a.get("block-bytes", "0").c_str()), std::atoi(a.get("device", "0").c_str()), &ix);
+    if (rc) return fail_gm("cannot load the index onto the GPU", rc);
+    { std::vector<uint8_t>().swap(bf); std::vector<uint8_t>().swap(br); std::vector<uint32_t>().swap(sa); }
+
+    const double start = wall();
+    uint64_t textBegin = 0; uint32_t firstSeq = 0;
+    for (size_t fi = 0; fi < fileNames.size(); ++fi) {
+        const uint32_t nSeq = (uint32_t)seqsPerFile[fi];
+        gmh::SeqTable seqs; uint64_t textLen = 0;
+        std::vector<uint64_t> intervals;
+        for (uint32_t s = 0; s < nSeq; ++s) {
+            const auto& row = meta.ids[firstSeq + s];
+            auto it = selection.find(row.name);
+            if (it != selection.end())
+                for (auto& iv : it->second) {
+                    if (iv.first >= row.length || iv.second > row.length) {
+                        std::cerr << "Error in BED file! Coordinates exceed sequence length: Seq. \"" << row.name << "\" has a length of " << row.length
+                                  << ", but half-closed interval [" << iv.first << ", " << iv.second << ") given.\n";
+                        gm_index_free(ix); return 1;
+                    }
+                    intervals.push_back(textLen + iv.first); intervals.push_back(textLen + iv.second);
+                }
+            seqs.names.push_back(row.name); seqs.lengths.push_back(row.length); textLen += row.length;
+        }
+        // no output at all for fasta files without an interval of interest (src/mappability.hpp:308-314)
+        if (!(haveSelection && intervals.empty())) {
+            gm_map_params p; memset(&p, 0, sizeof p);
+            p.K = K; p.E = E; p.overlap = xo; p.infix = 0; p.revcompl = revCompl; p.value_bits = fs ? 8 : 16; p.exclude_pseudo = ep;
+            const int width = fs ? 1 : 2;
+            std::vector<uint8_t> c((size_t)textLen * width + 16);
+            rc = gm_map(ix, textBegin, textLen, firstSeq, nSeq, &p, intervals.empty() ? nullptr : intervals.data(), intervals.size() / 2, seqFile.data(), c.data());
+            if (rc) { gm_index_free(ix); return fail_gm("computeMappability failed", rc); }
+            std::string stem = outputPath;
+            if (!outputIncludesFilename) stem += fileNames[fi].substr(0, fileNames[fi].find_last_of('.')) + ".genmap";   // src/mappability.hpp:76-78
+            bool ok = true; double t;
+            auto report = [&](const char* what) { if (verbose) std::cout << "- " << what << " written in " << (std::round((wall() - t) * 100.0) / 100.0) << " seconds\n"; };
+            if (raw) { t = wall(); ok = ok && gmh::save_raw(c.data(), textLen, width, stem, kind, err); report("RAW file"); }
+            if (txt) { t = wall(); ok = ok && gmh::save_txt(c.data(), textLen, width, stem, seqs, mappability, err); report("TXT file"); }
+            if (wig) { t = wall(); ok = ok && gmh::save_wig(c.data(), textLen, width, stem, seqs, mappability, err); report("WIG file"); }
+            if (bg) { t = wall(); ok = ok && gmh::save_bedgraph(c.data(), textLen, width, stem, seqs, true, mappability, err); report("bedgraph file"); }
+            if (bed) { t = wall(); ok = ok && gmh::save_bedgraph(c.data(), textLen, width, stem, seqs, false, mappability, err); report("BED file"); }
+            if (csv && ok) {
+                t = wall();
+                // windows of k-mer positions, halved whenever one holds too many occurrences for a single gm_locate call
+                const uint64_t numKmers = textLen >= K ? textLen - K + 1 : 0;
+                uint64_t begin = 0, window = std::max<uint64_t>(numKmers, 1); bool first = true;
+                if (numKmers == 0) { gmh::CsvInput in; uint64_t z[1] = {0}; in.plusOff = in.minusOff = z; ok = gmh::save_csv(stem, in, seqs, K, revCompl, fileNames, seqsPerFile, false, err); }
+                while (ok && begin < numKmers) {
+                    p.kmer_begin = begin; p.kmer_end = std::min(numKmers, begin + window);
+                    gm_locations* L = nullptr;
+                    rc = gm_locate(ix, textBegin, textLen, firstSeq, nSeq, &p, intervals.empty() ? nullptr : intervals.data(), intervals.size() / 2, &L);
+                    if (rc == GM_ERR_TOO_LONG && window > 1) { window = std::max<uint64_t>(1, window / 2); continue; }
+                    if (rc) { gm_index_free(ix); return fail_gm("locate failed", rc); }
+                    gmh::CsvInput in; in.posBegin = L->pos_begin; in.nPositions = L->n_positions; in.plusOff = L->plus_off; in.minusOff = L->minus_off; in.plus = L->plus; in.minus = L->minus;
+                    ok = gmh::save_csv(stem, in, seqs, K, revCompl, fileNames, seqsPerFile, !first, err);
+                    first = false;
+                    // the window is rounded to whole k-mer blocks by the library: continue after what it covered
+                    begin = std::max<uint64_t>(p.kmer_end, L->n_positions ? L->pos_begin + L->n_positions : p.kmer_end);
+                    gm_locations_free(L);
+                }
+                report("CSV file");
+            }
+            if (!ok) { std::cerr << "ERROR: " << err << "\n"; gm_index_free(ix); return 1; }
+        }
+        textBegin += textLen; firstSeq += nSeq;
+    }
+    if (verbose) std::cout << "Mappability computed in " << (std::round((wall() - start) * 100.0) / 100.0) << " seconds\n";
+    gm_index_free(ix);
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, const char** argv)
+{
+    // first non-flag token selects the sub-command (src/genmap.cpp:27-64)
+    int cmd = 0;
+    for (int i = 1; i < argc; ++i) if (argv[i][0] != '-') { cmd = i; break; }
+    if (cmd == 0) {
+        for (int i = 1; i < argc; ++i) if (!strcmp(argv[i], "--version")) { std::cout << "GenMap version: " << kVersion << "\n"; return 0; }
+        std::cerr << "GenMap (MI355X build) - Fast and Exact Computation of Genome Mappability\nUsage: genmap [index|map] [OPTIONS]\n";
+        return 1;
+    }
+    std::vector<const char*> sub; sub.push_back(argv[0]);
+    for (int i = 1; i < argc; ++i) if (i != cmd) sub.push_back(argv[i]);
+    if (!strcmp(argv[cmd], "index")) return index_main((int)sub.size(), sub.data());
+    if (!strcmp(argv[cmd], "map")) return map_main((int)sub.size(), sub.data());
+    std::cerr << "Invalid argument " << argv[cmd] << ". Use 'genmap index' or 'genmap map'.\n";
+    return 1;
+}

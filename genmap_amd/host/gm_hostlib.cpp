@@ -1,0 +1,374 @@
+// gm_hostlib.cpp -- FASTA ingestion, index directory and output writers of the `genmap` host program.
+// See gm_hostlib.h for the byte-compatibility targets (file:line in /root/reference).
+#include "gm_hostlib.h"
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <dirent.h>
+#include <fstream>
+#include <set>
+#include <sstream>
+#include <sys/stat.h>
+
+namespace gmh {
+
+// ---- FASTA ------------------------------------------------------------------------------------------------
+static inline uint8_t code_of(unsigned char ch)
+{
+    switch (ch) {   // Dna5 conversion; anything that is not A,C,G,T/U becomes N (src/indexing.hpp:13-20)
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': case 'U': case 'u': return 3;
+        default: return 4;
+    }
+}
+
+bool read_fasta(const std::string& path, std::vector<FastaRecord>& out, std::string& err)
+{
+    std::ifstream in(path, std::ios::binary);
+    if (!in) { err = "cannot open " + path; return false; }
+    std::vector<FastaRecord> recs;
+    std::string line;
+    bool have = false;
+    const bool fastq = path.size() > 6 && path.compare(path.size() - 6, 6, ".fastq") == 0;
+    if (fastq) {   // 4-line records
+        while (std::getline(in, line)) {
+            if (line.empty()) continue;
+            FastaRecord r; r.id = line.substr(1);
+            if (!r.id.empty() && r.id.back() == '\r') r.id.pop_back();
+            std::string seq, plus, qual;
+            std::getline(in, seq); std::getline(in, plus); std::getline(in, qual);
+            for (unsigned char ch : seq) if (!std::isspace(ch)) r.codes.push_back(code_of(ch));
+            recs.push_back(std::move(r));
+        }
+    } else {
+        while (std::getline(in, line)) {
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            if (!line.empty() && line[0] == '>') {
+                recs.emplace_back();
+                recs.back().id = line.substr(1);
+                have = true;
+            } else if (have) {
+                for (unsigned char ch : line) if (!std::isspace(ch)) recs.back().codes.push_back(code_of(ch));
+            }
+        }
+    }
+    // skip empty sequences (src/indexing.hpp:228-231)
+    std::vector<FastaRecord> kept;
+    for (auto& r : recs) if (!r.codes.empty()) kept.push_back(std::move(r));
+    // if shortened ids are still unique, use them instead (src/indexing.hpp:238-266)
+    std::vector<std::string> shortIds;
+    for (auto& r : kept) {
+        size_t w = 0;
+        while (w < r.id.size() && !std::isspace((unsigned char)r.id[w])) ++w;
+        shortIds.push_back(r.id.substr(0, w));
+    }
+    std::set<std::string> uniq(shortIds.begin(), shortIds.end());
+    if (uniq.size() == shortIds.size())
+        for (size_t i = 0; i < kept.size(); ++i) kept[i].id = shortIds[i];
+    out = std::move(kept);
+    return true;
+}
+
+static void scan_dir(const std::string& path, std::vector<std::pair<std::string, std::string>>& files)
+{
+    static const char* kTypes[] = {"fsa", "fna", "fastq", "fasta", "fas", "faa", "fa"};   // src/indexing.hpp:290
+    DIR* d = opendir(path.c_str());
+    if (!d) return;
+    while (dirent* e = readdir(d)) {
+        std::string name = e->d_name;
+        if (name == "." || name == "..") continue;
+        std::string full = path + "/" + name;
+        struct stat st;
+        if (stat(full.c_str(), &st) != 0) continue;
+        if (S_ISDIR(st.st_mode)) { scan_dir(full, files); continue; }
+        size_t dot = name.find_last_of('.');
+        std::string ext = dot == std::string::npos ? name : name.substr(dot + 1);
+        for (const char* t : kTypes) if (ext == t) { files.push_back({path + "/", name}); break; }
+    }
+    closedir(d);
+}
+
+bool list_fasta_directory(const std::string& dir, std::vector<std::pair<std::string, std::string>>& out, std::string& err)
+{
+    out.clear();
+    scan_dir(dir, out);
+    std::sort(out.begin(), out.end(), [](const auto& a, const auto& b) { return a.second < b.second; });   // src/indexing.hpp:407
+    for (size_t i = 0; i + 1 < out.size(); ++i)
+        if (out[i].second == out[i + 1].second) {
+            err = "ERROR: At least two fasta files with the same filename found (this is not supported)! Please rename them and run again.\n       " +
+                  out[i].first + out[i].second + "!\n       " + out[i + 1].first + out[i + 1].second + "!\n";
+            return false;
+        }
+    return true;
+}
+
+// ---- index directory --------------------------------------------------------------------------------------
+static bool write_packed4(const std::string& path, const std::vector<uint8_t>& v, std::string& err)
+{
+    std::ofstream f(path, std::ios::binary);
+    if (!f) { err = "cannot write " + path; return false; }
+    uint64_t n = v.size();
+    f.write((const char*)&n, 8);
+    std::vector<uint8_t> buf((n + 1) / 2);
+    for (uint64_t i = 0; i < n; ++i) buf[i >> 1] |= (uint8_t)((v[i] & 15u) << ((i & 1u) * 4u));
+    f.write((const char*)buf.data(), (std::streamsize)buf.size());
+    return (bool)f;
+}
+static bool read_packed4(const std::string& path, std::vector<uint8_t>& v, std::string& err)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) { err = "cannot read " + path; return false; }
+    uint64_t n = 0;
+    f.read((char*)&n, 8);
+    std::vector<uint8_t> buf((n + 1) / 2);
+    f.read((char*)buf.data(), (std::streamsize)buf.size());
+    if (!f) { err = "truncated " + path; return false; }
+    v.resize(n);
+    for (uint64_t i = 0; i < n; ++i) v[i] = (buf[i >> 1] >> ((i & 1u) * 4u)) & 15u;
+    return true;
+}
+
+bool write_index_dir(const std::string& dir, const IndexMeta& m, const std::vector<uint8_t>& text, const std::vector<uint8_t>& bf,
+                     const std::vector<uint8_t>& br, const uint32_t* sa, std::string& err)
+{
+    const std::string p = dir + (dir.empty() || dir.back() == '/' ? "" : "/") + "index";
+    {
+        std::ofstream f(p + ".info");   // keys of src/indexing.hpp:102-112
+        if (!f) { err = "cannot write " + p + ".info"; return false; }
+        f << "alphabet_size:" << m.alphabetSize << '\n' << "sa_dimensions_i1:" << m.seqNoBits << '\n' << "sa_dimensions_i2:" << m.seqPosBits << '\n'
+          << "bwt_dimensions:" << m.bwtBits << '\n' << "sampling_rate:" << m.sampling << '\n' << "fasta_directory:" << (m.directory ? "true" : "false") << '\n'
+          << "packed_text:true\n";
+    }
+    {
+        std::ofstream f(p + ".ids");    // rows of src/indexing.hpp:268-274
+        if (!f) { err = "cannot write " + p + ".ids"; return false; }
+        for (auto& r : m.ids) f << r.file << ';' << r.length << ';' << r.name << '\n';
+    }
+    if (!write_packed4(p + ".txt4", text, err) || !write_packed4(p + ".bwt4", bf, err) || !write_packed4(p + ".rev.bwt4", br, err)) return false;
+    if (sa) {
+        std::ofstream f(p + ".sa", std::ios::binary);
+        if (!f) { err = "cannot write " + p + ".sa"; return false; }
+        f.write((const char*)sa, (std::streamsize)(bf.size() * 4));
+    }
+    return true;
+}
+
+bool read_index_dir(const std::string& dir, IndexMeta& m, std::vector<uint8_t>& text, std::vector<uint8_t>& bf, std::vector<uint8_t>& br,
+                    std::vector<uint32_t>& sa, std::string& err)
+{
+    const std::string p = dir + (dir.empty() || dir.back() == '/' ? "" : "/") + "index";
+    std::ifstream fi(p + ".info");
+    if (!fi) { err = "cannot read " + p + ".info"; return false; }
+    std::map<std::string, std::string> kv;
+    std::string line;
+    while (std::getline(fi, line)) { size_t c = line.find(':'); if (c != std::string::npos) kv[line.substr(0, c)] = line.substr(c + 1); }
+    auto need = [&](const char* k, std::string& v) {   // retrieve(): src/mappability.hpp:49-66
+        auto it = kv.find(k);
+        if (it == kv.end()) { err = std::string("ERROR: Malformed index.info file! Could not find key '") + k + "'.\n"; return false; }
+        v = it->second; return true;
+    };
+    std::string v;
+    if (!need("alphabet_size", v)) return false;
+    m.alphabetSize = (uint32_t)std::stoi(v);
+    if (!need("sa_dimensions_i1", v)) return false;
+    m.seqNoBits = (uint32_t)std::stoi(v);
+    if (!need("sa_dimensions_i2", v)) return false;
+    m.seqPosBits = (uint32_t)std::stoi(v);
+    if (!need("bwt_dimensions", v)) return false;
+    m.bwtBits = (uint32_t)std::stoi(v);
+    if (!need("sampling_rate", v)) return false;
+    m.sampling = (uint32_t)std::stoi(v);
+    if (!need("fasta_directory", v)) return false;
+    m.directory = (v == "true");
+    std::ifstream fd(p + ".ids");
+    if (!fd) { err = "cannot read " + p + ".ids"; return false; }
+    m.ids.clear();
+    while (std::getline(fd, line)) {
+        if (line.empty()) continue;
+        size_t a = line.find(';'), b = line.find(';', a + 1);   // retrieveDirectoryInformationLine: src/common.hpp:10-19
+        if (a == std::string::npos || b == std::string::npos) { err = "malformed row in " + p + ".ids"; return false; }
+        m.ids.push_back({line.substr(0, a), (uint64_t)std::stoull(line.substr(a + 1, b - a - 1)), line.substr(b + 1)});
+    }
+    if (!read_packed4(p + ".txt4", text, err) || !read_packed4(p + ".bwt4", bf, err) || !read_packed4(p + ".rev.bwt4", br, err)) return false;
+    sa.clear();
+    std::ifstream fs(p + ".sa", std::ios::binary);
+    if (fs) { sa.resize(bf.size()); fs.read((char*)sa.data(), (std::streamsize)(sa.size() * 4)); if (!fs) { err = "truncated " + p + ".sa"; return false; } }
+    return true;
+}
+
+// ---- writers ----------------------------------------------------------------------------------------------
+static inline uint32_t val_at(const void* c, int width, uint64_t i) { return width == 1 ? ((const uint8_t*)c)[i] : ((const uint16_t*)c)[i]; }
+
+// operator<<(ostream&, float) with default flags == printf("%g")
+static inline int fmt_float(char* buf, float f) { return snprintf(buf, 32, "%g", (double)f); }
+static inline float inverse_of(uint32_t v) { return v != 0 ? 1.0f / static_cast<float>(v) : 0.0f; }
+
+class BufferedFile {
+public:
+    explicit BufferedFile(const std::string& path, bool append = false) { f_ = fopen(path.c_str(), append ? "ab" : "wb"); if (f_) setvbuf(f_, nullptr, _IOFBF, 1 << 20); }
+    ~BufferedFile() { if (f_) fclose(f_); }
+    bool ok() const { return f_ != nullptr; }
+    void put(char ch) { fputc(ch, f_); }
+    void put(const std::string& s) { fwrite(s.data(), 1, s.size(), f_); }
+    void put(const char* s, size_t n) { fwrite(s, 1, n, f_); }
+    void put_u64(uint64_t v) { char b[24]; int n = snprintf(b, sizeof b, "%llu", (unsigned long long)v); fwrite(b, 1, (size_t)n, f_); }
+    void put_float(float f) { char b[32]; int n = fmt_float(b, f); fwrite(b, 1, (size_t)n, f_); }
+    void put_value(uint32_t v, bool mappability) { if (mappability) put_float(inverse_of(v)); else put_u64(v); }
+private:
+    FILE* f_ = nullptr;
+};
+
+bool save_raw(const void* c, uint64_t n, int width, const std::string& stem, ValueKind kind, std::string& err)
+{
+    const char* ext = kind == ValueKind::Mappability ? ".map" : kind == ValueKind::Freq8 ? ".freq8" : ".freq16";   // src/mappability.hpp:104-112
+    BufferedFile f(stem + ext);
+    if (!f.ok()) { err = "cannot write " + stem + ext; return false; }
+    if (kind == ValueKind::Mappability) {   // float32 of 1/v, 0 stays 0 (src/output.hpp:17-24)
+        std::vector<float> buf(1 << 16);
+        for (uint64_t i = 0; i < n; i += buf.size()) {
+            uint64_t m = std::min<uint64_t>(buf.size(), n - i);
+            for (uint64_t j = 0; j < m; ++j) buf[j] = inverse_of(val_at(c, width, i + j));
+            f.put((const char*)buf.data(), m * sizeof(float));
+        }
+    } else {
+        f.put((const char*)c, n * (uint64_t)width);
+    }
+    return true;
+}
+
+bool save_txt(const void* c, uint64_t n, int width, const std::string& stem, const SeqTable& seqs, bool mappability, std::string& err)
+{
+    BufferedFile f(stem + ".txt");
+    if (!f.ok()) { err = "cannot write " + stem + ".txt"; return false; }
+    uint64_t pos = 0;
+    for (size_t s = 0; s < seqs.lengths.size(); ++s) {   // src/output.hpp:43-69
+        f.put('>'); f.put(seqs.names[s]); f.put('\n');
+        for (uint64_t k = 0; k < seqs.lengths[s]; ++k, ++pos) {
+            if (k) f.put(' ');
+            f.put_value(val_at(c, width, pos), mappability);
+        }
+        f.put('\n');
+    }
+    (void)n;
+    return true;
+}
+
+// Calls fn(seqIndex, startInSeq, runLength, value) for every maximal run of equal values inside one sequence.
+template <class Fn> static void for_each_run(const void* c, int width, const SeqTable& seqs, Fn fn)
+{
+    uint64_t base = 0;
+    for (size_t s = 0; s < seqs.lengths.size(); ++s) {
+        const uint64_t len = seqs.lengths[s];
+        uint64_t k = 0;
+        while (k < len) {
+            const uint32_t v = val_at(c, width, base + k);
+            uint64_t e = k + 1;
+            while (e < len && val_at(c, width, base + e) == v) ++e;
+            fn(s, k, e - k, v);
+            k = e;
+        }
+        base += len;
+    }
+}
+
+bool save_wig(const void* c, uint64_t n, int width, const std::string& stem, const SeqTable& seqs, bool mappability, std::string& err)
+{
+    (void)n;
+    {
+        BufferedFile f(stem + ".wig");
+        if (!f.ok()) { err = "cannot write " + stem + ".wig"; return false; }
+        size_t curSeq = (size_t)-1;
+        uint64_t lastSpan = 0;
+        for_each_run(c, width, seqs, [&](size_t s, uint64_t start, uint64_t len, uint32_t v) {
+            if (s != curSeq) { curSeq = s; lastSpan = 0; }   // last_occ is per sequence (src/output.hpp:88-90)
+            if (v == 0) return;                               // runs of 0 are skipped (:98)
+            if (lastSpan != len) { f.put("variableStep chrom="); f.put(seqs.names[s]); f.put(" span="); f.put_u64(len); f.put('\n'); }
+            f.put_u64(start + 1); f.put(' '); f.put_value(v, mappability); f.put('\n');   // wig positions start at 1
+            lastSpan = len;
+        });
+    }
+    BufferedFile g(stem + ".chrom.sizes");   // src/output.hpp:129-133
+    if (!g.ok()) { err = "cannot write " + stem + ".chrom.sizes"; return false; }
+    for (size_t s = 0; s < seqs.lengths.size(); ++s) { g.put(seqs.names[s]); g.put('\t'); g.put_u64(seqs.lengths[s]); g.put('\n'); }
+    return true;
+}
+
+bool save_bedgraph(const void* c, uint64_t n, int width, const std::string& stem, const SeqTable& seqs, bool bedgraph, bool mappability, std::string& err)
+{
+    (void)n;
+    BufferedFile f(stem + (bedgraph ? ".bedgraph" : ".bed"));
+    if (!f.ok()) { err = "cannot write " + stem; return false; }
+    for_each_run(c, width, seqs, [&](size_t s, uint64_t start, uint64_t len, uint32_t v) {   // src/output.hpp:150-186
+        if (v == 0) return;
+        f.put(seqs.names[s]); f.put('\t'); f.put_u64(start); f.put('\t'); f.put_u64(start + len); f.put('\t');
+        if (!bedgraph) { f.put('-'); f.put('\t'); }
+        f.put_value(v, mappability); f.put('\n');
+    });
+    return true;
+}
+
+bool save_csv(const std::string& stem, const CsvInput& in, const SeqTable& seqs, uint32_t K, bool revCompl,
+              const std::vector<std::string>& fileNames, const std::vector<uint64_t>& seqsPerFile, bool append, std::string& err)
+{
+    BufferedFile f(stem + ".csv", append);
+    if (!f.ok()) { err = "cannot write " + stem + ".csv"; return false; }
+    if (!append) {   // header: src/output.hpp:214-222
+        f.put("\"k-mer\"");
+        for (auto& n : fileNames) { f.put(";\"+ strand "); f.put(n); f.put('"'); }
+        if (revCompl) for (auto& n : fileNames) { f.put(";\"- strand "); f.put(n); f.put('"'); }
+        f.put('\n');
+    }
+    std::vector<uint64_t> lastSeqOfFile;   // cumulative number of sequences - 1 per fasta file (:199-211)
+    uint64_t acc = 0;
+    for (uint64_t c : seqsPerFile) { acc += c; lastSeqOfFile.push_back(acc - 1); }
+    std::vector<uint64_t> cum(seqs.lengths.size() + 1, 0);
+    for (size_t s = 0; s < seqs.lengths.size(); ++s) cum[s + 1] = cum[s] + seqs.lengths[s];
+
+    auto put_lists = [&](const uint64_t* list, uint64_t b, uint64_t e) {   // :246-265 / :267-284
+        uint64_t i = b, prevSeqs = 0;
+        for (size_t fi = 0; fi < lastSeqOfFile.size(); ++fi) {
+            f.put(';');
+            bool first = true;
+            while (i < e && (list[i] >> 32) <= lastSeqOfFile[fi]) {
+                if (!first) f.put('|');
+                f.put_u64((list[i] >> 32) - prevSeqs); f.put(','); f.put_u64(list[i] & 0xFFFFFFFFull);
+                first = false; ++i;
+            }
+            prevSeqs = lastSeqOfFile[fi] + 1;
+        }
+    };
+    size_t s = 0;
+    for (uint64_t jj = 0; jj < in.nPositions; ++jj) {
+        const uint64_t pb = in.plusOff[jj], pe = in.plusOff[jj + 1], mb = in.minusOff[jj], me = in.minusOff[jj + 1];
+        if (pb == pe && mb == me) continue;                    // "is there at least a hit" (src/algo.hpp:378)
+        const uint64_t j = in.posBegin + jj;
+        while (s + 1 < seqs.lengths.size() && cum[s + 1] <= j) ++s;   // myPosLocalize (src/common.hpp:21-28)
+        const uint64_t off = j - cum[s];
+        if ((int64_t)off > (int64_t)seqs.lengths[s] - (int64_t)K) continue;   // k-mer spans two sequences (src/algo.hpp:381)
+        f.put_u64(s); f.put(','); f.put_u64(off);
+        put_lists(in.plus, pb, pe);
+        if (revCompl) put_lists(in.minus, mb, me);
+        f.put('\n');
+    }
+    return true;
+}
+
+uint32_t default_infix_length(uint32_t K, uint32_t E, int32_t xo)
+{
+    unsigned overlap;
+    if (xo >= 0) overlap = (unsigned)xo;
+    else if (E == 0) overlap = (unsigned)(K * 0.7);
+    else {
+        unsigned mm = std::min(std::max(K, 30u), 100u);
+        overlap = (unsigned)((K * mm) * std::pow((double)0.7f, (double)E) / 100.0);
+    }
+    uint64_t maxPossibleOverlap = std::min(K - 1u, K - E - 2u);
+    if (overlap > maxPossibleOverlap) { if (xo >= 0) return 0; overlap = (unsigned)maxPossibleOverlap; }
+    return K - overlap;
+}
+
+}  // namespace gmh

@@ -75,6 +75,9 @@ int gm_index_import(const uint8_t *bwt_fwd, const uint8_t *bwt_rev, const uint32
 /* Copy the BWTs (codes 0..5, n_rows bytes each) back to the host: index files, parity tests. */
 int gm_index_export_bwt(const gm_index *idx, uint8_t *bwt_fwd, uint8_t *bwt_rev);
 
+/* Copy the forward suffix array (n_rows x uint32, sentinel-text positions) back to the host; needs sampling 1. */
+int gm_index_export_sa(const gm_index *idx, uint32_t *sa_fwd);
+
 int gm_index_get_info(const gm_index *idx, gm_index_info *info);
 void gm_index_free(gm_index *idx);
 

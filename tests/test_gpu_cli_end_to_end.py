@@ -1,0 +1,75 @@
+"""The reference's end-to-end harness (/root/reference/tests/tests.sh + tests/CMakeLists.txt:27-73) against the
+`genmap` program of this build: `genmap index` (GPU suffix sort) + `genmap map` with the flags of every case,
+every output format and every -xo rerun; all produced files must equal tests/golden/reference_cases."""
+import filecmp
+import shutil
+import subprocess
+
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+GENMAP = H.ROOT / "genmap_amd" / "bin" / "genmap"
+
+FORMAT_FLAGS = {  # tests/CMakeLists.txt:29-52
+    "raw_map": ["-r"], "raw_freq8": ["-r", "-fs"], "raw_freq16": ["-r", "-fl"], "txt_map": ["-t"], "txt_freq16": ["-t", "-fl"],
+    "txt_freq8": ["-t", "-fs"], "wig_map": ["-w"], "wig_freq16": ["-w", "-fl"], "bed_map": ["-bg"], "bed_freq16": ["-bg", "-fl"], "csv": ["-d"],
+}
+
+
+def _same_tree(a, b):
+    cmp = filecmp.dircmp(a, b)
+    assert not cmp.left_only and not cmp.right_only, (cmp.left_only, cmp.right_only)
+    for f in cmp.common_files:
+        assert filecmp.cmp(a / f, b / f, shallow=False), f
+
+
+@pytest.mark.parametrize("case", sorted(H.CASES))
+def test_cli_reproduces_reference_outputs(case, tmp_path):
+    assert GENMAP.exists(), "genmap binary not built (python -c 'import __graft_entry__ as g; g.build()')"
+    d = H.CASES_DIR / f"case_{case}"
+    directory, fl = H.CASES[case]
+    idx = tmp_path / "index"
+    if directory:
+        src = tmp_path / "fastas"
+        src.mkdir()
+        for f in d.glob("*.fa"):
+            shutil.copy(f, src / f.name)
+        subprocess.check_call([str(GENMAP), "index", "-FD", str(src), "-I", str(idx), "-A", "skew"], stdout=subprocess.DEVNULL)
+    else:
+        subprocess.check_call([str(GENMAP), "index", "-F", str(d / "genome.fa"), "-I", str(idx), "-A", "divsufsort"], stdout=subprocess.DEVNULL)
+    flags = ["-E", str(fl["E"]), "-K", str(fl["K"])] + (["-nc"] if fl.get("nc") else []) + (["-ep"] if fl.get("ep") else [])
+    if (d / "subset.bed").exists():
+        flags += ["-S", str(d / "subset.bed")]
+    for sub, ff in FORMAT_FLAGS.items():
+        if not (d / sub).is_dir():
+            continue
+        for xo in H.xo_variants(case):
+            out = tmp_path / f"out_{sub}_{xo}"
+            out.mkdir()
+            cmd = [str(GENMAP), "map", "-I", str(idx), "-O", str(out)] + flags + ff + (["-xo", str(xo)] if xo is not None else [])
+            subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+            _same_tree(out, d / sub)
+
+
+def test_cli_error_paths(tmp_path):
+    d = H.CASES_DIR / "case_1a"
+    idx = tmp_path / "index"
+    subprocess.check_call([str(GENMAP), "index", "-F", str(d / "genome.fa"), "-I", str(idx)], stdout=subprocess.DEVNULL)
+    out = tmp_path / "o"; out.mkdir()
+    base = [str(GENMAP), "map", "-I", str(idx), "-O", str(out), "-K", "3", "-E", "0"]
+    r = subprocess.run(base, capture_output=True, text=True)                         # no output format
+    assert r.returncode != 0 and "Please choose at least one output format" in r.stderr
+    r = subprocess.run(base + ["-r", "-fs", "-fl"], capture_output=True, text=True)  # -fs and -fl
+    assert r.returncode != 0 and "Cannot use both" in r.stderr
+    r = subprocess.run(base[:-1] + ["5", "-r"], capture_output=True, text=True)      # E > 4
+    assert r.returncode != 0 and "E > 4 not yet supported." in r.stderr
+    r = subprocess.run(base + ["-r", "-xo", "3"], capture_output=True, text=True)    # overlap too large
+    assert r.returncode != 0 and "overlap cannot be larger than" in r.stderr
+    r = subprocess.run([str(GENMAP), "index", "-F", str(d / "genome.fa"), "-I", str(idx)], capture_output=True, text=True)
+    assert r.returncode != 0 and "already exists" in r.stderr
+    # -O as a file name for single-fasta indices (src/mappability.hpp:562-619)
+    subprocess.check_call(base[:4] + ["-O", str(tmp_path / "named"), "-K", "3", "-E", "0", "-nc", "-r", "-fl"], stdout=subprocess.DEVNULL)
+    assert filecmp.cmp(tmp_path / "named.freq16", d / "raw_freq16" / "genome.genmap.freq16", shallow=False)

@@ -1,0 +1,131 @@
+"""Host logic of the `genmap` program (no GPU): the C++ writers of genmap_amd/host reproduce the reference's
+output files byte for byte when fed the golden frequency vectors; FASTA ingestion matches the fixtures' ids.
+Golden data: tests/golden/reference_cases (copied data files of /root/reference/tests/test_cases)."""
+import ctypes as C
+import filecmp
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+
+@pytest.fixture(scope="module")
+def hostlib():
+    subprocess.check_call(["make", "-s", "-C", str(H.ROOT / "genmap_amd" / "host"), "../lib/libgenmap_host.so"])
+    lib = C.CDLL(str(H.ROOT / "genmap_amd" / "lib" / "libgenmap_host.so"))
+    lib.gmh_last_error.restype = C.c_char_p
+    lib.gmh_save_outputs.restype = C.c_int
+    lib.gmh_save_outputs.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_void_p, C.c_uint32]
+    lib.gmh_save_csv.restype = C.c_int
+    lib.gmh_save_csv.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p,
+                                 C.c_uint32, C.c_uint32, C.c_int, C.c_char_p, C.c_void_p, C.c_uint32, C.c_int]
+    lib.gmh_read_fasta.restype = C.c_int
+    lib.gmh_read_fasta.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.gmh_default_infix_length.restype = C.c_uint32
+    lib.gmh_default_infix_length.argtypes = [C.c_uint32, C.c_uint32, C.c_int32]
+    return lib
+
+
+def _names(ns):
+    return b"".join(n.encode() + b"\0" for n in ns)
+
+
+FORMATS = {  # golden sub-directory -> (kind, format bit, source raw dir, dtype, produced extensions)
+    "raw_map": (0, 1, "raw_freq16", np.uint16, [".map"]),
+    "raw_freq8": (1, 1, "raw_freq8", np.uint8, [".freq8"]),
+    "raw_freq16": (2, 1, "raw_freq16", np.uint16, [".freq16"]),
+    "txt_map": (0, 2, "raw_freq16", np.uint16, [".txt"]),
+    "txt_freq16": (2, 2, "raw_freq16", np.uint16, [".txt"]),
+    "txt_freq8": (1, 2, "raw_freq8", np.uint8, [".txt"]),
+    "wig_map": (0, 4, "raw_freq16", np.uint16, [".wig", ".chrom.sizes"]),
+    "wig_freq16": (2, 4, "raw_freq16", np.uint16, [".wig", ".chrom.sizes"]),
+    "bed_map": (0, 8, "raw_freq16", np.uint16, [".bedgraph"]),
+    "bed_freq16": (2, 8, "raw_freq16", np.uint16, [".bedgraph"]),
+}
+
+
+@pytest.mark.parametrize("case", sorted(H.CASES))
+def test_writers_reproduce_reference_files(case, hostlib, tmp_path):
+    d = H.CASES_DIR / f"case_{case}"
+    g, _, _, _ = H.load_case(case)
+    checked = 0
+    for sub, (kind, bit, src, dt, exts) in FORMATS.items():
+        if not (d / sub).is_dir():
+            continue
+        for name, first, nseq, tb, tl in g.file_slices():
+            stem_name = name.rsplit(".", 1)[0] + ".genmap"
+            raw = d / src / (stem_name + (".freq8" if dt == np.uint8 else ".freq16"))
+            if not raw.exists():
+                continue  # selection cases: no output for this fasta file
+            c = np.fromfile(raw, dtype=dt)
+            assert len(c) == tl
+            lens = np.ascontiguousarray(g.seq_len[first:first + nseq], dtype=np.uint64)
+            out = tmp_path / sub
+            out.mkdir(exist_ok=True)
+            rc = hostlib.gmh_save_outputs(H._ptr(c), len(c), c.itemsize, str(out / stem_name).encode(), kind, bit,
+                                          _names(g.seq_names[first:first + nseq]), H._ptr(lens), nseq)
+            assert rc == 0, hostlib.gmh_last_error()
+            for ext in exts:
+                assert filecmp.cmp(out / (stem_name + ext), d / sub / (stem_name + ext), shallow=False), (case, sub, name, ext)
+                checked += 1
+    assert checked >= 10
+
+
+@pytest.mark.parametrize("case", sorted(H.CASES))
+def test_csv_writer_reproduces_reference_files(case, hostlib, tmp_path):
+    """oracle location lists -> gm_locate's CSR layout -> C++ csv writer == golden csv"""
+    d = H.CASES_DIR / f"case_{case}"
+    g, directory, fl, bed = H.load_case(case)
+    ix = H.OracleIndex(g.codes, g.seq_len, keep_sa=True)
+    rc_strand = not fl.get("nc", False)
+    file_names = [n for n, _ in g.files]
+    spf = np.asarray([len(r) for _, r in g.files], dtype=np.uint64)
+    for name, first, nseq, tb, tl in g.file_slices():
+        iv = None
+        if bed is not None:
+            iv = H.slice_intervals(g, first, nseq, bed)
+            if not iv:
+                continue
+        _, _, locs = ix.mappability(fl["K"], fl["E"], text_begin=tb, text_len=tl, first_seq=first, n_seq=nseq, revcompl=rc_strand,
+                                    directory=True, csv=True, intervals=iv, seq_file_id=g.seq_file)
+        # CSR over slice positions
+        po = np.zeros(tl + 1, dtype=np.uint64); mo = np.zeros(tl + 1, dtype=np.uint64)
+        plus, minus = [], []
+        by_pos = {}
+        for (s, p), pl, mi in locs:
+            by_pos[int(g.cum[first + s] - g.cum[first]) + p] = (pl, mi)
+        for j in range(tl):
+            pl, mi = by_pos.get(j, ([], []))
+            plus += [(a << 32) | b for a, b in pl]; minus += [(a << 32) | b for a, b in mi]
+            po[j + 1] = len(plus); mo[j + 1] = len(minus)
+        plus = np.asarray(plus + [0], dtype=np.uint64); minus = np.asarray(minus + [0], dtype=np.uint64)
+        lens = np.ascontiguousarray(g.seq_len[first:first + nseq], dtype=np.uint64)
+        stem = tmp_path / (name.rsplit(".", 1)[0] + ".genmap")
+        rc = hostlib.gmh_save_csv(str(stem).encode(), 0, tl, H._ptr(po), H._ptr(mo), H._ptr(plus), H._ptr(minus),
+                                  _names(g.seq_names[first:first + nseq]), H._ptr(lens), nseq, fl["K"], int(rc_strand),
+                                  _names(file_names), H._ptr(spf), len(file_names), 0)
+        assert rc == 0, hostlib.gmh_last_error()
+        assert (tmp_path / (stem.name + ".csv")).read_bytes() == (d / "csv" / (stem.name + ".csv")).read_bytes(), (case, name)
+
+
+def test_fasta_reader_matches_fixture_parsing(hostlib):
+    for case in ("1c", "2c", "3a"):
+        d = H.CASES_DIR / f"case_{case}"
+        for fa in sorted(d.glob("*.fa")):
+            n, tot, nb = C.c_uint64(), C.c_uint64(), C.c_uint64()
+            assert hostlib.gmh_read_fasta(str(fa).encode(), None, None, None, 0, C.byref(n), C.byref(tot), C.byref(nb)) == 0
+            codes = np.zeros(tot.value, np.uint8); lens = np.zeros(n.value, np.uint64); names = C.create_string_buffer(nb.value + 1)
+            assert hostlib.gmh_read_fasta(str(fa).encode(), H._ptr(codes), H._ptr(lens), names, nb.value + 1, C.byref(n), C.byref(tot), C.byref(nb)) == 0
+            ref = H.read_fasta(fa)
+            assert names.raw[:nb.value].split(b"\0")[:-1] == [r[0].encode() for r in ref]
+            assert np.array_equal(codes, np.concatenate([r[1] for r in ref]))
+
+
+def test_host_infix_rule(hostlib):
+    for K in (3, 4, 8, 24, 30, 100, 128):
+        for E in range(5):
+            for xo in (None, 0, 1, 3):
+                b = H.default_infix_length(K, E, xo)
+                assert hostlib.gmh_default_infix_length(K, E, -1 if xo is None else xo) == (0 if b < 0 else b)
