@@ -34,7 +34,7 @@ class IndexInfo(C.Structure):
 
 class MapStats(C.Structure):
     _fields_ = [("kmers", C.c_uint64), ("roots", C.c_uint64), ("node_steps", C.c_uint64), ("rank_lines", C.c_uint64),
-                ("search_ms", C.c_double), ("total_ms", C.c_double)]
+                ("detail", C.c_uint64 * 6), ("search_ms", C.c_double), ("total_ms", C.c_double)]
 
 
 class Locations(C.Structure):
@@ -223,4 +223,6 @@ class Index:
     def last_stats(self):
         s = MapStats()
         _check(self._lib, self._lib.gm_last_map_stats(self._h, C.byref(s)))
-        return {k: getattr(s, k) for k, _ in MapStats._fields_}
+        d = {k: getattr(s, k) for k, _ in MapStats._fields_}
+        d["detail"] = dict(zip(("steps_oss", "steps_ext", "ext_w1", "ext_w2_4", "oss_w1", "pushes"), list(s.detail)))
+        return d

@@ -148,7 +148,7 @@ static int index_common_setup(gm_index* ix, const uint8_t* codes, const uint64_t
     GM_HIP(hipMemcpy(ix->d_text, codes, ix->textLen, hipMemcpyHostToDevice));
     GM_HIP(hipMalloc(&ix->d_cum, ((size_t)n_seq + 1) * 8));
     GM_HIP(hipMemcpy(ix->d_cum, ix->cum.data(), ((size_t)n_seq + 1) * 8, hipMemcpyHostToDevice));
-    GM_HIP(hipMalloc(&ix->d_small, 64));
+    GM_HIP(hipMalloc(&ix->d_small, 256));
     for (int i = 0; i < 4; ++i) GM_HIP(hipEventCreate(&ix->ev[i]));
     return GM_OK;
 }
@@ -473,7 +473,7 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
     GM_HIP(hipEventRecord(ix->ev[0], st));
     if (ep) GM_HIP(hipMemsetAsync(ix->d_bits, 0, (text_len + 1) * wordsPerKmer * sizeof(uint32_t), st));
     else GM_HIP(hipMemsetAsync(ix->d_acc, 0, (text_len + 4) * sizeof(uint32_t), st));
-    GM_HIP(hipMemsetAsync(ix->d_small, 0, 64, st));
+    GM_HIP(hipMemsetAsync(ix->d_small, 0, 256, st));
     A.acc = ix->d_acc; A.fileBits = ix->d_bits; A.wordsPerKmer = wordsPerKmer; A.seqFile = ix->d_seqFile;
 
     GM_HIP(hipEventRecord(ix->ev[1], st));
@@ -522,7 +522,7 @@ static int locate_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uin
 #define LC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); rc = (e_ == hipErrorOutOfMemory) ? GM_ERR_OOM : GM_ERR_HIP; goto done; } } while (0)
     {
         LC(hipMalloc(&d_cnt, (slots + 1) * 4)); LC(hipMalloc(&d_offs, (slots + 1) * 8));
-        LC(hipMemset(d_cnt, 0, (slots + 1) * 4)); LC(hipMemset(ix->d_small, 0, 64));
+        LC(hipMemset(d_cnt, 0, (slots + 1) * 4)); LC(hipMemset(ix->d_small, 0, 256));
         A.cnt2 = d_cnt;
         rc = launch_search(ix, LEAF_OCC_COUNT, A, S.blocks, st); if (rc) goto done;
         LC(rocprim::exclusive_scan(nullptr, tmpBytes, d_cnt, d_offs, (uint64_t)0, slots + 1, rocprim::plus<uint64_t>()));
@@ -539,7 +539,7 @@ static int locate_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uin
         if (!L->plus || !L->minus) { rc = GM_ERR_OOM; goto done; }
         if (total > 0) {
             LC(hipMalloc(&d_emit, total * 8)); LC(hipMalloc(&d_sorted, total * 8));
-            LC(hipMemset(d_cnt, 0, (slots + 1) * 4)); LC(hipMemset(ix->d_small, 0, 64));
+            LC(hipMemset(d_cnt, 0, (slots + 1) * 4)); LC(hipMemset(ix->d_small, 0, 256));
             A.offs = d_offs; A.emit = d_emit;
             rc = launch_search(ix, LEAF_OCC_EMIT, A, S.blocks, st); if (rc) goto done;
             // std::sort of every list (algo.hpp:336,348): segmented radix sort, segments = (position, strand) slots
@@ -627,9 +627,10 @@ int gm_last_map_stats(const gm_index* cix, gm_map_stats* out)
     GM_HIP(hipEventElapsedTime(&a, ix->ev[1], ix->ev[2]));
     GM_HIP(hipEventElapsedTime(&b, ix->ev[0], ix->ev[3]));
     ix->stats.search_ms = a; ix->stats.total_ms = b;
-    unsigned long long cnt[2] = {0, 0};
-    GM_HIP(hipMemcpy(cnt, reinterpret_cast<char*>(ix->d_small) + 16, 16, hipMemcpyDeviceToHost));
+    unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    GM_HIP(hipMemcpy(cnt, reinterpret_cast<char*>(ix->d_small) + 16, 64, hipMemcpyDeviceToHost));
     ix->stats.node_steps = cnt[0]; ix->stats.rank_lines = cnt[1];
+    for (int i = 0; i < 6; ++i) ix->stats.detail[i] = cnt[2 + i];
     int rc = check_device_error(ix);
     *out = ix->stats;
     return rc;

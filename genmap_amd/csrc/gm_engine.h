@@ -130,11 +130,13 @@ GM_HD Post make_post(uint32_t meta, const Plan& pl, const OssRecord& rec, uint32
 //                                                     itAll.push_back, algo.hpp:42-48,185-191)
 //   void leaf_flush(const Root&, uint32_t kmer)       after the last leaf() of a step
 //   uint32_t C(uint32_t c)                            (first row of letter c)
+//   void note_step(uint32_t mode, uint32_t width)     (statistics hook)
 // On return `have` tells whether nd holds a node to continue with.
 template <class Env>
 GM_HD void lane_step(Node& nd, bool& have, const Root& rt, uint32_t K, uint32_t E, Env& env)
 {
     const Plan pl = make_plan(nd.meta, rt.rec, E);
+    env.note_step(meta_mode(nd.meta), nd.w);   // instrumentation hook (empty unless GM_COUNTERS)
     const uint32_t plo = pl.right ? nd.rlo : nd.flo;
     uint32_t rl[NLET], rh[NLET];
     env.rank2(pl.right, plo, plo + nd.w, rl, rh);

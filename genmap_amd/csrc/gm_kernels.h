@@ -65,7 +65,13 @@ template <int WPP> struct EnvBase {
     uint32_t sp;
     uint32_t K;
 #ifdef GM_COUNTERS
-    uint32_t steps = 0, lines = 0;
+    uint32_t steps = 0, lines = 0, stOss = 0, stExt = 0, stExtW1 = 0, stExtW4 = 0, stOssW1 = 0, pushes = 0;
+    __device__ __forceinline__ void note_step(uint32_t mode, uint32_t w)
+    {
+        if (mode == M_OSS) { stOss++; stOssW1 += (w == 1u); } else { stExt++; stExtW1 += (w == 1u); stExtW4 += (w > 1u && w <= 4u); }
+    }
+#else
+    __device__ __forceinline__ void note_step(uint32_t, uint32_t) {}
 #endif
     __device__ __forceinline__ EnvBase(const SearchArgs& a, uint4* s, uint32_t k) : A(a), stk(s), sp(0), K(k) {}
     __device__ __forceinline__ uint32_t slice_pos(const Root& rt, uint32_t kmer) const { return rt.win + (rt.strand ? rt.n - 1u - kmer : kmer); }
@@ -104,6 +110,9 @@ template <int WPP> struct EnvBase {
     }
     __device__ __forceinline__ void push(const Node& nd)
     {
+#ifdef GM_COUNTERS
+        pushes++;
+#endif
         if (sp < A.stackDepth) { stk[sp] = make_uint4(nd.flo, nd.rlo, nd.w, nd.meta); ++sp; }
         else *A.errorFlag = 1u;   // never expected: depth = stack_bound(E, stepSize)
     }
@@ -238,6 +247,12 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
 #ifdef GM_COUNTERS
     atomicAdd(&A.counters[0], (unsigned long long)env.steps);
     atomicAdd(&A.counters[1], (unsigned long long)env.lines);
+    atomicAdd(&A.counters[2], (unsigned long long)env.stOss);
+    atomicAdd(&A.counters[3], (unsigned long long)env.stExt);
+    atomicAdd(&A.counters[4], (unsigned long long)env.stExtW1);
+    atomicAdd(&A.counters[5], (unsigned long long)env.stExtW4);
+    atomicAdd(&A.counters[6], (unsigned long long)env.stOssW1);
+    atomicAdd(&A.counters[7], (unsigned long long)env.pushes);
 #endif
 }
 

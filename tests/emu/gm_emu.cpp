@@ -58,6 +58,7 @@ template <int WPP> struct EmuEnv {
         return rt.strand ? complement(text[rt.win + (W - 1 - pos)]) : text[rt.win + pos];
     }
     void push(const Node& nd) { stack.push_back(nd); if (stack.size() > maxDepth) maxDepth = stack.size(); }
+    void note_step(uint32_t, uint32_t) {}
     uint32_t leafSum = 0;
     void leaf(const Root&, uint32_t, uint32_t, uint32_t w) { leafSum += w; }
     void leaf_flush(const Root& rt, uint32_t kmer)

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Device-side step statistics of one computeMappability call (instrumented twin library; never timed)."""
+import argparse, json, sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np, torch
+import genmap_amd as g
+from genmap_amd import synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="chr1"); ap.add_argument("--scale", type=float, default=1.0)
+ap.add_argument("--cfg", nargs="+", default=["30,0", "30,1", "30,2", "100,1"])
+a = ap.parse_args()
+codes, lens, desc = synth.workload(a.workload, a.scale)
+ix = g.Index.build(codes, lens, sampling=0, profiling=True)
+out = torch.zeros(len(codes) + 16, dtype=torch.uint8, device="cuda:0")
+for cfg in a.cfg:
+    K, E = map(int, cfg.split(","))
+    ix.map_device(out.data_ptr(), K, E, value_bits=8)
+    st = ix.last_stats()
+    nk = st["kmers"]
+    d = st["detail"]
+    print(json.dumps({"workload": desc, "K": K, "E": E, "kmers": nk, "steps_per_kmer": st["node_steps"] / nk, "lines_per_kmer": st["rank_lines"] / nk,
+                      "oss_frac": d["steps_oss"] / st["node_steps"], "ext_w1_frac": d["ext_w1"] / st["node_steps"], "ext_w2_4_frac": d["ext_w2_4"] / st["node_steps"],
+                      "oss_w1_frac": d["oss_w1"] / st["node_steps"], "pushes_per_step": d["pushes"] / st["node_steps"], "search_ms_instrumented": st["search_ms"]}))
