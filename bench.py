@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--K", type=int, default=30)
     ap.add_argument("--E", type=int, default=0)
     ap.add_argument("--block-bytes", type=int, default=0)
+    ap.add_argument("--sampling", type=int, default=1, help="1: keep the suffix array resident (narrow nodes are verified against the text); 0: rank queries only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true")
     args = ap.parse_args()
@@ -88,7 +89,7 @@ def main():
     log(f"workload {desc}: generated in {time.time() - t0:.1f} s")
     K, E = args.K, args.E
     t0 = time.time()
-    ix = g.Index.build(codes, lens, block_bytes=args.block_bytes, device=local_rank)
+    ix = g.Index.build(codes, lens, sampling=args.sampling, block_bytes=args.block_bytes, device=local_rank)
     t_build = time.time() - t0
     info = ix.info()
     log(f"index built on the GPU in {t_build:.1f} s: {info['n_rows']} rows, {info['block_bytes']}-B blocks, {info['device_bytes'] / 2**30:.2f} GiB")
@@ -155,7 +156,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_counters and g.lib_path(True).exists():
         try:
             bf, br = ix.export_bwt()
-            ixp = g.Index.from_bwt(bf, br, codes, lens, block_bytes=info["block_bytes"], device=local_rank, profiling=True)
+            ixp = g.Index.from_bwt(bf, br, codes, lens, sa_fwd=(ix.export_sa() if args.sampling == 1 else None), sampling=args.sampling,
+                                   block_bytes=info["block_bytes"], device=local_rank, profiling=True)
             tmp = torch.zeros(n + 16, dtype=torch.uint8, device=dev)
             ixp.map_device(tmp.data_ptr(), K, E, value_bits=8, stream=stream)
             sp = ixp.last_stats()

@@ -68,6 +68,30 @@ __global__ __launch_bounds__(256) void unpack_blocks_kernel(const uint32_t* __re
     bwt[i] = (uint8_t)(((b[5 + w] >> t) & 1u) | (((b[5 + WPP + w] >> t) & 1u) << 1) | (((b[5 + 2 * WPP + w] >> t) & 1u) << 2));
 }
 
+// sentinel text: sequence s occupies [cum[s] + s, cum[s+1] + s), its sentinel follows
+__global__ __launch_bounds__(256) void sentinel_text_kernel(const uint8_t* __restrict__ codes, const uint64_t* __restrict__ cum, uint32_t nSeq, uint64_t textLen,
+                                                            uint8_t* __restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < textLen) {
+        uint32_t lo = 0, hi = nSeq;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cum[mid] <= i) lo = mid; else hi = mid; }
+        out[i + lo] = codes[i];
+    } else if (i < textLen + nSeq) {
+        const uint32_t s = (uint32_t)(i - textLen);
+        out[cum[s + 1] + s] = (uint8_t)SYM_SENT;
+    }
+}
+
+static int make_sentinel_text(gm_index* ix)
+{
+    GM_HIP(hipMalloc(&ix->d_textS, ix->nRows + 16));
+    hipLaunchKernelGGL(sentinel_text_kernel, dim3(grid_for(ix->nRows)), dim3(256), 0, 0, ix->d_text, ix->d_cum, ix->nSeq, ix->textLen, ix->d_textS);
+    GM_HIP(hipGetLastError());
+    GM_HIP(hipDeviceSynchronize());
+    return GM_OK;
+}
+
 template <int WPP>
 static int pack_direction(gm_index* ix, int d, const uint8_t* d_bwt)
 {
@@ -193,7 +217,7 @@ void gm_index_free(gm_index* ix)
 {
     if (!ix) return;
     hipSetDevice(ix->device);
-    hipFree(ix->d_blk[0]); hipFree(ix->d_blk[1]); hipFree(ix->d_text); hipFree(ix->d_cum); hipFree(ix->d_sa); hipFree(ix->d_seqFile); hipFree(ix->d_bits);
+    hipFree(ix->d_blk[0]); hipFree(ix->d_blk[1]); hipFree(ix->d_text); hipFree(ix->d_cum); hipFree(ix->d_sa); hipFree(ix->d_textS); hipFree(ix->d_seqFile); hipFree(ix->d_bits);
     hipFree(ix->d_acc); hipFree(ix->d_stack); hipFree(ix->d_small); hipFree(ix->d_table); hipFree(ix->d_blocks); hipFree(ix->d_cumLocal);
     for (int i = 0; i < 4; ++i) if (ix->ev[i]) hipEventDestroy(ix->ev[i]);
     delete ix;
@@ -219,6 +243,7 @@ int gm_index_build(const uint8_t* codes, const uint64_t* seq_len, uint32_t n_seq
         }
     }
     hipFree(d_sa); hipFree(d_bwt);
+    if (!rc && ix->d_sa) rc = make_sentinel_text(ix);
     if (rc) { gm_index_free(ix); return rc; }
     *out = ix;
     return GM_OK;
@@ -243,6 +268,7 @@ int gm_index_import(const uint8_t* bwt_fwd, const uint8_t* bwt_rev, const uint32
     if (!rc && sa_fwd && sampling == 1) {
         if (hipMalloc(&ix->d_sa, ix->nRows * 4) != hipSuccess) rc = GM_ERR_OOM;
         else if (hipMemcpy(ix->d_sa, sa_fwd, ix->nRows * 4, hipMemcpyHostToDevice) != hipSuccess) rc = GM_ERR_HIP;
+        if (!rc) rc = make_sentinel_text(ix);
     }
     if (rc) { gm_index_free(ix); return rc; }
     *out = ix;
@@ -282,7 +308,7 @@ int gm_index_get_info(const gm_index* ix, gm_index_info* info)
     info->n_rows = ix->nRows; info->text_len = ix->textLen; info->n_seq = ix->nSeq; info->sampling = ix->sampling;
     info->alphabet_size = ix->alphabet;
     info->block_bytes = ix->wpp == 1 ? 32 : ix->wpp == 3 ? 64 : 128;
-    info->device_bytes = 2 * ix->blkBytes + ix->textLen + (ix->nSeq + 1) * 8ull + (ix->d_sa ? ix->nRows * 4ull : 0ull);
+    info->device_bytes = 2 * ix->blkBytes + ix->textLen + (ix->nSeq + 1) * 8ull + (ix->d_sa ? ix->nRows * 5ull : 0ull);
     if (!ix->d_sa) info->sampling = 0;
     info->device = ix->device;
     return GM_OK;
@@ -435,6 +461,13 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     A.counters = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ix->d_small) + 16);
     A.sa = ix->d_sa; A.cumGlobal = ix->d_cum; A.nSeqGlobal = ix->nSeq;
     A.posBase = S->posBase; A.windowLen = S->posEnd - S->posBase;
+    A.textS = ix->d_textS;
+    A.verifyT = 0;
+    if (ix->d_sa && ix->d_textS) {   // narrow nodes are resolved against the text when the SA is resident
+        int t = 1;
+        if (const char* e = getenv("GM_VERIFY_T")) t = atoi(e);
+        A.verifyT = (uint32_t)std::max(0, std::min(t, (int)VERIFY_TMAX));
+    }
     *Aout = A;
     return GM_OK;
 }

@@ -44,6 +44,7 @@ struct Root {
     uint32_t win;      // slice-relative text offset of the block's window = position of its first k-mer
     uint32_t n;        // k-mers in the block; window length W = K + n - 1; common infix = [n-1, K)
     uint32_t strand;   // 1: the window is read reverse-complemented (algo.hpp:286-287)
+    uint32_t search;   // index of the OSS search inside the scheme (selects rec)
     OssRecord rec;
 };
 
@@ -180,6 +181,93 @@ GM_HD void lane_step(Node& nd, bool& have, const Root& rt, uint32_t K, uint32_t 
     }
     if (ps.leaf) env.leaf_flush(rt, ps.kmer);
     nd = keep; have = haveKeep;
+}
+
+// ---- verification of narrow nodes ------------------------------------------------------------------------------
+// A node whose SA range holds a single row has exactly one candidate text location for EVERY string below it in
+// the search tree.  Instead of walking that subtree with rank queries (one or two random HBM lines per character),
+// look the location up in the resident suffix array (one read) and compare the needle window with the text there:
+//   * OSS phase: the remaining blocks of the current search are replayed with their cumulative error bounds
+//     l[b] <= errors <= u[b] at every block end -- exactly the paths _optimalSearchSchemeChildrenGM / ...ExactGM
+//     (find2_index_approx.hpp:223-369) would follow at this location (the lower-bound pruning :254-258 is an early
+//     form of "errors >= l[b] at the block end"), so no error configuration is counted by two searches;
+//   * extension phase: every k-mer the node still covers (starts in [smin, smax]) is a hit iff the location
+//     extends to it without leaving the sequence and with at most E mismatches in total (algo.hpp:26-218 explores the
+//     same single path per k-mer; pattern N and text N count as mismatches, a sentinel ends the occurrence).
+// Env additionally supplies:
+//   uint32_t sa(uint32_t row)                         text position (sentinel text) of a forward SA row
+//   uint32_t text_s(uint32_t pos)                     sentinel-text symbol (5 = sentinel)
+//   uint32_t rows()                                   length of the sentinel text
+//   void leaf_at(const Root&, uint32_t kmer, uint32_t textPos)   one occurrence of k-mer `kmer` at textPos
+template <class Env>
+GM_HD void verify_item(uint32_t row, uint32_t meta, const Root& rt, uint32_t K, uint32_t E, Env& env)
+{
+    uint32_t a = meta_a(meta), bx = meta_bx(meta), t = meta_t(meta), errs = meta_errs(meta), mode = meta_mode(meta);
+    const uint32_t nRows = env.rows();
+    const uint32_t p0 = env.sa(row);   // aligned with needle coordinate a0 (a changes below, keep the anchor)
+    const uint32_t a0 = a;
+    // symbol of the text at the place needle coordinate q maps to; sentinel when outside the text
+    auto tsym = [&](uint32_t q) -> uint32_t {
+        const uint32_t idx = p0 + q - a0;                       // wraps for q < a0 - p0: caught by idx >= nRows
+        return (q + p0 < a0 || idx >= nRows) ? (uint32_t)SYM_SENT : env.text_s(idx);
+    };
+    if (mode == M_OSS) {
+        const uint32_t nb = oss_nb(rt.rec);
+        for (uint32_t bi = t; bi < nb; ++bi) {
+            const uint32_t right = oss_right(rt.rec, bi), blen = oss_bl(rt.rec, bi), u = oss_u(rt.rec, bi), l = oss_l(rt.rec, bi);
+            while (bx - a < blen) {
+                const uint32_t q = right ? bx : a - 1u;
+                const uint32_t tc = tsym(q);
+                if (tc == SYM_SENT) return;
+                const uint32_t nc = env.text_char(rt, q);
+                errs += (nc == SYM_N || nc != tc) ? 1u : 0u;
+                if (errs > u) return;
+                if (right) ++bx; else --a;
+            }
+            if (errs < l) return;
+        }
+        mode = M_SPLIT;   // infix complete: [a,bx) == [n-1, K)
+    }
+    uint32_t smin, smax;
+    if (mode == M_EXT_R) { smin = t - K; smax = a; }
+    else if (mode == M_EXT_L) { smin = bx - K; smax = t; }
+    else { smin = bx - K; smax = a; }
+    const uint32_t budget = E - errs;                 // mismatches still allowed
+    // 1-based offsets of the first `budget` mismatches to the right of bx / to the left of a; rlim / llim = number of
+    // characters that can be added on that side at all (stops at a sentinel or at mismatch number budget + 1)
+    uint32_t rp[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu}, lp[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
+    const uint32_t rneed = smax + K - bx, lneed = a - smin;
+    uint32_t rlim = rneed, llim = lneed, rc = 0, lc = 0;
+    for (uint32_t i = 0; i < rneed; ++i) {
+        const uint32_t q = bx + i, tc = tsym(q);
+        if (tc == SYM_SENT) { rlim = i; break; }
+        const uint32_t nc = env.text_char(rt, q);
+        if (nc == SYM_N || nc != tc) {
+            if (rc == budget) { rlim = i; break; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if ((uint32_t)j == rc) rp[j] = i + 1u;
+            ++rc;
+        }
+    }
+    for (uint32_t i = 0; i < lneed; ++i) {
+        const uint32_t q = a - 1u - i, tc = tsym(q);
+        if (tc == SYM_SENT) { llim = i; break; }
+        const uint32_t nc = env.text_char(rt, q);
+        if (nc == SYM_N || nc != tc) {
+            if (lc == budget) { llim = i; break; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if ((uint32_t)j == lc) lp[j] = i + 1u;
+            ++lc;
+        }
+    }
+    for (uint32_t s = smin; s <= smax; ++s) {
+        const uint32_t lenL = a - s, lenR = s + K - bx;
+        if (lenL > llim || lenR > rlim) continue;
+        uint32_t d = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d += (lp[j] <= lenL ? 1u : 0u) + (rp[j] <= lenR ? 1u : 0u);
+        if (d <= budget) env.leaf_at(rt, s, p0 - (a0 - s));
+    }
 }
 
 // upper bound of simultaneously stacked nodes of one lane (DESIGN.md "stack bound")

@@ -29,6 +29,7 @@ struct gm_index {
     std::vector<uint64_t> cum;        // nSeq + 1
     uint64_t* d_cum = nullptr;
     uint32_t* d_sa = nullptr;         // forward suffix array (kept when sampling == 1): locate = one HBM read
+    uint8_t* d_textS = nullptr;       // sentinel text (verification of narrow nodes), present with d_sa
     uint32_t* d_seqFile = nullptr; uint64_t seqFileCap = 0;
     uint32_t* d_bits = nullptr; uint64_t bitsCap = 0;
     int numCU = 0;

@@ -47,6 +47,9 @@ struct SearchArgs {
     uint32_t* cnt2;                 // [strand * windowLen + pos - posBase]: occurrences (pass 1) / cursor (pass 2)
     const uint64_t* offs;           // exclusive scan of cnt2 (pass 2)
     uint64_t* emit;                 // packed (seqNo << 32 | seqPos) per occurrence
+    // ---- verification of narrow nodes (gm_engine.h: verify_item) ----
+    const uint8_t* textS;           // sentinel text (one code per byte, 5 = sentinel), nRows bytes
+    uint32_t verifyT;               // nodes with range width <= verifyT are resolved by verification (0 = off)
 };
 
 // sentinel-text position -> (seqNo, seqPos); sequence s starts at cum[s] + s
@@ -58,6 +61,8 @@ __device__ __forceinline__ uint2 locate_position(const uint64_t* __restrict__ cu
 }
 
 constexpr uint32_t WORK_CHUNK = 256;   // roots taken from the global counter per atomic
+constexpr uint32_t VERIFY_TMAX = 4;    // widest range resolved by verification
+constexpr uint32_t VQ_CAP = 64 + 64 * VERIFY_TMAX;
 
 template <int WPP> struct EnvBase {
     const SearchArgs& A;
@@ -117,6 +122,9 @@ template <int WPP> struct EnvBase {
         else *A.errorFlag = 1u;   // never expected: depth = stack_bound(E, stepSize)
     }
     __device__ __forceinline__ uint32_t C(uint32_t c) const { return A.C[c]; }
+    __device__ __forceinline__ uint32_t sa(uint32_t row) const { return A.sa[row]; }
+    __device__ __forceinline__ uint32_t text_s(uint32_t pos) const { return A.textS[pos]; }
+    __device__ __forceinline__ uint32_t rows() const { return A.nRows; }
 };
 
 // leaf policy 1: frequency only -- hits[a-ab] = min(countOccurrences(it) + hits[a-ab], max) (algo.hpp:48,191)
@@ -134,6 +142,11 @@ template <int WPP> struct CountEnv : EnvBase<WPP> {
         const uint32_t old = atomicAdd(&A.acc[pos], add);
         if (old > 0xFFFFFFFFu - add) atomicOr(&A.acc[pos], 0x80000000u);   // sticky saturation on (theoretical) wrap
     }
+    __device__ __forceinline__ void leaf_at(const Root& rt, uint32_t kmer, uint32_t)
+    {
+        uint32_t* p = &A.acc[this->slice_pos(rt, kmer)];
+        if (atomicAdd(p, 1u) == 0xFFFFFFFFu) atomicOr(p, 0x80000000u);
+    }
 };
 
 // leaf policy 2: --exclude-pseudo -- the set of fasta files that contain the k-mer (algo.hpp:351-364)
@@ -150,6 +163,11 @@ template <int WPP> struct FileSetEnv : EnvBase<WPP> {
         }
     }
     __device__ __forceinline__ void leaf_flush(const Root&, uint32_t) {}
+    __device__ __forceinline__ void leaf_at(const Root& rt, uint32_t kmer, uint32_t textPos)
+    {
+        const uint32_t f = A.seqFile[locate_position(A.cumGlobal, A.nSeqGlobal, textPos).x];
+        atomicOr(&A.fileBits[(size_t)this->slice_pos(rt, kmer) * A.wordsPerKmer + (f >> 5)], 1u << (f & 31u));
+    }
 };
 
 // leaf policy 3: csv pass 1 -- occurrences per (k-mer, strand)
@@ -161,6 +179,7 @@ template <int WPP> struct OccCountEnv : EnvBase<WPP> {
         atomicAdd(&A.cnt2[(size_t)rt.strand * A.windowLen + (this->slice_pos(rt, kmer) - A.posBase)], w);
     }
     __device__ __forceinline__ void leaf_flush(const Root&, uint32_t) {}
+    __device__ __forceinline__ void leaf_at(const Root& rt, uint32_t kmer, uint32_t) { leaf(rt, kmer, 0u, 1u); }
 };
 
 // leaf policy 4: csv pass 2 -- getOccurrences(iterator) of every leaf (algo.hpp:328-345), unsorted
@@ -177,6 +196,12 @@ template <int WPP> struct OccEmitEnv : EnvBase<WPP> {
         }
     }
     __device__ __forceinline__ void leaf_flush(const Root&, uint32_t) {}
+    __device__ __forceinline__ void leaf_at(const Root& rt, uint32_t kmer, uint32_t textPos)
+    {
+        const size_t slot = (size_t)rt.strand * A.windowLen + (this->slice_pos(rt, kmer) - A.posBase);
+        const uint2 sp = locate_position(A.cumGlobal, A.nSeqGlobal, textPos);
+        A.emit[A.offs[slot] + atomicAdd(&A.cnt2[slot], 1u)] = (uint64_t)sp.x << 32 | sp.y;
+    }
 };
 
 template <int WPP, class EnvT>
@@ -186,7 +211,12 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
     const size_t gl = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     EnvT env(A, A.stack + gl * A.stackDepth, A.K);
     Node nd; nd.flo = nd.rlo = nd.w = nd.meta = 0;
-    Root rt; rt.win = 0; rt.n = 1; rt.strand = 0; rt.rec = OssRecord{0, 0, 0, 0};
+    Root rt; rt.win = 0; rt.n = 1; rt.strand = 0; rt.search = 0; rt.rec = OssRecord{0, 0, 0, 0};
+    // per-wavefront queue of narrow nodes awaiting verification: filled by ballot rank, drained 64 at a time so that a
+    // verification round keeps every lane busy with the same kind of loop
+    __shared__ uint4 vqAll[4 * VQ_CAP];
+    uint4* vq = vqAll + (threadIdx.x >> 6) * VQ_CAP;
+    uint32_t qsize = 0;                             // wave-uniform
     bool have = false, exhausted = false;
     unsigned long long poolCur = 0, poolEnd = 0;   // wave-uniform
     bool globalDone = false;                        // wave-uniform
@@ -227,7 +257,8 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
                         rt.n = left < A.stepSize ? left : A.stepSize;
                     }
                     rt.strand = r / A.nSearches;
-                    const uint4 q = A.table[(size_t)(rt.n - 1u) * 8u + (r - rt.strand * A.nSearches)];
+                    rt.search = r - rt.strand * A.nSearches;
+                    const uint4 q = A.table[(size_t)(rt.n - 1u) * 8u + rt.search];
                     rt.rec.x = q.x; rt.rec.y = q.y; rt.rec.z = q.z; rt.rec.w = q.w;
                     nd = root_node(rt, A.nRows);
                     have = true;
@@ -237,7 +268,44 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
             }
             poolCur += want < avail ? want : avail;
         }
-        if (__ballot(have) == 0ull) break;   // nothing in flight in this wavefront, nothing left to draw
+        // ---- defer narrow nodes: one queue entry per SA row ----
+        if (A.verifyT) {
+            const bool narrow = have && nd.w <= A.verifyT;
+#pragma unroll 1
+            for (uint32_t r = 0; r < VERIFY_TMAX; ++r) {
+                const bool e = narrow && r < nd.w;
+                const unsigned long long m = __ballot(e);
+                if (m == 0ull) break;
+                if (e) {
+                    const uint32_t slot = qsize + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    vq[slot] = make_uint4(nd.flo + r, nd.meta, rt.win, rt.n | rt.strand << 8 | rt.search << 9);
+                }
+                qsize += (uint32_t)__popcll(m);
+            }
+            if (narrow) have = false;
+            // a partial round only when the wavefront has nothing else left to do
+            const bool finishing = (__ballot(have) == 0ull) && (__ballot(!exhausted) == 0ull);
+            if (qsize >= 64u || (finishing && qsize > 0u)) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t take = qsize < 64u ? qsize : 64u;
+                if (lane < take) {
+                    const uint4 it = vq[qsize - 1u - lane];
+                    Root vr; vr.win = it.z; vr.n = it.w & 0xFFu; vr.strand = (it.w >> 8) & 1u; vr.search = it.w >> 9;
+                    const uint4 q = A.table[(size_t)(vr.n - 1u) * 8u + vr.search];
+                    vr.rec.x = q.x; vr.rec.y = q.y; vr.rec.z = q.z; vr.rec.w = q.w;
+                    verify_item(it.x, it.y, vr, A.K, A.E, env);
+                }
+                qsize -= take;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (__ballot(have) == 0ull && qsize == 0u) {
+            if (__ballot(!exhausted) == 0ull) break;   // nothing in flight, nothing queued, nothing left to draw
+            continue;
+        }
 
         if (have) {
             if (meta_mode(nd.meta) == M_SPLIT) { Node left; split_node(nd, left, A.K); env.push(left); }

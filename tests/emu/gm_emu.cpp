@@ -37,6 +37,13 @@ template <int WPP> struct HostIndex {
 };
 
 template <int WPP> struct EmuEnv {
+    const uint32_t* saArr = nullptr;
+    const std::vector<uint8_t>* textSent = nullptr;
+    uint64_t verified = 0;
+    uint32_t sa(uint32_t row) const { return saArr[row]; }
+    uint32_t text_s(uint32_t pos) const { return (*textSent)[pos]; }
+    uint32_t rows() const { return (uint32_t)ix->n; }
+    void leaf_at(const Root& rt, uint32_t kmer, uint32_t) { leafSum += 1; leaf_flush(rt, kmer); }
     const HostIndex<WPP>* ix;
     const uint8_t* text;
     uint32_t K;
@@ -76,7 +83,8 @@ template <int WPP> struct EmuEnv {
 template <int WPP>
 static int run(const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nseqTotal, const uint8_t* text, uint64_t textLen,
                const uint64_t* seqCum, uint32_t nseqLocal, uint32_t K, uint32_t E, uint32_t infix, int revcompl, int valueBits,
-               const uint64_t* intervals, uint64_t nIntervals, void* out, uint64_t* stats)
+               const uint64_t* intervals, uint64_t nIntervals, void* out, uint64_t* stats, const uint32_t* sa, uint32_t verifyT,
+               const uint8_t* allCodes, const uint64_t* allCum)
 {
     MapPlan plan;
     int rc = make_map_plan(K, E, infix, revcompl, textLen, intervals, nIntervals, &plan);
@@ -84,6 +92,15 @@ static int run(const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nse
     HostIndex<WPP> ix; ix.build(bf, br, rows, nseqTotal);
     std::vector<uint32_t> acc(textLen ? textLen : 1, 0);
     EmuEnv<WPP> env; env.ix = &ix; env.text = text; env.K = K; env.acc = &acc;
+    std::vector<uint8_t> textS;
+    if (sa && verifyT) {   // sentinel text: sequence s occupies [cum[s] + s, cum[s+1] + s), sentinel after it
+        textS.resize(rows);
+        for (uint32_t q = 0; q < nseqTotal; ++q) {
+            for (uint64_t i = allCum[q]; i < allCum[q + 1]; ++i) textS[i + q] = allCodes[i];
+            textS[allCum[q + 1] + q] = (uint8_t)SYM_SENT;
+        }
+        env.saArr = sa; env.textSent = &textS;
+    }
     uint32_t bound = stack_bound(E, plan.stepSize);
     uint64_t roots = plan.numRoots();
     uint32_t rpb = plan.nSearches * plan.nStrands;
@@ -93,11 +110,16 @@ static int run(const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nse
         if (plan.useList) { rt.win = plan.blocks[b].first; rt.n = plan.blocks[b].second; }
         else { rt.win = (uint32_t)(b * plan.stepSize); rt.n = (uint32_t)std::min<uint64_t>(plan.stepSize, plan.numKmers - rt.win); }
         rt.strand = r / plan.nSearches;
-        rt.rec = plan.table[(size_t)(rt.n - 1) * 8 + (r % plan.nSearches)];
+        rt.search = r % plan.nSearches;
+        rt.rec = plan.table[(size_t)(rt.n - 1) * 8 + rt.search];
         Node nd = root_node(rt, (uint32_t)rows);
         bool have = true;
         for (;;) {
             if (!have) { if (env.stack.empty()) break; nd = env.stack.back(); env.stack.pop_back(); have = true; }
+            if (env.saArr && nd.w <= verifyT) {   // the device defers these to a wave-wide verification round
+                for (uint32_t r2 = 0; r2 < nd.w; ++r2) verify_item(nd.flo + r2, nd.meta, rt, K, E, env);
+                env.verified += nd.w; have = false; continue;
+            }
             if (meta_mode(nd.meta) == M_SPLIT) { Node left; split_node(nd, left, K); env.push(left); }
             lane_step(nd, have, rt, K, E, env);
         }
@@ -111,22 +133,22 @@ static int run(const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nse
         uint64_t lim = std::min<uint64_t>(K, seqCum[s] - seqCum[s - 1] + 1);
         for (uint64_t j = 1; j < lim; ++j) { if (valueBits == 8) ((uint8_t*)out)[seqCum[s] - j] = 0; else ((uint16_t*)out)[seqCum[s] - j] = 0; }
     }
-    if (stats) { stats[0] = env.maxDepth; stats[1] = bound; stats[2] = env.steps; }
+    if (stats) { stats[0] = env.maxDepth; stats[1] = bound; stats[2] = env.steps; stats[3] = env.verified; }
     return 0;
 }
 
 extern "C" int gm_emu_map(int wpp, const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nseqTotal, const uint8_t* text,
                           uint64_t textLen, const uint64_t* seqCum, uint32_t nseqLocal, uint32_t K, uint32_t E, int32_t xo,
                           int32_t infixOverride, int revcompl, int valueBits, const uint64_t* intervals, uint64_t nIntervals,
-                          void* out, uint64_t* stats)
+                          void* out, uint64_t* stats, const uint32_t* sa, uint32_t verifyT, const uint8_t* allCodes, const uint64_t* allCum)
 {
     uint32_t infix = infixOverride > 0 ? (uint32_t)infixOverride : default_infix_length(K, E, xo);
     if (infix == 0) return PLAN_BAD_OVERLAP;
     memset(out, 0, textLen * (valueBits / 8));
     switch (wpp) {
-        case 1: return run<1>(bf, br, rows, nseqTotal, text, textLen, seqCum, nseqLocal, K, E, infix, revcompl, valueBits, intervals, nIntervals, out, stats);
-        case 3: return run<3>(bf, br, rows, nseqTotal, text, textLen, seqCum, nseqLocal, K, E, infix, revcompl, valueBits, intervals, nIntervals, out, stats);
-        case 9: return run<9>(bf, br, rows, nseqTotal, text, textLen, seqCum, nseqLocal, K, E, infix, revcompl, valueBits, intervals, nIntervals, out, stats);
+        case 1: return run<1>(bf, br, rows, nseqTotal, text, textLen, seqCum, nseqLocal, K, E, infix, revcompl, valueBits, intervals, nIntervals, out, stats, sa, verifyT, allCodes, allCum);
+        case 3: return run<3>(bf, br, rows, nseqTotal, text, textLen, seqCum, nseqLocal, K, E, infix, revcompl, valueBits, intervals, nIntervals, out, stats, sa, verifyT, allCodes, allCum);
+        case 9: return run<9>(bf, br, rows, nseqTotal, text, textLen, seqCum, nseqLocal, K, E, infix, revcompl, valueBits, intervals, nIntervals, out, stats, sa, verifyT, allCodes, allCum);
     }
     return -100;
 }

@@ -1,6 +1,8 @@
 """GPU parity tests (run with -m gpu on an MI355X): everything goes through the C ABI of libgenmap_amd.so
 (genmap_amd.capi) and is compared bit-exactly with the CPU oracle / the reference's golden files.
 The GPU box has no /root/reference: only tests/golden and the oracle are used."""
+import os
+
 import numpy as np
 import pytest
 
@@ -143,15 +145,20 @@ def test_gpu_gtest_matrix(E, dna5):
     nseq, ln = 3, (1000 if E < 3 else 300)
     codes = rng.integers(0, 5 if dna5 else 4, size=nseq * ln, dtype=np.uint8)
     ora = H.OracleIndex(codes, [ln] * nseq, keep_sa=False)
-    ix = g.Index.build(codes, [ln] * nseq)
+    ix = g.Index.build(codes, [ln] * nseq, sampling=1)
     minK = E + 1 + (E >= 2)
     nblocks = [1, 2, 4, 5, 6][E]
-    for K in range(minK, 9 if E < 4 else 8):
-        rc = bool(rng.integers(0, 2))
-        triv = ora.trivial(K, E, revcompl=rc, value_bits=8)
-        for infix in range(max(minK, nblocks), K + 1):
-            out = ix.map(K, E, infix=infix, revcompl=rc, value_bits=8)
-            assert np.array_equal(out, triv), (E, dna5, K, infix)
+    try:
+        for K in range(minK, 9 if E < 4 else 8):
+            rc = bool(rng.integers(0, 2))
+            triv = ora.trivial(K, E, revcompl=rc, value_bits=8)
+            for infix in range(max(minK, nblocks), K + 1):
+                for T in ("0", "1", "4"):   # verification of narrow nodes off / width 1 / width <= 4
+                    os.environ["GM_VERIFY_T"] = T
+                    out = ix.map(K, E, infix=infix, revcompl=rc, value_bits=8)
+                    assert np.array_equal(out, triv), (E, dna5, K, infix, T)
+    finally:
+        os.environ.pop("GM_VERIFY_T", None)
     ix.close()
 
 
@@ -162,13 +169,18 @@ def test_gpu_baseline_settings_small(K, E):
     lens = [60000, 700, K - 1, 30000, 3]
     codes = _repeat_text(rng, sum(lens), True)
     ora = H.OracleIndex(codes, lens, keep_sa=False)
-    for bb in BLOCK_BYTES:
-        ix = g.Index.build(codes, lens, block_bytes=bb)
-        for bits in (8, 16):
-            exp = ora.mappability(K, E, value_bits=bits, threads=8)
-            out = ix.map(K, E, value_bits=bits)
-            assert np.array_equal(out, exp), (K, E, bits, bb)
-        ix.close()
+    try:
+        for bb in BLOCK_BYTES:
+            ix = g.Index.build(codes, lens, block_bytes=bb, sampling=1)
+            for bits in (8, 16):
+                exp = ora.mappability(K, E, value_bits=bits, threads=8)
+                for T in ("0", "1", "4"):
+                    os.environ["GM_VERIFY_T"] = T
+                    out = ix.map(K, E, value_bits=bits)
+                    assert np.array_equal(out, exp), (K, E, bits, bb, T)
+            ix.close()
+    finally:
+        os.environ.pop("GM_VERIFY_T", None)
 
 
 def test_gpu_shards_and_device_output():
@@ -202,7 +214,7 @@ def test_gpu_midsize_vs_oracle_and_properties():
     g = _gm()
     from genmap_amd import synth
     codes, lens, _ = synth.workload("chr1", 0.016)
-    ix = g.Index.build(codes, lens)
+    ix = g.Index.build(codes, lens, sampling=1)
     bf, br = ix.export_bwt()
     n = len(codes) + len(lens)
     # BWT is a permutation of the sentinel text
