@@ -85,7 +85,9 @@ __global__ __launch_bounds__(256) void sentinel_text_kernel(const uint8_t* __res
 
 static int make_sentinel_text(gm_index* ix)
 {
-    GM_HIP(hipMalloc(&ix->d_textS, ix->nRows + 16));
+    GM_HIP(hipMalloc(&ix->d_textSAlloc, ix->nRows + 1024));
+    GM_HIP(hipMemset(ix->d_textSAlloc, (int)SYM_SENT, ix->nRows + 1024));   // padding reads as sentinels
+    ix->d_textS = ix->d_textSAlloc + 512;
     hipLaunchKernelGGL(sentinel_text_kernel, dim3(grid_for(ix->nRows)), dim3(256), 0, 0, ix->d_text, ix->d_cum, ix->nSeq, ix->textLen, ix->d_textS);
     GM_HIP(hipGetLastError());
     GM_HIP(hipDeviceSynchronize());
@@ -168,7 +170,9 @@ static int index_common_setup(gm_index* ix, const uint8_t* codes, const uint64_t
     hipDeviceProp_t prop;
     GM_HIP(hipGetDeviceProperties(&prop, device));
     ix->numCU = prop.multiProcessorCount;
-    GM_HIP(hipMalloc(&ix->d_text, ix->textLen + 16));
+    GM_HIP(hipMalloc(&ix->d_textAlloc, ix->textLen + 64));
+    GM_HIP(hipMemset(ix->d_textAlloc, 0, ix->textLen + 64));
+    ix->d_text = ix->d_textAlloc + 16;
     GM_HIP(hipMemcpy(ix->d_text, codes, ix->textLen, hipMemcpyHostToDevice));
     GM_HIP(hipMalloc(&ix->d_cum, ((size_t)n_seq + 1) * 8));
     GM_HIP(hipMemcpy(ix->d_cum, ix->cum.data(), ((size_t)n_seq + 1) * 8, hipMemcpyHostToDevice));
@@ -217,7 +221,7 @@ void gm_index_free(gm_index* ix)
 {
     if (!ix) return;
     hipSetDevice(ix->device);
-    hipFree(ix->d_blk[0]); hipFree(ix->d_blk[1]); hipFree(ix->d_text); hipFree(ix->d_cum); hipFree(ix->d_sa); hipFree(ix->d_textS); hipFree(ix->d_seqFile); hipFree(ix->d_bits);
+    hipFree(ix->d_blk[0]); hipFree(ix->d_blk[1]); hipFree(ix->d_textAlloc); hipFree(ix->d_cum); hipFree(ix->d_sa); hipFree(ix->d_textSAlloc); hipFree(ix->d_seqFile); hipFree(ix->d_bits);
     hipFree(ix->d_acc); hipFree(ix->d_stack); hipFree(ix->d_small); hipFree(ix->d_table); hipFree(ix->d_blocks); hipFree(ix->d_cumLocal);
     for (int i = 0; i < 4; ++i) if (ix->ev[i]) hipEventDestroy(ix->ev[i]);
     delete ix;

@@ -195,36 +195,75 @@ GM_HD void lane_step(Node& nd, bool& have, const Root& rt, uint32_t K, uint32_t 
 //     extends to it without leaving the sequence and with at most E mismatches in total (algo.hpp:26-218 explores the
 //     same single path per k-mer; pattern N and text N count as mismatches, a sentinel ends the occurrence).
 // Env additionally supplies:
-//   uint32_t sa(uint32_t row)                         text position (sentinel text) of a forward SA row
-//   uint32_t text_s(uint32_t pos)                     sentinel-text symbol (5 = sentinel)
-//   uint32_t rows()                                   length of the sentinel text
-//   void leaf_at(const Root&, uint32_t kmer, uint32_t textPos)   one occurrence of k-mer `kmer` at textPos
+//   uint32_t sa(uint32_t row)                                   text position (sentinel text) of a forward SA row
+//   uint64_t needle8(const Root&, uint32_t q, bool down)        8 needle symbols, byte j = needle(q + j) or needle(q - j)
+//   uint64_t text8(uint32_t p0, int32_t off, bool down)         8 sentinel-text symbols, byte j = textS[p0 + off +- j];
+//                                                               positions outside the text read as sentinels (5)
+//   void leaf_at(const Root&, uint32_t kmer, uint32_t textPos)  one occurrence of k-mer `kmer` at textPos
+// Symbols are compared eight at a time (one 64-bit word per side).
+
+GM_HD uint64_t bytes_nonzero(uint64_t x)   // 0x80 in every byte of x that is not zero
+{
+    return (((x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | x) & 0x8080808080808080ull;
+}
+GM_HD uint32_t ctz64(uint64_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__ffsll((long long)x) - 1u;
+#else
+    return (uint32_t)__builtin_ctzll(x);
+#endif
+}
+
+// Scan up to `need` characters from needle coordinate q0 (upwards or downwards) at the location anchored by (p0, a0).
+// Returns how many characters can be taken: the scan stops in front of a sentinel and in front of mismatch number
+// budget + 1.  cnt = mismatches among the taken characters, pos[j] = 1-based offset of mismatch j (j < 4).
+template <class Env>
+GM_HD uint32_t scan_side(Env& env, const Root& rt, uint32_t p0, uint32_t a0, uint32_t q0, bool down, uint32_t need, uint32_t budget,
+                         uint32_t& cnt, uint32_t pos[4])
+{
+    cnt = 0;
+    for (uint32_t i = 0; i < need; i += 8u) {
+        const uint32_t q = down ? q0 - i : q0 + i;
+        const uint64_t n8 = env.needle8(rt, q, down);
+        const uint64_t t8 = env.text8(p0, (int32_t)q - (int32_t)a0, down);
+        uint64_t ev = bytes_nonzero(n8 ^ t8) | (0x8080808080808080ull & ~bytes_nonzero(n8 ^ 0x0404040404040404ull))   // mismatch, pattern N
+                      | (0x8080808080808080ull & ~bytes_nonzero(t8 ^ 0x0505050505050505ull));                           // sentinel
+        const uint32_t left = need - i;
+        if (left < 8u) ev &= (1ull << (8u * left)) - 1ull;
+        const uint64_t sent = 0x8080808080808080ull & ~bytes_nonzero(t8 ^ 0x0505050505050505ull);
+        while (ev) {
+            const uint32_t bit = ctz64(ev);
+            ev &= ev - 1ull;
+            const uint32_t j = bit >> 3;
+            if ((sent >> bit) & 1ull) return i + j;          // the occurrence ends here
+            if (cnt == budget) return i + j;                 // one mismatch too many
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if ((uint32_t)k == cnt) pos[k] = i + j + 1u;
+            ++cnt;
+        }
+    }
+    return need;
+}
+
 template <class Env>
 GM_HD void verify_item(uint32_t row, uint32_t meta, const Root& rt, uint32_t K, uint32_t E, Env& env)
 {
     uint32_t a = meta_a(meta), bx = meta_bx(meta), t = meta_t(meta), errs = meta_errs(meta), mode = meta_mode(meta);
-    const uint32_t nRows = env.rows();
     const uint32_t p0 = env.sa(row);   // aligned with needle coordinate a0 (a changes below, keep the anchor)
     const uint32_t a0 = a;
-    // symbol of the text at the place needle coordinate q maps to; sentinel when outside the text
-    auto tsym = [&](uint32_t q) -> uint32_t {
-        const uint32_t idx = p0 + q - a0;                       // wraps for q < a0 - p0: caught by idx >= nRows
-        return (q + p0 < a0 || idx >= nRows) ? (uint32_t)SYM_SENT : env.text_s(idx);
-    };
+    uint32_t scratch[4];
     if (mode == M_OSS) {
         const uint32_t nb = oss_nb(rt.rec);
         for (uint32_t bi = t; bi < nb; ++bi) {
             const uint32_t right = oss_right(rt.rec, bi), blen = oss_bl(rt.rec, bi), u = oss_u(rt.rec, bi), l = oss_l(rt.rec, bi);
-            while (bx - a < blen) {
-                const uint32_t q = right ? bx : a - 1u;
-                const uint32_t tc = tsym(q);
-                if (tc == SYM_SENT) return;
-                const uint32_t nc = env.text_char(rt, q);
-                errs += (nc == SYM_N || nc != tc) ? 1u : 0u;
-                if (errs > u) return;
-                if (right) ++bx; else --a;
-            }
-            if (errs < l) return;
+            const uint32_t need = blen - (bx - a);
+            uint32_t c = 0;
+            const uint32_t got = scan_side(env, rt, p0, a0, right ? bx : a - 1u, !right, need, u - errs, c, scratch);
+            if (got < need) return;            // sentinel, or more than u[b] errors (find2:388,397-401)
+            errs += c;
+            if (errs < l) return;              // lower bound of the block not met (find2:254-258, :389-392)
+            if (right) bx += need; else a -= need;
         }
         mode = M_SPLIT;   // infix complete: [a,bx) == [n-1, K)
     }
@@ -233,33 +272,10 @@ GM_HD void verify_item(uint32_t row, uint32_t meta, const Root& rt, uint32_t K, 
     else if (mode == M_EXT_L) { smin = bx - K; smax = t; }
     else { smin = bx - K; smax = a; }
     const uint32_t budget = E - errs;                 // mismatches still allowed
-    // 1-based offsets of the first `budget` mismatches to the right of bx / to the left of a; rlim / llim = number of
-    // characters that can be added on that side at all (stops at a sentinel or at mismatch number budget + 1)
     uint32_t rp[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu}, lp[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
-    const uint32_t rneed = smax + K - bx, lneed = a - smin;
-    uint32_t rlim = rneed, llim = lneed, rc = 0, lc = 0;
-    for (uint32_t i = 0; i < rneed; ++i) {
-        const uint32_t q = bx + i, tc = tsym(q);
-        if (tc == SYM_SENT) { rlim = i; break; }
-        const uint32_t nc = env.text_char(rt, q);
-        if (nc == SYM_N || nc != tc) {
-            if (rc == budget) { rlim = i; break; }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if ((uint32_t)j == rc) rp[j] = i + 1u;
-            ++rc;
-        }
-    }
-    for (uint32_t i = 0; i < lneed; ++i) {
-        const uint32_t q = a - 1u - i, tc = tsym(q);
-        if (tc == SYM_SENT) { llim = i; break; }
-        const uint32_t nc = env.text_char(rt, q);
-        if (nc == SYM_N || nc != tc) {
-            if (lc == budget) { llim = i; break; }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if ((uint32_t)j == lc) lp[j] = i + 1u;
-            ++lc;
-        }
-    }
+    uint32_t rc = 0, lc = 0;
+    const uint32_t rlim = scan_side(env, rt, p0, a0, bx, false, smax + K - bx, budget, rc, rp);
+    const uint32_t llim = scan_side(env, rt, p0, a0, a - 1u, true, a - smin, budget, lc, lp);
     for (uint32_t s = smin; s <= smax; ++s) {
         const uint32_t lenL = a - s, lenR = s + K - bx;
         if (lenL > llim || lenR > rlim) continue;

@@ -25,7 +25,8 @@ struct gm_index {
     uint32_t* d_blk[2] = {nullptr, nullptr};
     uint64_t blkBytes = 0;            // per direction
     uint32_t C[gm::NLET + 1] = {0, 0, 0, 0, 0, 0};
-    uint8_t* d_text = nullptr;        // sentinel-free codes, one byte each
+    uint8_t* d_text = nullptr;        // sentinel-free codes, one byte each (= d_textAlloc + 16: readers may touch a few bytes around)
+    uint8_t* d_textAlloc = nullptr; uint8_t* d_textSAlloc = nullptr;
     std::vector<uint64_t> cum;        // nSeq + 1
     uint64_t* d_cum = nullptr;
     uint32_t* d_sa = nullptr;         // forward suffix array (kept when sampling == 1): locate = one HBM read

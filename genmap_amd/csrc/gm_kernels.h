@@ -123,8 +123,32 @@ template <int WPP> struct EnvBase {
     }
     __device__ __forceinline__ uint32_t C(uint32_t c) const { return A.C[c]; }
     __device__ __forceinline__ uint32_t sa(uint32_t row) const { return A.sa[row]; }
-    __device__ __forceinline__ uint32_t text_s(uint32_t pos) const { return A.textS[pos]; }
-    __device__ __forceinline__ uint32_t rows() const { return A.nRows; }
+    // eight consecutive bytes starting at p (any alignment): two aligned 64-bit loads and a funnel shift
+    static __device__ __forceinline__ uint64_t load8_up(const uint8_t* p)
+    {
+        const uintptr_t u = reinterpret_cast<uintptr_t>(p);
+        const uint64_t* b = reinterpret_cast<const uint64_t*>(u & ~static_cast<uintptr_t>(7));
+        const uint32_t sh = (uint32_t)(u & 7u) * 8u;
+        const uint64_t lo = b[0], hi = b[1];
+        return sh ? (lo >> sh) | (hi << (64u - sh)) : lo;
+    }
+    static __device__ __forceinline__ uint64_t load8_down(const uint8_t* p) { return __builtin_bswap64(load8_up(p - 7)); }   // p[0], p[-1], ..
+    static __device__ __forceinline__ uint64_t complement8(uint64_t x)   // A<->T, C<->G, N stays N, per byte
+    {
+        const uint64_t n4 = x & 0x0404040404040404ull;
+        return (x ^ 0x0303030303030303ull) ^ ((n4 >> 1) | (n4 >> 2));
+    }
+    __device__ __forceinline__ uint64_t needle8(const Root& rt, uint32_t q, bool down) const
+    {
+        if (!rt.strand) { const uint8_t* p = A.text + (size_t)rt.win + q; return down ? load8_down(p) : load8_up(p); }
+        const uint8_t* p = A.text + (size_t)rt.win + (K + rt.n - 2u - q);   // needle(q) = comp(text[win + W - 1 - q])
+        return complement8(down ? load8_up(p) : load8_down(p));
+    }
+    __device__ __forceinline__ uint64_t text8(uint32_t p0, int32_t off, bool down) const
+    {
+        const uint8_t* p = A.textS + ((long long)p0 + off);   // 512 sentinel bytes of padding on both sides
+        return down ? load8_down(p) : load8_up(p);
+    }
 };
 
 // leaf policy 1: frequency only -- hits[a-ab] = min(countOccurrences(it) + hits[a-ab], max) (algo.hpp:48,191)
@@ -285,7 +309,7 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
             if (narrow) have = false;
             // a partial round only when the wavefront has nothing else left to do
             const bool finishing = (__ballot(have) == 0ull) && (__ballot(!exhausted) == 0ull);
-            if (qsize >= 64u || (finishing && qsize > 0u)) {
+            while (qsize >= 64u || (finishing && qsize > 0u)) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -41,8 +41,28 @@ template <int WPP> struct EmuEnv {
     const std::vector<uint8_t>* textSent = nullptr;
     uint64_t verified = 0;
     uint32_t sa(uint32_t row) const { return saArr[row]; }
-    uint32_t text_s(uint32_t pos) const { return (*textSent)[pos]; }
-    uint32_t rows() const { return (uint32_t)ix->n; }
+    uint64_t needle8(const Root& rt, uint32_t q, bool down) const
+    {
+        uint64_t v = 0;
+        const uint32_t W = K + rt.n - 1;
+        for (uint32_t j = 0; j < 8; ++j) {
+            const int64_t qq = down ? (int64_t)q - j : (int64_t)q + j;
+            uint64_t c = 0;   // outside the window: any value (the scanner masks those bytes)
+            if (qq >= 0 && qq < (int64_t)W) c = text_char(rt, (uint32_t)qq);
+            v |= c << (8 * j);
+        }
+        return v;
+    }
+    uint64_t text8(uint32_t p0, int32_t off, bool down) const
+    {
+        uint64_t v = 0;
+        for (uint32_t j = 0; j < 8; ++j) {
+            const int64_t idx = (int64_t)p0 + off + (down ? -(int64_t)j : (int64_t)j);
+            const uint64_t c = (idx < 0 || idx >= (int64_t)ix->n) ? (uint64_t)SYM_SENT : (*textSent)[idx];
+            v |= c << (8 * j);
+        }
+        return v;
+    }
     void leaf_at(const Root& rt, uint32_t kmer, uint32_t) { leafSum += 1; leaf_flush(rt, kmer); }
     const HostIndex<WPP>* ix;
     const uint8_t* text;
