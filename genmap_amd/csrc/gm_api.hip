@@ -468,10 +468,12 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     A.textS = ix->d_textS;
     A.verifyT = 0;
     if (ix->d_sa && ix->d_textS) {   // narrow nodes are resolved against the text when the SA is resident
-        int t = 1;
+        int t = 4;
         if (const char* e = getenv("GM_VERIFY_T")) t = atoi(e);
         A.verifyT = (uint32_t)std::max(0, std::min(t, (int)VERIFY_TMAX));
     }
+    A.verifyCost = 3;
+    if (const char* e = getenv("GM_VERIFY_COST")) A.verifyCost = (uint32_t)std::max(0, atoi(e));
     *Aout = A;
     return GM_OK;
 }

@@ -50,6 +50,7 @@ struct SearchArgs {
     // ---- verification of narrow nodes (gm_engine.h: verify_item) ----
     const uint8_t* textS;           // sentinel text (one code per byte, 5 = sentinel), nRows bytes
     uint32_t verifyT;               // nodes with range width <= verifyT are resolved by verification (0 = off)
+    uint32_t verifyCost;            // ... when width * verifyCost <= estimated rank steps left below the node
 };
 
 // sentinel-text position -> (seqNo, seqPos); sequence s starts at cum[s] + s
@@ -294,7 +295,13 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
         }
         // ---- defer narrow nodes: one queue entry per SA row ----
         if (A.verifyT) {
-            const bool narrow = have && nd.w <= A.verifyT;
+            bool narrow = have && nd.w <= A.verifyT;
+            if (narrow) {   // is the subtree below worth one SA read + one text comparison per row?
+                const uint32_t m = nd.meta, a = meta_a(m), bx = meta_bx(m), t = meta_t(m), md = meta_mode(m);
+                const uint32_t covered = md == M_OSS ? rt.n : md == M_EXT_R ? a + A.K - t + 1u : md == M_EXT_L ? t + A.K - bx + 1u : a + A.K - bx + 1u;
+                const uint32_t est = (A.K - (bx - a)) + covered - 1u;   // lower bound of the steps still needed
+                narrow = nd.w * A.verifyCost <= est;
+            }
 #pragma unroll 1
             for (uint32_t r = 0; r < VERIFY_TMAX; ++r) {
                 const bool e = narrow && r < nd.w;
