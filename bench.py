@@ -153,6 +153,7 @@ def main():
         }
     # ---- roofline numerator: count node steps / distinct rank lines with the instrumented twin (untimed) ----
     lines = steps_cnt = None
+    v_items = v_chunks = 0
     if rank == 0 and world == 1 and not args.no_counters and g.lib_path(True).exists():
         try:
             bf, br = ix.export_bwt()
@@ -162,6 +163,7 @@ def main():
             ixp.map_device(tmp.data_ptr(), K, E, value_bits=8, stream=stream)
             sp = ixp.last_stats()
             lines, steps_cnt = sp["rank_lines"], sp["node_steps"]
+            v_items, v_chunks = sp["detail"]["verify_items"], sp["detail"]["verify_chunks"]
             ixp.close()
             del tmp
         except Exception as e:  # measurement aid only
@@ -169,7 +171,8 @@ def main():
     if rank == 0:
         bb = info["block_bytes"]
         if lines:
-            alg = bb * lines + 2 * n + n   # rank lines + text read once per strand (1 B/char) + 8-bit output
+            # rank blocks + text read once per strand (1 B/char) + 8-bit output + verification (SA entry, 2 x 8 symbols per chunk)
+            alg = bb * lines + 2 * n + n + 4 * v_items + 16 * v_chunks
             ach = alg / (kernel_ms * 1e-3) / 1e9
             traffic = None
             tf = ROOT / "profiles" / "pmc_traffic.json"
@@ -183,7 +186,8 @@ def main():
             result["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                   "traffic": traffic, "kernel": "search_kernel", "kernel_ms": kernel_ms,
                                   "algorithmic_bytes": alg, "rank_lines": lines, "node_steps": steps_cnt,
-                                  "node_steps_per_kmer": steps_cnt / num_kmers}
+                                  "node_steps_per_kmer": steps_cnt / num_kmers,
+                                  "verify_items": v_items, "verify_chunks": v_chunks}
         else:
             result["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                                   "kernel": "search_kernel", "kernel_ms": kernel_ms}

@@ -34,7 +34,7 @@ class IndexInfo(C.Structure):
 
 class MapStats(C.Structure):
     _fields_ = [("kmers", C.c_uint64), ("roots", C.c_uint64), ("node_steps", C.c_uint64), ("rank_lines", C.c_uint64),
-                ("detail", C.c_uint64 * 6), ("search_ms", C.c_double), ("total_ms", C.c_double)]
+                ("detail", C.c_uint64 * 9), ("search_ms", C.c_double), ("total_ms", C.c_double)]
 
 
 class Locations(C.Structure):
@@ -61,6 +61,13 @@ def load_library(profiling=False):
         return _LIB
     if not path.exists():
         raise GenmapError(-1, f"{path} not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
+    # One HIP runtime per process: PyTorch ships its own libamdhip64 (same SONAME as /opt/rocm's).  If this library
+    # pulled in /opt/rocm's copy first, a later `import torch` would be bound to it and fail to see the GPU; loading
+    # torch first makes both share torch's runtime, so torch tensors' device pointers are valid here.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is optional for the binding itself
+        pass
     lib = C.CDLL(str(path))
     vp = C.c_void_p
     lib.gm_status_string.restype = C.c_char_p
@@ -224,5 +231,5 @@ class Index:
         s = MapStats()
         _check(self._lib, self._lib.gm_last_map_stats(self._h, C.byref(s)))
         d = {k: getattr(s, k) for k, _ in MapStats._fields_}
-        d["detail"] = dict(zip(("steps_oss", "steps_ext", "ext_w1", "ext_w2_4", "oss_w1", "pushes"), list(s.detail)))
+        d["detail"] = dict(zip(("steps_oss", "steps_ext", "ext_w1", "ext_w2_4", "oss_w1", "pushes", "verify_items", "verify_items_oss", "verify_chunks"), list(s.detail)))
         return d

@@ -468,7 +468,8 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     A.textS = ix->d_textS;
     A.verifyT = 0;
     if (ix->d_sa && ix->d_textS) {   // narrow nodes are resolved against the text when the SA is resident
-        int t = 4;
+        int t = 1;
+        if (plan.stepSize >= 32) t = 4;   // long blocks (e.g. K=100): a narrow node still covers many k-mers (profiles/r01c)
         if (const char* e = getenv("GM_VERIFY_T")) t = atoi(e);
         A.verifyT = (uint32_t)std::max(0, std::min(t, (int)VERIFY_TMAX));
     }
@@ -666,10 +667,10 @@ int gm_last_map_stats(const gm_index* cix, gm_map_stats* out)
     GM_HIP(hipEventElapsedTime(&a, ix->ev[1], ix->ev[2]));
     GM_HIP(hipEventElapsedTime(&b, ix->ev[0], ix->ev[3]));
     ix->stats.search_ms = a; ix->stats.total_ms = b;
-    unsigned long long cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    GM_HIP(hipMemcpy(cnt, reinterpret_cast<char*>(ix->d_small) + 16, 64, hipMemcpyDeviceToHost));
+    unsigned long long cnt[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    GM_HIP(hipMemcpy(cnt, reinterpret_cast<char*>(ix->d_small) + 16, 88, hipMemcpyDeviceToHost));
     ix->stats.node_steps = cnt[0]; ix->stats.rank_lines = cnt[1];
-    for (int i = 0; i < 6; ++i) ix->stats.detail[i] = cnt[2 + i];
+    for (int i = 0; i < 9; ++i) ix->stats.detail[i] = cnt[2 + i];
     int rc = check_device_error(ix);
     *out = ix->stats;
     return rc;

@@ -227,6 +227,7 @@ GM_HD uint32_t scan_side(Env& env, const Root& rt, uint32_t p0, uint32_t a0, uin
         const uint32_t q = down ? q0 - i : q0 + i;
         const uint64_t n8 = env.needle8(rt, q, down);
         const uint64_t t8 = env.text8(p0, (int32_t)q - (int32_t)a0, down);
+        env.note_chunk();
         uint64_t ev = bytes_nonzero(n8 ^ t8) | (0x8080808080808080ull & ~bytes_nonzero(n8 ^ 0x0404040404040404ull))   // mismatch, pattern N
                       | (0x8080808080808080ull & ~bytes_nonzero(t8 ^ 0x0505050505050505ull));                           // sentinel
         const uint32_t left = need - i;
@@ -251,6 +252,7 @@ GM_HD void verify_item(uint32_t row, uint32_t meta, const Root& rt, uint32_t K, 
 {
     uint32_t a = meta_a(meta), bx = meta_bx(meta), t = meta_t(meta), errs = meta_errs(meta), mode = meta_mode(meta);
     const uint32_t p0 = env.sa(row);   // aligned with needle coordinate a0 (a changes below, keep the anchor)
+    env.note_item(mode);
     const uint32_t a0 = a;
     uint32_t scratch[4];
     if (mode == M_OSS) {

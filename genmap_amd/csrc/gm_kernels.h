@@ -71,13 +71,17 @@ template <int WPP> struct EnvBase {
     uint32_t sp;
     uint32_t K;
 #ifdef GM_COUNTERS
-    uint32_t steps = 0, lines = 0, stOss = 0, stExt = 0, stExtW1 = 0, stExtW4 = 0, stOssW1 = 0, pushes = 0;
+    uint32_t steps = 0, lines = 0, stOss = 0, stExt = 0, stExtW1 = 0, stExtW4 = 0, stOssW1 = 0, pushes = 0, vItems = 0, vItemsOss = 0, vChunks = 0;
+    __device__ __forceinline__ void note_chunk() { vChunks++; }
+    __device__ __forceinline__ void note_item(uint32_t mode) { vItems++; vItemsOss += (mode == M_OSS); }
     __device__ __forceinline__ void note_step(uint32_t mode, uint32_t w)
     {
         if (mode == M_OSS) { stOss++; stOssW1 += (w == 1u); } else { stExt++; stExtW1 += (w == 1u); stExtW4 += (w > 1u && w <= 4u); }
     }
 #else
     __device__ __forceinline__ void note_step(uint32_t, uint32_t) {}
+    __device__ __forceinline__ void note_chunk() {}
+    __device__ __forceinline__ void note_item(uint32_t) {}
 #endif
     __device__ __forceinline__ EnvBase(const SearchArgs& a, uint4* s, uint32_t k) : A(a), stk(s), sp(0), K(k) {}
     __device__ __forceinline__ uint32_t slice_pos(const Root& rt, uint32_t kmer) const { return rt.win + (rt.strand ? rt.n - 1u - kmer : kmer); }
@@ -352,6 +356,9 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
     atomicAdd(&A.counters[5], (unsigned long long)env.stExtW4);
     atomicAdd(&A.counters[6], (unsigned long long)env.stOssW1);
     atomicAdd(&A.counters[7], (unsigned long long)env.pushes);
+    atomicAdd(&A.counters[8], (unsigned long long)env.vItems);
+    atomicAdd(&A.counters[9], (unsigned long long)env.vItemsOss);
+    atomicAdd(&A.counters[10], (unsigned long long)env.vChunks);
 #endif
 }
 

@@ -86,6 +86,8 @@ template <int WPP> struct EmuEnv {
     }
     void push(const Node& nd) { stack.push_back(nd); if (stack.size() > maxDepth) maxDepth = stack.size(); }
     void note_step(uint32_t, uint32_t) {}
+    void note_chunk() {}
+    void note_item(uint32_t) {}
     uint32_t leafSum = 0;
     void leaf(const Root&, uint32_t, uint32_t, uint32_t w) { leafSum += w; }
     void leaf_flush(const Root& rt, uint32_t kmer)

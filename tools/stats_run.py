@@ -12,7 +12,7 @@ ap.add_argument("--workload", default="chr1"); ap.add_argument("--scale", type=f
 ap.add_argument("--cfg", nargs="+", default=["30,0", "30,1", "30,2", "100,1"])
 a = ap.parse_args()
 codes, lens, desc = synth.workload(a.workload, a.scale)
-ix = g.Index.build(codes, lens, sampling=0, profiling=True)
+ix = g.Index.build(codes, lens, sampling=1, profiling=True)
 out = torch.zeros(len(codes) + 16, dtype=torch.uint8, device="cuda:0")
 for cfg in a.cfg:
     K, E = map(int, cfg.split(","))
@@ -22,4 +22,4 @@ for cfg in a.cfg:
     d = st["detail"]
     print(json.dumps({"workload": desc, "K": K, "E": E, "kmers": nk, "steps_per_kmer": st["node_steps"] / nk, "lines_per_kmer": st["rank_lines"] / nk,
                       "oss_frac": d["steps_oss"] / st["node_steps"], "ext_w1_frac": d["ext_w1"] / st["node_steps"], "ext_w2_4_frac": d["ext_w2_4"] / st["node_steps"],
-                      "oss_w1_frac": d["oss_w1"] / st["node_steps"], "pushes_per_step": d["pushes"] / st["node_steps"], "search_ms_instrumented": st["search_ms"]}))
+                      "oss_w1_frac": d["oss_w1"] / st["node_steps"], "pushes_per_step": d["pushes"] / st["node_steps"], "verify_items_per_kmer": d["verify_items"] / nk, "verify_items_oss_frac": d["verify_items_oss"] / max(1, d["verify_items"]), "chunks_per_item": d["verify_chunks"] / max(1, d["verify_items"]), "search_ms_instrumented": st["search_ms"]}))
