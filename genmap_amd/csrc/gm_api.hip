@@ -68,6 +68,16 @@ __global__ __launch_bounds__(256) void unpack_blocks_kernel(const uint32_t* __re
     bwt[i] = (uint8_t)(((b[5 + w] >> t) & 1u) | (((b[5 + WPP + w] >> t) & 1u) << 1) | (((b[5 + 2 * WPP + w] >> t) & 1u) << 2));
 }
 
+// 4-bit packed copy of the text: chunk c holds symbols [32c, 32c + 32), symbol i in nibble (i & 1) of byte (i >> 1)
+__global__ __launch_bounds__(256) void pack_text4_kernel(const uint8_t* __restrict__ codes, uint64_t textLen, uint32_t* __restrict__ out, uint64_t nWords)
+{
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nWords) return;
+    uint32_t v = 0;
+    for (uint32_t j = 0; j < 8; ++j) { const uint64_t i = w * 8 + j; const uint32_t c = i < textLen ? codes[i] : 0u; v |= (c & 15u) << (4u * j); }
+    out[w] = v;
+}
+
 // sentinel text: sequence s occupies [cum[s] + s, cum[s+1] + s), its sentinel follows
 __global__ __launch_bounds__(256) void sentinel_text_kernel(const uint8_t* __restrict__ codes, const uint64_t* __restrict__ cum, uint32_t nSeq, uint64_t textLen,
                                                             uint8_t* __restrict__ out)
@@ -174,6 +184,12 @@ static int index_common_setup(gm_index* ix, const uint8_t* codes, const uint64_t
     GM_HIP(hipMemset(ix->d_textAlloc, 0, ix->textLen + 64));
     ix->d_text = ix->d_textAlloc + 16;
     GM_HIP(hipMemcpy(ix->d_text, codes, ix->textLen, hipMemcpyHostToDevice));
+    {
+        const uint64_t nChunks = ix->textLen / 32 + 12, nWords = nChunks * 4;   // +12 chunks: window staging may read past the end
+        GM_HIP(hipMalloc(&ix->d_text4, nChunks * 16));
+        hipLaunchKernelGGL(pack_text4_kernel, dim3(grid_for(nWords)), dim3(256), 0, 0, ix->d_text, ix->textLen, reinterpret_cast<uint32_t*>(ix->d_text4), nWords);
+        GM_HIP(hipGetLastError());
+    }
     GM_HIP(hipMalloc(&ix->d_cum, ((size_t)n_seq + 1) * 8));
     GM_HIP(hipMemcpy(ix->d_cum, ix->cum.data(), ((size_t)n_seq + 1) * 8, hipMemcpyHostToDevice));
     GM_HIP(hipMalloc(&ix->d_small, 256));
@@ -221,7 +237,7 @@ void gm_index_free(gm_index* ix)
 {
     if (!ix) return;
     hipSetDevice(ix->device);
-    hipFree(ix->d_blk[0]); hipFree(ix->d_blk[1]); hipFree(ix->d_textAlloc); hipFree(ix->d_cum); hipFree(ix->d_sa); hipFree(ix->d_textSAlloc); hipFree(ix->d_seqFile); hipFree(ix->d_bits);
+    hipFree(ix->d_blk[0]); hipFree(ix->d_blk[1]); hipFree(ix->d_textAlloc); hipFree(ix->d_text4); hipFree(ix->d_cum); hipFree(ix->d_sa); hipFree(ix->d_textSAlloc); hipFree(ix->d_seqFile); hipFree(ix->d_bits);
     hipFree(ix->d_acc); hipFree(ix->d_stack); hipFree(ix->d_small); hipFree(ix->d_table); hipFree(ix->d_blocks); hipFree(ix->d_cumLocal);
     for (int i = 0; i < 4; ++i) if (ix->ev[i]) hipEventDestroy(ix->ev[i]);
     delete ix;
@@ -335,10 +351,12 @@ template <typename T> static int grow(T** p, uint64_t* cap, uint64_t need)
 
 enum LeafMode { LEAF_COUNT = 0, LEAF_FILESET = 1, LEAF_OCC_COUNT = 2, LEAF_OCC_EMIT = 3 };
 
+static inline size_t search_lds_bytes(const SearchArgs& A) { return (size_t)(4u * A.vqCap + 4u * 64u * (A.ldsDepth + A.winChunks)) * 16u; }
+
 template <int WPP, class EnvT>
 static int launch_one(const SearchArgs& A, unsigned blocks, hipStream_t st)
 {
-    hipLaunchKernelGGL((search_kernel<WPP, EnvT>), dim3(blocks), dim3(256), 0, st, A);
+    hipLaunchKernelGGL((search_kernel<WPP, EnvT>), dim3(blocks), dim3(256), search_lds_bytes(A), st, A);
     GM_HIP(hipGetLastError());
     return GM_OK;
 }
@@ -361,10 +379,10 @@ static int launch_search(const gm_index* ix, int mode, const SearchArgs& A, unsi
     }
 }
 
-template <int WPP> static int occupancy_blocks(int* out)
+template <int WPP> static int occupancy_blocks(int* out, size_t ldsBytes)
 {
     int nb = 0;
-    GM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (search_kernel<WPP, CountEnv<WPP>>), 256, 0));
+    GM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (search_kernel<WPP, CountEnv<WPP>>), 256, ldsBytes));
     *out = nb;
     return GM_OK;
 }
@@ -427,8 +445,23 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     rc = grow(&ix->d_table, &ix->tableCap, (uint64_t)plan.table.size()); if (rc) return rc;
     rc = grow(&ix->d_cumLocal, &ix->cumLocalCap, (uint64_t)n_seq + 1); if (rc) return rc;
     if (plan.useList) { rc = grow(&ix->d_blocks, &ix->blocksCap, std::max<uint64_t>(plan.blocks.size(), 1)); if (rc) return rc; }
+    // LDS staging per block of 4 wavefronts: verification queue, top of the lane stacks, packed needle windows
+    uint32_t verifyT = 0;
+    if (ix->d_sa && ix->d_textS) {   // narrow nodes are resolved against the text when the SA is resident
+        int t = 1;
+        if (plan.stepSize >= 32) t = 4;   // long blocks (e.g. K=100): a narrow node still covers many k-mers (profiles/r01c)
+        if (const char* e = getenv("GM_VERIFY_T")) t = atoi(e);
+        verifyT = (uint32_t)std::max(0, std::min(t, (int)VERIFY_TMAX));
+    }
+    const uint32_t depth = stack_bound(p->E, plan.stepSize);
+    const uint32_t vqCap = verifyT ? 64u + 64u * verifyT : 1u;
+    const uint32_t winChunks = (31u + p->K + plan.stepSize - 1u + 31u) / 32u;
+    uint32_t ldsDepth = 4;
+    if (const char* e = getenv("GM_LDS_STACK")) ldsDepth = (uint32_t)std::max(0, atoi(e));
+    ldsDepth = std::min(ldsDepth, depth);
+    const size_t ldsBytes = (size_t)(4u * vqCap + 4u * 64u * (ldsDepth + winChunks)) * 16u;
     int perCU = 0;
-    switch (ix->wpp) { case 1: rc = occupancy_blocks<1>(&perCU); break; case 3: rc = occupancy_blocks<3>(&perCU); break; default: rc = occupancy_blocks<9>(&perCU); break; }
+    switch (ix->wpp) { case 1: rc = occupancy_blocks<1>(&perCU, ldsBytes); break; case 3: rc = occupancy_blocks<3>(&perCU, ldsBytes); break; default: rc = occupancy_blocks<9>(&perCU, ldsBytes); break; }
     if (rc) return rc;
     int wantPerCU = 4;   // measured (profiles/r01a): 16 waves/CU beat full occupancy (less cache/TLB pressure)
     if (const char* e = getenv("GM_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0) wantPerCU = v; }
@@ -437,8 +470,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     const uint64_t useful = (S->numRoots + 255) / 256;
     if (blocks > useful) blocks = std::max<uint64_t>(useful, 1);
     S->blocks = (unsigned)blocks;
-    const uint32_t depth = stack_bound(p->E, plan.stepSize);
-    rc = grow(&ix->d_stack, &ix->stackCap, blocks * 256ull * depth); if (rc) return rc;
+    rc = grow(&ix->d_stack, &ix->stackCap, blocks * 256ull * std::max<uint32_t>(depth - ldsDepth, 1u)); if (rc) return rc;
 
     GM_HIP(hipMemcpyAsync(ix->d_table, plan.table.data(), plan.table.size() * sizeof(OssRecord), hipMemcpyHostToDevice, st));
     if (plan.useList && !plan.blocks.empty())
@@ -459,20 +491,15 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     A.blockBegin = blockBegin; A.numRoots = S->numRoots;
     A.blockList = plan.useList ? ix->d_blocks : nullptr;
     A.table = ix->d_table;
-    A.stack = ix->d_stack; A.stackDepth = depth;
+    A.stack = ix->d_stack; A.stackDepth = depth; A.spillDepth = std::max<uint32_t>(depth - ldsDepth, 1u);
+    A.text4 = ix->d_text4; A.textBegin = text_begin; A.vqCap = vqCap; A.ldsDepth = ldsDepth; A.winChunks = winChunks;
     A.workCounter = reinterpret_cast<unsigned long long*>(ix->d_small);
     A.errorFlag = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ix->d_small) + 8);
     A.counters = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ix->d_small) + 16);
     A.sa = ix->d_sa; A.cumGlobal = ix->d_cum; A.nSeqGlobal = ix->nSeq;
     A.posBase = S->posBase; A.windowLen = S->posEnd - S->posBase;
     A.textS = ix->d_textS;
-    A.verifyT = 0;
-    if (ix->d_sa && ix->d_textS) {   // narrow nodes are resolved against the text when the SA is resident
-        int t = 1;
-        if (plan.stepSize >= 32) t = 4;   // long blocks (e.g. K=100): a narrow node still covers many k-mers (profiles/r01c)
-        if (const char* e = getenv("GM_VERIFY_T")) t = atoi(e);
-        A.verifyT = (uint32_t)std::max(0, std::min(t, (int)VERIFY_TMAX));
-    }
+    A.verifyT = verifyT;
     A.verifyCost = 3;
     if (const char* e = getenv("GM_VERIFY_COST")) A.verifyCost = (uint32_t)std::max(0, atoi(e));
     *Aout = A;

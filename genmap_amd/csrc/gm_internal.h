@@ -27,6 +27,7 @@ struct gm_index {
     uint32_t C[gm::NLET + 1] = {0, 0, 0, 0, 0, 0};
     uint8_t* d_text = nullptr;        // sentinel-free codes, one byte each (= d_textAlloc + 16: readers may touch a few bytes around)
     uint8_t* d_textAlloc = nullptr; uint8_t* d_textSAlloc = nullptr;
+    uint4* d_text4 = nullptr;         // the text at 4 bits per symbol: needle windows are staged into LDS from it
     std::vector<uint64_t> cum;        // nSeq + 1
     uint64_t* d_cum = nullptr;
     uint32_t* d_sa = nullptr;         // forward suffix array (kept when sampling == 1): locate = one HBM read

@@ -31,7 +31,8 @@ struct SearchArgs {
     const uint2* blockList;     // (first k-mer, count) per block, or nullptr for the arithmetic partition
     const uint4* table;         // OssRecord[(n-1)*8 + s]
     uint4* stack;               // lane-private LIFOs: stack[lane * stackDepth + i]
-    uint32_t stackDepth;
+    uint32_t stackDepth;            // total entries a lane may stack (LDS part + spill part)
+    uint32_t spillDepth;            // entries per lane in `stack`
     unsigned long long* workCounter;
     uint32_t* errorFlag;
     unsigned long long* counters;   // [0] node steps, [1] distinct rank lines (only with GM_COUNTERS)
@@ -51,6 +52,12 @@ struct SearchArgs {
     const uint8_t* textS;           // sentinel text (one code per byte, 5 = sentinel), nRows bytes
     uint32_t verifyT;               // nodes with range width <= verifyT are resolved by verification (0 = off)
     uint32_t verifyCost;            // ... when width * verifyCost <= estimated rank steps left below the node
+    // ---- LDS staging (per wavefront): verification queue | top of the lane stacks | packed needle windows ----
+    const uint4* text4;             // whole text, 4 bits per symbol (32 symbols per 16-byte chunk), sentinel-free
+    uint64_t textBegin;             // slice offset inside the text (symbols)
+    uint32_t vqCap;                 // queue entries per wavefront
+    uint32_t ldsDepth;              // stack entries per lane kept in LDS (deeper ones spill to `stack`)
+    uint32_t winChunks;             // 16-byte chunks per lane for the needle window
 };
 
 // sentinel-text position -> (seqNo, seqPos); sequence s starts at cum[s] + s
@@ -63,11 +70,13 @@ __device__ __forceinline__ uint2 locate_position(const uint64_t* __restrict__ cu
 
 constexpr uint32_t WORK_CHUNK = 256;   // roots taken from the global counter per atomic
 constexpr uint32_t VERIFY_TMAX = 4;    // widest range resolved by verification
-constexpr uint32_t VQ_CAP = 64 + 64 * VERIFY_TMAX;
 
 template <int WPP> struct EnvBase {
     const SearchArgs& A;
-    uint4* stk;
+    uint4* stk;          // global spill area of this lane
+    uint4* lstk;         // LDS: [depth][lane] of this wavefront, already offset by the lane
+    const uint8_t* lwin; // LDS: [chunk][lane] 16-byte chunks of this lane's packed window, already offset by the lane
+    uint32_t woff;       // nibble offset of the window inside its first chunk
     uint32_t sp;
     uint32_t K;
 #ifdef GM_COUNTERS
@@ -83,7 +92,22 @@ template <int WPP> struct EnvBase {
     __device__ __forceinline__ void note_chunk() {}
     __device__ __forceinline__ void note_item(uint32_t) {}
 #endif
-    __device__ __forceinline__ EnvBase(const SearchArgs& a, uint4* s, uint32_t k) : A(a), stk(s), sp(0), K(k) {}
+    __device__ __forceinline__ EnvBase(const SearchArgs& a, uint4* s, uint32_t k) : A(a), stk(s), lstk(nullptr), lwin(nullptr), woff(0), sp(0), K(k) {}
+    // stage the root's window: W = K + n - 1 symbols starting at text position textBegin + win
+    __device__ __forceinline__ void load_window(const Root& rt)
+    {
+        const uint64_t g = A.textBegin + rt.win;
+        woff = (uint32_t)(g & 31u);
+        const uint4* src = A.text4 + (g >> 5);
+        const uint32_t nch = (woff + K + rt.n - 1u + 31u) >> 5;
+        uint4* dst = reinterpret_cast<uint4*>(const_cast<uint8_t*>(lwin));
+        for (uint32_t c = 0; c < nch; ++c) dst[c * 64u] = src[c];
+    }
+    __device__ __forceinline__ uint4 pop()
+    {
+        --sp;
+        return sp < A.ldsDepth ? lstk[sp * 64u] : stk[sp - A.ldsDepth];
+    }
     __device__ __forceinline__ uint32_t slice_pos(const Root& rt, uint32_t kmer) const { return rt.win + (rt.strand ? rt.n - 1u - kmer : kmer); }
 
     __device__ __forceinline__ void rank2(uint32_t right, uint32_t lo, uint32_t hi, uint32_t rl[NLET], uint32_t rh[NLET])
@@ -114,8 +138,9 @@ template <int WPP> struct EnvBase {
     __device__ __forceinline__ uint32_t text_char(const Root& rt, uint32_t pos) const
     {
         const uint32_t W = K + rt.n - 1u;
-        const uint32_t idx = rt.strand ? (W - 1u - pos) : pos;
-        const uint32_t c = A.text[(size_t)rt.win + idx];
+        const uint32_t nib = woff + (rt.strand ? (W - 1u - pos) : pos);
+        const uint32_t b = lwin[(nib >> 5) * 1024u + ((nib & 31u) >> 1)];   // chunk stride = 64 lanes x 16 bytes
+        const uint32_t c = (b >> ((nib & 1u) * 4u)) & 15u;
         return rt.strand ? complement(c) : c;
     }
     __device__ __forceinline__ void push(const Node& nd)
@@ -123,7 +148,9 @@ template <int WPP> struct EnvBase {
 #ifdef GM_COUNTERS
         pushes++;
 #endif
-        if (sp < A.stackDepth) { stk[sp] = make_uint4(nd.flo, nd.rlo, nd.w, nd.meta); ++sp; }
+        const uint4 v = make_uint4(nd.flo, nd.rlo, nd.w, nd.meta);
+        if (sp < A.ldsDepth) { lstk[sp * 64u] = v; ++sp; }
+        else if (sp < A.stackDepth) { stk[sp - A.ldsDepth] = v; ++sp; }
         else *A.errorFlag = 1u;   // never expected: depth = stack_bound(E, stepSize)
     }
     __device__ __forceinline__ uint32_t C(uint32_t c) const { return A.C[c]; }
@@ -238,13 +265,16 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const size_t gl = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    EnvT env(A, A.stack + gl * A.stackDepth, A.K);
+    EnvT env(A, A.stack + gl * A.spillDepth, A.K);
     Node nd; nd.flo = nd.rlo = nd.w = nd.meta = 0;
     Root rt; rt.win = 0; rt.n = 1; rt.strand = 0; rt.search = 0; rt.rec = OssRecord{0, 0, 0, 0};
     // per-wavefront queue of narrow nodes awaiting verification: filled by ballot rank, drained 64 at a time so that a
     // verification round keeps every lane busy with the same kind of loop
-    __shared__ uint4 vqAll[4 * VQ_CAP];
-    uint4* vq = vqAll + (threadIdx.x >> 6) * VQ_CAP;
+    extern __shared__ uint4 smem[];
+    const uint32_t wv = threadIdx.x >> 6;
+    uint4* vq = smem + wv * A.vqCap;
+    env.lstk = smem + 4u * A.vqCap + wv * (A.ldsDepth * 64u) + lane;
+    env.lwin = reinterpret_cast<const uint8_t*>(smem + 4u * A.vqCap + 4u * A.ldsDepth * 64u + wv * (A.winChunks * 64u) + lane);
     uint32_t qsize = 0;                             // wave-uniform
     bool have = false, exhausted = false;
     unsigned long long poolCur = 0, poolEnd = 0;   // wave-uniform
@@ -252,7 +282,7 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
 
     for (;;) {
         if (!have && env.sp > 0) {
-            const uint4 v = env.stk[--env.sp];
+            const uint4 v = env.pop();
             nd.flo = v.x; nd.rlo = v.y; nd.w = v.z; nd.meta = v.w;
             have = true;
         }
@@ -289,6 +319,7 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
                     rt.search = r - rt.strand * A.nSearches;
                     const uint4 q = A.table[(size_t)(rt.n - 1u) * 8u + rt.search];
                     rt.rec.x = q.x; rt.rec.y = q.y; rt.rec.z = q.z; rt.rec.w = q.w;
+                    env.load_window(rt);
                     nd = root_node(rt, A.nRows);
                     have = true;
                 } else if (globalDone && avail == 0u) {
