@@ -132,6 +132,7 @@ GM_HD Post make_post(uint32_t meta, const Plan& pl, const OssRecord& rec, uint32
 //   void leaf_flush(const Root&, uint32_t kmer)       after the last leaf() of a step
 //   uint32_t C(uint32_t c)                            (first row of letter c)
 //   void note_step(uint32_t mode, uint32_t width)     (statistics hook)
+//   bool any(bool)                                    (true if the predicate holds in any lane of the wavefront)
 // On return `have` tells whether nd holds a node to continue with.
 template <class Env>
 GM_HD void lane_step(Node& nd, bool& have, const Root& rt, uint32_t K, uint32_t E, Env& env)
@@ -146,37 +147,45 @@ GM_HD void lane_step(Node& nd, bool& have, const Root& rt, uint32_t K, uint32_t 
     const uint32_t errs = meta_errs(nd.meta);
     const uint32_t olo = pl.right ? nd.flo : nd.rlo;
 
-    uint32_t cnt[NLET], sm[NLET], tot = 0;
+    // per letter: occurrences, rows below it inside the range, first row of the child; validity as a bit mask
+    uint32_t cnt[NLET], sm[NLET], pn[NLET], tot = 0;
 #pragma unroll
-    for (int x = 0; x < (int)NLET; ++x) { cnt[x] = rh[x] - rl[x]; tot += cnt[x]; }
+    for (int x = 0; x < (int)NLET; ++x) { cnt[x] = rh[x] - rl[x]; tot += cnt[x]; pn[x] = env.C((uint32_t)x) + rl[x]; }
     uint32_t run = nd.w - tot;   // sentinels in BWT[lo,hi) sort before every letter
+    uint32_t valid = 0;
 #pragma unroll
-    for (int x = 0; x < (int)NLET; ++x) { sm[x] = run; run += cnt[x]; }
+    for (int x = 0; x < (int)NLET; ++x) {
+        sm[x] = run; run += cnt[x];
+        const uint32_t delta = ((uint32_t)x != tc || tc == SYM_N) ? 1u : 0u;       // find2:250, algo.hpp:111-112,148-149
+        const bool ok = cnt[x] != 0u && !(pl.exact && delta)                         // exact segment: only the needle letter
+                        && !(pl.minErr > 0u && pl.charsLeft + delta < pl.minErr + 1u);   // find2:254-258
+        valid |= (ok ? 1u : 0u) << x;
+    }
 
     Node keep; keep.flo = keep.rlo = keep.w = keep.meta = 0;
     bool haveKeep = false;
-    // order: the matching child first (it ends up deepest in the LIFO), mismatching children after it;
-    // the lane continues with the last one.  This bounds the stack by 4*E + log2(n) + c.
+    // Children are visited in the lane's own rotated order tc, tc+1, .. (mod 5): the matching child first (it ends
+    // up deepest in the LIFO), mismatching children after it; the lane continues with the last one.  This bounds the
+    // stack by 4*E + log2(n) + c and lets exact-mode lanes finish in the first round.
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-        for (int x = 0; x < (int)NLET; ++x) {
-            const bool isMatch = ((uint32_t)x == tc);        // tc == N never "matches" (delta = 1 below)
-            if (pass == 0 ? !isMatch : isMatch) continue;
-            if (cnt[x] == 0) continue;
-            const uint32_t delta = (!isMatch || tc == SYM_N) ? 1u : 0u;   // find2:250, algo.hpp:111-112,148-149
-            if (pl.exact && delta) continue;                  // exact segment: pattern N or another letter fails
-            if (pl.minErr > 0 && pl.charsLeft + delta < pl.minErr + 1u) continue;   // find2:254-258
-            const uint32_t pnew = env.C((uint32_t)x) + rl[x];
-            const uint32_t onew = olo + sm[x];
-            if (ps.leaf) { env.leaf(rt, ps.kmer, pl.right ? onew : pnew, cnt[x]); continue; }
-            Node ch;
-            ch.flo = pl.right ? onew : pnew;
-            ch.rlo = pl.right ? pnew : onew;
-            ch.w = cnt[x];
-            ch.meta = ps.meta0 | ((errs + delta) << 24);
-            if (haveKeep) env.push(keep);
-            keep = ch; haveKeep = true;
+    for (int k = 0; k < (int)NLET; ++k) {
+        uint32_t x = tc + (uint32_t)k; if (x >= NLET) x -= NLET;
+        const bool on = ((valid >> x) & 1u) != 0u;
+        if (!env.any(on)) continue;
+        if (on) {
+            const uint32_t cx = x == 0 ? cnt[0] : x == 1 ? cnt[1] : x == 2 ? cnt[2] : x == 3 ? cnt[3] : cnt[4];
+            const uint32_t pnew = x == 0 ? pn[0] : x == 1 ? pn[1] : x == 2 ? pn[2] : x == 3 ? pn[3] : pn[4];
+            const uint32_t onew = olo + (x == 0 ? sm[0] : x == 1 ? sm[1] : x == 2 ? sm[2] : x == 3 ? sm[3] : sm[4]);
+            const uint32_t delta = (k != 0 || tc == SYM_N) ? 1u : 0u;
+            if (ps.leaf) env.leaf(rt, ps.kmer, pl.right ? onew : pnew, cx);
+            else {
+                if (haveKeep) env.push(keep);
+                keep.flo = pl.right ? onew : pnew;
+                keep.rlo = pl.right ? pnew : onew;
+                keep.w = cx;
+                keep.meta = ps.meta0 | ((errs + delta) << 24);
+                haveKeep = true;
+            }
         }
     }
     if (ps.leaf) env.leaf_flush(rt, ps.kmer);

@@ -154,6 +154,7 @@ template <int WPP> struct EnvBase {
         else *A.errorFlag = 1u;   // never expected: depth = stack_bound(E, stepSize)
     }
     __device__ __forceinline__ uint32_t C(uint32_t c) const { return A.C[c]; }
+    __device__ __forceinline__ bool any(bool b) const { return __ballot(b) != 0ull; }
     __device__ __forceinline__ uint32_t sa(uint32_t row) const { return A.sa[row]; }
     // eight consecutive bytes starting at p (any alignment): two aligned 64-bit loads and a funnel shift
     static __device__ __forceinline__ uint64_t load8_up(const uint8_t* p)

@@ -86,6 +86,7 @@ template <int WPP> struct EmuEnv {
     }
     void push(const Node& nd) { stack.push_back(nd); if (stack.size() > maxDepth) maxDepth = stack.size(); }
     void note_step(uint32_t, uint32_t) {}
+    bool any(bool b) const { return b; }
     void note_chunk() {}
     void note_item(uint32_t) {}
     uint32_t leafSum = 0;
