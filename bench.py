@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--K", type=int, default=30)
     ap.add_argument("--E", type=int, default=0)
     ap.add_argument("--block-bytes", type=int, default=0)
+    ap.add_argument("--infix", type=int, default=0, help="common-infix length (SearchParams.overlap); 0 = library default")
     ap.add_argument("--sampling", type=int, default=1, help="1: keep the suffix array resident (narrow nodes are verified against the text); 0: rank queries only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true")
@@ -94,7 +95,7 @@ def main():
     info = ix.info()
     log(f"index built on the GPU in {t_build:.1f} s: {info['n_rows']} rows, {info['block_bytes']}-B blocks, {info['device_bytes'] / 2**30:.2f} GiB")
 
-    infix = g.default_infix_length(K, E)
+    infix = args.infix or g.default_infix_length(K, E)
     step_sz = K - infix + 1
     num_kmers = n - K + 1
     from genmap_amd.distributed import gather_frequency, max_shard_len, shard_ranges
@@ -108,7 +109,7 @@ def main():
     search_ms = []
 
     def one_step():
-        ix.map_device(out.data_ptr(), K, E, value_bits=8, kmer_range=(kb, ke) if world > 1 else None, stream=stream)
+        ix.map_device(out.data_ptr(), K, E, infix=args.infix, value_bits=8, kmer_range=(kb, ke) if world > 1 else None, stream=stream)
         if world > 1:
             gather_frequency(out, ranges, rank, world, dist, recv_bufs=gathered)
 
@@ -135,7 +136,7 @@ def main():
     # per-launch kernel time over a few extra (untimed-by-wall) launches, each measured with HIP events
     kms = []
     for _ in range(min(args.steps, 5)):
-        ix.map_device(out.data_ptr(), K, E, value_bits=8, kmer_range=(kb, ke) if world > 1 else None, stream=stream)
+        ix.map_device(out.data_ptr(), K, E, infix=args.infix, value_bits=8, kmer_range=(kb, ke) if world > 1 else None, stream=stream)
         kms.append(ix.last_stats()["search_ms"])
     kernel_ms = float(np.mean(kms))
 
@@ -160,7 +161,7 @@ def main():
             ixp = g.Index.from_bwt(bf, br, codes, lens, sa_fwd=(ix.export_sa() if args.sampling == 1 else None), sampling=args.sampling,
                                    block_bytes=info["block_bytes"], device=local_rank, profiling=True)
             tmp = torch.zeros(n + 16, dtype=torch.uint8, device=dev)
-            ixp.map_device(tmp.data_ptr(), K, E, value_bits=8, stream=stream)
+            ixp.map_device(tmp.data_ptr(), K, E, infix=args.infix, value_bits=8, stream=stream)
             sp = ixp.last_stats()
             lines, steps_cnt = sp["rank_lines"], sp["node_steps"]
             v_items, v_chunks = sp["detail"]["verify_items"], sp["detail"]["verify_chunks"]

@@ -237,7 +237,8 @@ void gm_index_free(gm_index* ix)
 {
     if (!ix) return;
     hipSetDevice(ix->device);
-    hipFree(ix->d_blk[0]); hipFree(ix->d_blk[1]); hipFree(ix->d_textAlloc); hipFree(ix->d_text4); hipFree(ix->d_cum); hipFree(ix->d_sa); hipFree(ix->d_textSAlloc); hipFree(ix->d_seqFile); hipFree(ix->d_bits);
+    hipFree(ix->d_blk[0]); hipFree(ix->d_blk[1]); hipFree(ix->d_textAlloc); hipFree(ix->d_text4); hipFree(ix->d_cum); hipFree(ix->d_sa); hipFree(ix->d_textSAlloc); hipFree(ix->d_C);
+    for (auto& kv : ix->qtables) hipFree(kv.second); hipFree(ix->d_seqFile); hipFree(ix->d_bits);
     hipFree(ix->d_acc); hipFree(ix->d_stack); hipFree(ix->d_small); hipFree(ix->d_table); hipFree(ix->d_blocks); hipFree(ix->d_cumLocal);
     for (int i = 0; i < 4; ++i) if (ix->ev[i]) hipEventDestroy(ix->ev[i]);
     delete ix;
@@ -389,6 +390,27 @@ template <int WPP> static int occupancy_blocks(int* out, size_t ldsBytes)
 
 static int check_device_error(gm_index* ix);
 
+// table of all q-mers for this index (cached)
+static int get_qtable(gm_index* ix, uint32_t q, const uint4** out)
+{
+    auto it = ix->qtables.find(q);
+    if (it != ix->qtables.end()) { *out = it->second; return GM_OK; }
+    uint4* d = nullptr;
+    const uint64_t n = 1ull << (2 * q);
+    GM_HIP(hipMalloc(&d, n * sizeof(uint4)));
+    if (!ix->d_C) { GM_HIP(hipMalloc(&ix->d_C, sizeof(ix->C))); GM_HIP(hipMemcpy(ix->d_C, ix->C, sizeof(ix->C), hipMemcpyHostToDevice)); }
+    switch (ix->wpp) {
+        case 1: hipLaunchKernelGGL(qmer_table_kernel<1>, dim3(grid_for(n)), dim3(256), 0, 0, ix->d_blk[1], ix->d_C, (uint32_t)ix->nRows, q, d); break;
+        case 3: hipLaunchKernelGGL(qmer_table_kernel<3>, dim3(grid_for(n)), dim3(256), 0, 0, ix->d_blk[1], ix->d_C, (uint32_t)ix->nRows, q, d); break;
+        default: hipLaunchKernelGGL(qmer_table_kernel<9>, dim3(grid_for(n)), dim3(256), 0, 0, ix->d_blk[1], ix->d_C, (uint32_t)ix->nRows, q, d); break;
+    }
+    GM_HIP(hipGetLastError());
+    GM_HIP(hipDeviceSynchronize());
+    ix->qtables[q] = d;
+    *out = d;
+    return GM_OK;
+}
+
 struct SearchSetup {
     MapPlan plan;
     uint64_t blockBegin = 0, blockEnd = 0, numRoots = 0, kmers = 0;
@@ -492,6 +514,20 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     A.blockList = plan.useList ? ix->d_blocks : nullptr;
     A.table = ix->d_table;
     A.stack = ix->d_stack; A.stackDepth = depth; A.spillDepth = std::max<uint32_t>(depth - ldsDepth, 1u);
+    {   // q-mer tables for the first block of every search: q = min(Qmax, length of that block - 1) for the regular block shape
+        uint32_t qmax = 12;
+        while (qmax > 0 && (1ull << (2 * qmax)) > ix->nRows) --qmax;       // no point in tables larger than the text
+        if (const char* e = getenv("GM_QTABLE")) qmax = (uint32_t)std::max(0, std::min(atoi(e), 13));
+        for (uint32_t s = 0; s < OSS_MAXS; ++s) { A.qtab[s] = nullptr; A.qlen[s] = 0; }
+        for (uint32_t s = 0; s < plan.nSearches && qmax > 0; ++s) {
+            const OssRecord& r = plan.table[(size_t)(plan.stepSize - 1) * 8 + s];
+            const uint32_t bl0 = oss_bl(r, 0);
+            const uint32_t q = std::min(qmax, bl0 > 0 ? bl0 - 1u : 0u);
+            if (q == 0) continue;
+            rc = get_qtable(ix, q, &A.qtab[s]); if (rc) return rc;
+            A.qlen[s] = q;
+        }
+    }
     A.text4 = ix->d_text4; A.textBegin = text_begin; A.vqCap = vqCap; A.ldsDepth = ldsDepth; A.winChunks = winChunks;
     A.workCounter = reinterpret_cast<unsigned long long*>(ix->d_small);
     A.errorFlag = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ix->d_small) + 8);
@@ -694,10 +730,10 @@ int gm_last_map_stats(const gm_index* cix, gm_map_stats* out)
     GM_HIP(hipEventElapsedTime(&a, ix->ev[1], ix->ev[2]));
     GM_HIP(hipEventElapsedTime(&b, ix->ev[0], ix->ev[3]));
     ix->stats.search_ms = a; ix->stats.total_ms = b;
-    unsigned long long cnt[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    GM_HIP(hipMemcpy(cnt, reinterpret_cast<char*>(ix->d_small) + 16, 88, hipMemcpyDeviceToHost));
+    unsigned long long cnt[17] = {0};
+    GM_HIP(hipMemcpy(cnt, reinterpret_cast<char*>(ix->d_small) + 16, 136, hipMemcpyDeviceToHost));
     ix->stats.node_steps = cnt[0]; ix->stats.rank_lines = cnt[1];
-    for (int i = 0; i < 9; ++i) ix->stats.detail[i] = cnt[2 + i];
+    for (int i = 0; i < 15; ++i) ix->stats.detail[i] = cnt[2 + i];
     int rc = check_device_error(ix);
     *out = ix->stats;
     return rc;

@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdarg>
 #include <vector>
+#include <map>
 #include "../../include/genmap_amd.h"
 #include "gm_common.h"
 
@@ -32,6 +33,8 @@ struct gm_index {
     uint64_t* d_cum = nullptr;
     uint32_t* d_sa = nullptr;         // forward suffix array (kept when sampling == 1): locate = one HBM read
     uint8_t* d_textS = nullptr;       // sentinel text (verification of narrow nodes), present with d_sa
+    std::map<uint32_t, uint4*> qtables;   // q -> device table of 4^q entries (built on first use)
+    uint32_t* d_C = nullptr;
     uint32_t* d_seqFile = nullptr; uint64_t seqFileCap = 0;
     uint32_t* d_bits = nullptr; uint64_t bitsCap = 0;
     int numCU = 0;

@@ -58,6 +58,9 @@ struct SearchArgs {
     uint32_t vqCap;                 // queue entries per wavefront
     uint32_t ldsDepth;              // stack entries per lane kept in LDS (deeper ones spill to `stack`)
     uint32_t winChunks;             // 16-byte chunks per lane for the needle window
+    // ---- q-mer range tables: the first (always exact) OSS block of a root starts from a lookup instead of q steps ----
+    const uint4* qtab[OSS_MAXS];    // per search: {fwd lo, rev lo, width, 0} of every ACGT string of length qlen[s], or nullptr
+    uint32_t qlen[OSS_MAXS];
 };
 
 // sentinel-text position -> (seqNo, seqPos); sequence s starts at cum[s] + s
@@ -277,10 +280,20 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
     env.lstk = smem + 4u * A.vqCap + wv * (A.ldsDepth * 64u) + lane;
     env.lwin = reinterpret_cast<const uint8_t*>(smem + 4u * A.vqCap + 4u * A.ldsDepth * 64u + wv * (A.winChunks * 64u) + lane);
     uint32_t qsize = 0;                             // wave-uniform
+#ifdef GM_COUNTERS
+    uint32_t wvIter = 0, wvActive = 0, wvRounds = 0;
+#endif
     bool have = false, exhausted = false;
-    unsigned long long poolCur = 0, poolEnd = 0;   // wave-uniform
+    unsigned long long poolCur = 0, poolEnd = 0, poolBase = 0, poolBlock = 0;   // wave-uniform
+    uint32_t poolRem = 0;
     bool globalDone = false;                        // wave-uniform
 
+#ifdef GM_COUNTERS
+    unsigned long long tFetch = 0, tVerify = 0, tStep = 0, tMark = __builtin_amdgcn_s_memtime();
+#define GM_LAP(acc) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tMark; tMark = now_; } while (0)
+#else
+#define GM_LAP(acc) do { } while (0)
+#endif
     for (;;) {
         if (!have && env.sp > 0) {
             const uint4 v = env.pop();
@@ -299,36 +312,54 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
                 if ((int)lane == leader) base = atomicAdd(A.workCounter, (unsigned long long)WORK_CHUNK);
                 base = __shfl(base, leader);
                 if (base >= A.numRoots) globalDone = true;
-                else { poolCur = base; poolEnd = base + WORK_CHUNK < A.numRoots ? base + WORK_CHUNK : A.numRoots; }
+                else {
+                    poolCur = base; poolEnd = base + WORK_CHUNK < A.numRoots ? base + WORK_CHUNK : A.numRoots;
+                    poolBlock = base / A.rootsPerBlock;                       // one 64-bit division per chunk, not per root
+                    poolRem = (uint32_t)(base - poolBlock * A.rootsPerBlock);
+                    poolBase = base;
+                }
             }
             const uint32_t avail = (uint32_t)(poolEnd - poolCur);
             const uint32_t want = (uint32_t)__popcll(m);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             if (need) {
                 if (rank < avail) {
-                    const unsigned long long id = poolCur + rank;
-                    const unsigned long long b = id / A.rootsPerBlock;
-                    const uint32_t r = (uint32_t)(id - b * A.rootsPerBlock);
-                    const unsigned long long gb = A.blockBegin + b;
+                    const uint32_t off = (uint32_t)(poolCur - poolBase) + rank + poolRem;   // < WORK_CHUNK + rootsPerBlock
+                    const uint32_t db = off / A.rootsPerBlock;
+                    const uint32_t r = off - db * A.rootsPerBlock;
+                    const unsigned long long gb = A.blockBegin + poolBlock + db;
                     if (A.blockList) { const uint2 e = A.blockList[gb]; rt.win = e.x; rt.n = e.y; }
                     else {
-                        rt.win = (uint32_t)(gb * A.stepSize);
+                        rt.win = (uint32_t)gb * A.stepSize;                   // slice positions fit 32 bits
                         const uint32_t left = A.numKmers - rt.win;
                         rt.n = left < A.stepSize ? left : A.stepSize;
                     }
-                    rt.strand = r / A.nSearches;
+                    rt.strand = r >= A.nSearches ? 1u : 0u;
                     rt.search = r - rt.strand * A.nSearches;
                     const uint4 q = A.table[(size_t)(rt.n - 1u) * 8u + rt.search];
                     rt.rec.x = q.x; rt.rec.y = q.y; rt.rec.z = q.z; rt.rec.w = q.w;
                     env.load_window(rt);
                     nd = root_node(rt, A.nRows);
                     have = true;
+                    const uint32_t ql = A.qlen[rt.search];
+                    if (ql) {   // jump over the first q characters of the (exact) first block: find2_index_approx.hpp:303-345
+                        const uint32_t a0 = meta_a(nd.meta);
+                        uint32_t idx = 0, bad = 0;
+                        for (uint32_t i = 0; i < ql; ++i) { const uint32_t c = env.text_char(rt, a0 + i); bad |= (c > 3u) ? 1u : 0u; idx = idx << 2 | (c & 3u); }
+                        if (bad) have = false;   // a pattern N never matches in an exact block (find2:330): this root finds nothing
+                        else {
+                            const uint4 e = A.qtab[rt.search][idx];
+                            if (e.z == 0u) have = false;
+                            else { nd.flo = e.x; nd.rlo = e.y; nd.w = e.z; nd.meta = meta_pack(a0, a0 + ql, 0, 0, M_OSS); }
+                        }
+                    }
                 } else if (globalDone && avail == 0u) {
                     exhausted = true;
                 }
             }
             poolCur += want < avail ? want : avail;
         }
+        GM_LAP(tFetch);
         // ---- defer narrow nodes: one queue entry per SA row ----
         if (A.verifyT) {
             bool narrow = have && nd.w <= A.verifyT;
@@ -356,6 +387,9 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef GM_COUNTERS
+                wvRounds += 1;
+#endif
                 const uint32_t take = qsize < 64u ? qsize : 64u;
                 if (lane < take) {
                     const uint4 it = vq[qsize - 1u - lane];
@@ -369,15 +403,20 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        GM_LAP(tVerify);
         if (__ballot(have) == 0ull && qsize == 0u) {
             if (__ballot(!exhausted) == 0ull) break;   // nothing in flight, nothing queued, nothing left to draw
             continue;
         }
 
+#ifdef GM_COUNTERS
+        wvIter += 1; wvActive += (uint32_t)__popcll(__ballot(have));
+#endif
         if (have) {
             if (meta_mode(nd.meta) == M_SPLIT) { Node left; split_node(nd, left, A.K); env.push(left); }
             lane_step(nd, have, rt, A.K, A.E, env);
         }
+        GM_LAP(tStep);
     }
 #ifdef GM_COUNTERS
     atomicAdd(&A.counters[0], (unsigned long long)env.steps);
@@ -391,7 +430,40 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
     atomicAdd(&A.counters[8], (unsigned long long)env.vItems);
     atomicAdd(&A.counters[9], (unsigned long long)env.vItemsOss);
     atomicAdd(&A.counters[10], (unsigned long long)env.vChunks);
+    if (lane == 0) {
+        atomicAdd(&A.counters[11], (unsigned long long)wvIter);
+        atomicAdd(&A.counters[12], (unsigned long long)wvActive);
+        atomicAdd(&A.counters[13], (unsigned long long)wvRounds);
+        atomicAdd(&A.counters[14], tFetch);
+        atomicAdd(&A.counters[15], tVerify);
+        atomicAdd(&A.counters[16], tStep);
+    }
 #endif
+}
+
+// SA ranges of every ACGT string of length q in both indexes (right extensions from the root): the top of the search
+// tree, tabulated once per index and q.
+template <int WPP>
+__global__ __launch_bounds__(256) void qmer_table_kernel(const uint32_t* __restrict__ blkRev, const uint32_t* __restrict__ Cin, uint32_t nRows, uint32_t q,
+                                                         uint4* __restrict__ out)
+{
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (1u << (2u * q))) return;
+    constexpr uint32_t SPB = BlockGeom<WPP>::SPB, WPB = BlockGeom<WPP>::WPB;
+    uint32_t flo = 0, rlo = 0, w = nRows;
+    for (uint32_t i = 0; i < q && w; ++i) {
+        const uint32_t c = (idx >> (2u * (q - 1u - i))) & 3u;
+        uint32_t rl[NLET], rh[NLET];
+        const uint32_t lo = rlo, hi = rlo + w;
+        block_rank<WPP>(blkRev + (size_t)(lo / SPB) * WPB, lo % SPB, rl);
+        block_rank<WPP>(blkRev + (size_t)(hi / SPB) * WPB, hi % SPB, rh);
+        uint32_t tot = 0, below = 0;
+        for (uint32_t x = 0; x < NLET; ++x) { const uint32_t cx = rh[x] - rl[x]; tot += cx; if (x < c) below += cx; }
+        flo += (w - tot) + below;           // sentinels sort before every letter
+        rlo = Cin[c] + rl[c];
+        w = rh[c] - rl[c];
+    }
+    out[idx] = make_uint4(flo, rlo, w, 0u);
 }
 
 // acc -> c[]  (4 positions per thread)
