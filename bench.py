@@ -95,7 +95,7 @@ def main():
     info = ix.info()
     log(f"index built on the GPU in {t_build:.1f} s: {info['n_rows']} rows, {info['block_bytes']}-B blocks, {info['device_bytes'] / 2**30:.2f} GiB")
 
-    infix = args.infix or g.default_infix_length(K, E)
+    infix = args.infix or g.tuned_infix_length(K, E)
     step_sz = K - infix + 1
     num_kmers = n - K + 1
     from genmap_amd.distributed import gather_frequency, max_shard_len, shard_ranges
@@ -148,7 +148,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32 ranks / u8 counts",
             "data": "synthetic",
-            "config": {"workload": f"{desc}, K={K} E={E}, both strands, -fs (8-bit), default overlap", "K": K, "E": E,
+            "config": {"workload": f"{desc}, K={K} E={E}, both strands, -fs (8-bit), common infix {infix}", "K": K, "E": E,
                        "text_len": n, "block_bytes": info["block_bytes"], "parallelism": f"text-range shards x{world}, index replicated",
                        "index_build_s": round(t_build, 2)},
         }

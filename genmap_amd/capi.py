@@ -43,7 +43,7 @@ class Locations(C.Structure):
                 ("minus_off", C.POINTER(C.c_uint64)), ("plus", C.POINTER(C.c_uint64)), ("minus", C.POINTER(C.c_uint64))]
 
 
-EXPORTS = ["gm_index_export_sa", "gm_locate", "gm_locations_free", "gm_status_string", "gm_last_error", "gm_device_count", "gm_index_build", "gm_index_import",
+EXPORTS = ["gm_tuned_infix_length", "gm_index_export_sa", "gm_locate", "gm_locations_free", "gm_status_string", "gm_last_error", "gm_device_count", "gm_index_build", "gm_index_import",
            "gm_index_export_bwt", "gm_index_get_info", "gm_index_free", "gm_map", "gm_map_device",
            "gm_last_map_stats", "gm_default_infix_length"]
 
@@ -94,6 +94,8 @@ def load_library(profiling=False):
     lib.gm_locations_free.argtypes = [C.POINTER(Locations)]
     lib.gm_last_map_stats.restype = C.c_int
     lib.gm_last_map_stats.argtypes = [vp, C.POINTER(MapStats)]
+    lib.gm_tuned_infix_length.restype = C.c_uint32
+    lib.gm_tuned_infix_length.argtypes = [C.c_uint32, C.c_uint32]
     lib.gm_default_infix_length.restype = C.c_uint32
     lib.gm_default_infix_length.argtypes = [C.c_uint32, C.c_uint32, C.c_int32]
     _LIB, _LIB_NAME = lib, str(path)
@@ -112,6 +114,10 @@ def device_count():
 
 def default_infix_length(K, E, xo=None):
     return int(load_library().gm_default_infix_length(K, E, -1 if xo is None else xo))
+
+
+def tuned_infix_length(K, E):
+    return int(load_library().gm_tuned_infix_length(K, E))
 
 
 def _ptr(a):

@@ -232,6 +232,7 @@ int gm_device_count(void)
 }
 
 uint32_t gm_default_infix_length(uint32_t K, uint32_t E, int32_t xo) { return default_infix_length(K, E, xo); }
+uint32_t gm_tuned_infix_length(uint32_t K, uint32_t E) { return (K < 1 || K > 128 || E > MAX_ERRORS) ? 0u : tuned_infix_length(K, E); }
 
 void gm_index_free(gm_index* ix)
 {
@@ -429,7 +430,8 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     if (p->E > MAX_ERRORS) return GM_ERR_BAD_ERRORS;
     GM_HIP(hipSetDevice(ix->device));
 
-    const uint32_t infix = p->infix > 0 ? (uint32_t)p->infix : default_infix_length(p->K, p->E, p->overlap);
+    if (p->K < 1 || p->K > 128) return GM_ERR_BAD_K;
+    const uint32_t infix = p->infix > 0 ? (uint32_t)p->infix : (p->overlap >= 0 ? default_infix_length(p->K, p->E, p->overlap) : tuned_infix_length(p->K, p->E));
     if (infix == 0) return GM_ERR_BAD_OVERLAP;
     MapPlan& plan = S->plan;
     int rc = make_map_plan(p->K, p->E, infix, p->revcompl, text_len, intervals, n_intervals, &plan);

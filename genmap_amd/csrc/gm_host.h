@@ -33,6 +33,29 @@ inline uint32_t default_infix_length(uint32_t K, uint32_t E, int32_t xo)
     return K - overlap;
 }
 
+// Common-infix length this build uses when the caller gives neither -xo nor an explicit infix.  The reference's rule
+// (default_infix_length) was tuned for a CPU; the result of computeMappability does not depend on it (the reference's
+// own tests rerun every case with other -xo values, tests/tests.sh:47-60), so the GPU picks the block shape that
+// measured fastest on MI355X (profiles/r01e_infix_sweeps.txt): with a q-mer table and verification of narrow nodes,
+// e = 0 wants a 16-character infix (one lookup + ~4 steps per half) and blocks of at most 31 k-mers; e >= 1 wants
+// the infix long enough that the OSS search ends on narrow ranges.
+inline uint32_t tuned_infix_length(uint32_t K, uint32_t E)
+{
+    auto clampu = [](uint32_t v, uint32_t lo, uint32_t hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    uint32_t n;
+    switch (E) {
+        case 0: n = K > 15 ? clampu(K - 15, 1, 31) : 1; break;
+        case 1: n = clampu(K / 6, 5, 16); break;
+        case 2: n = clampu(K / 6, 7, 16); break;
+        case 3: n = clampu(K / 4, 9, 16); break;
+        default: n = clampu(K / 4, 11, 16); break;
+    }
+    if (n > K) n = K;
+    uint32_t infix = K - n + 1;
+    const uint32_t minInfix = std::min(K, std::max<uint32_t>(E + 2, oss_scheme(E > MAX_ERRORS ? 0 : E).s[0].nb));
+    return std::max(infix, minInfix);
+}
+
 struct MapPlan {
     uint32_t K = 0, E = 0, infix = 0, stepSize = 0, nSearches = 0, nStrands = 0;
     uint64_t textLen = 0, numKmers = 0;

@@ -88,7 +88,9 @@ void gm_index_free(gm_index *idx);
 typedef struct gm_map_params {
     uint32_t K;               /* -K  SearchParams.length */
     uint32_t E;               /* -E  0..4 */
-    int32_t  overlap;         /* hidden -xo; < 0 = reference default (src/mappability.hpp:519-525) */
+    int32_t  overlap;         /* hidden -xo (src/mappability.hpp:463-465).  < 0 = not given: the library then uses its own
+                                 MI355X-tuned block shape, gm_tuned_infix_length(); results do not depend on it.  The
+                                 reference's default is available as infix = gm_default_infix_length(K, E, -1). */
     int32_t  infix;           /* > 0: set the common-infix length (SearchParams.overlap) directly, as
                                  tests/tests.cpp:179-181 does; overrides `overlap` */
     int32_t  revcompl;        /* 0 with -nc */
@@ -153,6 +155,8 @@ int gm_last_map_stats(const gm_index *idx, gm_map_stats *stats);
 /* reference default of SearchParams.overlap (common-infix length) for (K,E,-xo): src/mappability.hpp:519-543.
  * Returns 0 if -xo is too large. */
 uint32_t gm_default_infix_length(uint32_t K, uint32_t E, int32_t xo);
+/* common-infix length this build schedules with when neither -xo nor params.infix is given (0 for invalid K/E) */
+uint32_t gm_tuned_infix_length(uint32_t K, uint32_t E);
 
 #ifdef __cplusplus
 }

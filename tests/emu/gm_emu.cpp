@@ -165,7 +165,7 @@ extern "C" int gm_emu_map(int wpp, const uint8_t* bf, const uint8_t* br, uint64_
                           int32_t infixOverride, int revcompl, int valueBits, const uint64_t* intervals, uint64_t nIntervals,
                           void* out, uint64_t* stats, const uint32_t* sa, uint32_t verifyT, const uint8_t* allCodes, const uint64_t* allCum)
 {
-    uint32_t infix = infixOverride > 0 ? (uint32_t)infixOverride : default_infix_length(K, E, xo);
+    uint32_t infix = infixOverride > 0 ? (uint32_t)infixOverride : (xo >= 0 ? default_infix_length(K, E, xo) : tuned_infix_length(K, E));
     if (infix == 0) return PLAN_BAD_OVERLAP;
     memset(out, 0, textLen * (valueBits / 8));
     switch (wpp) {

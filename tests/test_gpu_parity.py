@@ -193,7 +193,7 @@ def test_gpu_shards_and_device_output():
     ix = g.Index.build(codes, lens)
     K, E = 30, 1
     full = ix.map(K, E, value_bits=8)
-    step = 30 - g.default_infix_length(K, E) + 1
+    step = 30 - g.tuned_infix_length(K, E) + 1
     nk = sum(lens) - K + 1
     cuts = [0, (nk // 3 // step) * step, (2 * nk // 3 // step) * step, nk]
     acc = torch.zeros(sum(lens), dtype=torch.uint8, device="cuda:0")
