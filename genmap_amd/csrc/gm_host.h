@@ -7,6 +7,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <utility>
 #include <vector>
 #include <algorithm>

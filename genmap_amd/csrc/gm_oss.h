@@ -61,7 +61,10 @@ GM_HD uint32_t oss_right(const OssRecord& r, uint32_t bi) { return (r.z >> (18u 
 
 // infixLen = length of the common infix of the block's k-mers (the reference's local `overlap`,
 // src/algo.hpp:246).  Returns false if the infix is shorter than the number of scheme blocks.
-inline bool oss_make_record(uint32_t E, uint32_t s, uint32_t infixLen, OssRecord* out)
+// blockLens (optional): lengths of blocks 1..nb in left-to-right order, summing to infixLen.  The scheme covers every
+// error distribution exactly once for ANY positive block lengths (l/u constrain errors per block, not per position);
+// the reference always uses equal lengths (:167-172).
+inline bool oss_make_record(uint32_t E, uint32_t s, uint32_t infixLen, OssRecord* out, const uint32_t* blockLens = nullptr)
 {
     const OssSearch& S = oss_scheme(E).s[s];
     uint32_t blocks = S.nb;
@@ -69,7 +72,7 @@ inline bool oss_make_record(uint32_t E, uint32_t s, uint32_t infixLen, OssRecord
     uint32_t base = infixLen / blocks, rest = infixLen - blocks * base;   // :167-172
     uint32_t bl[OSS_MAXB] = {0, 0, 0, 0, 0, 0}, cum = 0, start = 0;
     for (uint32_t i = 0; i < blocks; ++i) {
-        uint32_t len = base + ((uint32_t)(S.pi[i] - 1) < rest ? 1u : 0u);   // :145 blocklength[pi[i]-1]
+        uint32_t len = blockLens ? blockLens[S.pi[i] - 1] : base + ((uint32_t)(S.pi[i] - 1) < rest ? 1u : 0u);   // :145 blocklength[pi[i]-1]
         cum += len;
         bl[i] = cum;
         if (S.pi[i] < S.pi[0]) start += len;                               // :158-160
