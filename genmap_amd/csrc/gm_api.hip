@@ -351,7 +351,7 @@ template <typename T> static int grow(T** p, uint64_t* cap, uint64_t need)
     return GM_OK;
 }
 
-enum LeafMode { LEAF_COUNT = 0, LEAF_FILESET = 1, LEAF_OCC_COUNT = 2, LEAF_OCC_EMIT = 3 };
+enum LeafMode { LEAF_COUNT = 0, LEAF_FILESET = 1, LEAF_OCC_COUNT = 2, LEAF_OCC_EMIT = 3, LEAF_STORE = 4 };
 
 static inline size_t search_lds_bytes(const SearchArgs& A) { return (size_t)(4u * A.vqCap + 4u * 64u * (A.ldsDepth + A.winChunks)) * 16u; }
 
@@ -369,6 +369,7 @@ static int launch_mode(int mode, const SearchArgs& A, unsigned blocks, hipStream
         case LEAF_COUNT: return launch_one<WPP, CountEnv<WPP>>(A, blocks, st);
         case LEAF_FILESET: return launch_one<WPP, FileSetEnv<WPP>>(A, blocks, st);
         case LEAF_OCC_COUNT: return launch_one<WPP, OccCountEnv<WPP>>(A, blocks, st);
+        case LEAF_STORE: return launch_one<WPP, StoreEnv<WPP>>(A, blocks, st);
         default: return launch_one<WPP, OccEmitEnv<WPP>>(A, blocks, st);
     }
 }
@@ -572,26 +573,31 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
         rc = grow(&ix->d_bits, &ix->bitsCap, (text_len + 1) * wordsPerKmer); if (rc) return rc;
         GM_HIP(hipStreamSynchronize(st));
     } else {
-        rc = grow(&ix->d_acc, &ix->accCap, text_len + 4); if (rc) return rc;
+        rc = grow(&ix->d_acc, &ix->accCap, 2 * (text_len + 4)); if (rc) return rc;
     }
+    // E = 0 with single-row verification: plain stores into one plane per strand instead of atomics
+    const bool store = !ep && p->E == 0 && A.verifyT <= 1 && getenv("GM_NO_STORE") == nullptr;
+    const uint64_t plane = text_len + 4;
 
     GM_HIP(hipEventRecord(ix->ev[0], st));
     if (ep) GM_HIP(hipMemsetAsync(ix->d_bits, 0, (text_len + 1) * wordsPerKmer * sizeof(uint32_t), st));
-    else GM_HIP(hipMemsetAsync(ix->d_acc, 0, (text_len + 4) * sizeof(uint32_t), st));
+    else GM_HIP(hipMemsetAsync(ix->d_acc, 0, (store ? 2 : 1) * plane * sizeof(uint32_t), st));
     GM_HIP(hipMemsetAsync(ix->d_small, 0, 256, st));
-    A.acc = ix->d_acc; A.fileBits = ix->d_bits; A.wordsPerKmer = wordsPerKmer; A.seqFile = ix->d_seqFile;
+    A.acc = ix->d_acc; A.accPlane = plane; A.fileBits = ix->d_bits; A.wordsPerKmer = wordsPerKmer; A.seqFile = ix->d_seqFile;
 
     GM_HIP(hipEventRecord(ix->ev[1], st));
-    if (S.numRoots > 0) { rc = launch_search(ix, ep ? LEAF_FILESET : LEAF_COUNT, A, S.blocks, st); if (rc) return rc; }
+    if (S.numRoots > 0) { rc = launch_search(ix, ep ? LEAF_FILESET : store ? LEAF_STORE : LEAF_COUNT, A, S.blocks, st); if (rc) return rc; }
     GM_HIP(hipEventRecord(ix->ev[2], st));
     if (text_len > 0) {
         const unsigned g4 = grid_for((text_len + 3) / 4), g1 = grid_for(text_len);
         if (p->value_bits == 8) {
             if (ep) hipLaunchKernelGGL(finalize_fileset_kernel<uint8_t>, dim3(g1), dim3(256), 0, st, ix->d_bits, wordsPerKmer, (uint8_t*)d_out, text_len);
+            else if (store) hipLaunchKernelGGL(finalize2_kernel<uint8_t>, dim3(g1), dim3(256), 0, st, ix->d_acc, ix->d_acc + plane, (uint8_t*)d_out, text_len, 255u);
             else hipLaunchKernelGGL(finalize_kernel<uint8_t>, dim3(g4), dim3(256), 0, st, ix->d_acc, (uint8_t*)d_out, text_len, 255u);
             rc = launch_reset_limits(ix, (uint8_t*)d_out, n_seq, p->K, st);
         } else {
             if (ep) hipLaunchKernelGGL(finalize_fileset_kernel<uint16_t>, dim3(g1), dim3(256), 0, st, ix->d_bits, wordsPerKmer, (uint16_t*)d_out, text_len);
+            else if (store) hipLaunchKernelGGL(finalize2_kernel<uint16_t>, dim3(g1), dim3(256), 0, st, ix->d_acc, ix->d_acc + plane, (uint16_t*)d_out, text_len, 65535u);
             else hipLaunchKernelGGL(finalize_kernel<uint16_t>, dim3(g4), dim3(256), 0, st, ix->d_acc, (uint16_t*)d_out, text_len, 65535u);
             rc = launch_reset_limits(ix, (uint16_t*)d_out, n_seq, p->K, st);
         }
