@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--block-bytes", type=int, default=0)
     ap.add_argument("--infix", type=int, default=0, help="common-infix length (SearchParams.overlap); 0 = library default")
     ap.add_argument("--sampling", type=int, default=1, help="1: keep the suffix array resident (narrow nodes are verified against the text); 0: rank queries only")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the single-GPU rehearsal of the N>1 path)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true")
     args = ap.parse_args()
@@ -76,13 +78,18 @@ def main():
     from genmap_amd import synth
     if not torch.cuda.is_available() or g.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     t0 = time.time()
     codes, lens, desc = synth.workload(args.workload, args.scale)
@@ -111,9 +118,10 @@ def main():
     def one_step():
         ix.map_device(out.data_ptr(), K, E, infix=args.infix, value_bits=8, kmer_range=(kb, ke) if world > 1 else None, stream=stream)
         if world > 1:
-            gather_frequency(out, ranges, rank, world, dist, recv_bufs=gathered)
+            gather_frequency(out, ranges, rank, world, dist, recv_bufs=gathered, stage_on_host=(args.backend != "nccl"))
 
     def sync():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -130,6 +138,8 @@ def main():
     st = ix.last_stats()   # HIP events of the last step on the launch stream
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
+        if args.backend != "nccl":
+            t = t.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 

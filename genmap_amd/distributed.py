@@ -23,7 +23,7 @@ def max_shard_len(ranges) -> int:
     return max((e - b) for b, e in ranges) if ranges else 0
 
 
-def gather_frequency(local_full, ranges, rank: int, world: int, dist, recv_bufs=None, dst: int = 0):
+def gather_frequency(local_full, ranges, rank: int, world: int, dist, recv_bufs=None, dst: int = 0, stage_on_host: bool = False):
     """local_full: this rank's frequency vector (1-D tensor with at least ranges[-1][1] + max shard elements,
     own shard filled, zeros elsewhere).  After the call the dst rank's local_full holds every rank's shard.
     recv_bufs: optional preallocated list of `world` tensors of max_shard_len elements on dst."""
@@ -32,13 +32,16 @@ def gather_frequency(local_full, ranges, rank: int, world: int, dist, recv_bufs=
     m = max_shard_len(ranges)
     b, _ = ranges[rank]
     send = local_full[b:b + m]
+    if stage_on_host:   # backends without device-memory collectives (gloo rehearsal): same data path through host buffers
+        send = send.cpu()
+        recv_bufs = None
     if rank == dst:
         if recv_bufs is None:
             recv_bufs = [send.new_empty(m) for _ in range(world)]
         dist.gather(send, recv_bufs, dst=dst)
         for r, (rb, re) in enumerate(ranges):
             if r != dst and re > rb:
-                local_full[rb:re] = recv_bufs[r][:re - rb]
+                local_full[rb:re] = recv_bufs[r][:re - rb].to(local_full.device)
     else:
         dist.gather(send, None, dst=dst)
     return local_full
