@@ -521,14 +521,19 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         uint32_t qmax = 12;
         while (qmax > 0 && (1ull << (2 * qmax)) > ix->nRows) --qmax;       // no point in tables larger than the text
         if (const char* e = getenv("GM_QTABLE")) qmax = (uint32_t)std::max(0, std::min(atoi(e), 13));
-        for (uint32_t s = 0; s < OSS_MAXS; ++s) { A.qtab[s] = nullptr; A.qlen[s] = 0; }
-        for (uint32_t s = 0; s < plan.nSearches && qmax > 0; ++s) {
+        A.qtabA = A.qtabB = nullptr; A.qlenPacked = 0; A.qselMask = 0; A.startPacked[0] = A.startPacked[1] = 0;
+        uint32_t qA = 0, qB = 0;
+        for (uint32_t s = 0; s < plan.nSearches; ++s) {
             const OssRecord& r = plan.table[(size_t)(plan.stepSize - 1) * 8 + s];
+            A.startPacked[s >> 2] |= oss_start(r) << (8u * (s & 3u));
+            if (qmax == 0) continue;
             const uint32_t bl0 = oss_bl(r, 0);
             const uint32_t q = std::min(qmax, bl0 > 0 ? bl0 - 1u : 0u);
             if (q == 0) continue;
-            rc = get_qtable(ix, q, &A.qtab[s]); if (rc) return rc;
-            A.qlen[s] = q;
+            if (qA == 0 || qA == q) { if (qA == 0) { rc = get_qtable(ix, q, &A.qtabA); if (rc) return rc; qA = q; } }
+            else if (qB == 0 || qB == q) { if (qB == 0) { rc = get_qtable(ix, q, &A.qtabB); if (rc) return rc; qB = q; } A.qselMask |= 1u << s; }
+            else continue;   // a third distinct prefix length: this search starts from the root
+            A.qlenPacked |= q << (4u * s);
         }
     }
     A.text4 = ix->d_text4; A.textBegin = text_begin; A.vqCap = vqCap; A.ldsDepth = ldsDepth; A.winChunks = winChunks;

@@ -60,8 +60,11 @@ struct SearchArgs {
     uint32_t ldsDepth;              // stack entries per lane kept in LDS (deeper ones spill to `stack`)
     uint32_t winChunks;             // 16-byte chunks per lane for the needle window
     // ---- q-mer range tables: the first (always exact) OSS block of a root starts from a lookup instead of q steps ----
-    const uint4* qtab[OSS_MAXS];    // per search: {fwd lo, rev lo, width, 0} of every ACGT string of length qlen[s], or nullptr
-    uint32_t qlen[OSS_MAXS];
+    const uint4* qtabA;             // {fwd lo, rev lo, width, 0} of every ACGT string of length q (two tables at most per call)
+    const uint4* qtabB;
+    uint32_t qlenPacked;            // 4 bits per search: table prefix length q_s (0 = no table for that search)
+    uint32_t qselMask;              // bit s: search s uses qtabB
+    uint32_t startPacked[2];        // 8 bits per search: startPos of the regular block shape (n == stepSize)
 };
 
 // sentinel-text position -> (seqNo, seqPos); sequence s starts at cum[s] + s
@@ -299,6 +302,12 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
     uint32_t wvIter = 0, wvActive = 0, wvRounds = 0;
 #endif
     bool have = false, exhausted = false;
+    // root fetch pipeline of this lane: 0 idle, 1 window/record loads in flight, 2 q-mer table lookup in flight
+    uint32_t fs = 0, fa0 = 0, fql = 0, fwoff = 0, fnch = 0, fshift = 0;
+    Root frt; frt.win = 0; frt.n = 1; frt.strand = 0; frt.search = 0; frt.rec = OssRecord{0, 0, 0, 0};
+    uint4 fw0 = make_uint4(0, 0, 0, 0), fw1 = fw0, fw2 = fw0, frec = fw0, ftab = fw0;
+    unsigned long long fx0 = 0, fx1 = 0;
+    const uint4* fsrc = A.text4;
     unsigned long long poolCur = 0, poolEnd = 0, poolBase = 0, poolBlock = 0;   // wave-uniform
     uint32_t poolRem = 0;
     bool globalDone = false;                        // wave-uniform
@@ -315,10 +324,44 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
             nd.flo = v.x; nd.rlo = v.y; nd.w = v.z; nd.meta = v.w;
             have = true;
         }
-        // ---- wavefront work queue: lanes without a node draw roots, ranked by ballot ----
+        // ---- root fetch, pipelined over iterations so that the wavefront never waits for it ----
+        // stage 3: the q-mer table entry has arrived -> the root becomes the lane's node (or turns out empty)
+        if (fs == 2u) {
+            fs = 0u;
+            if (ftab.z != 0u) {
+                rt = frt;
+                nd.flo = ftab.x; nd.rlo = ftab.y; nd.w = ftab.z; nd.meta = meta_pack(fa0, fa0 + fql, 0, 0, M_OSS);
+                have = true;
+            }
+        }
+        // stage 2: window chunks and record have arrived -> stage the window in LDS, look the first q characters up
+        if (fs == 1u) {
+            env.woff = fwoff;
+            uint4* dst = reinterpret_cast<uint4*>(const_cast<uint8_t*>(env.lwin));
+            dst[0] = fw0;
+            if (fnch > 1u) dst[64] = fw1;
+            if (fnch > 2u) dst[128] = fw2;
+            for (uint32_t c = 3u; c < fnch; ++c) dst[c * 64u] = fsrc[c];   // long windows (K > ~45): remaining chunks
+            frt.rec.x = frec.x; frt.rec.y = frec.y; frt.rec.z = frec.z; frt.rec.w = frec.w;
+            if (fql == 0u) { rt = frt; nd = root_node(rt, A.nRows); have = true; fs = 0u; }
+            else {
+                // 16 symbols starting at the lowest text position of the q-mer, 4 bits each
+                const unsigned long long v = fshift ? (fx0 >> fshift) | (fx1 << (64u - fshift)) : fx0;
+                uint32_t idx = 0, bad = 0;
+                for (uint32_t i = 0; i < fql; ++i) {
+                    const uint32_t c = (uint32_t)(v >> (4u * i)) & 15u;
+                    bad |= c > 3u ? 1u : 0u;
+                    // forward strand: symbol i is needle(a0 + i), most significant first; reverse strand: needle(a0 + q-1-i) = 3 - c
+                    idx |= frt.strand ? (3u - (c & 3u)) << (2u * i) : (c & 3u) << (2u * (fql - 1u - i));
+                }
+                if (bad) fs = 0u;   // a pattern N never matches in an exact block (find2:330): this root finds nothing
+                else { ftab = (((A.qselMask >> frt.search) & 1u) ? A.qtabB : A.qtabA)[idx]; fs = 2u; }
+            }
+        }
+        // stage 1: lanes without node, stack or fetch in flight draw a root (ballot rank) and issue its loads
 #pragma unroll 1
         for (int round = 0; round < 2; ++round) {
-            const bool need = !have && !exhausted;
+            const bool need = !have && fs == 0u && env.sp == 0u && !exhausted;
             const unsigned long long m = __ballot(need);
             if (m == 0ull) break;
             if (poolCur == poolEnd && !globalDone) {
@@ -343,31 +386,32 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
                     const uint32_t db = off / A.rootsPerBlock;
                     const uint32_t r = off - db * A.rootsPerBlock;
                     const unsigned long long gb = A.blockBegin + poolBlock + db;
-                    if (A.blockList) { const uint2 e = A.blockList[gb]; rt.win = e.x; rt.n = e.y; }
+                    if (A.blockList) { const uint2 e = A.blockList[gb]; frt.win = e.x; frt.n = e.y; }
                     else {
-                        rt.win = (uint32_t)gb * A.stepSize;                   // slice positions fit 32 bits
-                        const uint32_t left = A.numKmers - rt.win;
-                        rt.n = left < A.stepSize ? left : A.stepSize;
+                        frt.win = (uint32_t)gb * A.stepSize;                  // slice positions fit 32 bits
+                        const uint32_t left = A.numKmers - frt.win;
+                        frt.n = left < A.stepSize ? left : A.stepSize;
                     }
-                    rt.strand = r >= A.nSearches ? 1u : 0u;
-                    rt.search = r - rt.strand * A.nSearches;
-                    const uint4 q = A.table[(size_t)(rt.n - 1u) * 8u + rt.search];
-                    rt.rec.x = q.x; rt.rec.y = q.y; rt.rec.z = q.z; rt.rec.w = q.w;
-                    env.load_window(rt);
-                    nd = root_node(rt, A.nRows);
-                    have = true;
-                    const uint32_t ql = A.qlen[rt.search];
-                    if (ql) {   // jump over the first q characters of the (exact) first block: find2_index_approx.hpp:303-345
-                        const uint32_t a0 = meta_a(nd.meta);
-                        uint32_t idx = 0, bad = 0;
-                        for (uint32_t i = 0; i < ql; ++i) { const uint32_t c = env.text_char(rt, a0 + i); bad |= (c > 3u) ? 1u : 0u; idx = idx << 2 | (c & 3u); }
-                        if (bad) have = false;   // a pattern N never matches in an exact block (find2:330): this root finds nothing
-                        else {
-                            const uint4 e = A.qtab[rt.search][idx];
-                            if (e.z == 0u) have = false;
-                            else { nd.flo = e.x; nd.rlo = e.y; nd.w = e.z; nd.meta = meta_pack(a0, a0 + ql, 0, 0, M_OSS); }
-                        }
-                    }
+                    frt.strand = r >= A.nSearches ? 1u : 0u;
+                    frt.search = r - frt.strand * A.nSearches;
+                    const uint4* recp = A.table + ((size_t)(frt.n - 1u) * 8u + frt.search);
+                    uint32_t startPos;
+                    fql = (A.qlenPacked >> (4u * frt.search)) & 15u;
+                    if (frt.n == A.stepSize) startPos = (A.startPacked[frt.search >> 2] >> (8u * (frt.search & 3u))) & 0xFFu;
+                    else { const uint4 q = *recp; startPos = (q.y >> 16) & 0xFFu; }   // odd block shape (end of text / interval): rare
+                    fa0 = frt.n - 1u + startPos;
+                    const uint32_t W = A.K + frt.n - 1u;
+                    const uint64_t g = A.textBegin + frt.win;
+                    fwoff = (uint32_t)(g & 31u);
+                    fsrc = A.text4 + (g >> 5);
+                    fnch = (fwoff + W + 31u) >> 5;
+                    frec = *recp;
+                    fw0 = fsrc[0]; fw1 = fsrc[1]; fw2 = fsrc[2];              // the text has 12 chunks of padding behind it
+                    const uint64_t p = g + (frt.strand ? (uint64_t)(W - fa0 - fql) : (uint64_t)fa0);   // lowest text position of the q-mer
+                    const unsigned long long* t64 = reinterpret_cast<const unsigned long long*>(A.text4) + (p >> 4);
+                    fshift = (uint32_t)(p & 15u) * 4u;
+                    fx0 = t64[0]; fx1 = t64[1];
+                    fs = 1u;
                 } else if (globalDone && avail == 0u) {
                     exhausted = true;
                 }
@@ -397,7 +441,7 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
             }
             if (narrow) have = false;
             // a partial round only when the wavefront has nothing else left to do
-            const bool finishing = (__ballot(have) == 0ull) && (__ballot(!exhausted) == 0ull);
+            const bool finishing = (__ballot(have || fs != 0u) == 0ull) && (__ballot(!exhausted) == 0ull);
             while (qsize >= 64u || (finishing && qsize > 0u)) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -420,7 +464,7 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
         }
         GM_LAP(tVerify);
         if (__ballot(have) == 0ull && qsize == 0u) {
-            if (__ballot(!exhausted) == 0ull) break;   // nothing in flight, nothing queued, nothing left to draw
+            if (__ballot(!exhausted || fs != 0u) == 0ull) break;   // nothing in flight, nothing queued, nothing left to draw
             continue;
         }
 
