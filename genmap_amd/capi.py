@@ -37,13 +37,18 @@ class MapStats(C.Structure):
                 ("detail", C.c_uint64 * 15), ("search_ms", C.c_double), ("total_ms", C.c_double)]
 
 
+class Runs(C.Structure):
+    """struct gm_runs"""
+    _fields_ = [("n_runs", C.c_uint64), ("start", C.POINTER(C.c_uint64)), ("length", C.POINTER(C.c_uint64)), ("value", C.POINTER(C.c_uint16))]
+
+
 class Locations(C.Structure):
     """struct gm_locations"""
     _fields_ = [("pos_begin", C.c_uint64), ("n_positions", C.c_uint64), ("plus_off", C.POINTER(C.c_uint64)),
                 ("minus_off", C.POINTER(C.c_uint64)), ("plus", C.POINTER(C.c_uint64)), ("minus", C.POINTER(C.c_uint64))]
 
 
-EXPORTS = ["gm_tuned_infix_length", "gm_index_export_sa", "gm_locate", "gm_locations_free", "gm_status_string", "gm_last_error", "gm_device_count", "gm_index_build", "gm_index_import",
+EXPORTS = ["gm_map_runs", "gm_runs_free", "gm_tuned_infix_length", "gm_index_export_sa", "gm_locate", "gm_locations_free", "gm_status_string", "gm_last_error", "gm_device_count", "gm_index_build", "gm_index_import",
            "gm_index_export_bwt", "gm_index_get_info", "gm_index_free", "gm_map", "gm_map_device",
            "gm_last_map_stats", "gm_default_infix_length"]
 
@@ -89,6 +94,9 @@ def load_library(profiling=False):
     lib.gm_map.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(MapParams), vp, C.c_uint64, vp, vp]
     lib.gm_map_device.restype = C.c_int
     lib.gm_map_device.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(MapParams), vp, C.c_uint64, vp, vp, vp]
+    lib.gm_map_runs.restype = C.c_int
+    lib.gm_map_runs.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(MapParams), vp, C.c_uint64, vp, C.POINTER(C.POINTER(Runs))]
+    lib.gm_runs_free.argtypes = [C.POINTER(Runs)]
     lib.gm_locate.restype = C.c_int
     lib.gm_locate.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(MapParams), vp, C.c_uint64, C.POINTER(C.POINTER(Locations))]
     lib.gm_locations_free.argtypes = [C.POINTER(Locations)]
@@ -213,6 +221,24 @@ class Index:
         sf = None if seq_file_id is None else np.ascontiguousarray(seq_file_id, dtype=np.uint32)
         _check(self._lib, self._lib.gm_map_device(self._h, tb, tl, first_seq, n_seq, C.byref(p), _ptr(iv), 0 if iv is None else len(iv) // 2,
                                                   _ptr(sf), C.c_void_p(out_ptr), C.c_void_p(stream or 0)))
+
+    def map_runs(self, K, E, first_seq=0, n_seq=None, overlap=None, infix=0, revcompl=True, value_bits=16, exclude_pseudo=False,
+                 intervals=None, seq_file_id=None):
+        """gm_map_runs: (start, length, value) arrays of the non-zero runs of the result."""
+        n_seq, tb, tl = self._slice(first_seq, n_seq)
+        p = self._params(K, E, overlap, infix, revcompl, value_bits, exclude_pseudo, None)
+        iv = None if not intervals else np.ascontiguousarray(np.asarray(intervals, dtype=np.uint64).reshape(-1))
+        sf = None if seq_file_id is None else np.ascontiguousarray(seq_file_id, dtype=np.uint32)
+        R = C.POINTER(Runs)()
+        _check(self._lib, self._lib.gm_map_runs(self._h, tb, tl, first_seq, n_seq, C.byref(p), _ptr(iv), 0 if iv is None else len(iv) // 2, _ptr(sf), C.byref(R)))
+        try:
+            n = int(R.contents.n_runs)
+            if n == 0:
+                return np.zeros(0, np.uint64), np.zeros(0, np.uint64), np.zeros(0, np.uint16)
+            return (np.ctypeslib.as_array(R.contents.start, shape=(n,)).copy(), np.ctypeslib.as_array(R.contents.length, shape=(n,)).copy(),
+                    np.ctypeslib.as_array(R.contents.value, shape=(n,)).copy())
+        finally:
+            self._lib.gm_runs_free(R)
 
     def locate(self, K, E, first_seq=0, n_seq=None, overlap=None, infix=0, revcompl=True, intervals=None, kmer_range=None):
         """gm_locate: (pos_begin, plus_off, plus, minus_off, minus) -- occurrence lists per slice position,

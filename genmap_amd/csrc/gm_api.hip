@@ -4,6 +4,8 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_segmented_radix_sort.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -730,6 +732,67 @@ void gm_locations_free(gm_locations* L)
 {
     if (!L) return;
     free(L->plus_off); free(L->minus_off); free(L->plus); free(L->minus); free(L);
+}
+
+int gm_map_runs(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t first_seq, uint32_t n_seq, const gm_map_params* p,
+                const uint64_t* intervals, uint64_t n_intervals, const uint32_t* seq_file_id, gm_runs** out)
+{
+    if (!ix || !p || !out) { set_error("null argument"); return GM_ERR_BAD_ARG; }
+    if (p->value_bits != 8 && p->value_bits != 16) return GM_ERR_BAD_VALUE_BITS;
+    GM_HIP(hipSetDevice(ix->device));
+    gm_runs* R = (gm_runs*)calloc(1, sizeof(gm_runs));
+    if (!R) return GM_ERR_OOM;
+    void* d_c = nullptr; uint8_t* d_head = nullptr; uint32_t *d_starts = nullptr, *d_count = nullptr; uint16_t* d_val = nullptr; void* d_tmp = nullptr;
+    size_t tmpBytes = 0;
+    int rc = GM_OK;
+#define RC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); rc = (e_ == hipErrorOutOfMemory) ? GM_ERR_OOM : GM_ERR_HIP; goto done; } } while (0)
+    {
+        const uint64_t n = text_len;
+        RC(hipMalloc(&d_c, n * (p->value_bits / 8) + 16));
+        rc = map_impl(ix, text_begin, text_len, first_seq, n_seq, p, intervals, n_intervals, seq_file_id, d_c, nullptr);
+        if (rc) goto done;
+        if (n > 0) {
+            RC(hipMalloc(&d_head, n)); RC(hipMalloc(&d_starts, (n + 1) * 4)); RC(hipMalloc(&d_count, 4));
+            if (p->value_bits == 8) hipLaunchKernelGGL(run_heads_kernel<uint8_t>, dim3(grid_for(n)), dim3(256), 0, 0, (const uint8_t*)d_c, n, d_head);
+            else hipLaunchKernelGGL(run_heads_kernel<uint16_t>, dim3(grid_for(n)), dim3(256), 0, 0, (const uint16_t*)d_c, n, d_head);
+            hipLaunchKernelGGL(seq_heads_kernel, dim3(grid_for(n_seq)), dim3(256), 0, 0, ix->d_cumLocal, n_seq, n, d_head);
+            rocprim::counting_iterator<uint32_t> iota(0);
+            RC(rocprim::select(nullptr, tmpBytes, iota, d_head, d_starts, d_count, n));
+            RC(hipMalloc(&d_tmp, tmpBytes ? tmpBytes : 16));
+            RC(rocprim::select(d_tmp, tmpBytes, iota, d_head, d_starts, d_count, n));
+            uint32_t nHeads = 0;
+            RC(hipMemcpy(&nHeads, d_count, 4, hipMemcpyDeviceToHost));
+            RC(hipMalloc(&d_val, ((size_t)nHeads + 1) * 2));
+            if (p->value_bits == 8) hipLaunchKernelGGL(run_values_kernel<uint8_t>, dim3(grid_for(nHeads)), dim3(256), 0, 0, (const uint8_t*)d_c, d_starts, nHeads, d_val);
+            else hipLaunchKernelGGL(run_values_kernel<uint16_t>, dim3(grid_for(nHeads)), dim3(256), 0, 0, (const uint16_t*)d_c, d_starts, nHeads, d_val);
+            std::vector<uint32_t> starts(nHeads); std::vector<uint16_t> vals(nHeads);
+            RC(hipMemcpy(starts.data(), d_starts, (size_t)nHeads * 4, hipMemcpyDeviceToHost));
+            RC(hipMemcpy(vals.data(), d_val, (size_t)nHeads * 2, hipMemcpyDeviceToHost));
+            uint64_t keep = 0;
+            for (uint32_t r = 0; r < nHeads; ++r) keep += vals[r] != 0;
+            R->start = (uint64_t*)malloc((keep + 1) * 8); R->length = (uint64_t*)malloc((keep + 1) * 8); R->value = (uint16_t*)malloc((keep + 1) * 2);
+            if (!R->start || !R->length || !R->value) { rc = GM_ERR_OOM; goto done; }
+            uint64_t k = 0;
+            for (uint32_t r = 0; r < nHeads; ++r) {
+                if (vals[r] == 0) continue;   // runs of 0 are never written (src/output.hpp:98,152)
+                R->start[k] = starts[r]; R->length[k] = (r + 1 < nHeads ? starts[r + 1] : n) - starts[r]; R->value[k] = vals[r]; ++k;
+            }
+            R->n_runs = k;
+        }
+        rc = check_device_error(ix);
+    }
+done:
+#undef RC
+    hipFree(d_c); hipFree(d_head); hipFree(d_starts); hipFree(d_count); hipFree(d_val); hipFree(d_tmp);
+    if (rc) { gm_runs_free(R); return rc; }
+    *out = R;
+    return GM_OK;
+}
+
+void gm_runs_free(gm_runs* R)
+{
+    if (!R) return;
+    free(R->start); free(R->length); free(R->value); free(R);
 }
 
 int gm_last_map_stats(const gm_index* cix, gm_map_stats* out)

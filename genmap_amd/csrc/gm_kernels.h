@@ -562,6 +562,25 @@ __global__ __launch_bounds__(256) void finalize_fileset_kernel(const uint32_t* _
     out[j] = (TValue)c;
 }
 
+// ---- run-length form of c[] (saveWig / saveBedGraph scans, src/output.hpp:74-187) --------------------------------
+template <typename TValue>
+__global__ __launch_bounds__(256) void run_heads_kernel(const TValue* __restrict__ c, uint64_t n, uint8_t* __restrict__ head)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) head[i] = (i == 0 || c[i] != c[i - 1]) ? 1 : 0;
+}
+__global__ void seq_heads_kernel(const uint64_t* __restrict__ cumLocal, uint32_t nSeq, uint64_t n, uint8_t* __restrict__ head)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < nSeq && cumLocal[s] < n) head[cumLocal[s]] = 1;   // runs never cross a sequence boundary
+}
+template <typename TValue>
+__global__ __launch_bounds__(256) void run_values_kernel(const TValue* __restrict__ c, const uint32_t* __restrict__ starts, uint64_t nRuns, uint16_t* __restrict__ val)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < nRuns) val[r] = (uint16_t)c[starts[r]];
+}
+
 // resetLimits (algo.hpp:10-22): zero the last K-1 positions of every sequence of the slice.
 template <typename TValue>
 __global__ void reset_limits_kernel(TValue* out, const uint64_t* cumLocal, uint32_t nSeq, uint32_t K)

@@ -253,13 +253,27 @@ int map_main(int argc, const char** argv)
             gm_map_params p; memset(&p, 0, sizeof p);
             p.K = K; p.E = E; p.overlap = xo; p.infix = 0; p.revcompl = revCompl; p.value_bits = fs ? 8 : 16; p.exclude_pseudo = ep;
             const int width = fs ? 1 : 2;
-            std::vector<uint8_t> c((size_t)textLen * width + 16);
-            rc = gm_map(ix, textBegin, textLen, firstSeq, nSeq, &p, intervals.empty() ? nullptr : intervals.data(), intervals.size() / 2, seqFile.data(), c.data());
-            if (rc) { gm_index_free(ix); return fail_gm("computeMappability failed", rc); }
             std::string stem = outputPath;
             if (!outputIncludesFilename) stem += fileNames[fi].substr(0, fileNames[fi].find_last_of('.')) + ".genmap";   // src/mappability.hpp:76-78
             bool ok = true; double t;
             auto report = [&](const char* what) { if (verbose) std::cout << "- " << what << " written in " << (std::round((wall() - t) * 100.0) / 100.0) << " seconds\n"; };
+            const uint64_t* ivp = intervals.empty() ? nullptr : intervals.data();
+            if (!raw && !txt && !csv) {
+                // only run-length formats requested: the GPU hands back the runs, the frequency vector never crosses PCIe
+                gm_runs* R = nullptr;
+                rc = gm_map_runs(ix, textBegin, textLen, firstSeq, nSeq, &p, ivp, intervals.size() / 2, seqFile.data(), &R);
+                if (rc) { gm_index_free(ix); return fail_gm("computeMappability failed", rc); }
+                gmh::RunsInput ri; ri.n = R->n_runs; ri.start = R->start; ri.length = R->length; ri.value = R->value;
+                if (wig) { t = wall(); ok = ok && gmh::save_wig_runs(ri, stem, seqs, mappability, err); report("WIG file"); }
+                if (bg) { t = wall(); ok = ok && gmh::save_bedgraph_runs(ri, stem, seqs, true, mappability, err); report("bedgraph file"); }
+                if (bed) { t = wall(); ok = ok && gmh::save_bedgraph_runs(ri, stem, seqs, false, mappability, err); report("BED file"); }
+                gm_runs_free(R);
+            } else {
+            std::vector<uint8_t> c((size_t)textLen * width + 16);
+            if (raw || txt || wig || bg || bed) {
+                rc = gm_map(ix, textBegin, textLen, firstSeq, nSeq, &p, ivp, intervals.size() / 2, seqFile.data(), c.data());
+                if (rc) { gm_index_free(ix); return fail_gm("computeMappability failed", rc); }
+            }
             if (raw) { t = wall(); ok = ok && gmh::save_raw(c.data(), textLen, width, stem, kind, err); report("RAW file"); }
             if (txt) { t = wall(); ok = ok && gmh::save_txt(c.data(), textLen, width, stem, seqs, mappability, err); report("TXT file"); }
             if (wig) { t = wall(); ok = ok && gmh::save_wig(c.data(), textLen, width, stem, seqs, mappability, err); report("WIG file"); }
@@ -274,7 +288,7 @@ int map_main(int argc, const char** argv)
                 while (ok && begin < numKmers) {
                     p.kmer_begin = begin; p.kmer_end = std::min(numKmers, begin + window);
                     gm_locations* L = nullptr;
-                    rc = gm_locate(ix, textBegin, textLen, firstSeq, nSeq, &p, intervals.empty() ? nullptr : intervals.data(), intervals.size() / 2, &L);
+                    rc = gm_locate(ix, textBegin, textLen, firstSeq, nSeq, &p, ivp, intervals.size() / 2, &L);
                     if (rc == GM_ERR_TOO_LONG && window > 1) { window = std::max<uint64_t>(1, window / 2); continue; }
                     if (rc) { gm_index_free(ix); return fail_gm("locate failed", rc); }
                     gmh::CsvInput in; in.posBegin = L->pos_begin; in.nPositions = L->n_positions; in.plusOff = L->plus_off; in.minusOff = L->minus_off; in.plus = L->plus; in.minus = L->minus;
@@ -285,6 +299,7 @@ int map_main(int argc, const char** argv)
                     gm_locations_free(L);
                 }
                 report("CSV file");
+            }
             }
             if (!ok) { std::cerr << "ERROR: " << err << "\n"; gm_index_free(ix); return 1; }
         }

@@ -275,15 +275,25 @@ template <class Fn> static void for_each_run(const void* c, int width, const Seq
     }
 }
 
-bool save_wig(const void* c, uint64_t n, int width, const std::string& stem, const SeqTable& seqs, bool mappability, std::string& err)
+// Same callback protocol, runs taken from the GPU (only non-zero runs exist there).
+template <class Fn> static void for_each_given_run(const RunsInput& runs, const SeqTable& seqs, Fn fn)
 {
-    (void)n;
+    size_t s = 0; uint64_t base = 0;
+    for (uint64_t r = 0; r < runs.n; ++r) {
+        while (s + 1 < seqs.lengths.size() && runs.start[r] >= base + seqs.lengths[s]) { base += seqs.lengths[s]; ++s; }
+        fn(s, runs.start[r] - base, runs.length[r], (uint32_t)runs.value[r]);
+    }
+}
+
+template <class Each>
+static bool write_wig(Each each, const std::string& stem, const SeqTable& seqs, bool mappability, std::string& err)
+{
     {
         BufferedFile f(stem + ".wig");
         if (!f.ok()) { err = "cannot write " + stem + ".wig"; return false; }
         size_t curSeq = (size_t)-1;
         uint64_t lastSpan = 0;
-        for_each_run(c, width, seqs, [&](size_t s, uint64_t start, uint64_t len, uint32_t v) {
+        each([&](size_t s, uint64_t start, uint64_t len, uint32_t v) {
             if (s != curSeq) { curSeq = s; lastSpan = 0; }   // last_occ is per sequence (src/output.hpp:88-90)
             if (v == 0) return;                               // runs of 0 are skipped (:98)
             if (lastSpan != len) { f.put("variableStep chrom="); f.put(seqs.names[s]); f.put(" span="); f.put_u64(len); f.put('\n'); }
@@ -297,18 +307,38 @@ bool save_wig(const void* c, uint64_t n, int width, const std::string& stem, con
     return true;
 }
 
-bool save_bedgraph(const void* c, uint64_t n, int width, const std::string& stem, const SeqTable& seqs, bool bedgraph, bool mappability, std::string& err)
+bool save_wig(const void* c, uint64_t n, int width, const std::string& stem, const SeqTable& seqs, bool mappability, std::string& err)
 {
     (void)n;
+    return write_wig([&](auto fn) { for_each_run(c, width, seqs, fn); }, stem, seqs, mappability, err);
+}
+bool save_wig_runs(const RunsInput& runs, const std::string& stem, const SeqTable& seqs, bool mappability, std::string& err)
+{
+    return write_wig([&](auto fn) { for_each_given_run(runs, seqs, fn); }, stem, seqs, mappability, err);
+}
+
+template <class Each>
+static bool write_bedgraph(Each each, const std::string& stem, const SeqTable& seqs, bool bedgraph, bool mappability, std::string& err)
+{
     BufferedFile f(stem + (bedgraph ? ".bedgraph" : ".bed"));
     if (!f.ok()) { err = "cannot write " + stem; return false; }
-    for_each_run(c, width, seqs, [&](size_t s, uint64_t start, uint64_t len, uint32_t v) {   // src/output.hpp:150-186
+    each([&](size_t s, uint64_t start, uint64_t len, uint32_t v) {   // src/output.hpp:150-186
         if (v == 0) return;
         f.put(seqs.names[s]); f.put('\t'); f.put_u64(start); f.put('\t'); f.put_u64(start + len); f.put('\t');
         if (!bedgraph) { f.put('-'); f.put('\t'); }
         f.put_value(v, mappability); f.put('\n');
     });
     return true;
+}
+
+bool save_bedgraph(const void* c, uint64_t n, int width, const std::string& stem, const SeqTable& seqs, bool bedgraph, bool mappability, std::string& err)
+{
+    (void)n;
+    return write_bedgraph([&](auto fn) { for_each_run(c, width, seqs, fn); }, stem, seqs, bedgraph, mappability, err);
+}
+bool save_bedgraph_runs(const RunsInput& runs, const std::string& stem, const SeqTable& seqs, bool bedgraph, bool mappability, std::string& err)
+{
+    return write_bedgraph([&](auto fn) { for_each_given_run(runs, seqs, fn); }, stem, seqs, bedgraph, mappability, err);
 }
 
 bool save_csv(const std::string& stem, const CsvInput& in, const SeqTable& seqs, uint32_t K, bool revCompl,

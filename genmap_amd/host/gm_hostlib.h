@@ -50,6 +50,11 @@ bool save_txt(const void* c, uint64_t n, int width, const std::string& stem, con
 bool save_wig(const void* c, uint64_t n, int width, const std::string& stem, const SeqTable& seqs, bool mappability, std::string& err);
 bool save_bedgraph(const void* c, uint64_t n, int width, const std::string& stem, const SeqTable& seqs, bool bedgraph, bool mappability, std::string& err);
 
+// the same two writers fed from the GPU's run-length form (gm_map_runs): non-zero runs in text order, never across sequences
+struct RunsInput { uint64_t n = 0; const uint64_t* start = nullptr; const uint64_t* length = nullptr; const uint16_t* value = nullptr; };
+bool save_wig_runs(const RunsInput& runs, const std::string& stem, const SeqTable& seqs, bool mappability, std::string& err);
+bool save_bedgraph_runs(const RunsInput& runs, const std::string& stem, const SeqTable& seqs, bool bedgraph, bool mappability, std::string& err);
+
 // csv: occurrence lists per slice position as returned by gm_locate (packed seqNo << 32 | seqPos, global seqNo)
 struct CsvInput {
     uint64_t posBegin = 0, nPositions = 0;

@@ -30,6 +30,22 @@ int gmh_save_outputs(const void* c, uint64_t n, int width, const char* stem, int
     return ok ? 0 : 1;
 }
 
+// wig (bit 2) / bedgraph (bit 3) / bed (bit 4) from precomputed non-zero runs (the form gm_map_runs returns)
+int gmh_save_outputs_runs(uint64_t n_runs, const uint64_t* start, const uint64_t* length, const uint16_t* value, const char* stem, int kind, int formats,
+                          const char* names, const uint64_t* lengths, uint32_t n_seq)
+{
+    gmh::SeqTable seqs;
+    const char* p = names;
+    for (uint32_t s = 0; s < n_seq; ++s) { seqs.names.emplace_back(p); p += strlen(p) + 1; seqs.lengths.push_back(lengths[s]); }
+    gmh::RunsInput r; r.n = n_runs; r.start = start; r.length = length; r.value = value;
+    const bool mapp = kind == 0;
+    bool ok = true;
+    if (formats & 4) ok = ok && gmh::save_wig_runs(r, stem, seqs, mapp, g_err);
+    if (formats & 8) ok = ok && gmh::save_bedgraph_runs(r, stem, seqs, true, mapp, g_err);
+    if (formats & 16) ok = ok && gmh::save_bedgraph_runs(r, stem, seqs, false, mapp, g_err);
+    return ok ? 0 : 1;
+}
+
 int gmh_save_csv(const char* stem, uint64_t pos_begin, uint64_t n_positions, const uint64_t* plus_off, const uint64_t* minus_off,
                  const uint64_t* plus, const uint64_t* minus, const char* seq_names, const uint64_t* lengths, uint32_t n_seq, uint32_t K,
                  int revcompl, const char* file_names, const uint64_t* seqs_per_file, uint32_t n_files, int append)

@@ -136,6 +136,23 @@ int gm_locate(gm_index *idx, uint64_t text_begin, uint64_t text_len, uint32_t fi
               const gm_map_params *params, const uint64_t *intervals, uint64_t n_intervals, gm_locations **out);
 void gm_locations_free(gm_locations *loc);
 
+/* ------------------------------------------------------------------------------------------------
+ * Run-length form of the result for wig / bedgraph / bed output (the scans of saveWig / saveBedGraph,
+ * src/output.hpp:74-187, done on the GPU): maximal runs of equal NON-ZERO value that do not cross a
+ * sequence boundary, in text order.  Same arguments as gm_map; only the runs cross PCIe.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct gm_runs {
+    uint64_t n_runs;
+    uint64_t *start;      /* slice position of the run's first value */
+    uint64_t *length;
+    uint16_t *value;      /* the frequency (8-bit results are widened) */
+} gm_runs;
+
+int gm_map_runs(gm_index *idx, uint64_t text_begin, uint64_t text_len, uint32_t first_seq, uint32_t n_seq,
+                const gm_map_params *params, const uint64_t *intervals, uint64_t n_intervals,
+                const uint32_t *seq_file_id, gm_runs **out);
+void gm_runs_free(gm_runs *runs);
+
 /* counters of the most recent gm_map* call on this index (for the roofline numerator) */
 typedef struct gm_map_stats {
     uint64_t kmers;           /* k-mer positions searched */

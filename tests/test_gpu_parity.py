@@ -208,6 +208,33 @@ def test_gpu_shards_and_device_output():
     ix.close()
 
 
+def test_gpu_run_length_form_matches_vector():
+    """gm_map_runs == run-length encoding of gm_map's vector (non-zero runs, never across sequences)"""
+    g = _gm()
+    rng = np.random.default_rng(9)
+    lens = [5000, 1, 29, 30, 31, 4000]
+    codes = _repeat_text(rng, sum(lens), True)
+    codes[5000 + 1 + 29:5000 + 1 + 29 + 30] = codes[100:130]   # a whole short sequence that repeats
+    ix = g.Index.build(codes, lens, sampling=1)
+    for K, E, bits in ((30, 0, 8), (30, 1, 16), (12, 0, 8)):
+        vec = ix.map(K, E, value_bits=bits)
+        st, ln, va = ix.map_runs(K, E, value_bits=bits)
+        rec = np.zeros_like(vec)
+        cum = np.concatenate([[0], np.cumsum(lens)])
+        for s, l, v in zip(st, ln, va):
+            assert v != 0 and l > 0
+            rec[int(s):int(s + l)] = v
+            q = int(np.searchsorted(cum, int(s), side="right") - 1)
+            assert s + l <= cum[q + 1], "run crosses a sequence boundary"
+        assert np.array_equal(rec, vec), (K, E, bits)
+        # maximality: neighbouring runs inside one sequence differ in value or are separated by zeros
+        for i in range(1, len(st)):
+            if st[i] == st[i - 1] + ln[i - 1] and va[i] == va[i - 1]:
+                q = int(np.searchsorted(cum, int(st[i]), side="right") - 1)
+                assert st[i] == cum[q], "two adjacent runs of equal value inside a sequence"
+    ix.close()
+
+
 def test_gpu_midsize_vs_oracle_and_properties():
     """4 Mbp chr1-like text: GPU-built index; oracle adopts the exported BWTs (its own suffix sort is the slow
     part) and checks e=0 everywhere and e=1/2 on selected intervals; plus size-independent properties."""

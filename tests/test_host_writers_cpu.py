@@ -18,6 +18,8 @@ def hostlib():
     lib.gmh_last_error.restype = C.c_char_p
     lib.gmh_save_outputs.restype = C.c_int
     lib.gmh_save_outputs.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_void_p, C.c_uint32]
+    lib.gmh_save_outputs_runs.restype = C.c_int
+    lib.gmh_save_outputs_runs.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_void_p, C.c_uint32]
     lib.gmh_save_csv.restype = C.c_int
     lib.gmh_save_csv.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p,
                                  C.c_uint32, C.c_uint32, C.c_int, C.c_char_p, C.c_void_p, C.c_uint32, C.c_int]
@@ -71,6 +73,49 @@ def test_writers_reproduce_reference_files(case, hostlib, tmp_path):
                 assert filecmp.cmp(out / (stem_name + ext), d / sub / (stem_name + ext), shallow=False), (case, sub, name, ext)
                 checked += 1
     assert checked >= 10
+
+
+def _runs_of(c, lens):
+    """what gm_map_runs returns: maximal non-zero runs that stay inside one sequence"""
+    starts, lengths, values = [], [], []
+    base = 0
+    for ln in lens:
+        k = 0
+        while k < ln:
+            e = k + 1
+            while e < ln and c[base + e] == c[base + k]:
+                e += 1
+            if c[base + k] != 0:
+                starts.append(base + k); lengths.append(e - k); values.append(int(c[base + k]))
+            k = e
+        base += ln
+    return (np.asarray(starts + [0], np.uint64), np.asarray(lengths + [0], np.uint64), np.asarray(values + [0], np.uint16), len(starts))
+
+
+@pytest.mark.parametrize("case", sorted(H.CASES))
+def test_run_length_writers_reproduce_reference_files(case, hostlib, tmp_path):
+    d = H.CASES_DIR / f"case_{case}"
+    g, _, _, _ = H.load_case(case)
+    checked = 0
+    for sub in ("wig_map", "wig_freq16", "bed_map", "bed_freq16"):
+        kind, bit, src, dt, exts = FORMATS[sub]
+        for name, first, nseq, tb, tl in g.file_slices():
+            stem_name = name.rsplit(".", 1)[0] + ".genmap"
+            raw = d / src / (stem_name + ".freq16")
+            if not raw.exists():
+                continue
+            c = np.fromfile(raw, dtype=dt)
+            lens = np.ascontiguousarray(g.seq_len[first:first + nseq], dtype=np.uint64)
+            st, ln, va, n = _runs_of(c, [int(x) for x in lens])
+            out = tmp_path / sub
+            out.mkdir(exist_ok=True)
+            rc = hostlib.gmh_save_outputs_runs(n, H._ptr(st), H._ptr(ln), H._ptr(va), str(out / stem_name).encode(), kind, bit,
+                                               _names(g.seq_names[first:first + nseq]), H._ptr(lens), nseq)
+            assert rc == 0, hostlib.gmh_last_error()
+            for ext in exts:
+                assert filecmp.cmp(out / (stem_name + ext), d / sub / (stem_name + ext), shallow=False), (case, sub, name, ext)
+                checked += 1
+    assert checked >= 4
 
 
 @pytest.mark.parametrize("case", sorted(H.CASES))
