@@ -590,7 +590,8 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
     if (ep) GM_HIP(hipMemsetAsync(ix->d_bits, 0, (text_len + 1) * wordsPerKmer * sizeof(uint32_t), st));
     else GM_HIP(hipMemsetAsync(ix->d_acc, 0, (store ? 2 : 1) * plane * sizeof(uint32_t), st));
     GM_HIP(hipMemsetAsync(ix->d_small, 0, 256, st));
-    A.acc = ix->d_acc; A.accPlane = plane; A.fileBits = ix->d_bits; A.wordsPerKmer = wordsPerKmer; A.seqFile = ix->d_seqFile;
+    A.acc = ix->d_acc; A.accPlane = plane; A.fileBits = ix->d_bits;
+    A.maxVal = (p->value_bits == 8 && getenv("GM_NO_SATURATE") == nullptr) ? 255u : (getenv("GM_NO_SATURATE") ? 0xFFFFFFFFu : 65535u); A.wordsPerKmer = wordsPerKmer; A.seqFile = ix->d_seqFile;
 
     GM_HIP(hipEventRecord(ix->ev[1], st));
     if (S.numRoots > 0) { rc = launch_search(ix, ep ? LEAF_FILESET : store ? LEAF_STORE : LEAF_COUNT, A, S.blocks, st); if (rc) return rc; }

@@ -24,6 +24,7 @@ struct SearchArgs {
     const uint8_t* text;        // slice base, one code per byte
     uint32_t* acc;              // per slice position, zeroed by the caller (two planes of accPlane entries with StoreEnv)
     uint64_t accPlane;
+    uint32_t maxVal;            // 255 or 65535: the result is min(total, maxVal), so saturated k-mers need no further hits
     uint32_t K, E;
     uint32_t stepSize, nSearches, rootsPerBlock;
     uint32_t numKmers;
@@ -75,6 +76,16 @@ __device__ __forceinline__ uint2 locate_position(const uint64_t* __restrict__ cu
     return make_uint2(lo, (uint32_t)(p - (cum[lo] + lo)));
 }
 
+// k-mer starts (block coordinates) still covered by a node
+__device__ __forceinline__ void covered_kmers(uint32_t meta, uint32_t n, uint32_t K, uint32_t& smin, uint32_t& smax)
+{
+    const uint32_t a = meta_a(meta), bx = meta_bx(meta), t = meta_t(meta), md = meta_mode(meta);
+    if (md == M_OSS) { smin = 0u; smax = n - 1u; }
+    else if (md == M_EXT_R) { smin = t - K; smax = a; }
+    else if (md == M_EXT_L) { smin = bx - K; smax = t; }
+    else { smin = bx - K; smax = a; }
+}
+
 constexpr uint32_t WORK_CHUNK = 256;   // roots taken from the global counter per atomic
 constexpr uint32_t VERIFY_TMAX = 4;    // widest range resolved by verification
 
@@ -100,16 +111,6 @@ template <int WPP> struct EnvBase {
     __device__ __forceinline__ void note_item(uint32_t) {}
 #endif
     __device__ __forceinline__ EnvBase(const SearchArgs& a, uint4* s, uint32_t k) : A(a), stk(s), lstk(nullptr), lwin(nullptr), woff(0), sp(0), K(k) {}
-    // stage the root's window: W = K + n - 1 symbols starting at text position textBegin + win
-    __device__ __forceinline__ void load_window(const Root& rt)
-    {
-        const uint64_t g = A.textBegin + rt.win;
-        woff = (uint32_t)(g & 31u);
-        const uint4* src = A.text4 + (g >> 5);
-        const uint32_t nch = (woff + K + rt.n - 1u + 31u) >> 5;
-        uint4* dst = reinterpret_cast<uint4*>(const_cast<uint8_t*>(lwin));
-        for (uint32_t c = 0; c < nch; ++c) dst[c * 64u] = src[c];
-    }
     __device__ __forceinline__ uint4 pop()
     {
         --sp;
@@ -160,6 +161,8 @@ template <int WPP> struct EnvBase {
         else if (sp < A.stackDepth) { stk[sp - A.ldsDepth] = v; ++sp; }
         else *A.errorFlag = 1u;   // never expected: depth = stack_bound(E, stepSize)
     }
+    __device__ __forceinline__ void on_root() {}
+    __device__ __forceinline__ bool saturated(const Root&, uint32_t, uint32_t) const { return false; }
     __device__ __forceinline__ uint32_t C(uint32_t c) const { return A.C[c]; }
     __device__ __forceinline__ bool any(bool b) const { return __ballot(b) != 0ull; }
     __device__ __forceinline__ uint32_t sa(uint32_t row) const { return A.sa[row]; }
@@ -195,12 +198,24 @@ template <int WPP> struct EnvBase {
 template <int WPP> struct CountEnv : EnvBase<WPP> {
     using EnvBase<WPP>::A;
     uint32_t leafSum = 0;
+    uint32_t rootHits = 0;   // hits this lane has added for its current root (gates the saturation check)
     __device__ __forceinline__ CountEnv(const SearchArgs& a, uint4* s, uint32_t k) : EnvBase<WPP>(a, s, k) {}
+    __device__ __forceinline__ void on_root() { rootHits = 0; }
+    // c[] = min(total, MAX) (algo.hpp:36,48,191): once every k-mer a node still covers has reached MAX, nothing below the
+    // node can change the result.  Checked only after this lane alone has produced MAX hits for the root (repeats).
+    __device__ __forceinline__ bool saturated(const Root& rt, uint32_t smin, uint32_t smax) const
+    {
+        if (rootHits < A.maxVal) return false;
+        const uint32_t lo = rt.win + (rt.strand ? rt.n - 1u - smax : smin), cnt = smax - smin + 1u;
+        for (uint32_t i = 0; i < cnt; ++i) if (__hip_atomic_load(&A.acc[lo + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < A.maxVal) return false;
+        return true;
+    }
     __device__ __forceinline__ void leaf(const Root&, uint32_t, uint32_t, uint32_t w) { leafSum += w; }
     __device__ __forceinline__ void leaf_flush(const Root& rt, uint32_t kmer)
     {
         const uint32_t count = leafSum; leafSum = 0;
         if (!count) return;
+        rootHits = rootHits + count < rootHits ? 0xFFFFFFFFu : rootHits + count;
         const uint32_t pos = this->slice_pos(rt, kmer);
         const uint32_t add = count < 0xFFFFu ? count : 0xFFFFu;   // every add is <= MAX of the widest value type
         const uint32_t old = atomicAdd(&A.acc[pos], add);
@@ -210,6 +225,7 @@ template <int WPP> struct CountEnv : EnvBase<WPP> {
     {
         uint32_t* p = &A.acc[this->slice_pos(rt, kmer)];
         if (atomicAdd(p, 1u) == 0xFFFFFFFFu) atomicOr(p, 0x80000000u);
+        // (verified hits are not added to rootHits: the verifying lane is not the root's lane)
     }
 };
 
@@ -319,17 +335,20 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
 #define GM_LAP(acc) do { } while (0)
 #endif
     for (;;) {
-        if (!have && env.sp > 0) {
+#pragma unroll 1
+        for (int tries = 0; tries < 4 && !have && env.sp > 0; ++tries) {
             const uint4 v = env.pop();
             nd.flo = v.x; nd.rlo = v.y; nd.w = v.z; nd.meta = v.w;
-            have = true;
+            uint32_t smin, smax;
+            covered_kmers(nd.meta, rt.n, A.K, smin, smax);
+            have = !env.saturated(rt, smin, smax);   // pending work for k-mers that already reached MAX is dropped
         }
         // ---- root fetch, pipelined over iterations so that the wavefront never waits for it ----
         // stage 3: the q-mer table entry has arrived -> the root becomes the lane's node (or turns out empty)
         if (fs == 2u) {
             fs = 0u;
             if (ftab.z != 0u) {
-                rt = frt;
+                rt = frt; env.on_root();
                 nd.flo = ftab.x; nd.rlo = ftab.y; nd.w = ftab.z; nd.meta = meta_pack(fa0, fa0 + fql, 0, 0, M_OSS);
                 have = true;
             }
@@ -343,7 +362,7 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
             if (fnch > 2u) dst[128] = fw2;
             for (uint32_t c = 3u; c < fnch; ++c) dst[c * 64u] = fsrc[c];   // long windows (K > ~45): remaining chunks
             frt.rec.x = frec.x; frt.rec.y = frec.y; frt.rec.z = frec.z; frt.rec.w = frec.w;
-            if (fql == 0u) { rt = frt; nd = root_node(rt, A.nRows); have = true; fs = 0u; }
+            if (fql == 0u) { rt = frt; env.on_root(); nd = root_node(rt, A.nRows); have = true; fs = 0u; }
             else {
                 // 16 symbols starting at the lowest text position of the q-mer, 4 bits each
                 const unsigned long long v = fshift ? (fx0 >> fshift) | (fx1 << (64u - fshift)) : fx0;
@@ -472,8 +491,16 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
         wvIter += 1; wvActive += (uint32_t)__popcll(__ballot(have));
 #endif
         if (have) {
-            if (meta_mode(nd.meta) == M_SPLIT) { Node left; split_node(nd, left, A.K); env.push(left); }
-            lane_step(nd, have, rt, A.K, A.E, env);
+            if (meta_mode(nd.meta) == M_SPLIT) {
+                Node left; split_node(nd, left, A.K);
+                uint32_t smin, smax;
+                covered_kmers(left.meta, rt.n, A.K, smin, smax);
+                const bool leftDone = env.saturated(rt, smin, smax);
+                covered_kmers(nd.meta, rt.n, A.K, smin, smax);
+                if (env.saturated(rt, smin, smax)) { if (leftDone) have = false; else nd = left; }
+                else if (!leftDone) env.push(left);
+            }
+            if (have) lane_step(nd, have, rt, A.K, A.E, env);
         }
         GM_LAP(tStep);
     }
