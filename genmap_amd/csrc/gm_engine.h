@@ -327,44 +327,33 @@ GM_HD void verify_item(uint32_t row, uint32_t meta, const Root& rt, uint32_t K, 
 //        (needle coordinate `skip` is exempt: it is the substituted position)
 //   uint4 qtable(uint32_t len, uint32_t idx)          {fwd lo, rev lo, width, -} of that string
 // Returns false if the node is dead (pattern N in an exact stretch, empty range, unmet lower bound).
-// Planning half: 0 = no jump possible, 1 = the node is dead, 2 = look up qtable(len, idx) and continue with newMeta.
 template <class Env>
-GM_HD int oss_jump_plan(const Node& nd, const Root& rt, uint32_t Q, Env& env, uint32_t& newMeta, uint32_t& len, uint32_t& idx)
+GM_HD bool oss_jump(Node& nd, const Root& rt, uint32_t Q, Env& env)
 {
     const uint32_t m = nd.meta;
     const uint32_t errs = meta_errs(m);
-    if (meta_mode(m) != M_OSS || errs > 1u || !meta_known(m)) return 0;
+    if (meta_mode(m) != M_OSS || errs > 1u || !meta_known(m)) return true;
     uint32_t a = meta_a(m), bx = meta_bx(m), b = meta_bi(m);
     const uint32_t len0 = bx - a, nb = oss_nb(rt.rec);
-    if (len0 >= Q || oss_u(rt.rec, b) != errs) return 0;
+    if (len0 >= Q) return true;
     while (b < nb && oss_u(rt.rec, b) == errs && bx - a < Q) {
         const uint32_t need = oss_bl(rt.rec, b) - (bx - a);
         uint32_t take = Q - (bx - a); if (need < take) take = need;
         if (b + 1u == nb && take == need) { if (take == 0u) break; take -= 1u; }   // the last character of the infix is taken by a normal step
         if (take == 0u) break;
         if (oss_right(rt.rec, b)) bx += take; else a -= take;
-        if (take == need) { if (errs < oss_l(rt.rec, b)) return 1; ++b; } else break;
+        if (take == need) { if (errs < oss_l(rt.rec, b)) return false; ++b; } else break;
     }
-    len = bx - a;
-    if (len == len0) return 0;
+    const uint32_t len = bx - a;
+    if (len == len0) return true;
     const uint32_t subp = (rt.n - 1u) + meta_subpos(m);          // needle coordinate of the substitution (if errs == 1)
-    idx = 0;
-    if (!env.window_string(rt, a, len, errs ? subp : 0xFFFFFFFFu, idx)) return 1;   // pattern N cannot match exactly (find2:330,354)
+    uint32_t idx = 0;
+    if (!env.window_string(rt, a, len, errs ? subp : 0xFFFFFFFFu, idx)) return false;   // pattern N cannot match exactly (find2:330,354)
     if (errs) { const uint32_t k = subp - a; idx = (idx & ~(3u << (2u * k))) | (meta_subchar(m) << (2u * k)); }
-    newMeta = (m & ~0x0007FFFFu) | a | bx << 8 | b << 16;
-    return 2;
-}
-
-template <class Env>
-GM_HD bool oss_jump(Node& nd, const Root& rt, uint32_t Q, Env& env)
-{
-    uint32_t newMeta = 0, len = 0, idx = 0;
-    const int r = oss_jump_plan(nd, rt, Q, env, newMeta, len, idx);
-    if (r == 0) return true;
-    if (r == 1) return false;
     const uint4 e = env.qtable(len, idx);
     if (e.z == 0u) return false;
-    nd.flo = e.x; nd.rlo = e.y; nd.w = e.z; nd.meta = newMeta;
+    nd.flo = e.x; nd.rlo = e.y; nd.w = e.z;
+    nd.meta = (m & ~0x0007FFFFu) | a | bx << 8 | b << 16;
     return true;
 }
 

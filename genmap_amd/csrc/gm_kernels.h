@@ -357,7 +357,6 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
     uint32_t wvIter = 0, wvActive = 0, wvRounds = 0;
 #endif
     bool have = false, exhausted = false;
-    bool jp = false; uint32_t jpMeta = 0; uint4 jpE = make_uint4(0, 0, 0, 0);   // table jump in flight
     // root fetch pipeline of this lane: 0 idle, 1 window/record loads in flight (consumed in the next iteration)
     uint32_t fs = 0, fwoff = 0, fnch = 0;
     Root frt; frt.win = 0; frt.n = 1; frt.strand = 0; frt.search = 0; frt.rec = OssRecord{0, 0, 0, 0};
@@ -374,11 +373,6 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
 #define GM_LAP(acc) do { } while (0)
 #endif
     for (;;) {
-        if (jp) {   // the table entry asked for in the previous iteration
-            jp = false;
-            if (jpE.z == 0u) have = false;
-            else { nd.flo = jpE.x; nd.rlo = jpE.y; nd.w = jpE.z; nd.meta = jpMeta; }
-        }
 #pragma unroll 1
         for (int tries = 0; tries < 4 && !have && env.sp > 0; ++tries) {
             const uint4 v = env.pop();
@@ -458,18 +452,16 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
             poolCur += want < avail ? want : avail;
         }
         GM_LAP(tFetch);
-        // ---- exact stretches of nodes with a known string jump through the q-mer tables: the lookup is issued now and
-        //      consumed at the top of the next iteration (the lane sits this round out, the wavefront does not wait) ----
+        // ---- exact stretches of nodes with a known string jump through the q-mer tables (one lookup, no step this round) ----
         bool jumped = false;
         if (A.jumpQ && have) {
-            uint32_t jl = 0, jidx = 0;
-            const int r = oss_jump_plan(nd, rt, A.jumpQ, env, jpMeta, jl, jidx);
-            if (r == 1) have = false;
-            else if (r == 2) { jpE = env.qtable(jl, jidx); jp = true; jumped = true; }
+            const uint32_t w0 = nd.w, m0 = nd.meta;
+            if (!oss_jump(nd, rt, A.jumpQ, env)) have = false;
+            else jumped = (nd.w != w0 || nd.meta != m0);
         }
         // ---- defer narrow nodes: one queue entry per SA row ----
         if (A.verifyT) {
-            bool narrow = have && !jumped && nd.w <= A.verifyT;
+            bool narrow = have && nd.w <= A.verifyT;
             if (narrow) {   // is the subtree below worth one SA read + one text comparison per row?
                 const uint32_t m = nd.meta, a = meta_a(m), bx = meta_bx(m), t = meta_t(m), md = meta_mode(m);
                 const uint32_t covered = md == M_OSS ? rt.n : md == M_EXT_R ? a + A.K - t + 1u : md == M_EXT_L ? t + A.K - bx + 1u : a + A.K - bx + 1u;
