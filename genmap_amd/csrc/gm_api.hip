@@ -240,7 +240,8 @@ void gm_index_free(gm_index* ix)
 {
     if (!ix) return;
     hipSetDevice(ix->device);
-    hipFree(ix->d_blk[0]); hipFree(ix->d_blk[1]); hipFree(ix->d_textAlloc); hipFree(ix->d_text4); hipFree(ix->d_cum); hipFree(ix->d_sa); hipFree(ix->d_textSAlloc); hipFree(ix->d_C); hipFree(ix->d_qtab); hipFree(ix->d_seqFile); hipFree(ix->d_bits);
+    hipFree(ix->d_blk[0]); hipFree(ix->d_blk[1]); hipFree(ix->d_textAlloc); hipFree(ix->d_text4); hipFree(ix->d_cum); hipFree(ix->d_sa); hipFree(ix->d_textSAlloc); hipFree(ix->d_C);
+    for (auto& kv : ix->qtables) hipFree(kv.second); hipFree(ix->d_seqFile); hipFree(ix->d_bits);
     hipFree(ix->d_acc); hipFree(ix->d_stack); hipFree(ix->d_small); hipFree(ix->d_table); hipFree(ix->d_blocks); hipFree(ix->d_cumLocal);
     for (int i = 0; i < 4; ++i) if (ix->ev[i]) hipEventDestroy(ix->ev[i]);
     delete ix;
@@ -354,7 +355,7 @@ template <typename T> static int grow(T** p, uint64_t* cap, uint64_t need)
 
 enum LeafMode { LEAF_COUNT = 0, LEAF_FILESET = 1, LEAF_OCC_COUNT = 2, LEAF_OCC_EMIT = 3, LEAF_STORE = 4 };
 
-static inline size_t search_lds_bytes(const SearchArgs& A) { return (size_t)(4u * A.vqCap + 4u * 64u * A.ldsDepth) * 16u + (size_t)4u * 64u * (3u * A.winChunks + 2u) * 4u; }
+static inline size_t search_lds_bytes(const SearchArgs& A) { return (size_t)(4u * A.vqCap + 4u * 64u * (A.ldsDepth + A.winChunks)) * 16u; }
 
 template <int WPP, class EnvT>
 static int launch_one(const SearchArgs& A, unsigned blocks, hipStream_t st)
@@ -393,30 +394,23 @@ template <int WPP> static int occupancy_blocks(int* out, size_t ldsBytes)
 
 static int check_device_error(gm_index* ix);
 
-// q-mer table arena of this index for lengths 0..Q (cached; rebuilt only if a longer one is asked for)
-static int get_qtables(gm_index* ix, uint32_t Q, const uint4** out)
+// table of all q-mers for this index (cached)
+static int get_qtable(gm_index* ix, uint32_t q, const uint4** out)
 {
-    if (ix->d_qtab && ix->qtabQ >= Q) { *out = ix->d_qtab; return GM_OK; }
-    if (ix->d_qtab) { hipFree(ix->d_qtab); ix->d_qtab = nullptr; ix->qtabQ = 0; }
-    const uint64_t total = ((1ull << (2 * (Q + 1))) - 1ull) / 3ull;   // sum of 4^L, L = 0..Q
+    auto it = ix->qtables.find(q);
+    if (it != ix->qtables.end()) { *out = it->second; return GM_OK; }
     uint4* d = nullptr;
-    GM_HIP(hipMalloc(&d, total * sizeof(uint4)));
+    const uint64_t n = 1ull << (2 * q);
+    GM_HIP(hipMalloc(&d, n * sizeof(uint4)));
     if (!ix->d_C) { GM_HIP(hipMalloc(&ix->d_C, sizeof(ix->C))); GM_HIP(hipMemcpy(ix->d_C, ix->C, sizeof(ix->C), hipMemcpyHostToDevice)); }
-    const uint4 root = make_uint4(0u, 0u, (uint32_t)ix->nRows, 0u);
-    GM_HIP(hipMemcpy(d, &root, sizeof(root), hipMemcpyHostToDevice));
-    for (uint32_t len = 1; len <= Q; ++len) {
-        const uint4* parent = d + ((1ull << (2 * (len - 1))) - 1ull) / 3ull;
-        uint4* child = d + ((1ull << (2 * len)) - 1ull) / 3ull;
-        const uint64_t np = 1ull << (2 * (len - 1));
-        switch (ix->wpp) {
-            case 1: hipLaunchKernelGGL(qtab_extend_kernel<1>, dim3(grid_for(np)), dim3(256), 0, 0, ix->d_blk[1], ix->d_C, len, parent, child); break;
-            case 3: hipLaunchKernelGGL(qtab_extend_kernel<3>, dim3(grid_for(np)), dim3(256), 0, 0, ix->d_blk[1], ix->d_C, len, parent, child); break;
-            default: hipLaunchKernelGGL(qtab_extend_kernel<9>, dim3(grid_for(np)), dim3(256), 0, 0, ix->d_blk[1], ix->d_C, len, parent, child); break;
-        }
+    switch (ix->wpp) {
+        case 1: hipLaunchKernelGGL(qmer_table_kernel<1>, dim3(grid_for(n)), dim3(256), 0, 0, ix->d_blk[1], ix->d_C, (uint32_t)ix->nRows, q, d); break;
+        case 3: hipLaunchKernelGGL(qmer_table_kernel<3>, dim3(grid_for(n)), dim3(256), 0, 0, ix->d_blk[1], ix->d_C, (uint32_t)ix->nRows, q, d); break;
+        default: hipLaunchKernelGGL(qmer_table_kernel<9>, dim3(grid_for(n)), dim3(256), 0, 0, ix->d_blk[1], ix->d_C, (uint32_t)ix->nRows, q, d); break;
     }
     GM_HIP(hipGetLastError());
     GM_HIP(hipDeviceSynchronize());
-    ix->d_qtab = d; ix->qtabQ = Q;
+    ix->qtables[q] = d;
     *out = d;
     return GM_OK;
 }
@@ -492,7 +486,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     uint32_t ldsDepth = 4;
     if (const char* e = getenv("GM_LDS_STACK")) ldsDepth = (uint32_t)std::max(0, atoi(e));
     ldsDepth = std::min(ldsDepth, depth);
-    const size_t ldsBytes = (size_t)(4u * vqCap + 4u * 64u * ldsDepth) * 16u + (size_t)4u * 64u * (3u * winChunks + 2u) * 4u;
+    const size_t ldsBytes = (size_t)(4u * vqCap + 4u * 64u * (ldsDepth + winChunks)) * 16u;
     int perCU = 0;
     switch (ix->wpp) { case 1: rc = occupancy_blocks<1>(&perCU, ldsBytes); break; case 3: rc = occupancy_blocks<3>(&perCU, ldsBytes); break; default: rc = occupancy_blocks<9>(&perCU, ldsBytes); break; }
     if (rc) return rc;
@@ -525,12 +519,24 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     A.blockList = plan.useList ? ix->d_blocks : nullptr;
     A.table = ix->d_table;
     A.stack = ix->d_stack; A.stackDepth = depth; A.spillDepth = std::max<uint32_t>(depth - ldsDepth, 1u);
-    {   // q-mer tables for exact-stretch jumps: all lengths up to Q
-        uint32_t q = 13;
-        while (q > 1 && (1ull << (2 * q)) > 4ull * ix->nRows) --q;          // no point in tables much larger than the text
-        if (const char* e = getenv("GM_QTABLE")) q = (uint32_t)std::max(0, std::min(atoi(e), 16));
-        A.qtabArena = nullptr; A.jumpQ = 0;
-        if (q > 0) { rc = get_qtables(ix, q, &A.qtabArena); if (rc) return rc; A.jumpQ = q; }
+    {   // q-mer tables for the first block of every search: q = min(Qmax, length of that block - 1) for the regular block shape
+        uint32_t qmax = 12;
+        while (qmax > 0 && (1ull << (2 * qmax)) > ix->nRows) --qmax;       // no point in tables larger than the text
+        if (const char* e = getenv("GM_QTABLE")) qmax = (uint32_t)std::max(0, std::min(atoi(e), 13));
+        A.qtabA = A.qtabB = nullptr; A.qlenPacked = 0; A.qselMask = 0; A.startPacked[0] = A.startPacked[1] = 0;
+        uint32_t qA = 0, qB = 0;
+        for (uint32_t s = 0; s < plan.nSearches; ++s) {
+            const OssRecord& r = plan.table[(size_t)(plan.stepSize - 1) * 8 + s];
+            A.startPacked[s >> 2] |= oss_start(r) << (8u * (s & 3u));
+            if (qmax == 0) continue;
+            const uint32_t bl0 = oss_bl(r, 0);
+            const uint32_t q = std::min(qmax, bl0 > 0 ? bl0 - 1u : 0u);
+            if (q == 0) continue;
+            if (qA == 0 || qA == q) { if (qA == 0) { rc = get_qtable(ix, q, &A.qtabA); if (rc) return rc; qA = q; } }
+            else if (qB == 0 || qB == q) { if (qB == 0) { rc = get_qtable(ix, q, &A.qtabB); if (rc) return rc; qB = q; } A.qselMask |= 1u << s; }
+            else continue;   // a third distinct prefix length: this search starts from the root
+            A.qlenPacked |= q << (4u * s);
+        }
     }
     A.text4 = ix->d_text4; A.textBegin = text_begin; A.vqCap = vqCap; A.ldsDepth = ldsDepth; A.winChunks = winChunks;
     A.workCounter = reinterpret_cast<unsigned long long*>(ix->d_small);

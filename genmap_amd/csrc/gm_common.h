@@ -12,10 +12,6 @@
 
 namespace gm {
 
-#if !defined(__HIPCC__)
-struct uint4 { uint32_t x, y, z, w; };   // host-only builds (tests/emu): same shape as HIP's uint4
-#endif
-
 // symbol codes of the text and of the BWTs (N is a real 5th index symbol, src/algo.hpp:111-112,148-149;
 // the sentinel is explicit in the rank planes, one after EVERY sequence, src/seqan_libdivsufsort.h:80-91)
 enum : uint32_t { SYM_A = 0, SYM_C = 1, SYM_G = 2, SYM_T = 3, SYM_N = 4, SYM_SENT = 5, NLET = 5 };

@@ -27,10 +27,7 @@ namespace gm {
 
 enum : uint32_t { M_OSS = 0, M_EXT_R = 1, M_EXT_L = 2, M_SPLIT = 3 };
 
-struct Node { uint32_t flo, rlo, w, meta; };   // meta: a | bx<<8 | t<<16 | errs<<24 | mode<<27 | subChar<<29 | known<<31
-// In OSS phase t = block index (3 bits) | subPos << 3: a node that has spent at most one error on a letter remembers
-// WHERE (infix coordinate) and WHICH letter, so its matched string is known exactly (`known`): exact stretches of
-// such nodes can jump through per-length q-mer tables (oss_jump).  In the extension phases t is the segment target.
+struct Node { uint32_t flo, rlo, w, meta; };   // meta: a | bx<<8 | t<<16 | errs<<24 | mode<<27
 
 GM_HD uint32_t meta_pack(uint32_t a, uint32_t bx, uint32_t t, uint32_t errs, uint32_t mode)
 {
@@ -41,12 +38,6 @@ GM_HD uint32_t meta_bx(uint32_t m) { return (m >> 8) & 0xFFu; }
 GM_HD uint32_t meta_t(uint32_t m) { return (m >> 16) & 0xFFu; }
 GM_HD uint32_t meta_errs(uint32_t m) { return (m >> 24) & 7u; }
 GM_HD uint32_t meta_mode(uint32_t m) { return (m >> 27) & 3u; }
-GM_HD uint32_t meta_bi(uint32_t m) { return (m >> 16) & 7u; }         // OSS phase only
-GM_HD uint32_t meta_subpos(uint32_t m) { return (m >> 19) & 31u; }   // OSS phase only
-GM_HD uint32_t meta_subchar(uint32_t m) { return (m >> 29) & 3u; }
-GM_HD uint32_t meta_known(uint32_t m) { return m >> 31; }
-constexpr uint32_t META_KNOWN = 0x80000000u;
-constexpr uint32_t META_SUB_MASK = (31u << 19) | (3u << 29) | META_KNOWN;
 
 // the root a lane is currently working on: one (k-mer block, strand, search) triple
 struct Root {
@@ -61,7 +52,7 @@ GM_HD Node root_node(const Root& rt, uint32_t nRows)
 {
     // _optimalSearchSchemeGM(..., s.startPos, s.startPos + 1, 0, s, 0, Rev()) find2_index_approx.hpp:441
     uint32_t a = (rt.n - 1u) + oss_start(rt.rec);
-    Node nd; nd.flo = 0; nd.rlo = 0; nd.w = nRows; nd.meta = meta_pack(a, a, 0, 0, M_OSS) | META_KNOWN;
+    Node nd; nd.flo = 0; nd.rlo = 0; nd.w = nRows; nd.meta = meta_pack(a, a, 0, 0, M_OSS);
     return nd;
 }
 
@@ -88,14 +79,13 @@ struct Plan {
 GM_HD Plan make_plan(uint32_t meta, const OssRecord& rec, uint32_t E)
 {
     Plan p;
-    uint32_t a = meta_a(meta), bx = meta_bx(meta), errs = meta_errs(meta), mode = meta_mode(meta);
+    uint32_t a = meta_a(meta), bx = meta_bx(meta), t = meta_t(meta), errs = meta_errs(meta), mode = meta_mode(meta);
     if (mode == M_OSS) {
-        const uint32_t bi = meta_bi(meta);
-        uint32_t u = oss_u(rec, bi), l = oss_l(rec, bi);
-        p.right = oss_right(rec, bi);
+        uint32_t u = oss_u(rec, t), l = oss_l(rec, t);
+        p.right = oss_right(rec, t);
         p.exact = (u == errs);                        // maxErrorsLeftInBlock == 0  (find2:388,397)
         p.minErr = l > errs ? l - errs : 0u;          // find2:389
-        p.charsLeft = oss_bl(rec, bi) - (bx - a);     // find2:247
+        p.charsLeft = oss_bl(rec, t) - (bx - a);      // find2:247
     } else {
         p.right = (mode == M_EXT_R);
         p.exact = (errs == E);                        // errorsLeft == 0  (algo.hpp:106,117,143,154,175)
@@ -115,9 +105,9 @@ GM_HD Post make_post(uint32_t meta, const Plan& pl, const OssRecord& rec, uint32
     bool done;
     if (mode == M_OSS) {
         done = false;
-        if (bx - a == oss_bl(rec, t & 7u)) {          // block complete (find2:263, :335-344, :358-367)
-            t += 1u;                                  // block index lives in the low 3 bits
-            done = ((t & 7u) == oss_nb(rec));         // "Done": delegate -> extend  (find2:392-395, algo.hpp:262-298)
+        if (bx - a == oss_bl(rec, t)) {               // block complete (find2:263, :335-344, :358-367)
+            t += 1u;
+            done = (t == oss_nb(rec));                // "Done": delegate -> extend  (find2:392-395, algo.hpp:262-298)
         }
     } else {
         done = pl.right ? (bx == t) : (a == t);       // algo.hpp:101-105,138-142
@@ -128,7 +118,7 @@ GM_HD Post make_post(uint32_t meta, const Plan& pl, const OssRecord& rec, uint32
         else mode = M_SPLIT;
         t = 0;
     }
-    ps.meta0 = meta_pack(a, bx, t, 0, mode) | (mode == M_OSS ? (meta & (3u << 29 | META_KNOWN)) : 0u);   // substitution memory survives inside OSS
+    ps.meta0 = meta_pack(a, bx, t, 0, mode);
     return ps;
 }
 
@@ -193,15 +183,7 @@ GM_HD void lane_step(Node& nd, bool& have, const Root& rt, uint32_t K, uint32_t 
                 keep.flo = pl.right ? onew : pnew;
                 keep.rlo = pl.right ? pnew : onew;
                 keep.w = cx;
-                uint32_t cm = ps.meta0 | ((errs + delta) << 24);
-                if (delta) {
-                    // first error on a real letter: remember it (position in infix coordinates, letter); anything else
-                    // (second error, text N) makes the matched string unknown to the table jump
-                    if (errs == 0u && (cm & META_KNOWN) && x <= 3u && meta_mode(cm) == M_OSS && pl.pos - (rt.n - 1u) < 32u)
-                        cm = (cm & ~((31u << 19) | (3u << 29))) | (((pl.pos - (rt.n - 1u)) & 31u) << 19) | (x << 29);
-                    else cm &= ~META_KNOWN;
-                }
-                keep.meta = cm;
+                keep.meta = ps.meta0 | ((errs + delta) << 24);
                 haveKeep = true;
             }
         }
@@ -284,7 +266,7 @@ GM_HD void verify_item(uint32_t row, uint32_t meta, const Root& rt, uint32_t K, 
     uint32_t scratch[4];
     if (mode == M_OSS) {
         const uint32_t nb = oss_nb(rt.rec);
-        for (uint32_t bi = t & 7u; bi < nb; ++bi) {
+        for (uint32_t bi = t; bi < nb; ++bi) {
             const uint32_t right = oss_right(rt.rec, bi), blen = oss_bl(rt.rec, bi), u = oss_u(rt.rec, bi), l = oss_l(rt.rec, bi);
             const uint32_t need = blen - (bx - a);
             uint32_t c = 0;
@@ -313,48 +295,6 @@ GM_HD void verify_item(uint32_t row, uint32_t meta, const Root& rt, uint32_t K, 
         for (int j = 0; j < 4; ++j) d += (lp[j] <= lenL ? 1u : 0u) + (rp[j] <= lenR ? 1u : 0u);
         if (d <= budget) env.leaf_at(rt, s, p0 - (a0 - s));
     }
-}
-
-// ---- exact-stretch jumps through q-mer tables -----------------------------------------------------------------
-// An OSS node whose matched string is known (no error, or one substitution) and whose next characters must match
-// exactly (u[b] == errors for the blocks ahead, the situation _optimalSearchSchemeExactGM handles character by
-// character, find2_index_approx.hpp:303-369) extends straight to the end of that exact stretch -- or to the table
-// length Q -- with ONE lookup of the longer string's SA ranges.  This covers the first block of every search from
-// the root and, more importantly, the exact continuation of every first-mismatch branch.
-// Env additionally supplies:
-//   bool window_string(const Root&, uint32_t a, uint32_t len, uint32_t skip, uint32_t& idx)
-//        2-bit codes of needle[a, a+len), symbol k in bits [2k, 2k+2); false if a pattern N lies in the range
-//        (needle coordinate `skip` is exempt: it is the substituted position)
-//   uint4 qtable(uint32_t len, uint32_t idx)          {fwd lo, rev lo, width, -} of that string
-// Returns false if the node is dead (pattern N in an exact stretch, empty range, unmet lower bound).
-template <class Env>
-GM_HD bool oss_jump(Node& nd, const Root& rt, uint32_t Q, Env& env)
-{
-    const uint32_t m = nd.meta;
-    const uint32_t errs = meta_errs(m);
-    if (meta_mode(m) != M_OSS || errs > 1u || !meta_known(m)) return true;
-    uint32_t a = meta_a(m), bx = meta_bx(m), b = meta_bi(m);
-    const uint32_t len0 = bx - a, nb = oss_nb(rt.rec);
-    if (len0 >= Q) return true;
-    while (b < nb && oss_u(rt.rec, b) == errs && bx - a < Q) {
-        const uint32_t need = oss_bl(rt.rec, b) - (bx - a);
-        uint32_t take = Q - (bx - a); if (need < take) take = need;
-        if (b + 1u == nb && take == need) { if (take == 0u) break; take -= 1u; }   // the last character of the infix is taken by a normal step
-        if (take == 0u) break;
-        if (oss_right(rt.rec, b)) bx += take; else a -= take;
-        if (take == need) { if (errs < oss_l(rt.rec, b)) return false; ++b; } else break;
-    }
-    const uint32_t len = bx - a;
-    if (len == len0) return true;
-    const uint32_t subp = (rt.n - 1u) + meta_subpos(m);          // needle coordinate of the substitution (if errs == 1)
-    uint32_t idx = 0;
-    if (!env.window_string(rt, a, len, errs ? subp : 0xFFFFFFFFu, idx)) return false;   // pattern N cannot match exactly (find2:330,354)
-    if (errs) { const uint32_t k = subp - a; idx = (idx & ~(3u << (2u * k))) | (meta_subchar(m) << (2u * k)); }
-    const uint4 e = env.qtable(len, idx);
-    if (e.z == 0u) return false;
-    nd.flo = e.x; nd.rlo = e.y; nd.w = e.z;
-    nd.meta = (m & ~0x0007FFFFu) | a | bx << 8 | b << 16;
-    return true;
 }
 
 // upper bound of simultaneously stacked nodes of one lane (DESIGN.md "stack bound")

@@ -33,7 +33,7 @@ struct gm_index {
     uint64_t* d_cum = nullptr;
     uint32_t* d_sa = nullptr;         // forward suffix array (kept when sampling == 1): locate = one HBM read
     uint8_t* d_textS = nullptr;       // sentinel text (verification of narrow nodes), present with d_sa
-    uint4* d_qtab = nullptr; uint32_t qtabQ = 0;   // q-mer table arena for lengths 0..qtabQ (built on first use)
+    std::map<uint32_t, uint4*> qtables;   // q -> device table of 4^q entries (built on first use)
     uint32_t* d_C = nullptr;
     uint32_t* d_seqFile = nullptr; uint64_t seqFileCap = 0;
     uint32_t* d_bits = nullptr; uint64_t bitsCap = 0;

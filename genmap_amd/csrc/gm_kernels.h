@@ -60,10 +60,12 @@ struct SearchArgs {
     uint32_t vqCap;                 // queue entries per wavefront
     uint32_t ldsDepth;              // stack entries per lane kept in LDS (deeper ones spill to `stack`)
     uint32_t winChunks;             // 16-byte chunks per lane for the needle window
-    // ---- q-mer range tables for exact-stretch jumps (gm_engine.h: oss_jump) ----
-    const uint4* qtabArena;         // tables of all lengths 0..jumpQ back to back: length L starts at entry (4^L - 1) / 3;
-                                    // entry idx (symbol k in bits [2k, 2k+2)) = {fwd lo, rev lo, width, 0} of that string
-    uint32_t jumpQ;                 // longest tabulated string (0 = no jumps)
+    // ---- q-mer range tables: the first (always exact) OSS block of a root starts from a lookup instead of q steps ----
+    const uint4* qtabA;             // {fwd lo, rev lo, width, 0} of every ACGT string of length q (two tables at most per call)
+    const uint4* qtabB;
+    uint32_t qlenPacked;            // 4 bits per search: table prefix length q_s (0 = no table for that search)
+    uint32_t qselMask;              // bit s: search s uses qtabB
+    uint32_t startPacked[2];        // 8 bits per search: startPos of the regular block shape (n == stepSize)
 };
 
 // sentinel-text position -> (seqNo, seqPos); sequence s starts at cum[s] + s
@@ -84,20 +86,6 @@ __device__ __forceinline__ void covered_kmers(uint32_t meta, uint32_t n, uint32_
     else { smin = bx - K; smax = a; }
 }
 
-// eight 4-bit symbols -> eight 2-bit codes (16 bits) / eight "is N" flags (8 bits)
-__device__ __forceinline__ uint32_t pack2(uint32_t x)
-{
-    uint32_t y = x & 0x33333333u;
-    y = (y | (y >> 2)) & 0x0F0F0F0Fu; y = (y | (y >> 4)) & 0x00FF00FFu; y = (y | (y >> 8)) & 0x0000FFFFu;
-    return y;
-}
-__device__ __forceinline__ uint32_t packN(uint32_t x)
-{
-    uint32_t z = (x >> 2) & 0x11111111u;
-    z = (z | (z >> 3)) & 0x03030303u; z = (z | (z >> 6)) & 0x000F000Fu; z = (z | (z >> 12)) & 0xFFu;
-    return z;
-}
-
 constexpr uint32_t WORK_CHUNK = 256;   // roots taken from the global counter per atomic
 constexpr uint32_t VERIFY_TMAX = 4;    // widest range resolved by verification
 
@@ -105,9 +93,8 @@ template <int WPP> struct EnvBase {
     const SearchArgs& A;
     uint4* stk;          // global spill area of this lane
     uint4* lstk;         // LDS: [depth][lane] of this wavefront, already offset by the lane
-    const uint32_t* lw2; // LDS: [word][lane] 2-bit codes of this lane's needle window, 16 symbols per word, offset by the lane
-    const uint32_t* lnf; // LDS: [word][lane] "is N" flags, 32 symbols per word, offset by the lane
-    uint32_t woff;       // symbol offset of the window inside its first 32-symbol chunk
+    const uint8_t* lwin; // LDS: [chunk][lane] 16-byte chunks of this lane's packed window, already offset by the lane
+    uint32_t woff;       // nibble offset of the window inside its first chunk
     uint32_t sp;
     uint32_t K;
 #ifdef GM_COUNTERS
@@ -123,7 +110,7 @@ template <int WPP> struct EnvBase {
     __device__ __forceinline__ void note_chunk() {}
     __device__ __forceinline__ void note_item(uint32_t) {}
 #endif
-    __device__ __forceinline__ EnvBase(const SearchArgs& a, uint4* s, uint32_t k) : A(a), stk(s), lstk(nullptr), lw2(nullptr), lnf(nullptr), woff(0), sp(0), K(k) {}
+    __device__ __forceinline__ EnvBase(const SearchArgs& a, uint4* s, uint32_t k) : A(a), stk(s), lstk(nullptr), lwin(nullptr), woff(0), sp(0), K(k) {}
     __device__ __forceinline__ uint4 pop()
     {
         --sp;
@@ -159,10 +146,10 @@ template <int WPP> struct EnvBase {
     __device__ __forceinline__ uint32_t text_char(const Root& rt, uint32_t pos) const
     {
         const uint32_t W = K + rt.n - 1u;
-        const uint32_t i = woff + (rt.strand ? (W - 1u - pos) : pos);
-        const uint32_t c = (lw2[(i >> 4) * 64u] >> (2u * (i & 15u))) & 3u;       // word stride = 64 lanes: every lane its own bank
-        const uint32_t isN = (lnf[(i >> 5) * 64u] >> (i & 31u)) & 1u;
-        return isN ? (uint32_t)SYM_N : (rt.strand ? 3u - c : c);
+        const uint32_t nib = woff + (rt.strand ? (W - 1u - pos) : pos);
+        const uint32_t b = lwin[(nib >> 5) * 1024u + ((nib & 31u) >> 1)];   // chunk stride = 64 lanes x 16 bytes
+        const uint32_t c = (b >> ((nib & 1u) * 4u)) & 15u;
+        return rt.strand ? complement(c) : c;
     }
     __device__ __forceinline__ void push(const Node& nd)
     {
@@ -178,29 +165,6 @@ template <int WPP> struct EnvBase {
     __device__ __forceinline__ bool saturated(const Root&, uint32_t, uint32_t) const { return false; }
     __device__ __forceinline__ uint32_t C(uint32_t c) const { return A.C[c]; }
     __device__ __forceinline__ bool any(bool b) const { return __ballot(b) != 0ull; }
-    // 2-bit codes of needle[a, a+len), symbol k in bits [2k, 2k+2) (len <= 16); false if a pattern N lies inside (except at `skip`)
-    __device__ __forceinline__ bool window_string(const Root& rt, uint32_t a, uint32_t len, uint32_t skip, uint32_t& idx) const
-    {
-        const uint32_t W = K + rt.n - 1u;
-        const uint32_t s = woff + (rt.strand ? W - a - len : a);                 // lowest window index of the range
-        const uint32_t wi = s >> 4, ni = s >> 5;
-        const unsigned long long two = ((unsigned long long)lw2[(wi + 1u) * 64u] << 32 | lw2[wi * 64u]) >> (2u * (s & 15u));
-        const unsigned long long nfl = ((unsigned long long)lnf[(ni + 1u) * 64u] << 32 | lnf[ni * 64u]) >> (s & 31u);
-        uint32_t f = (uint32_t)two, nmask = (uint32_t)nfl & ((len >= 32u) ? 0xFFFFFFFFu : ((1u << len) - 1u));
-        if (skip - a < len) nmask &= ~(1u << (rt.strand ? len - 1u - (skip - a) : skip - a));
-        if (nmask) return false;
-        if (rt.strand) {   // reverse the order of the 2-bit groups, then complement
-            f = __brev(f);
-            f = ((f >> 1) & 0x55555555u) | ((f & 0x55555555u) << 1);
-            f = (f >> (32u - 2u * len)) ^ 0xFFFFFFFFu;
-        }
-        idx = len >= 16u ? f : (f & ((1u << (2u * len)) - 1u));
-        return true;
-    }
-    __device__ __forceinline__ uint4 qtable(uint32_t len, uint32_t idx) const
-    {
-        return A.qtabArena[(size_t)(((1ull << (2u * len)) - 1ull) / 3ull) + idx];
-    }
     __device__ __forceinline__ uint32_t sa(uint32_t row) const { return A.sa[row]; }
     // eight consecutive bytes starting at p (any alignment): two aligned 64-bit loads and a funnel shift
     static __device__ __forceinline__ uint64_t load8_up(const uint8_t* p)
@@ -348,19 +312,17 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
     const uint32_t wv = threadIdx.x >> 6;
     uint4* vq = smem + wv * A.vqCap;
     env.lstk = smem + 4u * A.vqCap + wv * (A.ldsDepth * 64u) + lane;
-    // window words per wavefront: 2-bit codes (2 per chunk + 1 pad) then N flags (1 per chunk + 1 pad), [word][lane]
-    uint32_t* lwBase = reinterpret_cast<uint32_t*>(smem + 4u * A.vqCap + 4u * A.ldsDepth * 64u) + wv * ((3u * A.winChunks + 2u) * 64u) + lane;
-    env.lw2 = lwBase;
-    env.lnf = lwBase + (2u * A.winChunks + 1u) * 64u;
+    env.lwin = reinterpret_cast<const uint8_t*>(smem + 4u * A.vqCap + 4u * A.ldsDepth * 64u + wv * (A.winChunks * 64u) + lane);
     uint32_t qsize = 0;                             // wave-uniform
 #ifdef GM_COUNTERS
     uint32_t wvIter = 0, wvActive = 0, wvRounds = 0;
 #endif
     bool have = false, exhausted = false;
-    // root fetch pipeline of this lane: 0 idle, 1 window/record loads in flight (consumed in the next iteration)
-    uint32_t fs = 0, fwoff = 0, fnch = 0;
+    // root fetch pipeline of this lane: 0 idle, 1 window/record loads in flight, 2 q-mer table lookup in flight
+    uint32_t fs = 0, fa0 = 0, fql = 0, fwoff = 0, fnch = 0, fshift = 0;
     Root frt; frt.win = 0; frt.n = 1; frt.strand = 0; frt.search = 0; frt.rec = OssRecord{0, 0, 0, 0};
-    uint4 fw0 = make_uint4(0, 0, 0, 0), fw1 = fw0, fw2 = fw0, frec = fw0;
+    uint4 fw0 = make_uint4(0, 0, 0, 0), fw1 = fw0, fw2 = fw0, frec = fw0, ftab = fw0;
+    unsigned long long fx0 = 0, fx1 = 0;
     const uint4* fsrc = A.text4;
     unsigned long long poolCur = 0, poolEnd = 0, poolBase = 0, poolBlock = 0;   // wave-uniform
     uint32_t poolRem = 0;
@@ -382,23 +344,38 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
             have = !env.saturated(rt, smin, smax);   // pending work for k-mers that already reached MAX is dropped
         }
         // ---- root fetch, pipelined over iterations so that the wavefront never waits for it ----
-        // stage 2: window chunks and record have arrived -> stage the window in LDS (2-bit codes + N flags), activate the root
-        if (fs == 1u) {
+        // stage 3: the q-mer table entry has arrived -> the root becomes the lane's node (or turns out empty)
+        if (fs == 2u) {
             fs = 0u;
-            env.woff = fwoff;
-            uint32_t* w2 = const_cast<uint32_t*>(env.lw2);
-            uint32_t* nf = const_cast<uint32_t*>(env.lnf);
-            for (uint32_t c = 0; c < fnch; ++c) {
-                const uint4 ch = c == 0u ? fw0 : c == 1u ? fw1 : c == 2u ? fw2 : fsrc[c];   // long windows (K > ~45): remaining chunks now
-                w2[(2u * c) * 64u] = pack2(ch.x) | pack2(ch.y) << 16;
-                w2[(2u * c + 1u) * 64u] = pack2(ch.z) | pack2(ch.w) << 16;
-                nf[c * 64u] = packN(ch.x) | packN(ch.y) << 8 | packN(ch.z) << 16 | packN(ch.w) << 24;
+            if (ftab.z != 0u) {
+                rt = frt; env.on_root();
+                nd.flo = ftab.x; nd.rlo = ftab.y; nd.w = ftab.z; nd.meta = meta_pack(fa0, fa0 + fql, 0, 0, M_OSS);
+                have = true;
             }
-            w2[(2u * fnch) * 64u] = 0u; nf[fnch * 64u] = 0u;                               // pad words read by 64-bit extractions
+        }
+        // stage 2: window chunks and record have arrived -> stage the window in LDS, look the first q characters up
+        if (fs == 1u) {
+            env.woff = fwoff;
+            uint4* dst = reinterpret_cast<uint4*>(const_cast<uint8_t*>(env.lwin));
+            dst[0] = fw0;
+            if (fnch > 1u) dst[64] = fw1;
+            if (fnch > 2u) dst[128] = fw2;
+            for (uint32_t c = 3u; c < fnch; ++c) dst[c * 64u] = fsrc[c];   // long windows (K > ~45): remaining chunks
             frt.rec.x = frec.x; frt.rec.y = frec.y; frt.rec.z = frec.z; frt.rec.w = frec.w;
-            rt = frt; env.on_root();
-            nd = root_node(rt, A.nRows);
-            have = true;
+            if (fql == 0u) { rt = frt; env.on_root(); nd = root_node(rt, A.nRows); have = true; fs = 0u; }
+            else {
+                // 16 symbols starting at the lowest text position of the q-mer, 4 bits each
+                const unsigned long long v = fshift ? (fx0 >> fshift) | (fx1 << (64u - fshift)) : fx0;
+                uint32_t idx = 0, bad = 0;
+                for (uint32_t i = 0; i < fql; ++i) {
+                    const uint32_t c = (uint32_t)(v >> (4u * i)) & 15u;
+                    bad |= c > 3u ? 1u : 0u;
+                    // forward strand: symbol i is needle(a0 + i), most significant first; reverse strand: needle(a0 + q-1-i) = 3 - c
+                    idx |= frt.strand ? (3u - (c & 3u)) << (2u * i) : (c & 3u) << (2u * (fql - 1u - i));
+                }
+                if (bad) fs = 0u;   // a pattern N never matches in an exact block (find2:330): this root finds nothing
+                else { ftab = (((A.qselMask >> frt.search) & 1u) ? A.qtabB : A.qtabA)[idx]; fs = 2u; }
+            }
         }
         // stage 1: lanes without node, stack or fetch in flight draw a root (ballot rank) and issue its loads
 #pragma unroll 1
@@ -437,6 +414,11 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
                     frt.strand = r >= A.nSearches ? 1u : 0u;
                     frt.search = r - frt.strand * A.nSearches;
                     const uint4* recp = A.table + ((size_t)(frt.n - 1u) * 8u + frt.search);
+                    uint32_t startPos;
+                    fql = (A.qlenPacked >> (4u * frt.search)) & 15u;
+                    if (frt.n == A.stepSize) startPos = (A.startPacked[frt.search >> 2] >> (8u * (frt.search & 3u))) & 0xFFu;
+                    else { const uint4 q = *recp; startPos = (q.y >> 16) & 0xFFu; }   // odd block shape (end of text / interval): rare
+                    fa0 = frt.n - 1u + startPos;
                     const uint32_t W = A.K + frt.n - 1u;
                     const uint64_t g = A.textBegin + frt.win;
                     fwoff = (uint32_t)(g & 31u);
@@ -444,6 +426,10 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
                     fnch = (fwoff + W + 31u) >> 5;
                     frec = *recp;
                     fw0 = fsrc[0]; fw1 = fsrc[1]; fw2 = fsrc[2];              // the text has 12 chunks of padding behind it
+                    const uint64_t p = g + (frt.strand ? (uint64_t)(W - fa0 - fql) : (uint64_t)fa0);   // lowest text position of the q-mer
+                    const unsigned long long* t64 = reinterpret_cast<const unsigned long long*>(A.text4) + (p >> 4);
+                    fshift = (uint32_t)(p & 15u) * 4u;
+                    fx0 = t64[0]; fx1 = t64[1];
                     fs = 1u;
                 } else if (globalDone && avail == 0u) {
                     exhausted = true;
@@ -452,13 +438,6 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
             poolCur += want < avail ? want : avail;
         }
         GM_LAP(tFetch);
-        // ---- exact stretches of nodes with a known string jump through the q-mer tables (one lookup, no step this round) ----
-        bool jumped = false;
-        if (A.jumpQ && have) {
-            const uint32_t w0 = nd.w, m0 = nd.meta;
-            if (!oss_jump(nd, rt, A.jumpQ, env)) have = false;
-            else jumped = (nd.w != w0 || nd.meta != m0);
-        }
         // ---- defer narrow nodes: one queue entry per SA row ----
         if (A.verifyT) {
             bool narrow = have && nd.w <= A.verifyT;
@@ -511,7 +490,7 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
 #ifdef GM_COUNTERS
         wvIter += 1; wvActive += (uint32_t)__popcll(__ballot(have));
 #endif
-        if (have && !jumped) {
+        if (have) {
             if (meta_mode(nd.meta) == M_SPLIT) {
                 Node left; split_node(nd, left, A.K);
                 uint32_t smin, smax;
@@ -521,7 +500,7 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
                 if (env.saturated(rt, smin, smax)) { if (leftDone) have = false; else nd = left; }
                 else if (!leftDone) env.push(left);
             }
-            if (have && !jumped) lane_step(nd, have, rt, A.K, A.E, env);
+            if (have) lane_step(nd, have, rt, A.K, A.E, env);
         }
         GM_LAP(tStep);
     }
@@ -548,31 +527,29 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
 #endif
 }
 
-// q-mer tables, one level from the previous: entry p of length len-1 -> its four right extensions p | c << 2(len-1).
-// Level 0 is the root {0, 0, nRows}.  Levels are stored back to back (level L at entry (4^L - 1) / 3).
+// SA ranges of every ACGT string of length q in both indexes (right extensions from the root): the top of the search
+// tree, tabulated once per index and q.
 template <int WPP>
-__global__ __launch_bounds__(256) void qtab_extend_kernel(const uint32_t* __restrict__ blkRev, const uint32_t* __restrict__ Cin, uint32_t len,
-                                                          const uint4* __restrict__ parent, uint4* __restrict__ child)
+__global__ __launch_bounds__(256) void qmer_table_kernel(const uint32_t* __restrict__ blkRev, const uint32_t* __restrict__ Cin, uint32_t nRows, uint32_t q,
+                                                         uint4* __restrict__ out)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t np = 1u << (2u * (len - 1u));
-    if (p >= np) return;
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (1u << (2u * q))) return;
     constexpr uint32_t SPB = BlockGeom<WPP>::SPB, WPB = BlockGeom<WPP>::WPB;
-    const uint4 e = parent[p];
-    uint32_t rl[NLET] = {0, 0, 0, 0, 0}, rh[NLET] = {0, 0, 0, 0, 0};
-    if (e.z) {
-        const uint32_t lo = e.y, hi = e.y + e.z;
+    uint32_t flo = 0, rlo = 0, w = nRows;
+    for (uint32_t i = 0; i < q && w; ++i) {
+        const uint32_t c = (idx >> (2u * (q - 1u - i))) & 3u;
+        uint32_t rl[NLET], rh[NLET];
+        const uint32_t lo = rlo, hi = rlo + w;
         block_rank<WPP>(blkRev + (size_t)(lo / SPB) * WPB, lo % SPB, rl);
         block_rank<WPP>(blkRev + (size_t)(hi / SPB) * WPB, hi % SPB, rh);
+        uint32_t tot = 0, below = 0;
+        for (uint32_t x = 0; x < NLET; ++x) { const uint32_t cx = rh[x] - rl[x]; tot += cx; if (x < c) below += cx; }
+        flo += (w - tot) + below;           // sentinels sort before every letter
+        rlo = Cin[c] + rl[c];
+        w = rh[c] - rl[c];
     }
-    uint32_t tot = 0;
-    for (uint32_t x = 0; x < NLET; ++x) tot += rh[x] - rl[x];
-    uint32_t below = e.z - tot;   // sentinels sort before every letter
-    for (uint32_t c = 0; c < 4u; ++c) {
-        const uint32_t w = rh[c] - rl[c];
-        child[p | c << (2u * (len - 1u))] = e.z ? make_uint4(e.x + below, Cin[c] + rl[c], w, 0u) : make_uint4(0u, 0u, 0u, 0u);
-        below += w;
-    }
+    out[idx] = make_uint4(flo, rlo, w, 0u);
 }
 
 // acc -> c[]  (4 positions per thread)

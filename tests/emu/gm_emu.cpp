@@ -41,34 +41,6 @@ template <int WPP> struct EmuEnv {
     const std::vector<uint8_t>* textSent = nullptr;
     uint64_t verified = 0;
     uint32_t sa(uint32_t row) const { return saArr[row]; }
-    uint64_t jumps = 0;
-    bool window_string(const Root& rt, uint32_t a, uint32_t len, uint32_t skip, uint32_t& idx) const
-    {
-        idx = 0;
-        for (uint32_t k = 0; k < len; ++k) {
-            const uint32_t c = text_char(rt, a + k);
-            if (c > 3u && a + k != skip) return false;
-            idx |= (c & 3u) << (2u * k);
-        }
-        return true;
-    }
-    gm::uint4 qtable(uint32_t len, uint32_t idx)   // what the device reads from its tables: ranges of the string, by right extensions from the root
-    {
-        constexpr uint32_t SPB = BlockGeom<WPP>::SPB, WPB = BlockGeom<WPP>::WPB;
-        uint32_t flo = 0, rlo = 0, w = (uint32_t)ix->n;
-        for (uint32_t i = 0; i < len && w; ++i) {
-            const uint32_t c = (idx >> (2u * i)) & 3u;
-            uint32_t rl[NLET], rh[NLET];
-            const uint32_t* base = ix->blk[1].data();
-            block_rank<WPP>(base + (size_t)(rlo / SPB) * WPB, rlo % SPB, rl);
-            block_rank<WPP>(base + (size_t)((rlo + w) / SPB) * WPB, (rlo + w) % SPB, rh);
-            uint32_t tot = 0, below = 0;
-            for (uint32_t x = 0; x < NLET; ++x) { const uint32_t cx = rh[x] - rl[x]; tot += cx; if (x < c) below += cx; }
-            flo += (w - tot) + below; rlo = ix->C[c] + rl[c]; w = rh[c] - rl[c];
-        }
-        ++jumps;
-        return gm::uint4{flo, rlo, w, 0u};
-    }
     uint64_t needle8(const Root& rt, uint32_t q, bool down) const
     {
         uint64_t v = 0;
@@ -135,7 +107,7 @@ template <int WPP>
 static int run(const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nseqTotal, const uint8_t* text, uint64_t textLen,
                const uint64_t* seqCum, uint32_t nseqLocal, uint32_t K, uint32_t E, uint32_t infix, int revcompl, int valueBits,
                const uint64_t* intervals, uint64_t nIntervals, void* out, uint64_t* stats, const uint32_t* sa, uint32_t verifyT,
-               const uint8_t* allCodes, const uint64_t* allCum, uint32_t jumpQ)
+               const uint8_t* allCodes, const uint64_t* allCum)
 {
     MapPlan plan;
     int rc = make_map_plan(K, E, infix, revcompl, textLen, intervals, nIntervals, &plan);
@@ -167,7 +139,6 @@ static int run(const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nse
         bool have = true;
         for (;;) {
             if (!have) { if (env.stack.empty()) break; nd = env.stack.back(); env.stack.pop_back(); have = true; }
-            if (jumpQ && !oss_jump(nd, rt, jumpQ, env)) { have = false; continue; }
             if (env.saArr && nd.w <= verifyT) {   // the device defers these to a wave-wide verification round
                 for (uint32_t r2 = 0; r2 < nd.w; ++r2) verify_item(nd.flo + r2, nd.meta, rt, K, E, env);
                 env.verified += nd.w; have = false; continue;
@@ -185,22 +156,22 @@ static int run(const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nse
         uint64_t lim = std::min<uint64_t>(K, seqCum[s] - seqCum[s - 1] + 1);
         for (uint64_t j = 1; j < lim; ++j) { if (valueBits == 8) ((uint8_t*)out)[seqCum[s] - j] = 0; else ((uint16_t*)out)[seqCum[s] - j] = 0; }
     }
-    if (stats) { stats[0] = env.maxDepth; stats[1] = bound; stats[2] = env.steps; stats[3] = env.verified; stats[4] = env.jumps; }
+    if (stats) { stats[0] = env.maxDepth; stats[1] = bound; stats[2] = env.steps; stats[3] = env.verified; }
     return 0;
 }
 
 extern "C" int gm_emu_map(int wpp, const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nseqTotal, const uint8_t* text,
                           uint64_t textLen, const uint64_t* seqCum, uint32_t nseqLocal, uint32_t K, uint32_t E, int32_t xo,
                           int32_t infixOverride, int revcompl, int valueBits, const uint64_t* intervals, uint64_t nIntervals,
-                          void* out, uint64_t* stats, const uint32_t* sa, uint32_t verifyT, const uint8_t* allCodes, const uint64_t* allCum, uint32_t jumpQ)
+                          void* out, uint64_t* stats, const uint32_t* sa, uint32_t verifyT, const uint8_t* allCodes, const uint64_t* allCum)
 {
     uint32_t infix = infixOverride > 0 ? (uint32_t)infixOverride : (xo >= 0 ? default_infix_length(K, E, xo) : tuned_infix_length(K, E));
     if (infix == 0) return PLAN_BAD_OVERLAP;
     memset(out, 0, textLen * (valueBits / 8));
     switch (wpp) {
-        case 1: return run<1>(bf, br, rows, nseqTotal, text, textLen, seqCum, nseqLocal, K, E, infix, revcompl, valueBits, intervals, nIntervals, out, stats, sa, verifyT, allCodes, allCum, jumpQ);
-        case 3: return run<3>(bf, br, rows, nseqTotal, text, textLen, seqCum, nseqLocal, K, E, infix, revcompl, valueBits, intervals, nIntervals, out, stats, sa, verifyT, allCodes, allCum, jumpQ);
-        case 9: return run<9>(bf, br, rows, nseqTotal, text, textLen, seqCum, nseqLocal, K, E, infix, revcompl, valueBits, intervals, nIntervals, out, stats, sa, verifyT, allCodes, allCum, jumpQ);
+        case 1: return run<1>(bf, br, rows, nseqTotal, text, textLen, seqCum, nseqLocal, K, E, infix, revcompl, valueBits, intervals, nIntervals, out, stats, sa, verifyT, allCodes, allCum);
+        case 3: return run<3>(bf, br, rows, nseqTotal, text, textLen, seqCum, nseqLocal, K, E, infix, revcompl, valueBits, intervals, nIntervals, out, stats, sa, verifyT, allCodes, allCum);
+        case 9: return run<9>(bf, br, rows, nseqTotal, text, textLen, seqCum, nseqLocal, K, E, infix, revcompl, valueBits, intervals, nIntervals, out, stats, sa, verifyT, allCodes, allCum);
     }
     return -100;
 }

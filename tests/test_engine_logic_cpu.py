@@ -21,11 +21,11 @@ def emu():
         _emu.gm_emu_map.restype = C.c_int
         _emu.gm_emu_map.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64,
                                     C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_int, C.c_int,
-                                    C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
+                                    C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     return _emu
 
 
-def emu_map(ix, wpp, K, E, first_seq=0, n_seq=None, xo=None, infix=0, revcompl=True, value_bits=16, intervals=None, verify_t=0, jump_q=0):
+def emu_map(ix, wpp, K, E, first_seq=0, n_seq=None, xo=None, infix=0, revcompl=True, value_bits=16, intervals=None, verify_t=0):
     if n_seq is None:
         n_seq = len(ix.seq_len) - first_seq
     tb = int(ix.cum[first_seq])
@@ -37,13 +37,13 @@ def emu_map(ix, wpp, K, E, first_seq=0, n_seq=None, xo=None, infix=0, revcompl=T
     iv = None
     if intervals:
         iv = np.ascontiguousarray(np.asarray(intervals, dtype=np.uint64).reshape(-1))
-    stats = np.zeros(5, dtype=np.uint64)
+    stats = np.zeros(4, dtype=np.uint64)
     sa = ix.sa() if verify_t else None
     allcodes = np.ascontiguousarray(ix.codes)
     allcum = np.ascontiguousarray(ix.cum, dtype=np.uint64)
     rc = emu().gm_emu_map(wpp, H._ptr(bf), H._ptr(br), ix.n, len(ix.seq_len), H._ptr(text), tl, H._ptr(cum), n_seq, K, E,
                           -1 if xo is None else xo, infix, int(revcompl), value_bits, H._ptr(iv),
-                          0 if iv is None else len(iv) // 2, H._ptr(out), H._ptr(stats), H._ptr(sa), verify_t, H._ptr(allcodes), H._ptr(allcum), jump_q)
+                          0 if iv is None else len(iv) // 2, H._ptr(out), H._ptr(stats), H._ptr(sa), verify_t, H._ptr(allcodes), H._ptr(allcum))
     assert rc == 0, rc
     return out, stats
 
@@ -170,70 +170,3 @@ def test_verification_shortcut_baseline_settings(K, E):
         out, st = emu_map(ix, 1, K, E, value_bits=16, verify_t=T)
         assert np.array_equal(out, exp), (K, E, T)
         assert st[3] > 0
-
-
-@pytest.mark.parametrize("Q", [1, 3, 6, 16])
-@pytest.mark.parametrize("case", sorted(H.CASES))
-def test_table_jumps_on_reference_fixtures(case, Q):
-    d = H.CASES_DIR / f"case_{case}"
-    g, directory, fl, bed = H.load_case(case)
-    if fl.get("ep"):
-        pytest.skip("--exclude-pseudo goes through the locate path")
-    ix = H.OracleIndex(g.codes, g.seq_len, keep_sa=True)
-    for xo in H.xo_variants(case):
-        for name, first, nseq, tb, tl in g.file_slices():
-            iv = None
-            if bed is not None:
-                iv = H.slice_intervals(g, first, nseq, bed)
-                if not iv:
-                    continue
-            for T in (0, 1):
-                out, st = emu_map(ix, 1, fl["K"], fl["E"], first, nseq, xo=xo, revcompl=not fl.get("nc", False), intervals=iv, verify_t=T, jump_q=Q)
-                exp = np.fromfile(d / "raw_freq16" / (name.rsplit(".", 1)[0] + ".genmap.freq16"), dtype=np.uint16)
-                assert np.array_equal(out, exp), (case, xo, Q, T, name, out.tolist(), exp.tolist())
-
-
-@pytest.mark.parametrize("dna5", [False, True])
-@pytest.mark.parametrize("E", [0, 1, 2, 3, 4])
-def test_table_jumps_gtest_matrix(E, dna5):
-    rng = np.random.default_rng(5000 + 10 * E + dna5)
-    nseq, ln = 3, (500 if E < 3 else 200)
-    codes = rng.integers(0, 5 if dna5 else 4, size=nseq * ln, dtype=np.uint8)
-    ix = H.OracleIndex(codes, [ln] * nseq, keep_sa=True)
-    minK = E + 1 + (E >= 2)
-    nblocks = [1, 2, 4, 5, 6][E]
-    jumps = 0
-    for K in range(minK, 9 if E < 4 else 8):
-        rc = bool(rng.integers(0, 2))
-        triv = ix.trivial(K, E, revcompl=rc, value_bits=8)
-        for infix in range(max(minK, nblocks), K + 1):
-            for Q in (2, 4, 16):
-                out, st = emu_map(ix, 1, K, E, infix=infix, revcompl=rc, value_bits=8, verify_t=0, jump_q=Q)
-                assert np.array_equal(out, triv), (E, dna5, K, infix, Q)
-                jumps += int(st[4])
-    assert jumps > 0
-
-
-@pytest.mark.parametrize("K,E", [(30, 0), (30, 1), (30, 2), (100, 1), (24, 1), (50, 3), (36, 4), (128, 0)])
-def test_table_jumps_baseline_settings(K, E):
-    rng = np.random.default_rng(K * 10 + E + 11)
-    lens = [1500, 700, K - 1, 900, 3, K, K + 1]
-    n = sum(lens)
-    codes = rng.integers(0, 4, size=n, dtype=np.uint8)
-    fam = rng.integers(0, 4, size=200, dtype=np.uint8)
-    for s in (50, 400, 1600, 2300, 2900):
-        cp = fam.copy()
-        mut = rng.random(200) < 0.04
-        cp[mut] = rng.integers(0, 4, size=int(mut.sum()), dtype=np.uint8)
-        codes[s:s + 200] = cp
-    codes[700:760] = 4
-    codes[1234] = 4
-    codes[1236] = 4
-    codes[1000:1100] = 0
-    ix = H.OracleIndex(codes, lens, keep_sa=True)
-    exp = ix.mappability(K, E, value_bits=16, threads=4)
-    for Q in (5, 12, 16):
-        for T in (0, 1, 4):
-            out, st = emu_map(ix, 1, K, E, value_bits=16, verify_t=T, jump_q=Q)
-            assert np.array_equal(out, exp), (K, E, Q, T)
-            assert st[4] > 0
