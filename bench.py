@@ -55,8 +55,8 @@ def cpu_baseline(codes, lens, bwt, K, E, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="chr1")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--K", type=int, default=30)
