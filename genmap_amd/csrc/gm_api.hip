@@ -588,7 +588,7 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
 
     GM_HIP(hipEventRecord(ix->ev[0], st));
     if (ep) GM_HIP(hipMemsetAsync(ix->d_bits, 0, (text_len + 1) * wordsPerKmer * sizeof(uint32_t), st));
-    else GM_HIP(hipMemsetAsync(ix->d_acc, 0, (store ? 2 : 1) * plane * sizeof(uint32_t), st));
+    else GM_HIP(hipMemsetAsync(ix->d_acc, 0, store ? 2 * plane * sizeof(uint16_t) : plane * sizeof(uint32_t), st));
     GM_HIP(hipMemsetAsync(ix->d_small, 0, 256, st));
     A.acc = ix->d_acc; A.accPlane = plane; A.fileBits = ix->d_bits;
     A.maxVal = (p->value_bits == 8 && getenv("GM_NO_SATURATE") == nullptr) ? 255u : (getenv("GM_NO_SATURATE") ? 0xFFFFFFFFu : 65535u); A.wordsPerKmer = wordsPerKmer; A.seqFile = ix->d_seqFile;
@@ -600,12 +600,12 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
         const unsigned g4 = grid_for((text_len + 3) / 4), g1 = grid_for(text_len);
         if (p->value_bits == 8) {
             if (ep) hipLaunchKernelGGL(finalize_fileset_kernel<uint8_t>, dim3(g1), dim3(256), 0, st, ix->d_bits, wordsPerKmer, (uint8_t*)d_out, text_len);
-            else if (store) hipLaunchKernelGGL(finalize2_kernel<uint8_t>, dim3(g1), dim3(256), 0, st, ix->d_acc, ix->d_acc + plane, (uint8_t*)d_out, text_len, 255u);
+            else if (store) hipLaunchKernelGGL(finalize2_kernel<uint8_t>, dim3(g1), dim3(256), 0, st, (const uint16_t*)ix->d_acc, (const uint16_t*)ix->d_acc + plane, (uint8_t*)d_out, text_len, 255u);
             else hipLaunchKernelGGL(finalize_kernel<uint8_t>, dim3(g4), dim3(256), 0, st, ix->d_acc, (uint8_t*)d_out, text_len, 255u);
             rc = launch_reset_limits(ix, (uint8_t*)d_out, n_seq, p->K, st);
         } else {
             if (ep) hipLaunchKernelGGL(finalize_fileset_kernel<uint16_t>, dim3(g1), dim3(256), 0, st, ix->d_bits, wordsPerKmer, (uint16_t*)d_out, text_len);
-            else if (store) hipLaunchKernelGGL(finalize2_kernel<uint16_t>, dim3(g1), dim3(256), 0, st, ix->d_acc, ix->d_acc + plane, (uint16_t*)d_out, text_len, 65535u);
+            else if (store) hipLaunchKernelGGL(finalize2_kernel<uint16_t>, dim3(g1), dim3(256), 0, st, (const uint16_t*)ix->d_acc, (const uint16_t*)ix->d_acc + plane, (uint16_t*)d_out, text_len, 65535u);
             else hipLaunchKernelGGL(finalize_kernel<uint16_t>, dim3(g4), dim3(256), 0, st, ix->d_acc, (uint16_t*)d_out, text_len, 65535u);
             rc = launch_reset_limits(ix, (uint16_t*)d_out, n_seq, p->K, st);
         }

@@ -230,17 +230,20 @@ template <int WPP> struct CountEnv : EnvBase<WPP> {
 };
 
 // leaf policy 1b: frequency for E = 0 -- with a single exact search every (k-mer, strand) pair is reached by at most one
-// leaf or one verified row, so the count is written with a plain store into a per-strand plane (acc[strand * textLen +
-// pos]) instead of a device-scope atomic (which is a fabric transaction on a multi-XCD part); finalize adds the planes.
+// leaf or one verified row, so the count is written with a plain 16-bit store into a per-strand plane (plane[strand * accPlane +
+// pos], counts clamp at 65535) instead of a device-scope atomic (which is a fabric transaction on a multi-XCD part); finalize adds the planes.
 template <int WPP> struct StoreEnv : EnvBase<WPP> {
     using EnvBase<WPP>::A;
     __device__ __forceinline__ StoreEnv(const SearchArgs& a, uint4* s, uint32_t k) : EnvBase<WPP>(a, s, k) {}
     __device__ __forceinline__ void leaf(const Root& rt, uint32_t kmer, uint32_t, uint32_t w)
     {
-        A.acc[(size_t)rt.strand * A.accPlane + this->slice_pos(rt, kmer)] = w < 0xFFFFu ? w : 0xFFFFu;
+        reinterpret_cast<uint16_t*>(A.acc)[(size_t)rt.strand * A.accPlane + this->slice_pos(rt, kmer)] = (uint16_t)(w < 0xFFFFu ? w : 0xFFFFu);
     }
     __device__ __forceinline__ void leaf_flush(const Root&, uint32_t) {}
-    __device__ __forceinline__ void leaf_at(const Root& rt, uint32_t kmer, uint32_t) { A.acc[(size_t)rt.strand * A.accPlane + this->slice_pos(rt, kmer)] = 1u; }
+    __device__ __forceinline__ void leaf_at(const Root& rt, uint32_t kmer, uint32_t)
+    {
+        reinterpret_cast<uint16_t*>(A.acc)[(size_t)rt.strand * A.accPlane + this->slice_pos(rt, kmer)] = (uint16_t)1u;
+    }
 };
 
 // leaf policy 2: --exclude-pseudo -- the set of fasta files that contain the k-mer (algo.hpp:351-364)
@@ -554,11 +557,11 @@ __global__ __launch_bounds__(256) void qmer_table_kernel(const uint32_t* __restr
 
 // acc -> c[]  (4 positions per thread)
 template <typename TValue>
-__global__ __launch_bounds__(256) void finalize2_kernel(const uint32_t* __restrict__ accF, const uint32_t* __restrict__ accR, TValue* __restrict__ out, uint64_t n, uint32_t maxVal)
+__global__ __launch_bounds__(256) void finalize2_kernel(const uint16_t* __restrict__ accF, const uint16_t* __restrict__ accR, TValue* __restrict__ out, uint64_t n, uint32_t maxVal)
 {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    const uint32_t v = accF[j] + accR[j];   // each plane holds at most 65535
+    const uint32_t v = (uint32_t)accF[j] + accR[j];   // each plane holds at most 65535
     out[j] = (TValue)(v < maxVal ? v : maxVal);
 }
 
