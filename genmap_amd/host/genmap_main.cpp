@@ -17,6 +17,7 @@
 #include <sys/time.h>
 #include <unistd.h>
 #include <cmath>
+#include <thread>
 #include <vector>
 #include "../../include/genmap_amd.h"
 #include "gm_hostlib.h"
@@ -222,10 +223,24 @@ int map_main(int argc, const char** argv)
         if (fileNames.empty() || fileNames.back() != r.file) { fileNames.push_back(r.file); seqsPerFile.push_back(0); }
         seqLen.push_back(r.length); seqFile.push_back((uint32_t)fileNames.size() - 1); seqsPerFile.back()++;
     }
-    gm_index* ix = nullptr;
-    int rc = gm_index_import(bf.data(), br.data(), sa.empty() ? nullptr : sa.data(), text.data(), seqLen.data(), (uint32_t)seqLen.size(), sa.empty() ? 0 : 1,
-                             (uint32_t)std::atoi(a.get("block-bytes", "0").c_str()), std::atoi(a.get("device", "0").c_str()), &ix);
-    if (rc) return fail_gm("cannot load the index onto the GPU", rc);
+    // -D 0,1,2,...: one index replica per listed GPU; every fasta file's k-mer positions are split into contiguous shards,
+    // one host thread per device computes its shard (positions are independent given the read-only index)
+    std::vector<int> devices;
+    { std::string d = a.get("device", "0"); size_t p0 = 0; while (p0 <= d.size()) { size_t c = d.find(',', p0); if (c == std::string::npos) c = d.size(); if (c > p0) devices.push_back(std::atoi(d.substr(p0, c - p0).c_str())); p0 = c + 1; } }
+    if (devices.empty()) devices.push_back(0);
+    std::vector<gm_index*> replicas(devices.size(), nullptr);
+    std::vector<int> rcs(devices.size(), 0);
+    {
+        std::vector<std::thread> th;
+        const uint32_t bb = (uint32_t)std::atoi(a.get("block-bytes", "0").c_str());
+        for (size_t d = 0; d < devices.size(); ++d)
+            th.emplace_back([&, d] { rcs[d] = gm_index_import(bf.data(), br.data(), sa.empty() ? nullptr : sa.data(), text.data(), seqLen.data(), (uint32_t)seqLen.size(),
+                                                               sa.empty() ? 0 : 1, bb, devices[d], &replicas[d]); });
+        for (auto& t : th) t.join();
+    }
+    for (size_t d = 0; d < devices.size(); ++d) if (rcs[d]) { for (auto* r : replicas) gm_index_free(r); return fail_gm("cannot load the index onto the GPU", rcs[d]); }
+    gm_index* ix = replicas[0];
+    int rc = 0;
     { std::vector<uint8_t>().swap(bf); std::vector<uint8_t>().swap(br); std::vector<uint32_t>().swap(sa); }
 
     const double start = wall();
@@ -242,7 +257,8 @@ int map_main(int argc, const char** argv)
                     if (iv.first >= row.length || iv.second > row.length) {
                         std::cerr << "Error in BED file! Coordinates exceed sequence length: Seq. \"" << row.name << "\" has a length of " << row.length
                                   << ", but half-closed interval [" << iv.first << ", " << iv.second << ") given.\n";
-                        gm_index_free(ix); return 1;
+                        for (auto* r : replicas) gm_index_free(r);
+                        return 1;
                     }
                     intervals.push_back(textLen + iv.first); intervals.push_back(textLen + iv.second);
                 }
@@ -258,11 +274,11 @@ int map_main(int argc, const char** argv)
             bool ok = true; double t;
             auto report = [&](const char* what) { if (verbose) std::cout << "- " << what << " written in " << (std::round((wall() - t) * 100.0) / 100.0) << " seconds\n"; };
             const uint64_t* ivp = intervals.empty() ? nullptr : intervals.data();
-            if (!raw && !txt && !csv) {
+            if (!raw && !txt && !csv && replicas.size() == 1) {
                 // only run-length formats requested: the GPU hands back the runs, the frequency vector never crosses PCIe
                 gm_runs* R = nullptr;
                 rc = gm_map_runs(ix, textBegin, textLen, firstSeq, nSeq, &p, ivp, intervals.size() / 2, seqFile.data(), &R);
-                if (rc) { gm_index_free(ix); return fail_gm("computeMappability failed", rc); }
+                if (rc) { for (auto* r : replicas) gm_index_free(r); return fail_gm("computeMappability failed", rc); }
                 gmh::RunsInput ri; ri.n = R->n_runs; ri.start = R->start; ri.length = R->length; ri.value = R->value;
                 if (wig) { t = wall(); ok = ok && gmh::save_wig_runs(ri, stem, seqs, mappability, err); report("WIG file"); }
                 if (bg) { t = wall(); ok = ok && gmh::save_bedgraph_runs(ri, stem, seqs, true, mappability, err); report("bedgraph file"); }
@@ -271,8 +287,27 @@ int map_main(int argc, const char** argv)
             } else {
             std::vector<uint8_t> c((size_t)textLen * width + 16);
             if (raw || txt || wig || bg || bed) {
-                rc = gm_map(ix, textBegin, textLen, firstSeq, nSeq, &p, ivp, intervals.size() / 2, seqFile.data(), c.data());
-                if (rc) { gm_index_free(ix); return fail_gm("computeMappability failed", rc); }
+                if (replicas.size() == 1) {
+                    rc = gm_map(ix, textBegin, textLen, firstSeq, nSeq, &p, ivp, intervals.size() / 2, seqFile.data(), c.data());
+                } else {
+                    // shards of k-mer positions; every device returns a full-length vector that is zero outside its shard
+                    const uint64_t numKmers = textLen >= K ? textLen - K + 1 : 0;
+                    const size_t nd = replicas.size();
+                    std::vector<std::vector<uint8_t>> part(nd);
+                    std::vector<std::thread> th;
+                    for (size_t d = 0; d < nd; ++d)
+                        th.emplace_back([&, d] {
+                            gm_map_params q = p;
+                            q.kmer_begin = numKmers * d / nd; q.kmer_end = numKmers * (d + 1) / nd;
+                            if (q.kmer_end == 0 && d + 1 == nd) q.kmer_end = 1;   // (0,0) means "everything" in the ABI
+                            part[d].assign((size_t)textLen * width + 16, 0);
+                            rcs[d] = (q.kmer_begin == q.kmer_end) ? 0 : gm_map(replicas[d], textBegin, textLen, firstSeq, nSeq, &q, ivp, intervals.size() / 2, seqFile.data(), part[d].data());
+                        });
+                    for (auto& t : th) t.join();
+                    for (size_t d = 0; d < nd && !rc; ++d) rc = rcs[d];
+                    if (!rc) for (size_t d = 0; d < nd; ++d) for (size_t i = 0; i < (size_t)textLen * width; ++i) c[i] |= part[d][i];   // shards are disjoint
+                }
+                if (rc) { for (auto* r : replicas) gm_index_free(r); return fail_gm("computeMappability failed", rc); }
             }
             if (raw) { t = wall(); ok = ok && gmh::save_raw(c.data(), textLen, width, stem, kind, err); report("RAW file"); }
             if (txt) { t = wall(); ok = ok && gmh::save_txt(c.data(), textLen, width, stem, seqs, mappability, err); report("TXT file"); }
@@ -290,7 +325,7 @@ int map_main(int argc, const char** argv)
                     gm_locations* L = nullptr;
                     rc = gm_locate(ix, textBegin, textLen, firstSeq, nSeq, &p, ivp, intervals.size() / 2, &L);
                     if (rc == GM_ERR_TOO_LONG && window > 1) { window = std::max<uint64_t>(1, window / 2); continue; }
-                    if (rc) { gm_index_free(ix); return fail_gm("locate failed", rc); }
+                    if (rc) { for (auto* r : replicas) gm_index_free(r); return fail_gm("locate failed", rc); }
                     gmh::CsvInput in; in.posBegin = L->pos_begin; in.nPositions = L->n_positions; in.plusOff = L->plus_off; in.minusOff = L->minus_off; in.plus = L->plus; in.minus = L->minus;
                     ok = gmh::save_csv(stem, in, seqs, K, revCompl, fileNames, seqsPerFile, !first, err);
                     first = false;
@@ -301,12 +336,12 @@ int map_main(int argc, const char** argv)
                 report("CSV file");
             }
             }
-            if (!ok) { std::cerr << "ERROR: " << err << "\n"; gm_index_free(ix); return 1; }
+            if (!ok) { std::cerr << "ERROR: " << err << "\n"; for (auto* r : replicas) gm_index_free(r); return 1; }
         }
         textBegin += textLen; firstSeq += nSeq;
     }
     if (verbose) std::cout << "Mappability computed in " << (std::round((wall() - start) * 100.0) / 100.0) << " seconds\n";
-    gm_index_free(ix);
+    for (auto* r : replicas) gm_index_free(r);
     return 0;
 }
 

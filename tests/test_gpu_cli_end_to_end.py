@@ -73,3 +73,24 @@ def test_cli_error_paths(tmp_path):
     # -O as a file name for single-fasta indices (src/mappability.hpp:562-619)
     subprocess.check_call(base[:4] + ["-O", str(tmp_path / "named"), "-K", "3", "-E", "0", "-nc", "-r", "-fl"], stdout=subprocess.DEVNULL)
     assert filecmp.cmp(tmp_path / "named.freq16", d / "raw_freq16" / "genome.genmap.freq16", shallow=False)
+
+
+@pytest.mark.parametrize("case", ["1f", "2d", "3b"])
+def test_cli_multi_device_shards(case, tmp_path):
+    """-D a,b: one replica and one host thread per listed device, shards merged on the host.  The GPU box has one
+    device, so it is listed twice; the data path is the one eight devices would use."""
+    d = H.CASES_DIR / f"case_{case}"
+    directory, fl = H.CASES[case]
+    idx = tmp_path / "index"
+    if directory:
+        src = tmp_path / "fastas"; src.mkdir()
+        for f in d.glob("*.fa"):
+            shutil.copy(f, src / f.name)
+        subprocess.check_call([str(GENMAP), "index", "-FD", str(src), "-I", str(idx)], stdout=subprocess.DEVNULL)
+    else:
+        subprocess.check_call([str(GENMAP), "index", "-F", str(d / "genome.fa"), "-I", str(idx)], stdout=subprocess.DEVNULL)
+    flags = ["-E", str(fl["E"]), "-K", str(fl["K"])] + (["-nc"] if fl.get("nc") else [])
+    for sub in ("raw_freq16", "wig_freq16", "txt_map"):
+        out = tmp_path / f"out_{sub}"; out.mkdir()
+        subprocess.check_call([str(GENMAP), "map", "-I", str(idx), "-O", str(out), "-D", "0,0,0"] + flags + FORMAT_FLAGS[sub], stdout=subprocess.DEVNULL)
+        _same_tree(out, d / sub)
