@@ -54,3 +54,16 @@ def test_product_does_not_reference_oracle():
                 continue
             t = p.read_text(errors="ignore")
             assert "gm_oracle" not in t and "libgmoracle" not in t and "libgmemu" not in t, p
+
+
+def test_tuned_infix_is_always_schedulable():
+    """the GPU-tuned block shape keeps at least one symbol per OSS block and never exceeds K (any K, E the ABI accepts)"""
+    import genmap_amd as g
+    nb = [1, 2, 4, 5, 6]
+    for K in range(1, 129):
+        for E in range(5):
+            t = g.tuned_infix_length(K, E)
+            if K < nb[E]:
+                continue  # the call is rejected with GM_ERR_BAD_OVERLAP (infix shorter than the number of blocks)
+            assert nb[E] <= t <= K, (K, E, t)
+    assert g.tuned_infix_length(129, 0) == 0 and g.tuned_infix_length(30, 5) == 0

@@ -208,6 +208,35 @@ def test_gpu_shards_and_device_output():
     ix.close()
 
 
+def test_gpu_many_short_sequences_and_extremes():
+    """read-set-like input (thousands of short sequences, many shorter than K), K at the encoding limit, K == 1,
+    texts shorter than K, 8-bit saturation on a low-complexity text"""
+    g = _gm()
+    rng = np.random.default_rng(21)
+    lens = [int(x) for x in rng.integers(1, 120, size=4000)]
+    codes = rng.integers(0, 4, size=sum(lens), dtype=np.uint8)
+    codes[rng.integers(0, len(codes), size=300)] = 4
+    ora = H.OracleIndex(codes, lens, keep_sa=False)
+    ix = g.Index.build(codes, lens, sampling=1)
+    for K, E in ((30, 0), (30, 1), (50, 2), (100, 1), (1, 0), (2, 1), (128, 1)):
+        exp = ora.mappability(K, E, value_bits=16, threads=8)
+        assert np.array_equal(ix.map(K, E, value_bits=16), exp), (K, E)
+    ix.close()
+    # low complexity: counts far above 255 / 65535
+    codes = np.zeros(70000, dtype=np.uint8); codes[::7] = 1
+    ora = H.OracleIndex(codes, [70000], keep_sa=False)
+    ix = g.Index.build(codes, [70000], sampling=1)
+    for K, E, bits in ((20, 0, 8), (20, 1, 8), (20, 1, 16), (14, 2, 8)):
+        exp = ora.mappability(K, E, value_bits=bits, threads=8)
+        assert np.array_equal(ix.map(K, E, value_bits=bits), exp), (K, E, bits)
+        assert exp.max() == (255 if bits == 8 else 65535) or bits == 16
+    ix.close()
+    # a text shorter than K: every position is zero (the reference underflows here, src/algo.hpp:414)
+    ix = g.Index.build(np.array([0, 1, 2, 3, 0], dtype=np.uint8), [5])
+    assert (ix.map(30, 0, value_bits=8) == 0).all()
+    ix.close()
+
+
 def test_gpu_run_length_form_matches_vector():
     """gm_map_runs == run-length encoding of gm_map's vector (non-zero runs, never across sequences)"""
     g = _gm()
