@@ -77,7 +77,7 @@ inline int make_map_plan(uint32_t K, uint32_t E, uint32_t infix, int revcompl, u
 {
     MapPlan& p = *out;
     if (E > MAX_ERRORS) return PLAN_BAD_E;
-    if (K < 1 || K > 128) return PLAN_BAD_K;
+    if (K < 1 || K > MAX_K) return PLAN_BAD_K;
     if (infix < 1 || infix > K) return PLAN_BAD_OVERLAP;
     if (textLen >= 0xFFFFFFFFull) return PLAN_TOO_LONG;
     p.K = K; p.E = E; p.infix = infix; p.stepSize = K - infix + 1;   // algo.hpp:416

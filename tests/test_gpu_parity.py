@@ -298,3 +298,163 @@ def test_gpu_midsize_vs_oracle_and_properties():
         base = ix.map(K, 0, value_bits=16, intervals=iv)
         assert (out[sel] >= base[sel]).all()
     ix.close()
+
+
+def _torch_exact_counts(codes_np, K, max_val, device):
+    """Independent e = 0 restatement at full size with plain torch ops (no index at all): 2-bit pack every K-mer of both
+    strands into an int64 key (K <= 31), sort the forward keys once, count by two binary searches.
+    c[j] = min(MAX, occ(P_j) + occ(rc(P_j))); k-mers holding N count nothing and are found nowhere (src/algo.hpp:111-125).
+    Single-sequence texts only (no boundary handling)."""
+    import torch
+    assert K <= 31
+    c = torch.from_numpy(codes_np).to(device)
+    n = c.numel()
+    m = n - K + 1
+    isn = (c == 4)
+    ncs = torch.zeros(n + 1, dtype=torch.int32, device=device)
+    ncs[1:] = torch.cumsum(isn.to(torch.int32), 0)
+    valid = (ncs[K:K + m] - ncs[:m]) == 0
+    del ncs
+    c2 = torch.where(isn, torch.zeros_like(c), c).to(torch.int64)
+    del isn
+    fwd = torch.zeros(m, dtype=torch.int64, device=device)
+    rc = torch.zeros(m, dtype=torch.int64, device=device)
+    for i in range(K):
+        fwd.mul_(4).add_(c2[i:i + m])                       # P[i] is digit K-1-i
+        rc.mul_(4).add_(3 - c2[K - 1 - i:K - 1 - i + m])    # rc(P)[i] = 3 - P[K-1-i]
+    del c2
+    srt = torch.sort(fwd[valid]).values
+    def cnt(q):
+        return torch.searchsorted(srt, q, right=True) - torch.searchsorted(srt, q, right=False)
+    tot = cnt(fwd) + cnt(rc)
+    tot = torch.where(valid, tot, torch.zeros_like(tot)).clamp_(max=max_val)
+    out = torch.zeros(n, dtype=torch.int64, device=device)
+    out[:m] = tot
+    return out
+
+
+def test_gpu_full_size_chr1_e0_vs_sort_and_count():
+    """BASELINE config C2 at its full size (248,956,422 bp chr1-like, K=30, e=0, both strands): the index-free torch
+    sort-and-count restatement must agree at every position, for -fs and -fl, for the tuned and the reference's default
+    block shape; plus shard concatenation == whole and e=1 >= e=0 on intervals."""
+    import torch
+    g = _gm()
+    from genmap_amd import synth
+    scale = float(os.environ.get("GM_FULL_SCALE", "1.0"))
+    codes, lens, _ = synth.workload("chr1", scale)
+    assert len(lens) == 1
+    ix = g.Index.build(codes, lens, sampling=1)
+    K = 30
+    exp16 = _torch_exact_counts(codes, K, 65535, "cuda:0")
+    exp8 = exp16.clamp(max=255).to(torch.uint8).cpu().numpy()
+    exp16 = exp16.to(torch.int32).cpu().numpy().astype(np.uint16)
+    torch.cuda.empty_cache()
+    out8 = ix.map(K, 0, value_bits=8)
+    assert np.array_equal(out8, exp8)
+    assert np.array_equal(ix.map(K, 0, value_bits=16), exp16)
+    assert np.array_equal(ix.map(K, 0, value_bits=8, infix=g.default_infix_length(K, 0)), exp8)
+    assert (ix.map(K, 0, value_bits=8, revcompl=False) <= out8).all()
+    # three shards of whole k-mer blocks
+    n = len(codes)
+    step = K - g.tuned_infix_length(K, 0) + 1
+    cut1, cut2 = (n // 3) // step * step, (2 * n // 3) // step * step
+    parts = np.zeros(n, np.uint8)
+    for a, b in ((0, cut1), (cut1, cut2), (cut2, n)):
+        parts |= ix.map(K, 0, value_bits=8, kmer_range=(a, b))
+    assert np.array_equal(parts, exp8)
+    iv = [(5_000_000, 5_020_000), (n // 2, n // 2 + 20_000), (n - 40_000, n - 20_000)]
+    iv = [(min(a, n - 50_000), min(b, n - 30_000)) for a, b in iv] if scale < 1 else iv
+    e1 = ix.map(K, 1, value_bits=16, intervals=iv)
+    for a, b in iv:
+        assert (e1[a:b] >= exp16[a:b]).all()
+    ix.close()
+
+
+def _torch_hamming1_counts(codes_np, K, max_val, device):
+    """Independent e = 1 restatement at full size, index-free: c[j] = min(MAX, occ_1(P_j) + occ_1(rc(P_j))) where
+    occ_1(X) = #{text windows Q : #{i : X[i] != Q[i] or X[i] == N} <= 1} (src/find2_index_approx.hpp:250).
+    For every position i all windows are grouped by their string with position i blanked (exact 3-bit packing in two
+    int64 halves, dense-ranked and combined), so cnt_i(X) = #{Q equal to X everywhere except possibly at i};
+    N-free X: occ_1 = occ_0 + sum_i (cnt_i - occ_0); X with one N at i0: occ_1 = cnt_i0; more Ns: 0.
+    Single-sequence texts only."""
+    import torch
+    assert K <= 42
+    c = torch.from_numpy(codes_np).to(device)
+    n = c.numel()
+    m = n - K + 1
+    isn = (c == 4)
+    ncs = torch.zeros(n + 1, dtype=torch.int32, device=device)
+    ncs[1:] = torch.cumsum(isn.to(torch.int32), 0)
+    nN = ncs[K:K + m] - ncs[:m]
+    del ncs
+    c64 = c.to(torch.int64)
+    comp = torch.where(c64 < 4, 3 - c64, c64)
+    h = K // 2
+    def shift(p):
+        return 3 * (h - 1 - p) if p < h else 3 * (K - 1 - p)
+    def pack(src_of_p, lo, hi):
+        acc = torch.zeros(m, dtype=torch.int64, device=device)
+        for p in range(lo, hi):
+            acc += src_of_p(p) << shift(p)
+        return acc
+    fwd = [pack(lambda p: c64[p:p + m], 0, h), pack(lambda p: c64[p:p + m], h, K)]
+    rcq = [pack(lambda p: comp[K - 1 - p:K - 1 - p + m], 0, h), pack(lambda p: comp[K - 1 - p:K - 1 - p + m], h, K)]
+    del c64, comp
+    def ranks(vals, query):
+        U, inv = torch.unique(vals, return_inverse=True)
+        idx = torch.searchsorted(U, query).clamp_(max=U.numel() - 1)
+        return inv, idx, U[idx] == query
+    base = [ranks(fwd[0], rcq[0]), ranks(fwd[1], rcq[1])]
+    def count(hi, lo):
+        comb = (hi[0] << 32) | lo[0]
+        S = torch.sort(comb).values
+        cf = torch.searchsorted(S, comb, right=True) - torch.searchsorted(S, comb, right=False)
+        q = (hi[1] << 32) | lo[1]
+        cr = (torch.searchsorted(S, q, right=True) - torch.searchsorted(S, q, right=False)) * (hi[2] & lo[2])
+        return cf, cr
+    occ0_f, occ0_r = count(base[0], base[1])
+    acc_f = torch.zeros(m, dtype=torch.int64, device=device)
+    acc_r = torch.zeros(m, dtype=torch.int64, device=device)
+    clean, one = nN == 0, nN == 1
+    for i in range(K):
+        half = 0 if i < h else 1
+        keep = ~(7 << shift(i))
+        masked = ranks(fwd[half] & keep, rcq[half] & keep)
+        cf, cr = count(masked, base[1]) if half == 0 else count(base[0], masked)
+        acc_f += cf * (clean | (one & isn[i:i + m]))
+        acc_r += cr * (clean | (one & isn[K - 1 - i:K - 1 - i + m]))
+        del masked, cf, cr
+    tot = torch.where(clean, acc_f - (K - 1) * occ0_f + acc_r - (K - 1) * occ0_r, acc_f + acc_r).clamp_(max=max_val)
+    out = torch.zeros(n, dtype=torch.int64, device=device)
+    out[:m] = tot
+    return out
+
+
+def test_gpu_torch_restatements_are_pinned_on_the_oracle():
+    """the two index-free comparators used at full size agree with the C oracle on a 300 kbp Dna5 text"""
+    import torch
+    from genmap_amd import synth
+    codes, lens, _ = synth.workload("chr1", 0.0012)
+    ora = H.OracleIndex(codes, lens, keep_sa=False)
+    for K in (30, 13):
+        exp0 = ora.mappability(K, 0, value_bits=16, threads=8)
+        assert np.array_equal(_torch_exact_counts(codes, K, 65535, "cuda:0").cpu().numpy().astype(np.uint16), exp0), K
+    for K in (30, 12, 41):
+        exp1 = ora.mappability(K, 1, value_bits=16, threads=8)
+        assert np.array_equal(_torch_hamming1_counts(codes, K, 65535, "cuda:0").cpu().numpy().astype(np.uint16), exp1), K
+
+
+def test_gpu_full_size_chr1_e1_vs_group_and_count():
+    """BASELINE's (K=30, e=1) on the full 248,956,422 bp chr1-like text, every position, 16-bit counts"""
+    import torch
+    g = _gm()
+    from genmap_amd import synth
+    scale = float(os.environ.get("GM_FULL_SCALE", "1.0"))
+    codes, lens, _ = synth.workload("chr1", scale)
+    ix = g.Index.build(codes, lens, sampling=1)
+    exp = _torch_hamming1_counts(codes, 30, 65535, "cuda:0").to(torch.int32).cpu().numpy().astype(np.uint16)
+    torch.cuda.empty_cache()
+    out = ix.map(30, 1, value_bits=16)
+    assert np.array_equal(out, exp)
+    assert np.array_equal(ix.map(30, 1, value_bits=8), np.minimum(exp, 255).astype(np.uint8))
+    ix.close()
