@@ -300,36 +300,62 @@ def test_gpu_midsize_vs_oracle_and_properties():
     ix.close()
 
 
-def _torch_exact_counts(codes_np, K, max_val, device):
-    """Independent e = 0 restatement at full size with plain torch ops (no index at all): 2-bit pack every K-mer of both
-    strands into an int64 key (K <= 31), sort the forward keys once, count by two binary searches.
-    c[j] = min(MAX, occ(P_j) + occ(rc(P_j))); k-mers holding N count nothing and are found nowhere (src/algo.hpp:111-125).
-    Single-sequence texts only (no boundary handling)."""
+def _window_masks(codes_np, lens, K, device, begin=0, end=None):
+    """for the k-mer starts j in [begin, end) (default: all m = n-K+1): the symbols they cover, number of N in the window,
+    and whether the window stays inside one sequence"""
     import torch
-    assert K <= 31
-    c = torch.from_numpy(codes_np).to(device)
+    ntot = len(codes_np)
+    end = ntot - K + 1 if end is None else end
+    c = torch.from_numpy(codes_np[begin:end + K - 1]).to(device)
     n = c.numel()
     m = n - K + 1
     isn = (c == 4)
     ncs = torch.zeros(n + 1, dtype=torch.int32, device=device)
     ncs[1:] = torch.cumsum(isn.to(torch.int32), 0)
-    valid = (ncs[K:K + m] - ncs[:m]) == 0
-    del ncs
-    c2 = torch.where(isn, torch.zeros_like(c), c).to(torch.int64)
-    del isn
-    fwd = torch.zeros(m, dtype=torch.int64, device=device)
-    rc = torch.zeros(m, dtype=torch.int64, device=device)
-    for i in range(K):
-        fwd.mul_(4).add_(c2[i:i + m])                       # P[i] is digit K-1-i
-        rc.mul_(4).add_(3 - c2[K - 1 - i:K - 1 - i + m])    # rc(P)[i] = 3 - P[K-1-i]
-    del c2
-    srt = torch.sort(fwd[valid]).values
-    def cnt(q):
-        return torch.searchsorted(srt, q, right=True) - torch.searchsorted(srt, q, right=False)
-    tot = cnt(fwd) + cnt(rc)
-    tot = torch.where(valid, tot, torch.zeros_like(tot)).clamp_(max=max_val)
-    out = torch.zeros(n, dtype=torch.int64, device=device)
-    out[:m] = tot
+    nN = ncs[K:K + m] - ncs[:m]
+    last = torch.zeros(n + 1, dtype=torch.int32, device=device)      # 1 at the last symbol of every sequence but the final one
+    ends = np.cumsum(np.asarray(lens, dtype=np.int64))[:-1] - 1 - begin
+    ends = torch.from_numpy(ends[(ends >= 0) & (ends < n)]).to(device)
+    last[ends + 1] = 1
+    ncs = torch.cumsum(last, 0)                                       # ncs[x] = #ends among symbols [0, x)
+    inside = (ncs[K - 1:K - 1 + m] - ncs[:m]) == 0                    # no sequence end among the first K-1 symbols
+    return c, isn, nN, inside, n, m
+
+
+def _torch_exact_counts(codes_np, K, max_val, device, lens=None, chunk=1 << 30):
+    """Independent e = 0 restatement at full size with plain torch ops (no index at all): 2-bit pack every K-mer of both
+    strands into an int64 key (K <= 31), sort the forward keys, count by two binary searches.
+    c[j] = min(MAX, occ(P_j) + occ(rc(P_j))); k-mers holding N count nothing and are found nowhere
+    (src/algo.hpp:111-125); windows spanning two sequences are neither patterns nor occurrences (src/algo.hpp:10-22).
+    Works in chunks of 2^30 windows (torch's indexing kernels are 32-bit); returns a host int64 array."""
+    import torch
+    assert K <= 31
+    lens = lens if lens is not None else [len(codes_np)]
+    mtot = len(codes_np) - K + 1
+    parts = []
+    for a in range(0, mtot, chunk):
+        c, isn, nN, inside, n, m = _window_masks(codes_np, lens, K, device, a, min(mtot, a + chunk))
+        valid = (nN == 0) & inside
+        del nN, inside
+        c2 = torch.where(isn, torch.zeros_like(c), c).to(torch.int64)
+        del isn, c
+        fwd = torch.zeros(m, dtype=torch.int64, device=device)
+        rc = torch.zeros(m, dtype=torch.int64, device=device)
+        for i in range(K):
+            fwd.mul_(4).add_(c2[i:i + m])                       # P[i] is digit K-1-i
+            rc.mul_(4).add_(3 - c2[K - 1 - i:K - 1 - i + m])    # rc(P)[i] = 3 - P[K-1-i]
+        del c2
+        parts.append((fwd, rc, valid, torch.sort(fwd[valid]).values))
+    out = np.zeros(len(codes_np), dtype=np.int64)
+    a = 0
+    for fwd, rc, valid, _ in parts:
+        tot = torch.zeros_like(fwd)
+        for _, _, _, srt in parts:
+            for q in (fwd, rc):
+                tot += torch.searchsorted(srt, q, right=True) - torch.searchsorted(srt, q, right=False)
+        tot = torch.where(valid, tot, torch.zeros_like(tot)).clamp_(max=max_val)
+        out[a:a + tot.numel()] = tot.cpu().numpy()
+        a += tot.numel()
     return out
 
 
@@ -346,8 +372,8 @@ def test_gpu_full_size_chr1_e0_vs_sort_and_count():
     ix = g.Index.build(codes, lens, sampling=1)
     K = 30
     exp16 = _torch_exact_counts(codes, K, 65535, "cuda:0")
-    exp8 = exp16.clamp(max=255).to(torch.uint8).cpu().numpy()
-    exp16 = exp16.to(torch.int32).cpu().numpy().astype(np.uint16)
+    exp8 = np.minimum(exp16, 255).astype(np.uint8)
+    exp16 = exp16.astype(np.uint16)
     torch.cuda.empty_cache()
     out8 = ix.map(K, 0, value_bits=8)
     assert np.array_equal(out8, exp8)
@@ -370,23 +396,16 @@ def test_gpu_full_size_chr1_e0_vs_sort_and_count():
     ix.close()
 
 
-def _torch_hamming1_counts(codes_np, K, max_val, device):
+def _torch_hamming1_counts(codes_np, K, max_val, device, lens=None):
     """Independent e = 1 restatement at full size, index-free: c[j] = min(MAX, occ_1(P_j) + occ_1(rc(P_j))) where
     occ_1(X) = #{text windows Q : #{i : X[i] != Q[i] or X[i] == N} <= 1} (src/find2_index_approx.hpp:250).
     For every position i all windows are grouped by their string with position i blanked (exact 3-bit packing in two
     int64 halves, dense-ranked and combined), so cnt_i(X) = #{Q equal to X everywhere except possibly at i};
     N-free X: occ_1 = occ_0 + sum_i (cnt_i - occ_0); X with one N at i0: occ_1 = cnt_i0; more Ns: 0.
-    Single-sequence texts only."""
+    Windows spanning two sequences are neither patterns nor occurrences."""
     import torch
     assert K <= 42
-    c = torch.from_numpy(codes_np).to(device)
-    n = c.numel()
-    m = n - K + 1
-    isn = (c == 4)
-    ncs = torch.zeros(n + 1, dtype=torch.int32, device=device)
-    ncs[1:] = torch.cumsum(isn.to(torch.int32), 0)
-    nN = ncs[K:K + m] - ncs[:m]
-    del ncs
+    c, isn, nN, inside, n, m = _window_masks(codes_np, lens if lens is not None else [len(codes_np)], K, device)
     c64 = c.to(torch.int64)
     comp = torch.where(c64 < 4, 3 - c64, c64)
     h = K // 2
@@ -400,18 +419,21 @@ def _torch_hamming1_counts(codes_np, K, max_val, device):
     fwd = [pack(lambda p: c64[p:p + m], 0, h), pack(lambda p: c64[p:p + m], h, K)]
     rcq = [pack(lambda p: comp[K - 1 - p:K - 1 - p + m], 0, h), pack(lambda p: comp[K - 1 - p:K - 1 - p + m], h, K)]
     del c64, comp
+    all_inside = bool(inside.all())
     def ranks(vals, query):
-        U, inv = torch.unique(vals, return_inverse=True)
-        idx = torch.searchsorted(U, query).clamp_(max=U.numel() - 1)
-        return inv, idx, U[idx] == query
+        """dense ranks of the occurrence windows' half-keys, and where the two pattern sets fall among them"""
+        U, inv = torch.unique(vals if all_inside else vals[inside], return_inverse=True)
+        def look(q):
+            idx = torch.searchsorted(U, q).clamp_(max=U.numel() - 1)
+            return idx, U[idx] == q
+        return inv, look(vals), look(query)
     base = [ranks(fwd[0], rcq[0]), ranks(fwd[1], rcq[1])]
     def count(hi, lo):
-        comb = (hi[0] << 32) | lo[0]
-        S = torch.sort(comb).values
-        cf = torch.searchsorted(S, comb, right=True) - torch.searchsorted(S, comb, right=False)
-        q = (hi[1] << 32) | lo[1]
-        cr = (torch.searchsorted(S, q, right=True) - torch.searchsorted(S, q, right=False)) * (hi[2] & lo[2])
-        return cf, cr
+        S = torch.sort((hi[0] << 32) | lo[0]).values
+        def cnt(a, b):
+            q = (a[0] << 32) | b[0]
+            return (torch.searchsorted(S, q, right=True) - torch.searchsorted(S, q, right=False)) * (a[1] & b[1])
+        return cnt(hi[1], lo[1]), cnt(hi[2], lo[2])
     occ0_f, occ0_r = count(base[0], base[1])
     acc_f = torch.zeros(m, dtype=torch.int64, device=device)
     acc_r = torch.zeros(m, dtype=torch.int64, device=device)
@@ -424,7 +446,8 @@ def _torch_hamming1_counts(codes_np, K, max_val, device):
         acc_f += cf * (clean | (one & isn[i:i + m]))
         acc_r += cr * (clean | (one & isn[K - 1 - i:K - 1 - i + m]))
         del masked, cf, cr
-    tot = torch.where(clean, acc_f - (K - 1) * occ0_f + acc_r - (K - 1) * occ0_r, acc_f + acc_r).clamp_(max=max_val)
+    tot = torch.where(clean, acc_f - (K - 1) * occ0_f + acc_r - (K - 1) * occ0_r, acc_f + acc_r)
+    tot = torch.where(inside, tot, torch.zeros_like(tot)).clamp_(max=max_val)
     out = torch.zeros(n, dtype=torch.int64, device=device)
     out[:m] = tot
     return out
@@ -438,10 +461,22 @@ def test_gpu_torch_restatements_are_pinned_on_the_oracle():
     ora = H.OracleIndex(codes, lens, keep_sa=False)
     for K in (30, 13):
         exp0 = ora.mappability(K, 0, value_bits=16, threads=8)
-        assert np.array_equal(_torch_exact_counts(codes, K, 65535, "cuda:0").cpu().numpy().astype(np.uint16), exp0), K
+        assert np.array_equal(_torch_exact_counts(codes, K, 65535, "cuda:0").astype(np.uint16), exp0), K
+        assert np.array_equal(_torch_exact_counts(codes, K, 65535, "cuda:0", chunk=100_000).astype(np.uint16), exp0), K
     for K in (30, 12, 41):
         exp1 = ora.mappability(K, 1, value_bits=16, threads=8)
         assert np.array_equal(_torch_hamming1_counts(codes, K, 65535, "cuda:0").cpu().numpy().astype(np.uint16), exp1), K
+    # several sequences (boundary-spanning windows), with Ns
+    codes, lens, _ = synth.workload("grch38", 0.0001)
+    ora = H.OracleIndex(codes, lens, keep_sa=False)
+    assert len(lens) == 24
+    for K, E in ((30, 0), (9, 0), (30, 1), (11, 1)):
+        exp = ora.mappability(K, E, value_bits=16, threads=8)
+        if E == 0:
+            got = _torch_exact_counts(codes, K, 65535, "cuda:0", lens=lens, chunk=70_000)
+        else:
+            got = _torch_hamming1_counts(codes, K, 65535, "cuda:0", lens=lens).cpu().numpy()
+        assert np.array_equal(got.astype(np.uint16), exp), (K, E)
 
 
 def test_gpu_full_size_chr1_e1_vs_group_and_count():
@@ -457,4 +492,25 @@ def test_gpu_full_size_chr1_e1_vs_group_and_count():
     out = ix.map(30, 1, value_bits=16)
     assert np.array_equal(out, exp)
     assert np.array_equal(ix.map(30, 1, value_bits=8), np.minimum(exp, 255).astype(np.uint8))
+    ix.close()
+
+
+@pytest.mark.skipif(not os.environ.get("GM_FULL_GRCH38"), reason="opt-in (GM_FULL_GRCH38=1): 3.1 Gbp, ~3 min and ~150 GB of HBM")
+def test_gpu_full_size_grch38_vs_index_free_comparators():
+    """BASELINE config C3's text (24 sequences, 3.1 Gbp): e=0 at every position; e=1 on the first GM_FULL_E1_SCALE of it"""
+    import torch
+    g = _gm()
+    from genmap_amd import synth
+    codes, lens, _ = synth.workload("grch38", 1.0)
+    ix = g.Index.build(codes, lens, sampling=0)
+    exp = _torch_exact_counts(codes, 30, 255, "cuda:0", lens=lens).astype(np.uint8)
+    torch.cuda.empty_cache()
+    assert np.array_equal(ix.map(30, 0, value_bits=8), exp)
+    ix.close()
+    del exp
+    codes, lens, _ = synth.workload("grch38", float(os.environ.get("GM_FULL_E1_SCALE", "0.2")))
+    ix = g.Index.build(codes, lens, sampling=0)
+    exp = _torch_hamming1_counts(codes, 30, 65535, "cuda:0", lens=lens).to(torch.int32).cpu().numpy().astype(np.uint16)
+    torch.cuda.empty_cache()
+    assert np.array_equal(ix.map(30, 1, value_bits=16), exp)
     ix.close()
