@@ -514,3 +514,12 @@ def test_gpu_full_size_grch38_vs_index_free_comparators():
     torch.cuda.empty_cache()
     assert np.array_equal(ix.map(30, 1, value_bits=16), exp)
     ix.close()
+
+
+def test_gpu_rccl_collectives_next_to_the_library():
+    """one rank, backend nccl (= RCCL): the collectives of bench.py's N>1 path on device tensors filled by gm_map_device"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_one_rank_check.py")], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
