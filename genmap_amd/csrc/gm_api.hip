@@ -586,9 +586,19 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
     const bool store = !ep && p->E == 0 && A.verifyT <= 1 && getenv("GM_NO_STORE") == nullptr;
     const uint64_t plane = text_len + 4;
 
+    // a shard (kmer_begin/kmer_end) touches only its own positions [r0, r1) of the accumulators and of out
+    const bool sharded = p->kmer_begin != 0 || p->kmer_end != 0;
+    const uint64_t r0 = sharded ? std::min<uint64_t>(S.posBase, text_len) : 0;
+    const uint64_t r1 = sharded ? std::min<uint64_t>(std::max<uint64_t>(S.posEnd, r0), text_len) : text_len;
+    const uint64_t rn = r1 - r0;
     GM_HIP(hipEventRecord(ix->ev[0], st));
-    if (ep) GM_HIP(hipMemsetAsync(ix->d_bits, 0, (text_len + 1) * wordsPerKmer * sizeof(uint32_t), st));
-    else GM_HIP(hipMemsetAsync(ix->d_acc, 0, store ? 2 * plane * sizeof(uint16_t) : plane * sizeof(uint32_t), st));
+    if (rn > 0) {
+        if (ep) GM_HIP(hipMemsetAsync(ix->d_bits + r0 * wordsPerKmer, 0, rn * wordsPerKmer * sizeof(uint32_t), st));
+        else if (store) {
+            GM_HIP(hipMemsetAsync((uint16_t*)ix->d_acc + r0, 0, rn * sizeof(uint16_t), st));
+            GM_HIP(hipMemsetAsync((uint16_t*)ix->d_acc + plane + r0, 0, rn * sizeof(uint16_t), st));
+        } else GM_HIP(hipMemsetAsync(ix->d_acc + r0, 0, rn * sizeof(uint32_t), st));
+    }
     GM_HIP(hipMemsetAsync(ix->d_small, 0, 256, st));
     A.acc = ix->d_acc; A.accPlane = plane; A.fileBits = ix->d_bits;
     A.maxVal = (p->value_bits == 8 && getenv("GM_NO_SATURATE") == nullptr) ? 255u : (getenv("GM_NO_SATURATE") ? 0xFFFFFFFFu : 65535u); A.wordsPerKmer = wordsPerKmer; A.seqFile = ix->d_seqFile;
@@ -597,16 +607,21 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
     if (S.numRoots > 0) { rc = launch_search(ix, ep ? LEAF_FILESET : store ? LEAF_STORE : LEAF_COUNT, A, S.blocks, st); if (rc) return rc; }
     GM_HIP(hipEventRecord(ix->ev[2], st));
     if (text_len > 0) {
-        const unsigned g4 = grid_for((text_len + 3) / 4), g1 = grid_for(text_len);
+        const unsigned g4 = grid_for((rn + 3) / 4), g1 = grid_for(rn);
+        const uint16_t* pf = (const uint16_t*)ix->d_acc + r0;
         if (p->value_bits == 8) {
-            if (ep) hipLaunchKernelGGL(finalize_fileset_kernel<uint8_t>, dim3(g1), dim3(256), 0, st, ix->d_bits, wordsPerKmer, (uint8_t*)d_out, text_len);
-            else if (store) hipLaunchKernelGGL(finalize2_kernel<uint8_t>, dim3(g1), dim3(256), 0, st, (const uint16_t*)ix->d_acc, (const uint16_t*)ix->d_acc + plane, (uint8_t*)d_out, text_len, 255u);
-            else hipLaunchKernelGGL(finalize_kernel<uint8_t>, dim3(g4), dim3(256), 0, st, ix->d_acc, (uint8_t*)d_out, text_len, 255u);
+            uint8_t* o = (uint8_t*)d_out + r0;
+            if (rn == 0) {}
+            else if (ep) hipLaunchKernelGGL(finalize_fileset_kernel<uint8_t>, dim3(g1), dim3(256), 0, st, ix->d_bits + r0 * wordsPerKmer, wordsPerKmer, o, rn);
+            else if (store) hipLaunchKernelGGL(finalize2_kernel<uint8_t>, dim3(g1), dim3(256), 0, st, pf, pf + plane, o, rn, 255u);
+            else hipLaunchKernelGGL(finalize_kernel<uint8_t>, dim3(g4), dim3(256), 0, st, ix->d_acc + r0, o, rn, 255u);
             rc = launch_reset_limits(ix, (uint8_t*)d_out, n_seq, p->K, st);
         } else {
-            if (ep) hipLaunchKernelGGL(finalize_fileset_kernel<uint16_t>, dim3(g1), dim3(256), 0, st, ix->d_bits, wordsPerKmer, (uint16_t*)d_out, text_len);
-            else if (store) hipLaunchKernelGGL(finalize2_kernel<uint16_t>, dim3(g1), dim3(256), 0, st, (const uint16_t*)ix->d_acc, (const uint16_t*)ix->d_acc + plane, (uint16_t*)d_out, text_len, 65535u);
-            else hipLaunchKernelGGL(finalize_kernel<uint16_t>, dim3(g4), dim3(256), 0, st, ix->d_acc, (uint16_t*)d_out, text_len, 65535u);
+            uint16_t* o = (uint16_t*)d_out + r0;
+            if (rn == 0) {}
+            else if (ep) hipLaunchKernelGGL(finalize_fileset_kernel<uint16_t>, dim3(g1), dim3(256), 0, st, ix->d_bits + r0 * wordsPerKmer, wordsPerKmer, o, rn);
+            else if (store) hipLaunchKernelGGL(finalize2_kernel<uint16_t>, dim3(g1), dim3(256), 0, st, pf, pf + plane, o, rn, 65535u);
+            else hipLaunchKernelGGL(finalize_kernel<uint16_t>, dim3(g4), dim3(256), 0, st, ix->d_acc + r0, o, rn, 65535u);
             rc = launch_reset_limits(ix, (uint16_t*)d_out, n_seq, p->K, st);
         }
         if (rc) return rc;
@@ -710,6 +725,7 @@ int gm_map(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t first_
     void* d_out = nullptr;
     const size_t bytes = (size_t)text_len * (p->value_bits / 8);
     GM_HIP(hipMalloc(&d_out, bytes + 16));
+    if (p->kmer_begin != 0 || p->kmer_end != 0) GM_HIP(hipMemsetAsync(d_out, 0, bytes, nullptr));   // a shard leaves the other positions zero
     int rc = map_impl(ix, text_begin, text_len, first_seq, n_seq, p, intervals, n_intervals, seq_file_id, d_out, nullptr);
     if (!rc) { hipError_t e = hipMemcpy(out_host, d_out, bytes, hipMemcpyDeviceToHost); if (e != hipSuccess) { set_error("copy back failed: %s", hipGetErrorString(e)); rc = GM_ERR_HIP; } }
     if (!rc) rc = check_device_error(ix);

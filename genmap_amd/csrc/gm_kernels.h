@@ -569,7 +569,7 @@ template <typename TValue>
 __global__ __launch_bounds__(256) void finalize_kernel(const uint32_t* __restrict__ acc, TValue* __restrict__ out, uint64_t n, uint32_t maxVal)
 {
     const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4ull;
-    const bool aligned = ((reinterpret_cast<uintptr_t>(out + i)) & (sizeof(TValue) * 4 - 1)) == 0;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(out + i)) & (sizeof(TValue) * 4 - 1)) == 0 && ((reinterpret_cast<uintptr_t>(acc + i)) & 15) == 0;
     if (i + 4 <= n && aligned) {
         const uint4 v = *reinterpret_cast<const uint4*>(acc + i);
         TValue r[4] = {(TValue)(v.x < maxVal ? v.x : maxVal), (TValue)(v.y < maxVal ? v.y : maxVal),

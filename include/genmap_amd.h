@@ -98,7 +98,9 @@ typedef struct gm_map_params {
     int32_t  exclude_pseudo;  /* -ep: count distinct fasta files (needs SA samples) */
     int32_t  reserved0;
     uint64_t kmer_begin;      /* shard: compute only k-mer start positions in [kmer_begin, kmer_end) of   */
-    uint64_t kmer_end;        /*        the slice; both 0 = everything.  Other positions are left zero.   */
+    uint64_t kmer_end;        /*        the slice (whole k-mer blocks); both 0 = everything.  gm_map leaves   */
+                              /*        the other positions zero, gm_map_device does not touch them (apart  */
+                              /*        from the boundary reset), so shards can share one device buffer.    */
 } gm_map_params;
 
 /* text_begin/text_len: the slice in sentinel-free global coordinates (src/mappability.hpp:312);
