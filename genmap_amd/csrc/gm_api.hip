@@ -353,7 +353,7 @@ template <typename T> static int grow(T** p, uint64_t* cap, uint64_t need)
     return GM_OK;
 }
 
-enum LeafMode { LEAF_COUNT = 0, LEAF_FILESET = 1, LEAF_OCC_COUNT = 2, LEAF_OCC_EMIT = 3, LEAF_STORE = 4 };
+enum LeafMode { LEAF_COUNT = 0, LEAF_FILESET = 1, LEAF_OCC_COUNT = 2, LEAF_OCC_EMIT = 3, LEAF_STORE = 4, LEAF_STORE8 = 5 };
 
 static inline size_t search_lds_bytes(const SearchArgs& A) { return (size_t)(4u * A.vqCap + 4u * 64u * (A.ldsDepth + A.winChunks)) * 16u; }
 
@@ -371,7 +371,8 @@ static int launch_mode(int mode, const SearchArgs& A, unsigned blocks, hipStream
         case LEAF_COUNT: return launch_one<WPP, CountEnv<WPP>>(A, blocks, st);
         case LEAF_FILESET: return launch_one<WPP, FileSetEnv<WPP>>(A, blocks, st);
         case LEAF_OCC_COUNT: return launch_one<WPP, OccCountEnv<WPP>>(A, blocks, st);
-        case LEAF_STORE: return launch_one<WPP, StoreEnv<WPP>>(A, blocks, st);
+        case LEAF_STORE: return launch_one<WPP, StoreEnv<WPP, uint16_t>>(A, blocks, st);
+        case LEAF_STORE8: return launch_one<WPP, StoreEnv<WPP, uint8_t>>(A, blocks, st);
         default: return launch_one<WPP, OccEmitEnv<WPP>>(A, blocks, st);
     }
 }
@@ -595,8 +596,9 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
     if (rn > 0) {
         if (ep) GM_HIP(hipMemsetAsync(ix->d_bits + r0 * wordsPerKmer, 0, rn * wordsPerKmer * sizeof(uint32_t), st));
         else if (store) {
-            GM_HIP(hipMemsetAsync((uint16_t*)ix->d_acc + r0, 0, rn * sizeof(uint16_t), st));
-            GM_HIP(hipMemsetAsync((uint16_t*)ix->d_acc + plane + r0, 0, rn * sizeof(uint16_t), st));
+            const size_t pb = p->value_bits == 8 ? 1 : 2;   // plane element: as wide as the result
+            GM_HIP(hipMemsetAsync((uint8_t*)ix->d_acc + r0 * pb, 0, rn * pb, st));
+            GM_HIP(hipMemsetAsync((uint8_t*)ix->d_acc + (plane + r0) * pb, 0, rn * pb, st));
         } else GM_HIP(hipMemsetAsync(ix->d_acc + r0, 0, rn * sizeof(uint32_t), st));
     }
     GM_HIP(hipMemsetAsync(ix->d_small, 0, 256, st));
@@ -604,23 +606,24 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
     A.maxVal = (p->value_bits == 8 && getenv("GM_NO_SATURATE") == nullptr) ? 255u : (getenv("GM_NO_SATURATE") ? 0xFFFFFFFFu : 65535u); A.wordsPerKmer = wordsPerKmer; A.seqFile = ix->d_seqFile;
 
     GM_HIP(hipEventRecord(ix->ev[1], st));
-    if (S.numRoots > 0) { rc = launch_search(ix, ep ? LEAF_FILESET : store ? LEAF_STORE : LEAF_COUNT, A, S.blocks, st); if (rc) return rc; }
+    if (S.numRoots > 0) { rc = launch_search(ix, ep ? LEAF_FILESET : store ? (p->value_bits == 8 ? LEAF_STORE8 : LEAF_STORE) : LEAF_COUNT, A, S.blocks, st); if (rc) return rc; }
     GM_HIP(hipEventRecord(ix->ev[2], st));
     if (text_len > 0) {
         const unsigned g4 = grid_for((rn + 3) / 4), g1 = grid_for(rn);
         const uint16_t* pf = (const uint16_t*)ix->d_acc + r0;
+        const uint8_t* pf8 = (const uint8_t*)ix->d_acc + r0;
         if (p->value_bits == 8) {
             uint8_t* o = (uint8_t*)d_out + r0;
             if (rn == 0) {}
             else if (ep) hipLaunchKernelGGL(finalize_fileset_kernel<uint8_t>, dim3(g1), dim3(256), 0, st, ix->d_bits + r0 * wordsPerKmer, wordsPerKmer, o, rn);
-            else if (store) hipLaunchKernelGGL(finalize2_kernel<uint8_t>, dim3(g1), dim3(256), 0, st, pf, pf + plane, o, rn, 255u);
+            else if (store) hipLaunchKernelGGL((finalize2_kernel<uint8_t, uint8_t>), dim3(g1), dim3(256), 0, st, pf8, pf8 + plane, o, rn, 255u);
             else hipLaunchKernelGGL(finalize_kernel<uint8_t>, dim3(g4), dim3(256), 0, st, ix->d_acc + r0, o, rn, 255u);
             rc = launch_reset_limits(ix, (uint8_t*)d_out, n_seq, p->K, st);
         } else {
             uint16_t* o = (uint16_t*)d_out + r0;
             if (rn == 0) {}
             else if (ep) hipLaunchKernelGGL(finalize_fileset_kernel<uint16_t>, dim3(g1), dim3(256), 0, st, ix->d_bits + r0 * wordsPerKmer, wordsPerKmer, o, rn);
-            else if (store) hipLaunchKernelGGL(finalize2_kernel<uint16_t>, dim3(g1), dim3(256), 0, st, pf, pf + plane, o, rn, 65535u);
+            else if (store) hipLaunchKernelGGL((finalize2_kernel<uint16_t, uint16_t>), dim3(g1), dim3(256), 0, st, pf, pf + plane, o, rn, 65535u);
             else hipLaunchKernelGGL(finalize_kernel<uint16_t>, dim3(g4), dim3(256), 0, st, ix->d_acc + r0, o, rn, 65535u);
             rc = launch_reset_limits(ix, (uint16_t*)d_out, n_seq, p->K, st);
         }

@@ -230,19 +230,20 @@ template <int WPP> struct CountEnv : EnvBase<WPP> {
 };
 
 // leaf policy 1b: frequency for E = 0 -- with a single exact search every (k-mer, strand) pair is reached by at most one
-// leaf or one verified row, so the count is written with a plain 16-bit store into a per-strand plane (plane[strand * accPlane +
+// leaf or one verified row, so the count is written with a plain store into a per-strand plane (8-bit for -fs, else 16-bit) (plane[strand * accPlane +
 // pos], counts clamp at 65535) instead of a device-scope atomic (which is a fabric transaction on a multi-XCD part); finalize adds the planes.
-template <int WPP> struct StoreEnv : EnvBase<WPP> {
+template <int WPP, typename TPlane> struct StoreEnv : EnvBase<WPP> {
     using EnvBase<WPP>::A;
+    static constexpr uint32_t CAP = sizeof(TPlane) == 1 ? 0xFFu : 0xFFFFu;   // min(MAX, f + r) == min(MAX, min(MAX, f) + min(MAX, r))
     __device__ __forceinline__ StoreEnv(const SearchArgs& a, uint4* s, uint32_t k) : EnvBase<WPP>(a, s, k) {}
     __device__ __forceinline__ void leaf(const Root& rt, uint32_t kmer, uint32_t, uint32_t w)
     {
-        reinterpret_cast<uint16_t*>(A.acc)[(size_t)rt.strand * A.accPlane + this->slice_pos(rt, kmer)] = (uint16_t)(w < 0xFFFFu ? w : 0xFFFFu);
+        reinterpret_cast<TPlane*>(A.acc)[(size_t)rt.strand * A.accPlane + this->slice_pos(rt, kmer)] = (TPlane)(w < CAP ? w : CAP);
     }
     __device__ __forceinline__ void leaf_flush(const Root&, uint32_t) {}
     __device__ __forceinline__ void leaf_at(const Root& rt, uint32_t kmer, uint32_t)
     {
-        reinterpret_cast<uint16_t*>(A.acc)[(size_t)rt.strand * A.accPlane + this->slice_pos(rt, kmer)] = (uint16_t)1u;
+        reinterpret_cast<TPlane*>(A.acc)[(size_t)rt.strand * A.accPlane + this->slice_pos(rt, kmer)] = (TPlane)1u;
     }
 };
 
@@ -555,13 +556,13 @@ __global__ __launch_bounds__(256) void qmer_table_kernel(const uint32_t* __restr
     out[idx] = make_uint4(flo, rlo, w, 0u);
 }
 
-// acc -> c[]  (4 positions per thread)
-template <typename TValue>
-__global__ __launch_bounds__(256) void finalize2_kernel(const uint16_t* __restrict__ accF, const uint16_t* __restrict__ accR, TValue* __restrict__ out, uint64_t n, uint32_t maxVal)
+// store planes -> c[]
+template <typename TValue, typename TPlane>
+__global__ __launch_bounds__(256) void finalize2_kernel(const TPlane* __restrict__ accF, const TPlane* __restrict__ accR, TValue* __restrict__ out, uint64_t n, uint32_t maxVal)
 {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    const uint32_t v = (uint32_t)accF[j] + accR[j];   // each plane holds at most 65535
+    const uint32_t v = (uint32_t)accF[j] + accR[j];   // each plane holds min(count, its own maximum)
     out[j] = (TValue)(v < maxVal ? v : maxVal);
 }
 
