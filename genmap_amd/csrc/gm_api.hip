@@ -332,7 +332,7 @@ int gm_index_get_info(const gm_index* ix, gm_index_info* info)
     info->n_rows = ix->nRows; info->text_len = ix->textLen; info->n_seq = ix->nSeq; info->sampling = ix->sampling;
     info->alphabet_size = ix->alphabet;
     info->block_bytes = ix->wpp == 1 ? 32 : ix->wpp == 3 ? 64 : 128;
-    info->device_bytes = 2 * ix->blkBytes + ix->textLen + (ix->nSeq + 1) * 8ull + (ix->d_sa ? ix->nRows * 5ull : 0ull);
+    info->device_bytes = 2 * ix->blkBytes + ix->textLen + (ix->nSeq + 1) * 8ull + (ix->d_sa ? ix->nRows * 5ull : 0ull) + ix->qtableBytes;
     if (!ix->d_sa) info->sampling = 0;
     info->device = ix->device;
     return GM_OK;
@@ -396,13 +396,25 @@ template <int WPP> static int occupancy_blocks(int* out, size_t ldsBytes)
 static int check_device_error(gm_index* ix);
 
 // table of all q-mers for this index (cached)
-static int get_qtable(gm_index* ix, uint32_t q, const uint4** out)
+static int get_qtable(gm_index* ix, uint32_t* qio, const uint4** out)
 {
-    auto it = ix->qtables.find(q);
-    if (it != ix->qtables.end()) { *out = it->second; return GM_OK; }
+    uint32_t q = *qio;
+    {   // an existing table of this or (after an earlier out-of-memory) the next shorter length
+        auto it = ix->qtables.find(q);
+        if (it != ix->qtables.end()) { *out = it->second; return GM_OK; }
+        if (ix->qtableCap && q > ix->qtableCap) { q = ix->qtableCap; it = ix->qtables.find(q); if (it != ix->qtables.end()) { *qio = q; *out = it->second; return GM_OK; } }
+    }
     uint4* d = nullptr;
+    for (;; --q) {   // shorter prefixes when the device is short of memory (the table is an accelerator, not a requirement)
+        if (q == 0) { *qio = 0; *out = nullptr; return GM_OK; }
+        size_t freeB = 0, totalB = 0;
+        const uint64_t bytes = (1ull << (2 * q)) * sizeof(uint4);
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && bytes > freeB / 2) { ix->qtableCap = q - 1; continue; }
+        if (hipMalloc(&d, bytes) == hipSuccess) break;
+        (void)hipGetLastError();
+        ix->qtableCap = q - 1;
+    }
     const uint64_t n = 1ull << (2 * q);
-    GM_HIP(hipMalloc(&d, n * sizeof(uint4)));
     if (!ix->d_C) { GM_HIP(hipMalloc(&ix->d_C, sizeof(ix->C))); GM_HIP(hipMemcpy(ix->d_C, ix->C, sizeof(ix->C), hipMemcpyHostToDevice)); }
     switch (ix->wpp) {
         case 1: hipLaunchKernelGGL(qmer_table_kernel<1>, dim3(grid_for(n)), dim3(256), 0, 0, ix->d_blk[1], ix->d_C, (uint32_t)ix->nRows, q, d); break;
@@ -412,6 +424,8 @@ static int get_qtable(gm_index* ix, uint32_t q, const uint4** out)
     GM_HIP(hipGetLastError());
     GM_HIP(hipDeviceSynchronize());
     ix->qtables[q] = d;
+    ix->qtableBytes += n * sizeof(uint4);
+    *qio = q;
     *out = d;
     return GM_OK;
 }
@@ -521,9 +535,13 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     A.table = ix->d_table;
     A.stack = ix->d_stack; A.stackDepth = depth; A.spillDepth = std::max<uint32_t>(depth - ldsDepth, 1u);
     {   // q-mer tables for the first block of every search: q = min(Qmax, length of that block - 1) for the regular block shape
-        uint32_t qmax = 12;
-        while (qmax > 0 && (1ull << (2 * qmax)) > ix->nRows) --qmax;       // no point in tables larger than the text
-        if (const char* e = getenv("GM_QTABLE")) qmax = (uint32_t)std::max(0, std::min(atoi(e), 13));
+        // Longest tabulated prefix: one more symbol than it takes a random string to become unique in this text
+        // (ceil(log4 rows) + 1), at most 15: 4^15 entries x 16 B = 17 GB of the 288 GB -- every tabulated symbol
+        // replaces a bidirectional step (1-2 random rank reads) by a share of ONE table read
+        // (profiles/r01h_qtable_sweep.txt: e=0 +27 % on 249 Mbp, +30 % on 3.1 Gbp going from 12 to 15).
+        uint32_t qmax = 1;
+        while (qmax < 15 && (1ull << (2 * qmax)) < 4ull * ix->nRows) ++qmax;
+        if (const char* e = getenv("GM_QTABLE")) qmax = (uint32_t)std::max(0, std::min(atoi(e), 15));
         A.qtabA = A.qtabB = nullptr; A.qlenPacked = 0; A.qselMask = 0; A.startPacked[0] = A.startPacked[1] = 0;
         uint32_t qA = 0, qB = 0;
         for (uint32_t s = 0; s < plan.nSearches; ++s) {
@@ -531,11 +549,12 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
             A.startPacked[s >> 2] |= oss_start(r) << (8u * (s & 3u));
             if (qmax == 0) continue;
             const uint32_t bl0 = oss_bl(r, 0);
-            const uint32_t q = std::min(qmax, bl0 > 0 ? bl0 - 1u : 0u);
+            uint32_t q = std::min(qmax, bl0 > 0 ? bl0 - 1u : 0u);
             if (q == 0) continue;
-            if (qA == 0 || qA == q) { if (qA == 0) { rc = get_qtable(ix, q, &A.qtabA); if (rc) return rc; qA = q; } }
-            else if (qB == 0 || qB == q) { if (qB == 0) { rc = get_qtable(ix, q, &A.qtabB); if (rc) return rc; qB = q; } A.qselMask |= 1u << s; }
+            if (qA == 0 || qA == q) { if (qA == 0) { rc = get_qtable(ix, &q, &A.qtabA); if (rc) return rc; qA = q; } }
+            else if (qB == 0 || qB == q) { if (qB == 0) { rc = get_qtable(ix, &q, &A.qtabB); if (rc) return rc; qB = q; } A.qselMask |= 1u << s; }
             else continue;   // a third distinct prefix length: this search starts from the root
+            if (q == 0) continue;
             A.qlenPacked |= q << (4u * s);
         }
     }
