@@ -53,6 +53,9 @@ struct SearchArgs {
     // ---- verification of narrow nodes (gm_engine.h: verify_item) ----
     const uint8_t* textS;           // sentinel text (one code per byte, 5 = sentinel), nRows bytes
     uint32_t verifyT;               // nodes with range width <= verifyT are resolved by verification (0 = off)
+    uint32_t fetchBatch;            // roots are drawn when this many lanes are idle (or nothing else is left): the fetch code runs per batch
+    uint32_t satMinW;               // saturation is looked up (a global read per covered k-mer) only for nodes at least this wide
+    uint32_t probation;             // a single-row node that has spent every error is stepped this many times before it is verified
     uint32_t verifyCost;            // ... when width * verifyCost <= estimated rank steps left below the node
     // ---- LDS staging (per wavefront): verification queue | top of the lane stacks | packed needle windows ----
     const uint4* text4;             // whole text, 4 bits per symbol (32 symbols per 16-byte chunk), sentinel-free
@@ -114,7 +117,7 @@ template <int WPP> struct EnvBase {
     __device__ __forceinline__ uint4 pop()
     {
         --sp;
-        return sp < A.ldsDepth ? lstk[sp * 64u] : stk[sp - A.ldsDepth];
+        return sp < A.ldsDepth ? lstk[sp * 64u] : stk[(size_t)(sp - A.ldsDepth) * 64u];
     }
     __device__ __forceinline__ uint32_t slice_pos(const Root& rt, uint32_t kmer) const { return rt.win + (rt.strand ? rt.n - 1u - kmer : kmer); }
 
@@ -158,7 +161,7 @@ template <int WPP> struct EnvBase {
 #endif
         const uint4 v = make_uint4(nd.flo, nd.rlo, nd.w, nd.meta);
         if (sp < A.ldsDepth) { lstk[sp * 64u] = v; ++sp; }
-        else if (sp < A.stackDepth) { stk[sp - A.ldsDepth] = v; ++sp; }
+        else if (sp < A.stackDepth) { stk[(size_t)(sp - A.ldsDepth) * 64u] = v; ++sp; }
         else *A.errorFlag = 1u;   // never expected: depth = stack_bound(E, stepSize)
     }
     __device__ __forceinline__ void on_root() {}
@@ -302,12 +305,18 @@ template <int WPP> struct OccEmitEnv : EnvBase<WPP> {
     }
 };
 
+#ifdef GM_WAVES
+#define GM_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(GM_WAVES, GM_WAVES)))
+#else
+#define GM_WAVES_ATTR
+#endif
 template <int WPP, class EnvT>
-__global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
+__global__ __launch_bounds__(256) GM_WAVES_ATTR void search_kernel(const SearchArgs A)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const size_t gl = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    EnvT env(A, A.stack + gl * A.spillDepth, A.K);
+    // spilled stack levels: wavefront-interleaved (level i of the 64 lanes is one contiguous KiB), like the LDS levels
+    EnvT env(A, A.stack + (gl & ~(size_t)63) * A.spillDepth + lane, A.K);
     Node nd; nd.flo = nd.rlo = nd.w = nd.meta = 0;
     Root rt; rt.win = 0; rt.n = 1; rt.strand = 0; rt.search = 0; rt.rec = OssRecord{0, 0, 0, 0};
     // per-wavefront queue of narrow nodes awaiting verification: filled by ballot rank, drained 64 at a time so that a
@@ -322,6 +331,7 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
     uint32_t wvIter = 0, wvActive = 0, wvRounds = 0;
 #endif
     bool have = false, exhausted = false;
+    uint32_t w1run = 0;                             // consecutive steps this lane has taken on a single-row node
     // root fetch pipeline of this lane: 0 idle, 1 window/record loads in flight, 2 q-mer table lookup in flight
     uint32_t fs = 0, fa0 = 0, fql = 0, fwoff = 0, fnch = 0, fshift = 0;
     Root frt; frt.win = 0; frt.n = 1; frt.strand = 0; frt.search = 0; frt.rec = OssRecord{0, 0, 0, 0};
@@ -342,10 +352,10 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
 #pragma unroll 1
         for (int tries = 0; tries < 4 && !have && env.sp > 0; ++tries) {
             const uint4 v = env.pop();
-            nd.flo = v.x; nd.rlo = v.y; nd.w = v.z; nd.meta = v.w;
+            nd.flo = v.x; nd.rlo = v.y; nd.w = v.z; nd.meta = v.w; w1run = 0;
             uint32_t smin, smax;
             covered_kmers(nd.meta, rt.n, A.K, smin, smax);
-            have = !env.saturated(rt, smin, smax);   // pending work for k-mers that already reached MAX is dropped
+            have = !(nd.w >= A.satMinW && env.saturated(rt, smin, smax));   // pending work for k-mers that already reached MAX is dropped
         }
         // ---- root fetch, pipelined over iterations so that the wavefront never waits for it ----
         // stage 3: the q-mer table entry has arrived -> the root becomes the lane's node (or turns out empty)
@@ -354,7 +364,7 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
             if (ftab.z != 0u) {
                 rt = frt; env.on_root();
                 nd.flo = ftab.x; nd.rlo = ftab.y; nd.w = ftab.z; nd.meta = meta_pack(fa0, fa0 + fql, 0, 0, M_OSS);
-                have = true;
+                have = true; w1run = 0;
             }
         }
         // stage 2: window chunks and record have arrived -> stage the window in LDS, look the first q characters up
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
             if (fnch > 2u) dst[128] = fw2;
             for (uint32_t c = 3u; c < fnch; ++c) dst[c * 64u] = fsrc[c];   // long windows (K > ~45): remaining chunks
             frt.rec.x = frec.x; frt.rec.y = frec.y; frt.rec.z = frec.z; frt.rec.w = frec.w;
-            if (fql == 0u) { rt = frt; env.on_root(); nd = root_node(rt, A.nRows); have = true; fs = 0u; }
+            if (fql == 0u) { rt = frt; env.on_root(); nd = root_node(rt, A.nRows); have = true; fs = 0u; w1run = 0; }
             else {
                 // 16 symbols starting at the lowest text position of the q-mer, 4 bits each
                 const unsigned long long v = fshift ? (fx0 >> fshift) | (fx1 << (64u - fshift)) : fx0;
@@ -387,6 +397,8 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
             const bool need = !have && fs == 0u && env.sp == 0u && !exhausted;
             const unsigned long long m = __ballot(need);
             if (m == 0ull) break;
+            // the whole wavefront walks through the fetch stages for whoever needs a root: wait until enough lanes do
+            if ((uint32_t)__popcll(m) < A.fetchBatch && __ballot(have || fs != 0u || env.sp != 0u) != 0ull) break;
             if (poolCur == poolEnd && !globalDone) {
                 unsigned long long base = 0;
                 const int leader = __ffsll((long long)m) - 1;
@@ -450,6 +462,10 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
                 const uint32_t covered = md == M_OSS ? rt.n : md == M_EXT_R ? a + A.K - t + 1u : md == M_EXT_L ? t + A.K - bx + 1u : a + A.K - bx + 1u;
                 const uint32_t est = (A.K - (bx - a)) + covered - 1u;   // lower bound of the steps still needed
                 narrow = nd.w * A.verifyCost <= est;
+                // A lone row that may not mismatch any more is, more often than not, a chance hit that the next one or
+                // two characters kill with ONE rank line each (lo and hi share a block); verification costs an SA read
+                // plus a text read.  Step it a little first, verify only the survivors.
+                if (nd.w == 1u && meta_errs(m) == A.E && w1run < A.probation) narrow = false;
             }
 #pragma unroll 1
             for (uint32_t r = 0; r < VERIFY_TMAX; ++r) {
@@ -499,12 +515,16 @@ __global__ __launch_bounds__(256) void search_kernel(const SearchArgs A)
                 Node left; split_node(nd, left, A.K);
                 uint32_t smin, smax;
                 covered_kmers(left.meta, rt.n, A.K, smin, smax);
-                const bool leftDone = env.saturated(rt, smin, smax);
+                const bool leftDone = nd.w >= A.satMinW && env.saturated(rt, smin, smax);
                 covered_kmers(nd.meta, rt.n, A.K, smin, smax);
-                if (env.saturated(rt, smin, smax)) { if (leftDone) have = false; else nd = left; }
+                if (nd.w >= A.satMinW && env.saturated(rt, smin, smax)) { if (leftDone) have = false; else nd = left; }
                 else if (!leftDone) env.push(left);
             }
-            if (have) lane_step(nd, have, rt, A.K, A.E, env);
+            if (have) {
+                const bool lone = nd.w == 1u;
+                lane_step(nd, have, rt, A.K, A.E, env);
+                w1run = (lone && have && nd.w == 1u) ? w1run + 1u : 0u;
+            }
         }
         GM_LAP(tStep);
     }
