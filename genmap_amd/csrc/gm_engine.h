@@ -164,27 +164,41 @@ GM_HD void lane_step(Node& nd, bool& have, const Root& rt, uint32_t K, uint32_t 
 
     Node keep; keep.flo = keep.rlo = keep.w = keep.meta = 0;
     bool haveKeep = false;
-    // Children are visited in the lane's own rotated order tc, tc+1, .. (mod 5): the matching child first (it ends
-    // up deepest in the LIFO), mismatching children after it; the lane continues with the last one.  This bounds the
-    // stack by 4*E + log2(n) + c and lets exact-mode lanes finish in the first round.
+    // Order of the children: the matching child first (it ends up deepest in the LIFO), then the mismatching children in
+    // alphabet order; the lane continues with the last one.  Continuing with a child that has spent an error bounds the
+    // stack by 4*E + log2(n) + c and lets exact-mode lanes finish before the mismatch rounds.  Only the
+    // matching child needs a lane-dependent register pick; the mismatch rounds index cnt/pn/sm statically.
+    const bool hasMatch = tc < SYM_N && ((valid >> tc) & 1u) != 0u;
+    if (hasMatch) {
+        const uint32_t cx = tc == 0 ? cnt[0] : tc == 1 ? cnt[1] : tc == 2 ? cnt[2] : cnt[3];
+        const uint32_t pnew = tc == 0 ? pn[0] : tc == 1 ? pn[1] : tc == 2 ? pn[2] : pn[3];
+        const uint32_t onew = olo + (tc == 0 ? sm[0] : tc == 1 ? sm[1] : tc == 2 ? sm[2] : sm[3]);
+        if (ps.leaf) env.leaf(rt, ps.kmer, pl.right ? onew : pnew, cx);
+        else {
+            keep.flo = pl.right ? onew : pnew;
+            keep.rlo = pl.right ? pnew : onew;
+            keep.w = cx;
+            keep.meta = ps.meta0 | (errs << 24);
+            haveKeep = true;
+        }
+    }
+    const uint32_t miss = hasMatch ? valid & ~(1u << tc) : valid;   // pattern N: every child is a mismatch (find2:250)
+    if (env.any(miss != 0u)) {
 #pragma unroll
-    for (int k = 0; k < (int)NLET; ++k) {
-        uint32_t x = tc + (uint32_t)k; if (x >= NLET) x -= NLET;
-        const bool on = ((valid >> x) & 1u) != 0u;
-        if (!env.any(on)) continue;
-        if (on) {
-            const uint32_t cx = x == 0 ? cnt[0] : x == 1 ? cnt[1] : x == 2 ? cnt[2] : x == 3 ? cnt[3] : cnt[4];
-            const uint32_t pnew = x == 0 ? pn[0] : x == 1 ? pn[1] : x == 2 ? pn[2] : x == 3 ? pn[3] : pn[4];
-            const uint32_t onew = olo + (x == 0 ? sm[0] : x == 1 ? sm[1] : x == 2 ? sm[2] : x == 3 ? sm[3] : sm[4]);
-            const uint32_t delta = (k != 0 || tc == SYM_N) ? 1u : 0u;
-            if (ps.leaf) env.leaf(rt, ps.kmer, pl.right ? onew : pnew, cx);
-            else {
-                if (haveKeep) env.push(keep);
-                keep.flo = pl.right ? onew : pnew;
-                keep.rlo = pl.right ? pnew : onew;
-                keep.w = cx;
-                keep.meta = ps.meta0 | ((errs + delta) << 24);
-                haveKeep = true;
+        for (int x = 0; x < (int)NLET; ++x) {
+            const bool on = ((miss >> x) & 1u) != 0u;
+            if (!env.any(on)) continue;
+            if (on) {
+                const uint32_t pnew = pn[x], onew = olo + sm[x];
+                if (ps.leaf) env.leaf(rt, ps.kmer, pl.right ? onew : pnew, cnt[x]);
+                else {
+                    if (haveKeep) env.push(keep);
+                    keep.flo = pl.right ? onew : pnew;
+                    keep.rlo = pl.right ? pnew : onew;
+                    keep.w = cnt[x];
+                    keep.meta = ps.meta0 | ((errs + 1u) << 24);
+                    haveKeep = true;
+                }
             }
         }
     }
