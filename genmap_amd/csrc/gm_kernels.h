@@ -133,13 +133,10 @@ template <int WPP> struct EnvBase {
 #pragma unroll
         for (int j = 0; j < NV; ++j) { uint4 v = pl[j]; wl[4 * j] = v.x; wl[4 * j + 1] = v.y; wl[4 * j + 2] = v.z; wl[4 * j + 3] = v.w; }
         // range lo and range hi usually share a block once the range is narrow: one request instead of two
-        const bool other = (bh != bl);
+        // always two loads: when lo and hi share a block the second one is an L1 hit, which is cheaper than a divergent
+        // branch around it (r01h: +5..9 %); the miss count (algorithmic lines) is unchanged
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            uint4 v = make_uint4(wl[4 * j], wl[4 * j + 1], wl[4 * j + 2], wl[4 * j + 3]);
-            if (other) v = ph[j];
-            wh[4 * j] = v.x; wh[4 * j + 1] = v.y; wh[4 * j + 2] = v.z; wh[4 * j + 3] = v.w;
-        }
+        for (int j = 0; j < NV; ++j) { uint4 v = ph[j]; wh[4 * j] = v.x; wh[4 * j + 1] = v.y; wh[4 * j + 2] = v.z; wh[4 * j + 3] = v.w; }
         block_rank<WPP>(wl, lo - bl * SPB, rl);
         block_rank<WPP>(wh, hi - bh * SPB, rh);
 #ifdef GM_COUNTERS
