@@ -164,6 +164,7 @@ def main():
         }
     # ---- roofline numerator: count node steps / distinct rank lines with the instrumented twin (untimed) ----
     lines = steps_cnt = None
+    roots = 0
     v_items = v_chunks = 0
     if rank == 0 and world == 1 and not args.no_counters and g.lib_path(True).exists():
         try:
@@ -173,7 +174,7 @@ def main():
             tmp = torch.zeros(n + 16, dtype=torch.uint8, device=dev)
             ixp.map_device(tmp.data_ptr(), K, E, infix=args.infix, value_bits=8, stream=stream)
             sp = ixp.last_stats()
-            lines, steps_cnt = sp["rank_lines"], sp["node_steps"]
+            lines, steps_cnt, roots = sp["rank_lines"], sp["node_steps"], sp["roots"]
             v_items, v_chunks = sp["detail"]["verify_items"], sp["detail"]["verify_chunks"]
             ixp.close()
             del tmp
@@ -182,8 +183,9 @@ def main():
     if rank == 0:
         bb = info["block_bytes"]
         if lines:
-            # rank blocks + text read once per strand (1 B/char) + 8-bit output + verification (SA entry, 2 x 8 symbols per chunk)
-            alg = bb * lines + 2 * n + n + 4 * v_items + 16 * v_chunks
+            # rank blocks + one q-mer table entry per root + text read once per strand (4-bit packed) + 8-bit output
+            # + verification (SA entry per row, 8 needle + 8 text symbols per chunk)
+            alg = bb * lines + 16 * roots + n + n + 4 * v_items + 16 * v_chunks
             ach = alg / (kernel_ms * 1e-3) / 1e9
             traffic = None
             tf = ROOT / "profiles" / "pmc_traffic.json"
@@ -196,7 +198,7 @@ def main():
                     pass
             result["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                   "traffic": traffic, "kernel": "search_kernel", "kernel_ms": kernel_ms,
-                                  "algorithmic_bytes": alg, "rank_lines": lines, "node_steps": steps_cnt,
+                                  "algorithmic_bytes": alg, "rank_lines": lines, "roots": roots, "node_steps": steps_cnt,
                                   "node_steps_per_kmer": steps_cnt / num_kmers,
                                   "verify_items": v_items, "verify_chunks": v_chunks}
         else:

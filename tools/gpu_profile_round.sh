@@ -1,21 +1,21 @@
 #!/bin/bash
 # the measurement set that goes into profiles/: bench lines, rocprofv3 kernel stats, PMC traffic
-mkdir -p gpurun_out/r01g
+mkdir -p gpurun_out/r01h
 export TMPDIR=/tmp
-O=gpurun_out/r01g
+O=gpurun_out/r01h
 echo "== bench default (configs[1])"; timeout 1500 python bench.py > $O/bench_chr1_e0.json 2> $O/bench_chr1_e0.log; tail -1 $O/bench_chr1_e0.json | cut -c1-1800
 echo "== rocprofv3 kernel stats, same command"
-timeout 1500 rocprofv3 --kernel-trace --stats -d $O/prof -o r01g --output-format csv -- python bench.py --no-cpu-baseline > $O/prof.log 2>&1
+timeout 1500 rocprofv3 --kernel-trace --stats -d $O/prof -o r01h --output-format csv -- python bench.py --no-cpu-baseline > $O/prof.log 2>&1
 python - <<'PY'
 import csv,glob
-for f in glob.glob('gpurun_out/r01g/prof/*kernel_stats.csv'):
+for f in glob.glob('gpurun_out/r01h/prof/*kernel_stats.csv'):
     rows=list(csv.DictReader(open(f)))
-    out=open('gpurun_out/r01g/kernel_stats_short.csv','w'); w=csv.writer(out); w.writerow(['Name','Calls','TotalDurationNs','AverageNs','Percentage'])
+    out=open('gpurun_out/r01h/kernel_stats_short.csv','w'); w=csv.writer(out); w.writerow(['Name','Calls','TotalDurationNs','AverageNs','Percentage'])
     for r in rows:
         n=r['Name']; n=n if len(n)<90 else n[:60]+'...'+n[-25:]
         w.writerow([n,r['Calls'],r['TotalDurationNs'],r['AverageNs'],r['Percentage']])
     out.close()
-    print(open('gpurun_out/r01g/kernel_stats_short.csv').read()[:3000])
+    print(open('gpurun_out/r01h/kernel_stats_short.csv').read()[:3000])
 PY
 rm -rf $O/prof
 echo "== PMC traffic (FETCH_SIZE, WRITE_SIZE separate passes)"
@@ -24,11 +24,11 @@ for C in FETCH_SIZE WRITE_SIZE; do
   python - $C <<'PY'
 import csv,glob,sys
 c=sys.argv[1]; vals=[]
-for f in glob.glob(f'gpurun_out/r01g/pmc_{c}/*counter_collection.csv'):
+for f in glob.glob(f'gpurun_out/r01h/pmc_{c}/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         if 'search_kernel' in r['Kernel_Name'] and r['Counter_Name']==c: vals.append(float(r['Counter_Value']))
 print(c, 'per search_kernel dispatch (KB):', vals)
-open(f'gpurun_out/r01g/pmc_{c}.txt','w').write(f'{c} per search_kernel dispatch (KB): {vals}\n')
+open(f'gpurun_out/r01h/pmc_{c}.txt','w').write(f'{c} per search_kernel dispatch (KB): {vals}\n')
 PY
   rm -rf $O/pmc_$C
 done
