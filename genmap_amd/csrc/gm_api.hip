@@ -187,7 +187,7 @@ static int index_common_setup(gm_index* ix, const uint8_t* codes, const uint64_t
     ix->d_text = ix->d_textAlloc + 16;
     GM_HIP(hipMemcpy(ix->d_text, codes, ix->textLen, hipMemcpyHostToDevice));
     {
-        const uint64_t nChunks = ix->textLen / 32 + 12, nWords = nChunks * 4;   // +12 chunks: window staging may read past the end
+        const uint64_t nChunks = ix->textLen / 32 + 20, nWords = nChunks * 4;   // +20 chunks: window staging (up to 2K-1 = 509 symbols) may read past the end
         GM_HIP(hipMalloc(&ix->d_text4, nChunks * 16));
         hipLaunchKernelGGL(pack_text4_kernel, dim3(grid_for(nWords)), dim3(256), 0, 0, ix->d_text, ix->textLen, reinterpret_cast<uint32_t*>(ix->d_text4), nWords);
         GM_HIP(hipGetLastError());
@@ -214,7 +214,7 @@ const char* gm_status_string(int s)
         case GM_ERR_BAD_VALUE_BITS: return "value_bits must be 8 or 16";
         case GM_ERR_NEED_LOCATE: return "csv / --exclude-pseudo need an index with SA samples";
         case GM_ERR_BAD_OVERLAP: return "overlap cannot be larger than min(K - 1, K - E - 2)";
-        case GM_ERR_BAD_K: return "K out of range (1..128)";
+        case GM_ERR_BAD_K: return "K out of range (1..255)";
         case GM_ERR_TOO_LONG: return "index too long for 32-bit positions";
         case GM_ERR_BAD_ARG: return "bad argument";
         case GM_ERR_HIP: return "HIP runtime error";
@@ -234,7 +234,7 @@ int gm_device_count(void)
 }
 
 uint32_t gm_default_infix_length(uint32_t K, uint32_t E, int32_t xo) { return default_infix_length(K, E, xo); }
-uint32_t gm_tuned_infix_length(uint32_t K, uint32_t E) { return (K < 1 || K > 128 || E > MAX_ERRORS) ? 0u : tuned_infix_length(K, E); }
+uint32_t gm_tuned_infix_length(uint32_t K, uint32_t E) { return (K < 1 || K > MAX_K || E > MAX_ERRORS) ? 0u : tuned_infix_length(K, E); }
 
 void gm_index_free(gm_index* ix)
 {
@@ -360,7 +360,10 @@ static inline size_t search_lds_bytes(const SearchArgs& A) { return (size_t)(4u 
 template <int WPP, class EnvT>
 static int launch_one(const SearchArgs& A, unsigned blocks, hipStream_t st)
 {
-    hipLaunchKernelGGL((search_kernel<WPP, EnvT>), dim3(blocks), dim3(256), search_lds_bytes(A), st, A);
+    const size_t lds = search_lds_bytes(A);
+    if (lds > 65536)   // long needle windows (K + n - 1 up to 509 symbols per lane): ask for more than the default 64 KB of LDS
+        GM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&search_kernel<WPP, EnvT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((search_kernel<WPP, EnvT>), dim3(blocks), dim3(256), lds, st, A);
     GM_HIP(hipGetLastError());
     return GM_OK;
 }
@@ -448,7 +451,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     if (p->E > MAX_ERRORS) return GM_ERR_BAD_ERRORS;
     GM_HIP(hipSetDevice(ix->device));
 
-    if (p->K < 1 || p->K > 128) return GM_ERR_BAD_K;
+    if (p->K < 1 || p->K > MAX_K) return GM_ERR_BAD_K;
     const uint32_t infix = p->infix > 0 ? (uint32_t)p->infix : (p->overlap >= 0 ? default_infix_length(p->K, p->E, p->overlap) : tuned_infix_length(p->K, p->E));
     if (infix == 0) return GM_ERR_BAD_OVERLAP;
     MapPlan& plan = S->plan;

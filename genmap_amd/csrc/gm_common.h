@@ -17,7 +17,7 @@ namespace gm {
 enum : uint32_t { SYM_A = 0, SYM_C = 1, SYM_G = 2, SYM_T = 3, SYM_N = 4, SYM_SENT = 5, NLET = 5 };
 
 constexpr uint32_t MAX_ERRORS = 4;   // "E > 4 not yet supported." src/mappability.hpp:187
-constexpr uint32_t MAX_K = 128;      // 16-byte node encoding: needle-window coordinates <= 2K-1 <= 255 fit 8 bits
+constexpr uint32_t MAX_K = 255;      // 16-byte node encoding: needle-window coordinates <= 2K-1 <= 509 fit 9 bits; OSS block lengths fit 8
 
 GM_HD uint32_t complement(uint32_t c) { return c < 4u ? 3u - c : c; }   // N stays N (src/algo.hpp:5-8)
 

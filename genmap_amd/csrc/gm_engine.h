@@ -27,17 +27,19 @@ namespace gm {
 
 enum : uint32_t { M_OSS = 0, M_EXT_R = 1, M_EXT_L = 2, M_SPLIT = 3 };
 
-struct Node { uint32_t flo, rlo, w, meta; };   // meta: a | bx<<8 | t<<16 | errs<<24 | mode<<27
+// meta: a (9 bits) | bx<<9 (9) | t<<18 (9) | errs<<27 (3) | mode<<30 (2): window coordinates reach 2K-1 <= 509 (K <= MAX_K)
+struct Node { uint32_t flo, rlo, w, meta; };
+constexpr uint32_t META_ERRS_SHIFT = 27;
 
 GM_HD uint32_t meta_pack(uint32_t a, uint32_t bx, uint32_t t, uint32_t errs, uint32_t mode)
 {
-    return a | bx << 8 | t << 16 | errs << 24 | mode << 27;
+    return a | bx << 9 | t << 18 | errs << META_ERRS_SHIFT | mode << 30;
 }
-GM_HD uint32_t meta_a(uint32_t m) { return m & 0xFFu; }
-GM_HD uint32_t meta_bx(uint32_t m) { return (m >> 8) & 0xFFu; }
-GM_HD uint32_t meta_t(uint32_t m) { return (m >> 16) & 0xFFu; }
-GM_HD uint32_t meta_errs(uint32_t m) { return (m >> 24) & 7u; }
-GM_HD uint32_t meta_mode(uint32_t m) { return (m >> 27) & 3u; }
+GM_HD uint32_t meta_a(uint32_t m) { return m & 0x1FFu; }
+GM_HD uint32_t meta_bx(uint32_t m) { return (m >> 9) & 0x1FFu; }
+GM_HD uint32_t meta_t(uint32_t m) { return (m >> 18) & 0x1FFu; }
+GM_HD uint32_t meta_errs(uint32_t m) { return (m >> META_ERRS_SHIFT) & 7u; }
+GM_HD uint32_t meta_mode(uint32_t m) { return m >> 30; }
 
 // the root a lane is currently working on: one (k-mer block, strand, search) triple
 struct Root {
@@ -178,7 +180,7 @@ GM_HD void lane_step(Node& nd, bool& have, const Root& rt, uint32_t K, uint32_t 
             keep.flo = pl.right ? onew : pnew;
             keep.rlo = pl.right ? pnew : onew;
             keep.w = cx;
-            keep.meta = ps.meta0 | (errs << 24);
+            keep.meta = ps.meta0 | (errs << META_ERRS_SHIFT);
             haveKeep = true;
         }
     }
@@ -196,7 +198,7 @@ GM_HD void lane_step(Node& nd, bool& have, const Root& rt, uint32_t K, uint32_t 
                     keep.flo = pl.right ? onew : pnew;
                     keep.rlo = pl.right ? pnew : onew;
                     keep.w = cnt[x];
-                    keep.meta = ps.meta0 | ((errs + 1u) << 24);
+                    keep.meta = ps.meta0 | ((errs + 1u) << META_ERRS_SHIFT);
                     haveKeep = true;
                 }
             }

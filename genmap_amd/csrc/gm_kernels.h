@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) GM_WAVES_ATTR void search_kernel(const SearchA
                     fsrc = A.text4 + (g >> 5);
                     fnch = (fwoff + W + 31u) >> 5;
                     frec = *recp;
-                    fw0 = fsrc[0]; fw1 = fsrc[1]; fw2 = fsrc[2];              // the text has 12 chunks of padding behind it
+                    fw0 = fsrc[0]; fw1 = fsrc[1]; fw2 = fsrc[2];              // the text has 20 chunks of padding behind it
                     const uint64_t p = g + (frt.strand ? (uint64_t)(W - fa0 - fql) : (uint64_t)fa0);   // lowest text position of the q-mer
                     const unsigned long long* t64 = reinterpret_cast<const unsigned long long*>(A.text4) + (p >> 4);
                     fshift = (uint32_t)(p & 15u) * 4u;

@@ -38,7 +38,7 @@ def test_no_cpu_fallback_without_device():
 def test_default_infix_matches_oracle_rule():
     import genmap_amd as g
     import helpers as H
-    for K in (3, 4, 8, 24, 30, 36, 50, 100, 101, 128):
+    for K in (3, 4, 8, 24, 30, 36, 50, 100, 101, 128, 150, 255):
         for E in range(5):
             for xo in (None, 0, 1, 2, 5):
                 a = g.default_infix_length(K, E, xo)
@@ -60,10 +60,10 @@ def test_tuned_infix_is_always_schedulable():
     """the GPU-tuned block shape keeps at least one symbol per OSS block and never exceeds K (any K, E the ABI accepts)"""
     import genmap_amd as g
     nb = [1, 2, 4, 5, 6]
-    for K in range(1, 129):
+    for K in range(1, 256):
         for E in range(5):
             t = g.tuned_infix_length(K, E)
             if K < nb[E]:
                 continue  # the call is rejected with GM_ERR_BAD_OVERLAP (infix shorter than the number of blocks)
             assert nb[E] <= t <= K, (K, E, t)
-    assert g.tuned_infix_length(129, 0) == 0 and g.tuned_infix_length(30, 5) == 0
+    assert g.tuned_infix_length(256, 0) == 0 and g.tuned_infix_length(30, 5) == 0

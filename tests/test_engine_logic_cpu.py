@@ -86,7 +86,7 @@ def test_engine_logic_gtest_matrix(E, dna5):
             assert st[0] <= st[1], ("stack bound violated", st)
 
 
-@pytest.mark.parametrize("K,E", [(30, 0), (30, 1), (30, 2), (100, 1), (24, 1), (50, 3), (36, 4), (128, 0)])
+@pytest.mark.parametrize("K,E", [(30, 0), (30, 1), (30, 2), (100, 1), (24, 1), (50, 3), (36, 4), (128, 0), (150, 2), (250, 1), (255, 0)])
 def test_engine_logic_baseline_settings(K, E):
     rng = np.random.default_rng(K * 10 + E)
     lens = [1500, 700, K - 1, 900, 3]
@@ -148,7 +148,7 @@ def test_verification_shortcut_gtest_matrix(E, dna5):
                 assert np.array_equal(out, triv), (E, dna5, K, infix, T)
 
 
-@pytest.mark.parametrize("K,E", [(30, 0), (30, 1), (30, 2), (100, 1), (24, 1), (50, 3), (36, 4), (128, 0)])
+@pytest.mark.parametrize("K,E", [(30, 0), (30, 1), (30, 2), (100, 1), (24, 1), (50, 3), (36, 4), (128, 0), (200, 1), (255, 2)])
 def test_verification_shortcut_baseline_settings(K, E):
     rng = np.random.default_rng(K * 10 + E + 7)
     lens = [1500, 700, K - 1, 900, 3, K, K + 1]

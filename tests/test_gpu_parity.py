@@ -162,7 +162,7 @@ def test_gpu_gtest_matrix(E, dna5):
     ix.close()
 
 
-@pytest.mark.parametrize("K,E", [(30, 0), (30, 1), (30, 2), (100, 1), (24, 1), (50, 3), (36, 4), (128, 0)])
+@pytest.mark.parametrize("K,E", [(30, 0), (30, 1), (30, 2), (100, 1), (24, 1), (50, 3), (36, 4), (128, 0), (150, 2), (250, 1), (255, 0), (255, 4)])
 def test_gpu_baseline_settings_small(K, E):
     g = _gm()
     rng = np.random.default_rng(K * 10 + E)
@@ -218,7 +218,7 @@ def test_gpu_many_short_sequences_and_extremes():
     codes[rng.integers(0, len(codes), size=300)] = 4
     ora = H.OracleIndex(codes, lens, keep_sa=False)
     ix = g.Index.build(codes, lens, sampling=1)
-    for K, E in ((30, 0), (30, 1), (50, 2), (100, 1), (1, 0), (2, 1), (128, 1)):
+    for K, E in ((30, 0), (30, 1), (50, 2), (100, 1), (1, 0), (2, 1), (128, 1), (150, 0), (250, 1), (255, 2)):
         exp = ora.mappability(K, E, value_bits=16, threads=8)
         assert np.array_equal(ix.map(K, E, value_bits=16), exp), (K, E)
     ix.close()

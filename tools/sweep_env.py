@@ -26,12 +26,15 @@ out = torch.zeros(n + 16, dtype=torch.uint8, device="cuda:0")
 stream = torch.cuda.current_stream().cuda_stream
 base = None
 for st in a.settings:
-    keys = []
+    keys = []; infix = 0
     for kv in filter(None, st.split(",")):
-        k, v = kv.split("="); os.environ[k] = v; keys.append(k)
+        k, v = kv.split("=")
+        if k == "INFIX": infix = int(v); continue     # pseudo-knob: common-infix length of the call
+        os.environ[k] = v; keys.append(k)
     ms = []
+    out.zero_()
     for r in range(a.reps + 1):
-        ix.map_device(out.data_ptr(), a.K, a.E, value_bits=8, kmer_range=rng, stream=stream)
+        ix.map_device(out.data_ptr(), a.K, a.E, infix=infix, value_bits=8, kmer_range=rng, stream=stream)
         torch.cuda.synchronize()
         ms.append(ix.last_stats()["search_ms"])
     chk = int(out[:n].to(torch.int64).sum().item())
