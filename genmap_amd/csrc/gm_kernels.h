@@ -157,6 +157,8 @@ template <int WPP> struct EnvBase {
         pushes++;
 #endif
         const uint4 v = make_uint4(nd.flo, nd.rlo, nd.w, nd.meta);
+        // wave-uniform fast path (scalar branch, no exec-mask juggling): nobody in the wavefront is past the LDS levels
+        if (__ballot(sp >= A.ldsDepth) == 0ull) { lstk[sp * 64u] = v; ++sp; return; }
         if (sp < A.ldsDepth) { lstk[sp * 64u] = v; ++sp; }
         else if (sp < A.stackDepth) { stk[(size_t)(sp - A.ldsDepth) * 64u] = v; ++sp; }
         else *A.errorFlag = 1u;   // never expected: depth = stack_bound(E, stepSize)
@@ -346,8 +348,12 @@ __global__ __launch_bounds__(256) GM_WAVES_ATTR void search_kernel(const SearchA
 #define GM_LAP(acc) do { } while (0)
 #endif
     for (;;) {
+#ifndef GM_POP_LOOP
+        if (!have && env.sp > 0) {   // one pop per iteration: a node dropped as saturated costs the lane one idle turn
+#else
 #pragma unroll 1
         for (int tries = 0; tries < 4 && !have && env.sp > 0; ++tries) {
+#endif
             const uint4 v = env.pop();
             nd.flo = v.x; nd.rlo = v.y; nd.w = v.z; nd.meta = v.w; w1run = 0;
             uint32_t smin, smax;
