@@ -487,9 +487,13 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     S->kmers = kmers;
 
     // ---- workspace ----
-    rc = grow(&ix->d_table, &ix->tableCap, (uint64_t)plan.table.size()); if (rc) return rc;
-    rc = grow(&ix->d_cumLocal, &ix->cumLocalCap, (uint64_t)n_seq + 1); if (rc) return rc;
-    if (plan.useList) { rc = grow(&ix->d_blocks, &ix->blocksCap, std::max<uint64_t>(plan.blocks.size(), 1)); if (rc) return rc; }
+    {
+        const void *t0 = ix->d_table, *c0 = ix->d_cumLocal, *b0 = ix->d_blocks;
+        rc = grow(&ix->d_table, &ix->tableCap, (uint64_t)plan.table.size()); if (rc) return rc;
+        rc = grow(&ix->d_cumLocal, &ix->cumLocalCap, (uint64_t)n_seq + 1); if (rc) return rc;
+        if (plan.useList) { rc = grow(&ix->d_blocks, &ix->blocksCap, std::max<uint64_t>(plan.blocks.size(), 1)); if (rc) return rc; }
+        if (t0 != ix->d_table || c0 != ix->d_cumLocal || b0 != ix->d_blocks) ix->sigValid = false;   // reallocated: contents are gone
+    }
     // LDS staging per block of 4 wavefronts: verification queue, top of the lane stacks, packed needle windows
     uint32_t verifyT = 0;
     if (ix->d_sa && ix->d_textS) {   // narrow nodes are resolved against the text when the SA is resident
@@ -517,13 +521,24 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     S->blocks = (unsigned)blocks;
     rc = grow(&ix->d_stack, &ix->stackCap, blocks * 256ull * std::max<uint32_t>(depth - ldsDepth, 1u)); if (rc) return rc;
 
-    GM_HIP(hipMemcpyAsync(ix->d_table, plan.table.data(), plan.table.size() * sizeof(OssRecord), hipMemcpyHostToDevice, st));
-    if (plan.useList && !plan.blocks.empty())
-        GM_HIP(hipMemcpyAsync(ix->d_blocks, plan.blocks.data(), plan.blocks.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
-    std::vector<uint64_t> cumLocal((size_t)n_seq + 1);
-    for (uint32_t s = 0; s <= n_seq; ++s) cumLocal[s] = ix->cum[first_seq + s] - text_begin;
-    GM_HIP(hipMemcpyAsync(ix->d_cumLocal, cumLocal.data(), cumLocal.size() * 8, hipMemcpyHostToDevice, st));
-    GM_HIP(hipStreamSynchronize(st));   // host staging buffers go out of scope; also keeps the timed region device-only
+    {   // the call's small device-side tables (OSS records, block list, local sequence limits) are uploaded only when the
+        // call differs from the previous one on this index: a loop over shards or repeated passes launches without any
+        // host-device synchronisation
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&h](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
+        mix(p->K); mix(p->E); mix(plan.infix); mix(text_begin); mix(text_len); mix(first_seq); mix(n_seq); mix(n_intervals);
+        for (uint64_t k = 0; k < 2 * n_intervals; ++k) mix(intervals[k]);
+        if (!ix->sigValid || ix->sig != h) {
+            GM_HIP(hipMemcpyAsync(ix->d_table, plan.table.data(), plan.table.size() * sizeof(OssRecord), hipMemcpyHostToDevice, st));
+            if (plan.useList && !plan.blocks.empty())
+                GM_HIP(hipMemcpyAsync(ix->d_blocks, plan.blocks.data(), plan.blocks.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
+            std::vector<uint64_t> cumLocal((size_t)n_seq + 1);
+            for (uint32_t s = 0; s <= n_seq; ++s) cumLocal[s] = ix->cum[first_seq + s] - text_begin;
+            GM_HIP(hipMemcpyAsync(ix->d_cumLocal, cumLocal.data(), cumLocal.size() * 8, hipMemcpyHostToDevice, st));
+            GM_HIP(hipStreamSynchronize(st));   // host staging buffers go out of scope
+            ix->sig = h; ix->sigValid = true;
+        }
+    }
 
     SearchArgs A; memset(&A, 0, sizeof(A));
     A.blk[0] = ix->d_blk[0]; A.blk[1] = ix->d_blk[1];

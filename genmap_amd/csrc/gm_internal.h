@@ -34,6 +34,7 @@ struct gm_index {
     uint32_t* d_sa = nullptr;         // forward suffix array (kept when sampling == 1): locate = one HBM read
     uint8_t* d_textS = nullptr;       // sentinel text (verification of narrow nodes), present with d_sa
     std::map<uint32_t, uint4*> qtables;   // q -> device table of 4^q entries (built on first use)
+    uint64_t sig = 0; bool sigValid = false;   // signature of the call whose tables are on the device
     uint32_t qtableCap = 0;               // != 0: longest prefix that fitted the device so far
     uint64_t qtableBytes = 0;
     uint32_t* d_C = nullptr;
