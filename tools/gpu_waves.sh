@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs variant libraries: hipcc ... -DGM_WAVES=5 -shared -o tools/exp/libw5.so gm_api.hip gm_build.hip (likewise w6); not kept in the tree
 # occupancy experiment: forced waves/SIMD (spilling) vs the default 4
 run() { python bench.py --no-cpu-baseline --no-counters --K $1 --E $2 --steps $3 --warmup 1 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.4g k-mers/s  %.3f ms/step' % (d['value'], d['ms_per_step']))"; }
 cp genmap_amd/lib/libgenmap_amd.so /tmp/lib_default.so
