@@ -31,17 +31,71 @@ def gather_frequency(local_full, ranges, rank: int, world: int, dist, recv_bufs=
         return local_full
     m = max_shard_len(ranges)
     b, _ = ranges[rank]
-    send = local_full[b:b + m]
+    import torch
+    item = local_full.element_size()
+    send = local_full[b:b + m].view(torch.uint8)   # raw bytes: collectives do not take 16-bit unsigned elements
     if stage_on_host:   # backends without device-memory collectives (gloo rehearsal): same data path through host buffers
         send = send.cpu()
         recv_bufs = None
     if rank == dst:
         if recv_bufs is None:
-            recv_bufs = [send.new_empty(m) for _ in range(world)]
+            recv_bufs = [send.new_empty(m * item) for _ in range(world)]
+        else:
+            recv_bufs = [t.view(torch.uint8) for t in recv_bufs]
         dist.gather(send, recv_bufs, dst=dst)
+        raw = local_full.view(torch.uint8)
         for r, (rb, re) in enumerate(ranges):
             if r != dst and re > rb:
-                local_full[rb:re] = recv_bufs[r][:re - rb].to(local_full.device)
+                raw[rb * item:re * item] = recv_bufs[r][:(re - rb) * item].to(local_full.device)
     else:
         dist.gather(send, None, dst=dst)
     return local_full
+
+
+def gather_locations(loc, rank: int, world: int, dist, dst: int = 0, device=None):
+    """csv / --exclude-pseudo across ranks: `loc` = (pos_begin, plus_off, plus, minus_off, minus) of this rank's shard
+    (Index.locate(..., kmer_range=ranges[rank]); occurrence lists per slice position, variable length).
+    Counts first, then payload: one all_gather of the four sizes, one gather of a single padded int64 buffer
+    [plus_off | minus_off | plus | minus].  Returns the merged tuple on `dst` (shards are contiguous and ordered by rank),
+    None elsewhere.  `device`: where the exchanged tensors live (a cuda device for backend nccl = RCCL; None = host)."""
+    import numpy as np
+    import torch
+    pos_begin, po, pl, mo, mi = loc
+    n_pos = len(po) - 1
+    if world == 1:
+        return loc
+    sizes = torch.tensor([int(pos_begin), n_pos, len(pl), len(mi)], dtype=torch.int64, device=device)
+    all_sizes = [torch.zeros(4, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes)
+    all_sizes = [[int(v) for v in t.cpu().tolist()] for t in all_sizes]
+    need = max(2 * (s[1] + 1) + s[2] + s[3] for s in all_sizes)
+    buf = np.zeros(need, dtype=np.int64)
+    k = 0
+    for a in (po, mo, pl, mi):
+        buf[k:k + len(a)] = np.asarray(a).view(np.int64) if len(a) else 0
+        k += len(a)
+    send = torch.from_numpy(buf).to(device) if device is not None else torch.from_numpy(buf)
+    recv = [torch.empty(need, dtype=torch.int64, device=device) for _ in range(world)] if rank == dst else None
+    dist.gather(send, recv, dst=dst)
+    if rank != dst:
+        return None
+    out_po, out_mo, out_pl, out_mi = [np.zeros(1, np.uint64)], [np.zeros(1, np.uint64)], [], []
+    base_p = base_m = 0
+    begin = None
+    expect = None
+    for r, (pb, npos, npl, nmi) in enumerate(all_sizes):
+        if npos == 0:
+            continue
+        b = recv[r].cpu().numpy().view(np.uint64)
+        rpo, rmo = b[:npos + 1], b[npos + 1:2 * (npos + 1)]
+        rpl, rmi = b[2 * (npos + 1):2 * (npos + 1) + npl], b[2 * (npos + 1) + npl:2 * (npos + 1) + npl + nmi]
+        if begin is None:
+            begin = pb
+        elif pb != expect:
+            raise ValueError(f"location shards are not contiguous: rank {r} begins at {pb}, expected {expect}")
+        expect = pb + npos
+        out_po.append(rpo[1:] + np.uint64(base_p)); out_mo.append(rmo[1:] + np.uint64(base_m))
+        out_pl.append(rpl); out_mi.append(rmi)
+        base_p += npl; base_m += nmi
+    cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, np.uint64)
+    return (0 if begin is None else begin), cat(out_po), cat(out_pl), cat(out_mo), cat(out_mi)

@@ -320,18 +320,50 @@ int map_main(int argc, const char** argv)
                 const uint64_t numKmers = textLen >= K ? textLen - K + 1 : 0;
                 uint64_t begin = 0, window = std::max<uint64_t>(numKmers, 1); bool first = true;
                 if (numKmers == 0) { gmh::CsvInput in; uint64_t z[1] = {0}; in.plusOff = in.minusOff = z; ok = gmh::save_csv(stem, in, seqs, K, revCompl, fileNames, seqsPerFile, false, err); }
+                // every device of -D takes one contiguous range per round (its own halving windows inside); a round's
+                // results are written in position order
+                const size_t nd = replicas.size();
+                if (nd > 1) window = std::max<uint64_t>(1, (numKmers + nd - 1) / nd);
                 while (ok && begin < numKmers) {
-                    p.kmer_begin = begin; p.kmer_end = std::min(numKmers, begin + window);
-                    gm_locations* L = nullptr;
-                    rc = gm_locate(ix, textBegin, textLen, firstSeq, nSeq, &p, ivp, intervals.size() / 2, &L);
-                    if (rc == GM_ERR_TOO_LONG && window > 1) { window = std::max<uint64_t>(1, window / 2); continue; }
+                    std::vector<std::vector<gm_locations*>> got(nd);
+                    std::vector<int> lrc(nd, 0);
+                    std::vector<uint64_t> ends(nd, begin);
+                    auto work = [&](size_t d, uint64_t rb, uint64_t re) {
+                        uint64_t b2 = rb, w2 = std::max<uint64_t>(re - rb, 1);
+                        while (b2 < re) {
+                            gm_map_params q = p;
+                            q.kmer_begin = b2; q.kmer_end = std::min(re, b2 + w2);
+                            gm_locations* L = nullptr;
+                            int r2 = gm_locate(replicas[d], textBegin, textLen, firstSeq, nSeq, &q, ivp, intervals.size() / 2, &L);
+                            if (r2 == GM_ERR_TOO_LONG && w2 > 1) { w2 = std::max<uint64_t>(1, w2 / 2); continue; }
+                            if (r2) { lrc[d] = r2; return; }
+                            got[d].push_back(L);
+                            // the window is rounded to whole k-mer blocks by the library: continue after what it covered
+                            b2 = std::max<uint64_t>(q.kmer_end, L->n_positions ? L->pos_begin + L->n_positions : q.kmer_end);
+                        }
+                        ends[d] = b2;
+                    };
+                    std::vector<std::thread> th;
+                    uint64_t rb = begin;
+                    std::vector<std::pair<uint64_t, uint64_t>> rng(nd);
+                    for (size_t d = 0; d < nd; ++d) {   // a k-mer block belongs to the range that holds its first k-mer: no overlap
+                        const uint64_t re = std::min(numKmers, rb + window);
+                        rng[d] = {rb, re}; rb = re;
+                    }
+                    if (nd == 1) work(0, rng[0].first, rng[0].second);
+                    else { for (size_t d = 0; d < nd; ++d) if (rng[d].first < rng[d].second) th.emplace_back(work, d, rng[d].first, rng[d].second); for (auto& t2 : th) t2.join(); }
+                    for (size_t d = 0; d < nd && !rc; ++d) rc = lrc[d];
+                    for (size_t d = 0; d < nd; ++d)
+                        for (gm_locations* L : got[d]) {
+                            if (!rc && ok) {
+                                gmh::CsvInput in; in.posBegin = L->pos_begin; in.nPositions = L->n_positions; in.plusOff = L->plus_off; in.minusOff = L->minus_off; in.plus = L->plus; in.minus = L->minus;
+                                ok = gmh::save_csv(stem, in, seqs, K, revCompl, fileNames, seqsPerFile, !first, err);
+                                first = false;
+                            }
+                            gm_locations_free(L);
+                        }
                     if (rc) { for (auto* r : replicas) gm_index_free(r); return fail_gm("locate failed", rc); }
-                    gmh::CsvInput in; in.posBegin = L->pos_begin; in.nPositions = L->n_positions; in.plusOff = L->plus_off; in.minusOff = L->minus_off; in.plus = L->plus; in.minus = L->minus;
-                    ok = gmh::save_csv(stem, in, seqs, K, revCompl, fileNames, seqsPerFile, !first, err);
-                    first = false;
-                    // the window is rounded to whole k-mer blocks by the library: continue after what it covered
-                    begin = std::max<uint64_t>(p.kmer_end, L->n_positions ? L->pos_begin + L->n_positions : p.kmer_end);
-                    gm_locations_free(L);
+                    begin = rng[nd - 1].second;
                 }
                 report("CSV file");
             }

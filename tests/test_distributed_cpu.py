@@ -37,8 +37,14 @@ def _worker(rank, world, port, nk, step, q):
     b, e = ranges[rank]
     local[b:e] = truth[b:e]            # what this rank's gm_map_device(kmer_range=(b, e)) would have written
     gather_frequency(local, ranges, rank, world, dist)
+    # 16-bit frequencies (-fl / mappability): the same exchange as raw bytes
+    truth16 = torch.from_numpy(((np.arange(nk + 29, dtype=np.int64) * 977) % 65521).astype(np.uint16))
+    truth16[nk:] = 0
+    local16 = torch.zeros(nk + 29 + m, dtype=torch.uint16)
+    local16[b:e] = truth16[b:e]
+    gather_frequency(local16, ranges, rank, world, dist)
     if rank == 0:
-        q.put(bool(torch.equal(local[:nk + 29], truth)))
+        q.put(bool(torch.equal(local[:nk + 29], truth)) and bool(torch.equal(local16[:nk + 29].view(torch.int16), truth16.view(torch.int16))))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -49,6 +55,53 @@ def test_gather_reassembles_frequency_vector(world):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, 10007, 22, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+    assert ok
+
+
+def _fake_locations(begin, npos, seed):
+    rng = np.random.default_rng(seed)
+    cp, cm = rng.integers(0, 4, size=npos), rng.integers(0, 3, size=npos)
+    po = np.concatenate([[0], np.cumsum(cp)]).astype(np.uint64); mo = np.concatenate([[0], np.cumsum(cm)]).astype(np.uint64)
+    pl = rng.integers(0, 2**40, size=int(po[-1]), dtype=np.uint64); mi = rng.integers(0, 2**40, size=int(mo[-1]), dtype=np.uint64)
+    return begin, po, pl, mo, mi
+
+
+def _loc_worker(rank, world, port, q):
+    from genmap_amd.distributed import gather_locations
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ranges = shard_ranges(3001, 6, world)
+    ranges[-1] = (ranges[-1][0], ranges[-1][0]) if world == 3 else ranges[-1]     # world 3: the last shard is empty
+    shards = [_fake_locations(b, e - b, 100 + r) for r, (b, e) in enumerate(ranges)]
+    got = gather_locations(shards[rank], rank, world, dist)
+    if rank == 0:
+        pb, po, pl, mo, mi = got
+        ok = pb == 0 and len(po) == sum(len(s[1]) - 1 for s in shards) + 1
+        j = 0
+        for s in shards:                      # every position's two lists survive the exchange
+            for i in range(len(s[1]) - 1):
+                ok &= np.array_equal(pl[int(po[j]):int(po[j + 1])], s[2][int(s[1][i]):int(s[1][i + 1])])
+                ok &= np.array_equal(mi[int(mo[j]):int(mo[j + 1])], s[4][int(s[3][i]):int(s[3][i + 1])])
+                j += 1
+        q.put(bool(ok))
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_locations_counts_first_then_payload(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_loc_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     ok = q.get(timeout=120)

@@ -90,7 +90,7 @@ def test_cli_multi_device_shards(case, tmp_path):
     else:
         subprocess.check_call([str(GENMAP), "index", "-F", str(d / "genome.fa"), "-I", str(idx)], stdout=subprocess.DEVNULL)
     flags = ["-E", str(fl["E"]), "-K", str(fl["K"])] + (["-nc"] if fl.get("nc") else [])
-    for sub in ("raw_freq16", "wig_freq16", "txt_map"):
+    for sub in ("raw_freq16", "wig_freq16", "txt_map", "csv"):
         out = tmp_path / f"out_{sub}"; out.mkdir()
         subprocess.check_call([str(GENMAP), "map", "-I", str(idx), "-O", str(out), "-D", "0,0,0"] + flags + FORMAT_FLAGS[sub], stdout=subprocess.DEVNULL)
         _same_tree(out, d / sub)

@@ -25,6 +25,29 @@ for K, E in ((30, 0), (30, 1), (100, 1)):
         same = np.array_equal(out[:n].cpu().numpy(), full)
         print(f"K={K} E={E}: gathered == unsharded: {same}")
         ok &= same
+# config C5's shape: several FASTA files, --exclude-pseudo frequencies and csv location lists, sharded and gathered
+from genmap_amd.distributed import gather_locations
+files5 = synth.bacteria5(0.05)
+codes5 = np.concatenate([c for _, recs in files5 for _, c in recs]); lens5 = [len(c) for _, recs in files5 for _, c in recs]
+fid = np.array([f for f, (_, recs) in enumerate(files5) for _ in recs], dtype=np.uint32)
+ix5 = g.Index.build(codes5, lens5, sampling=1)
+K, E = 24, 1
+n5 = len(codes5); nk5 = n5 - K + 1
+step5 = K - g.tuned_infix_length(K, E) + 1
+ranges5 = shard_ranges(nk5, step5, world); m5 = max_shard_len(ranges5)
+out5 = torch.zeros(n5 + m5, dtype=torch.uint16, device="cuda:0")
+ix5.map_device(out5.data_ptr(), K, E, value_bits=16, exclude_pseudo=True, seq_file_id=fid, kmer_range=ranges5[rank])
+torch.cuda.synchronize()
+gather_frequency(out5, ranges5, rank, world, dist, stage_on_host=True)
+loc = ix5.locate(K, E, kmer_range=ranges5[rank])
+merged = gather_locations(loc, rank, world, dist)
+if rank == 0:
+    same = np.array_equal(out5[:n5].cpu().numpy(), ix5.map(K, E, value_bits=16, exclude_pseudo=True, seq_file_id=fid))
+    print(f"-ep K={K} E={E}: gathered == unsharded: {same}"); ok &= same
+    full = ix5.locate(K, E)
+    same = merged[0] == full[0] and all(np.array_equal(a, b) for a, b in zip(merged[1:], full[1:]))
+    print(f"csv locations K={K} E={E}: gathered == unsharded: {same} ({len(full[2])} + {len(full[4])} occurrences)"); ok &= same
+ix5.close()
 dist.barrier()
 if rank == 0:
     print("MULTI_OK" if ok else "MULTI_FAIL")
