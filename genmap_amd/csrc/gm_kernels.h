@@ -469,6 +469,9 @@ __global__ __launch_bounds__(256) GM_WAVES_ATTR void search_kernel(const SearchA
                 // two characters kill with ONE rank line each (lo and hi share a block); verification costs an SA read
                 // plus a text read.  Step it a little first, verify only the survivors.
                 if (nd.w == 1u && meta_errs(m) == A.E && w1run < A.probation) narrow = false;
+                // e = 0: the table leaves one infix character; taking it first costs one rank line and spares the
+                // reverse-strand chance hits their SA + text reads (5.31 vs 5.46 ms, profiles/r01e_infix_sweeps.txt)
+                if (A.E == 0u && md == M_OSS) narrow = false;
             }
 #pragma unroll 1
             for (uint32_t r = 0; r < VERIFY_TMAX; ++r) {
