@@ -453,6 +453,78 @@ def _torch_hamming1_counts(codes_np, K, max_val, device, lens=None):
     return out
 
 
+def _torch_hamming2_counts(codes_np, K, max_val, device, lens=None):
+    """Independent e = 2 restatement, index-free, same construction as _torch_hamming1_counts with pairs of blanked
+    positions: cnt_S(X) = #{windows Q equal to X outside S}.  With e0 = cnt_{}, A1 = sum_i cnt_i, A2 = sum_{i<j} cnt_ij:
+      N-free X:            occ_2 = e0 (1 - K + K(K-1)/2) + (2 - K) A1 + A2        (inclusion-exclusion over the exact distance)
+      X with one N at m:   occ_2 = (2 - K) cnt_m + sum_{j != m} cnt_mj            (the N always mismatches, find2:250)
+      X with Ns at m1, m2: occ_2 = cnt_{m1 m2};   more Ns: 0."""
+    import torch
+    assert K <= 42
+    c, isn, nN, inside, n, m = _window_masks(codes_np, lens if lens is not None else [len(codes_np)], K, device)
+    c64 = c.to(torch.int64)
+    comp = torch.where(c64 < 4, 3 - c64, c64)
+    h = K // 2
+    def shift(p):
+        return 3 * (h - 1 - p) if p < h else 3 * (K - 1 - p)
+    def pack(src_of_p, lo, hi):
+        acc = torch.zeros(m, dtype=torch.int64, device=device)
+        for p in range(lo, hi):
+            acc += src_of_p(p) << shift(p)
+        return acc
+    fwd = [pack(lambda p: c64[p:p + m], 0, h), pack(lambda p: c64[p:p + m], h, K)]
+    rcq = [pack(lambda p: comp[K - 1 - p:K - 1 - p + m], 0, h), pack(lambda p: comp[K - 1 - p:K - 1 - p + m], h, K)]
+    del c64, comp
+    all_inside = bool(inside.all())
+    def ranks(vals, query):
+        U, inv = torch.unique(vals if all_inside else vals[inside], return_inverse=True)
+        def look(q):
+            idx = torch.searchsorted(U, q).clamp_(max=U.numel() - 1)
+            return idx, U[idx] == q
+        return inv, look(vals), look(query)
+    def count(hi, lo):
+        S = torch.sort((hi[0] << 32) | lo[0]).values
+        def cnt(a, b):
+            q = (a[0] << 32) | b[0]
+            return (torch.searchsorted(S, q, right=True) - torch.searchsorted(S, q, right=False)) * (a[1] & b[1])
+        return cnt(hi[1], lo[1]), cnt(hi[2], lo[2])
+    def half_of(p):
+        return 0 if p < h else 1
+    def masked(half, ps):
+        keep = -1
+        for p in ps:
+            keep &= ~(7 << shift(p))
+        return ranks(fwd[half] & keep, rcq[half] & keep)
+    base = [ranks(fwd[0], rcq[0]), ranks(fwd[1], rcq[1])]
+    single = [masked(half_of(i), [i]) for i in range(K)]
+    e0_f, e0_r = count(base[0], base[1])
+    z = lambda: torch.zeros(m, dtype=torch.int64, device=device)
+    A1f, A1r, A2f, A2r = z(), z(), z(), z()
+    clean, one, two = nN == 0, nN == 1, nN == 2
+    nf = lambda i: isn[i:i + m]                       # forward pattern has N at position i
+    nr = lambda i: isn[K - 1 - i:K - 1 - i + m]       # reverse-complement pattern has N at position i
+    for i in range(K):
+        cf, cr = count(single[i], base[1]) if half_of(i) == 0 else count(base[0], single[i])
+        A1f += cf * (clean | (one & nf(i))); A1r += cr * (clean | (one & nr(i)))
+    for i in range(K):
+        for j in range(i + 1, K):
+            hi_, hj_ = half_of(i), half_of(j)
+            if hi_ == hj_:
+                mk = masked(hi_, [i, j])
+                cf, cr = count(mk, base[1]) if hi_ == 0 else count(base[0], mk)
+            else:
+                cf, cr = count(single[i], single[j])
+            A2f += cf * (clean | (one & (nf(i) | nf(j))) | (two & nf(i) & nf(j)))
+            A2r += cr * (clean | (one & (nr(i) | nr(j))) | (two & nr(i) & nr(j)))
+    k0 = 1 - K + K * (K - 1) // 2
+    tot_f = torch.where(clean, e0_f * k0 + (2 - K) * A1f + A2f, torch.where(one, (2 - K) * A1f + A2f, A2f))
+    tot_r = torch.where(clean, e0_r * k0 + (2 - K) * A1r + A2r, torch.where(one, (2 - K) * A1r + A2r, A2r))
+    tot = torch.where(inside & (nN <= 2), tot_f + tot_r, torch.zeros_like(tot_f)).clamp_(max=max_val)
+    out = torch.zeros(n, dtype=torch.int64, device=device)
+    out[:m] = tot
+    return out
+
+
 def test_gpu_torch_restatements_are_pinned_on_the_oracle():
     """the two index-free comparators used at full size agree with the C oracle on a 300 kbp Dna5 text"""
     import torch
@@ -470,12 +542,14 @@ def test_gpu_torch_restatements_are_pinned_on_the_oracle():
     codes, lens, _ = synth.workload("grch38", 0.0001)
     ora = H.OracleIndex(codes, lens, keep_sa=False)
     assert len(lens) == 24
-    for K, E in ((30, 0), (9, 0), (30, 1), (11, 1)):
+    for K, E in ((30, 0), (9, 0), (30, 1), (11, 1), (30, 2), (12, 2)):
         exp = ora.mappability(K, E, value_bits=16, threads=8)
         if E == 0:
             got = _torch_exact_counts(codes, K, 65535, "cuda:0", lens=lens, chunk=70_000)
-        else:
+        elif E == 1:
             got = _torch_hamming1_counts(codes, K, 65535, "cuda:0", lens=lens).cpu().numpy()
+        else:
+            got = _torch_hamming2_counts(codes, K, 65535, "cuda:0", lens=lens).cpu().numpy()
         assert np.array_equal(got.astype(np.uint16), exp), (K, E)
 
 
@@ -513,6 +587,21 @@ def test_gpu_full_size_grch38_vs_index_free_comparators():
     exp = _torch_hamming1_counts(codes, 30, 65535, "cuda:0", lens=lens).to(torch.int32).cpu().numpy().astype(np.uint16)
     torch.cuda.empty_cache()
     assert np.array_equal(ix.map(30, 1, value_bits=16), exp)
+    ix.close()
+
+
+def test_gpu_e2_vs_blank_two_positions_25mbp():
+    """BASELINE's (K=30, e=2) on a 24.9 Mbp chr1-like text (GM_FULL_SCALE_E2 to change), every position, 16-bit counts:
+    two orders of magnitude beyond what the CPU oracle checks in the default run"""
+    import torch
+    g = _gm()
+    from genmap_amd import synth
+    codes, lens, _ = synth.workload("chr1", float(os.environ.get("GM_FULL_SCALE_E2", "0.1")))
+    ix = g.Index.build(codes, lens, sampling=1)
+    exp = _torch_hamming2_counts(codes, 30, 65535, "cuda:0").to(torch.int32).cpu().numpy().astype(np.uint16)
+    torch.cuda.empty_cache()
+    assert np.array_equal(ix.map(30, 2, value_bits=16), exp)
+    assert np.array_equal(ix.map(30, 2, value_bits=8), np.minimum(exp, 255).astype(np.uint8))
     ix.close()
 
 
