@@ -587,7 +587,10 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     A.verifyCost = 3;
     A.satMinW = 256;   // narrow nodes finish sooner than the lookup takes (r01h sweep: 128-256 best)
     if (const char* e = getenv("GM_SAT_MINW")) A.satMinW = (uint32_t)std::max(1, atoi(e));
-    A.fetchBatch = p->E == 0 ? 16u : p->E == 1 ? (ix->nRows >= (1ull << 30) ? 16u : 8u) : 4u;   // profiles/r01e_infix_sweeps.txt (r01h)
+    // profiles/r01e_infix_sweeps.txt (r01h): 16 / 8 / 4 on the 249 Mbp index; beyond 2^30 rows the fetch loads are HBM
+    // misses and larger batches pay (3.09 Gbp: e=0 82.6 vs 90.2 ms, K100 e=1 861 vs 900 ms with 32)
+    const bool huge = ix->nRows >= (1ull << 30);
+    A.fetchBatch = p->E == 0 ? (huge ? 32u : 16u) : p->E == 1 ? (huge ? 32u : 8u) : 4u;
     if (const char* e = getenv("GM_FETCH_BATCH")) A.fetchBatch = (uint32_t)std::max(1, std::min(atoi(e), 64));
     // e = 0: a single row is almost always the k-mer's own location.  Beyond ~1 G rows a lone-row step is an HBM miss
     // like the verification reads it postpones, and no longer pays (3.09 Gbp e = 2: 90.7 vs 86.7 M k-mers/s without).
