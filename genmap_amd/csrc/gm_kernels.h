@@ -324,7 +324,8 @@ __global__ __launch_bounds__(256) GM_WAVES_ATTR void search_kernel(const SearchA
     const uint32_t wv = threadIdx.x >> 6;
     uint4* vq = smem + wv * A.vqCap;
     env.lstk = smem + 4u * A.vqCap + wv * (A.ldsDepth * 64u) + lane;
-    env.lwin = reinterpret_cast<const uint8_t*>(smem + 4u * A.vqCap + 4u * A.ldsDepth * 64u + wv * (A.winChunks * 64u) + lane);
+    uint4* const wbase = smem + 4u * A.vqCap + 4u * A.ldsDepth * 64u + wv * (A.winChunks * 64u);   // this wavefront's windows
+    env.lwin = reinterpret_cast<const uint8_t*>(wbase + lane);
     uint32_t qsize = 0;                             // wave-uniform
 #ifdef GM_COUNTERS
     uint32_t wvIter = 0, wvActive = 0, wvRounds = 0;
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(256) GM_WAVES_ATTR void search_kernel(const SearchA
     // root fetch pipeline of this lane: 0 idle, 1 window/record loads in flight, 2 q-mer table lookup in flight
     uint32_t fs = 0, fa0 = 0, fql = 0, fwoff = 0, fnch = 0, fshift = 0;
     Root frt; frt.win = 0; frt.n = 1; frt.strand = 0; frt.search = 0; frt.rec = OssRecord{0, 0, 0, 0};
-    uint4 fw0 = make_uint4(0, 0, 0, 0), fw1 = fw0, fw2 = fw0, frec = fw0, ftab = fw0;
+    uint4 frec = make_uint4(0, 0, 0, 0), ftab = frec;
     unsigned long long fx0 = 0, fx1 = 0;
     const uint4* fsrc = A.text4;
     unsigned long long poolCur = 0, poolEnd = 0, poolBase = 0, poolBlock = 0;   // wave-uniform
@@ -372,12 +373,7 @@ __global__ __launch_bounds__(256) GM_WAVES_ATTR void search_kernel(const SearchA
         }
         // stage 2: window chunks and record have arrived -> stage the window in LDS, look the first q characters up
         if (fs == 1u) {
-            env.woff = fwoff;
-            uint4* dst = reinterpret_cast<uint4*>(const_cast<uint8_t*>(env.lwin));
-            dst[0] = fw0;
-            if (fnch > 1u) dst[64] = fw1;
-            if (fnch > 2u) dst[128] = fw2;
-            for (uint32_t c = 3u; c < fnch; ++c) dst[c * 64u] = fsrc[c];   // long windows (K > ~45): remaining chunks
+            env.woff = fwoff;   // the window itself went from HBM straight into this lane's LDS slots (stage 1)
             frt.rec.x = frec.x; frt.rec.y = frec.y; frt.rec.z = frec.z; frt.rec.w = frec.w;
             if (fql == 0u) { rt = frt; env.on_root(); nd = root_node(rt, A.nRows); have = true; fs = 0u; w1run = 0; }
             else {
@@ -444,7 +440,14 @@ __global__ __launch_bounds__(256) GM_WAVES_ATTR void search_kernel(const SearchA
                     fsrc = A.text4 + (g >> 5);
                     fnch = (fwoff + W + 31u) >> 5;
                     frec = *recp;
-                    fw0 = fsrc[0]; fw1 = fsrc[1]; fw2 = fsrc[2];              // the text has 20 chunks of padding behind it
+                    // the window goes from HBM straight into this lane's LDS slots (global_load_lds_dwordx4: chunk c of
+                    // lane l lands at wbase + c * 1 KiB + l * 16 B -- exactly the [chunk][lane] layout text_char reads);
+                    // the text has 20 chunks of padding behind it
+                    __builtin_amdgcn_global_load_lds(fsrc, wbase, 16, 0, 0);
+                    if (fnch > 1u) __builtin_amdgcn_global_load_lds(fsrc + 1, wbase + 64, 16, 0, 0);
+                    if (fnch > 2u) __builtin_amdgcn_global_load_lds(fsrc + 2, wbase + 128, 16, 0, 0);
+                    for (uint32_t c = 3u; c < A.winChunks; ++c)   // long windows (K > ~45): remaining chunks
+                        if (c < fnch) __builtin_amdgcn_global_load_lds(fsrc + c, wbase + c * 64u, 16, 0, 0);
                     const uint64_t p = g + (frt.strand ? (uint64_t)(W - fa0 - fql) : (uint64_t)fa0);   // lowest text position of the q-mer
                     const unsigned long long* t64 = reinterpret_cast<const unsigned long long*>(A.text4) + (p >> 4);
                     fshift = (uint32_t)(p & 15u) * 4u;
