@@ -23,7 +23,7 @@ class MapParams(C.Structure):
     """struct gm_map_params"""
     _fields_ = [("K", C.c_uint32), ("E", C.c_uint32), ("overlap", C.c_int32), ("infix", C.c_int32),
                 ("revcompl", C.c_int32), ("value_bits", C.c_int32), ("exclude_pseudo", C.c_int32),
-                ("reserved0", C.c_int32), ("kmer_begin", C.c_uint64), ("kmer_end", C.c_uint64)]
+                ("flags", C.c_int32), ("kmer_begin", C.c_uint64), ("kmer_end", C.c_uint64)]
 
 
 class IndexInfo(C.Structure):
@@ -48,7 +48,9 @@ class Locations(C.Structure):
                 ("minus_off", C.POINTER(C.c_uint64)), ("plus", C.POINTER(C.c_uint64)), ("minus", C.POINTER(C.c_uint64))]
 
 
-EXPORTS = ["gm_map_runs", "gm_runs_free", "gm_tuned_infix_length", "gm_index_export_sa", "gm_locate", "gm_locations_free", "gm_status_string", "gm_last_error", "gm_device_count", "gm_index_build", "gm_index_import",
+MAP_FLAG_RANGE = 1
+
+EXPORTS = ["gm_index_set_tuning", "gm_index_sync", "gm_map_kernel_times", "gm_map_runs", "gm_runs_free", "gm_tuned_infix_length", "gm_index_export_sa", "gm_locate", "gm_locations_free", "gm_status_string", "gm_last_error", "gm_device_count", "gm_index_build", "gm_index_import",
            "gm_index_export_bwt", "gm_index_get_info", "gm_index_free", "gm_map", "gm_map_device",
            "gm_last_map_stats", "gm_default_infix_length"]
 
@@ -102,6 +104,12 @@ def load_library(profiling=False):
     lib.gm_locations_free.argtypes = [C.POINTER(Locations)]
     lib.gm_last_map_stats.restype = C.c_int
     lib.gm_last_map_stats.argtypes = [vp, C.POINTER(MapStats)]
+    lib.gm_index_set_tuning.restype = C.c_int
+    lib.gm_index_set_tuning.argtypes = [vp, C.c_char_p, C.c_int64]
+    lib.gm_index_sync.restype = C.c_int
+    lib.gm_index_sync.argtypes = [vp]
+    lib.gm_map_kernel_times.restype = C.c_int
+    lib.gm_map_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.c_uint32, C.POINTER(C.c_uint32)]
     lib.gm_tuned_infix_length.restype = C.c_uint32
     lib.gm_tuned_infix_length.argtypes = [C.c_uint32, C.c_uint32]
     lib.gm_default_infix_length.restype = C.c_uint32
@@ -192,8 +200,9 @@ class Index:
         return sa
 
     def _params(self, K, E, overlap, infix, revcompl, value_bits, exclude_pseudo, kmer_range):
-        kb, ke = kmer_range if kmer_range else (0, 0)
-        return MapParams(K, E, -1 if overlap is None else overlap, infix, int(revcompl), value_bits, int(exclude_pseudo), 0, kb, ke)
+        kb, ke = kmer_range if kmer_range is not None else (0, 0)
+        flags = MAP_FLAG_RANGE if kmer_range is not None else 0   # an explicit range is literal: (b, b) computes nothing
+        return MapParams(K, E, -1 if overlap is None else overlap, infix, int(revcompl), value_bits, int(exclude_pseudo), flags, kb, ke)
 
     def _slice(self, first_seq, n_seq):
         if n_seq is None:
@@ -253,11 +262,28 @@ class Index:
             n = int(c.n_positions)
             po = np.ctypeslib.as_array(c.plus_off, shape=(n + 1,)).copy()
             mo = np.ctypeslib.as_array(c.minus_off, shape=(n + 1,)).copy()
-            pl = np.ctypeslib.as_array(c.plus, shape=(max(int(po[-1]), 1),))[:int(po[-1])].copy()
-            mi = np.ctypeslib.as_array(c.minus, shape=(max(int(mo[-1]), 1),))[:int(mo[-1])].copy()
+            # empty windows / shards carry NULL payload pointers
+            pl = np.ctypeslib.as_array(c.plus, shape=(int(po[-1]),)).copy() if int(po[-1]) > 0 and c.plus else np.zeros(0, np.uint64)
+            mi = np.ctypeslib.as_array(c.minus, shape=(int(mo[-1]),)).copy() if int(mo[-1]) > 0 and c.minus else np.zeros(0, np.uint64)
             return int(c.pos_begin), po, pl, mo, mi
         finally:
             self._lib.gm_locations_free(L)
+
+    def set_tuning(self, **knobs):
+        """gm_index_set_tuning: scheduling knobs (verify_t, fetch_batch, ...); results never depend on them."""
+        for k, v in knobs.items():
+            _check(self._lib, self._lib.gm_index_set_tuning(self._h, k.encode(), int(v)))
+
+    def sync(self):
+        """gm_index_sync: wait for every call issued on this index; raises if a device-side check tripped."""
+        _check(self._lib, self._lib.gm_index_sync(self._h))
+
+    def kernel_times(self, n=64):
+        """gm_map_kernel_times: search-kernel ms of the last n calls (oldest first), HIP events on the calls' streams."""
+        buf = (C.c_double * n)()
+        got = C.c_uint32(0)
+        _check(self._lib, self._lib.gm_map_kernel_times(self._h, buf, n, C.byref(got)))
+        return [float(buf[i]) for i in range(got.value)]
 
     def last_stats(self):
         s = MapStats()

@@ -27,6 +27,10 @@ void set_error(const char* fmt, ...)
 
 static inline unsigned grid_for(uint64_t n, unsigned bs = 256) { return (unsigned)((n + bs - 1) / bs); }
 
+// d_small: work counter (8 B) | pad | statistics counters (17 x 8 B at +16), zeroed by every call  ||  +256: sticky error flag
+// (set by a device-side invariant check, surfaced and cleared by the next host-side check: gm_map, gm_index_sync, gm_last_map_stats)
+constexpr size_t SMALL_BYTES = 512, SMALL_ZEROED = 256, SMALL_ERR_OFF = 256;
+
 // ---- rank block construction -------------------------------------------------------------------------------
 // cnt[c * (nb + 1) + q] = letters c in block q; entry nb is zero so that the exclusive scan leaves the total there.
 template <int WPP>
@@ -158,10 +162,7 @@ static int select_device(int device)
 
 static uint32_t wpp_of_block_bytes(uint32_t bb)
 {
-    if (bb == 0) {
-        const char* e = getenv("GM_BLOCK_BYTES");
-        bb = e ? (uint32_t)atoi(e) : 32u;   // measured: 32-B blocks sustain the highest random-read rate (profiles/r01_gather_*)
-    }
+    if (bb == 0) bb = 32u;   // measured: 32-B blocks sustain the highest random-read rate (profiles/r01_gather_*)
     return bb == 32 ? 1u : bb == 64 ? 3u : bb == 128 ? 9u : 0u;
 }
 
@@ -194,8 +195,11 @@ static int index_common_setup(gm_index* ix, const uint8_t* codes, const uint64_t
     }
     GM_HIP(hipMalloc(&ix->d_cum, ((size_t)n_seq + 1) * 8));
     GM_HIP(hipMemcpy(ix->d_cum, ix->cum.data(), ((size_t)n_seq + 1) * 8, hipMemcpyHostToDevice));
-    GM_HIP(hipMalloc(&ix->d_small, 256));
+    GM_HIP(hipMalloc(&ix->d_small, SMALL_BYTES));
+    GM_HIP(hipMemset(ix->d_small, 0, SMALL_BYTES));
     for (int i = 0; i < 4; ++i) GM_HIP(hipEventCreate(&ix->ev[i]));
+    for (uint32_t i = 0; i < gm_index::EV_RING; ++i) for (int j = 0; j < 2; ++j) GM_HIP(hipEventCreate(&ix->evRing[i][j]));
+    GM_HIP(hipEventCreateWithFlags(&ix->evDone, hipEventDisableTiming));
     return GM_OK;
 }
 
@@ -244,6 +248,8 @@ void gm_index_free(gm_index* ix)
     for (auto& kv : ix->qtables) hipFree(kv.second); hipFree(ix->d_seqFile); hipFree(ix->d_bits);
     hipFree(ix->d_acc); hipFree(ix->d_stack); hipFree(ix->d_small); hipFree(ix->d_table); hipFree(ix->d_blocks); hipFree(ix->d_cumLocal);
     for (int i = 0; i < 4; ++i) if (ix->ev[i]) hipEventDestroy(ix->ev[i]);
+    for (uint32_t i = 0; i < gm_index::EV_RING; ++i) for (int j = 0; j < 2; ++j) if (ix->evRing[i][j]) hipEventDestroy(ix->evRing[i][j]);
+    if (ix->evDone) hipEventDestroy(ix->evDone);
     delete ix;
 }
 
@@ -449,7 +455,11 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     if (text_begin + text_len > ix->textLen || (uint64_t)first_seq + n_seq > ix->nSeq || n_seq == 0) { set_error("slice outside the index"); return GM_ERR_BAD_ARG; }
     if (ix->cum[first_seq] != text_begin || ix->cum[first_seq + n_seq] != text_begin + text_len) { set_error("slice does not match its sequences"); return GM_ERR_BAD_ARG; }
     if (p->E > MAX_ERRORS) return GM_ERR_BAD_ERRORS;
+    if (n_intervals > 0 && !intervals) { set_error("n_intervals > 0 with a null interval list"); return GM_ERR_BAD_ARG; }
     GM_HIP(hipSetDevice(ix->device));
+    // the workspaces of the index (work counter, accumulators, stacks, per-call tables) are shared by all calls: a call
+    // issued on another stream than its predecessor waits for the predecessor's end-of-call event
+    if (ix->doneValid) GM_HIP(hipStreamWaitEvent(st, ix->evDone, 0));
 
     if (p->K < 1 || p->K > MAX_K) return GM_ERR_BAD_K;
     const uint32_t infix = p->infix > 0 ? (uint32_t)p->infix : (p->overlap >= 0 ? default_infix_length(p->K, p->E, p->overlap) : tuned_infix_length(p->K, p->E));
@@ -460,7 +470,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
 
     // shard [kmer_begin, kmer_end): blocks whose first k-mer lies inside
     uint64_t blockBegin = 0, blockEnd = plan.numBlocks;
-    if (p->kmer_begin != 0 || p->kmer_end != 0) {
+    if ((p->flags & GM_MAP_FLAG_RANGE) || p->kmer_begin != 0 || p->kmer_end != 0) {
         if (plan.useList) {
             auto lo = std::lower_bound(plan.blocks.begin(), plan.blocks.end(), p->kmer_begin, [](const std::pair<uint32_t, uint32_t>& b, uint64_t v) { return b.first < v; });
             auto hi = std::lower_bound(plan.blocks.begin(), plan.blocks.end(), p->kmer_end, [](const std::pair<uint32_t, uint32_t>& b, uint64_t v) { return b.first < v; });
@@ -499,21 +509,19 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     if (ix->d_sa && ix->d_textS) {   // narrow nodes are resolved against the text when the SA is resident
         int t = 1;
         if (plan.stepSize >= 32) t = 4;   // long blocks (e.g. K=100): a narrow node still covers many k-mers (profiles/r01c)
-        if (const char* e = getenv("GM_VERIFY_T")) t = atoi(e);
+        if (ix->tune.verifyT >= 0) t = ix->tune.verifyT;
         verifyT = (uint32_t)std::max(0, std::min(t, (int)VERIFY_TMAX));
     }
     const uint32_t depth = stack_bound(p->E, plan.stepSize);
     const uint32_t vqCap = verifyT ? 64u + 64u * verifyT : 1u;
     const uint32_t winChunks = (31u + p->K + plan.stepSize - 1u + 31u) / 32u;
-    uint32_t ldsDepth = 4;
-    if (const char* e = getenv("GM_LDS_STACK")) ldsDepth = (uint32_t)std::max(0, atoi(e));
+    uint32_t ldsDepth = (uint32_t)std::max(0, ix->tune.ldsStack);
     ldsDepth = std::min(ldsDepth, depth);
     const size_t ldsBytes = (size_t)(4u * vqCap + 4u * 64u * (ldsDepth + winChunks)) * 16u;
     int perCU = 0;
     switch (ix->wpp) { case 1: rc = occupancy_blocks<1>(&perCU, ldsBytes); break; case 3: rc = occupancy_blocks<3>(&perCU, ldsBytes); break; default: rc = occupancy_blocks<9>(&perCU, ldsBytes); break; }
     if (rc) return rc;
-    int wantPerCU = 4;   // measured (profiles/r01a): 16 waves/CU beat full occupancy (less cache/TLB pressure)
-    if (const char* e = getenv("GM_BLOCKS_PER_CU")) { int v = atoi(e); if (v > 0) wantPerCU = v; }
+    const int wantPerCU = std::max(1, ix->tune.blocksPerCU);   // default 4 = 4 waves/SIMD, what the kernel's VGPR count allows
     perCU = std::max(1, std::min(perCU, wantPerCU));
     uint64_t blocks = (uint64_t)ix->numCU * perCU;
     const uint64_t useful = (S->numRoots + 255) / 256;
@@ -559,7 +567,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         // (profiles/r01h_qtable_sweep.txt: e=0 +27 % on 249 Mbp, +30 % on 3.1 Gbp going from 12 to 15).
         uint32_t qmax = 1;
         while (qmax < 15 && (1ull << (2 * qmax)) < 4ull * ix->nRows) ++qmax;
-        if (const char* e = getenv("GM_QTABLE")) qmax = (uint32_t)std::max(0, std::min(atoi(e), 15));
+        if (ix->tune.qtable >= 0) qmax = (uint32_t)std::min(ix->tune.qtable, 15);
         A.qtabA = A.qtabB = nullptr; A.qlenPacked = 0; A.qselMask = 0; A.startPacked[0] = A.startPacked[1] = 0;
         uint32_t qA = 0, qB = 0;
         for (uint32_t s = 0; s < plan.nSearches; ++s) {
@@ -578,25 +586,23 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     }
     A.text4 = ix->d_text4; A.textBegin = text_begin; A.vqCap = vqCap; A.ldsDepth = ldsDepth; A.winChunks = winChunks;
     A.workCounter = reinterpret_cast<unsigned long long*>(ix->d_small);
-    A.errorFlag = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ix->d_small) + 8);
+    A.errorFlag = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ix->d_small) + SMALL_ERR_OFF);
     A.counters = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ix->d_small) + 16);
     A.sa = ix->d_sa; A.cumGlobal = ix->d_cum; A.nSeqGlobal = ix->nSeq;
     A.posBase = S->posBase; A.windowLen = S->posEnd - S->posBase;
     A.textS = ix->d_textS;
     A.verifyT = verifyT;
-    A.verifyCost = 3;
-    A.satMinW = 256;   // narrow nodes finish sooner than the lookup takes (r01h sweep: 128-256 best)
-    if (const char* e = getenv("GM_SAT_MINW")) A.satMinW = (uint32_t)std::max(1, atoi(e));
+    A.satMinW = (uint32_t)std::max(1, ix->tune.satMinW);   // default 256: narrow nodes finish sooner than the lookup takes (r01h sweep: 128-256 best)
     // profiles/r01e_infix_sweeps.txt (r01h): 16 / 8 / 4 on the 249 Mbp index; beyond 2^30 rows the fetch loads are HBM
     // misses and larger batches pay (3.09 Gbp: e=0 82.6 vs 90.2 ms, K100 e=1 861 vs 900 ms with 32)
     const bool huge = ix->nRows >= (1ull << 30);
     A.fetchBatch = p->E == 0 ? (huge ? 32u : 16u) : p->E == 1 ? (huge ? 32u : 8u) : 4u;
-    if (const char* e = getenv("GM_FETCH_BATCH")) A.fetchBatch = (uint32_t)std::max(1, std::min(atoi(e), 64));
+    if (ix->tune.fetchBatch > 0) A.fetchBatch = (uint32_t)std::min(ix->tune.fetchBatch, 64);
     // e = 0: a single row is almost always the k-mer's own location.  Beyond ~1 G rows a lone-row step is an HBM miss
     // like the verification reads it postpones, and no longer pays (3.09 Gbp e = 2: 90.7 vs 86.7 M k-mers/s without).
     A.probation = (p->E == 0 || ix->nRows >= (1ull << 30)) ? 0u : 2u;
-    if (const char* e = getenv("GM_PROBATION")) A.probation = (uint32_t)std::max(0, atoi(e));
-    if (const char* e = getenv("GM_VERIFY_COST")) A.verifyCost = (uint32_t)std::max(0, atoi(e));
+    if (ix->tune.probation >= 0) A.probation = (uint32_t)ix->tune.probation;
+    A.verifyCost = (uint32_t)std::max(0, ix->tune.verifyCost);
     *Aout = A;
     return GM_OK;
 }
@@ -632,11 +638,11 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
         rc = grow(&ix->d_acc, &ix->accCap, 2 * (text_len + 4)); if (rc) return rc;
     }
     // E = 0 with single-row verification: plain stores into one plane per strand instead of atomics
-    const bool store = !ep && p->E == 0 && A.verifyT <= 1 && getenv("GM_NO_STORE") == nullptr;
+    const bool store = !ep && p->E == 0 && A.verifyT <= 1 && !ix->tune.noStore;
     const uint64_t plane = text_len + 4;
 
     // a shard (kmer_begin/kmer_end) touches only its own positions [r0, r1) of the accumulators and of out
-    const bool sharded = p->kmer_begin != 0 || p->kmer_end != 0;
+    const bool sharded = (p->flags & GM_MAP_FLAG_RANGE) || p->kmer_begin != 0 || p->kmer_end != 0;
     const uint64_t r0 = sharded ? std::min<uint64_t>(S.posBase, text_len) : 0;
     const uint64_t r1 = sharded ? std::min<uint64_t>(std::max<uint64_t>(S.posEnd, r0), text_len) : text_len;
     const uint64_t rn = r1 - r0;
@@ -649,13 +655,15 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
             GM_HIP(hipMemsetAsync((uint8_t*)ix->d_acc + (plane + r0) * pb, 0, rn * pb, st));
         } else GM_HIP(hipMemsetAsync(ix->d_acc + r0, 0, rn * sizeof(uint32_t), st));
     }
-    GM_HIP(hipMemsetAsync(ix->d_small, 0, 256, st));
+    GM_HIP(hipMemsetAsync(ix->d_small, 0, SMALL_ZEROED, st));
     A.acc = ix->d_acc; A.accPlane = plane; A.fileBits = ix->d_bits;
-    A.maxVal = (p->value_bits == 8 && getenv("GM_NO_SATURATE") == nullptr) ? 255u : (getenv("GM_NO_SATURATE") ? 0xFFFFFFFFu : 65535u); A.wordsPerKmer = wordsPerKmer; A.seqFile = ix->d_seqFile;
+    A.maxVal = ix->tune.noSaturate ? 0xFFFFFFFFu : (p->value_bits == 8 ? 255u : 65535u); A.wordsPerKmer = wordsPerKmer; A.seqFile = ix->d_seqFile;
 
-    GM_HIP(hipEventRecord(ix->ev[1], st));
+    const uint32_t slot = (uint32_t)(ix->evCount % gm_index::EV_RING);
+    GM_HIP(hipEventRecord(ix->evRing[slot][0], st));
     if (S.numRoots > 0) { rc = launch_search(ix, ep ? LEAF_FILESET : store ? (p->value_bits == 8 ? LEAF_STORE8 : LEAF_STORE) : LEAF_COUNT, A, S.blocks, st); if (rc) return rc; }
-    GM_HIP(hipEventRecord(ix->ev[2], st));
+    GM_HIP(hipEventRecord(ix->evRing[slot][1], st));
+    ix->evCount++;
     if (text_len > 0) {
         const unsigned g4 = grid_for((rn + 3) / 4), g1 = grid_for(rn);
         const uint16_t* pf = (const uint16_t*)ix->d_acc + r0;
@@ -678,6 +686,8 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
         if (rc) return rc;
     }
     GM_HIP(hipEventRecord(ix->ev[3], st));
+    GM_HIP(hipEventRecord(ix->evDone, st));
+    ix->doneValid = true;
     ix->evValid = true;
     ix->stats = gm_map_stats{};
     ix->stats.kmers = S.kmers; ix->stats.roots = S.numRoots;
@@ -707,7 +717,7 @@ static int locate_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uin
 #define LC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); rc = (e_ == hipErrorOutOfMemory) ? GM_ERR_OOM : GM_ERR_HIP; goto done; } } while (0)
     {
         LC(hipMalloc(&d_cnt, (slots + 1) * 4)); LC(hipMalloc(&d_offs, (slots + 1) * 8));
-        LC(hipMemset(d_cnt, 0, (slots + 1) * 4)); LC(hipMemset(ix->d_small, 0, 256));
+        LC(hipMemset(d_cnt, 0, (slots + 1) * 4)); LC(hipMemset(ix->d_small, 0, SMALL_ZEROED));
         A.cnt2 = d_cnt;
         rc = launch_search(ix, LEAF_OCC_COUNT, A, S.blocks, st); if (rc) goto done;
         LC(rocprim::exclusive_scan(nullptr, tmpBytes, d_cnt, d_offs, (uint64_t)0, slots + 1, rocprim::plus<uint64_t>()));
@@ -724,7 +734,7 @@ static int locate_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uin
         if (!L->plus || !L->minus) { rc = GM_ERR_OOM; goto done; }
         if (total > 0) {
             LC(hipMalloc(&d_emit, total * 8)); LC(hipMalloc(&d_sorted, total * 8));
-            LC(hipMemset(d_cnt, 0, (slots + 1) * 4)); LC(hipMemset(ix->d_small, 0, 256));
+            LC(hipMemset(d_cnt, 0, (slots + 1) * 4)); LC(hipMemset(ix->d_small, 0, SMALL_ZEROED));
             A.offs = d_offs; A.emit = d_emit;
             rc = launch_search(ix, LEAF_OCC_EMIT, A, S.blocks, st); if (rc) goto done;
             // std::sort of every list (algo.hpp:336,348): segmented radix sort, segments = (position, strand) slots
@@ -745,6 +755,7 @@ static int locate_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uin
 done:
 #undef LC
     hipFree(d_cnt); hipFree(d_offs); hipFree(d_emit); hipFree(d_sorted); hipFree(d_tmp); hipFree(d_segB);
+    if (hipEventRecord(ix->evDone, st) == hipSuccess) ix->doneValid = true;
     if (!rc) rc = check_device_error(ix);
     return rc;
 }
@@ -752,8 +763,12 @@ done:
 static int check_device_error(gm_index* ix)
 {
     uint32_t flag = 0;
-    GM_HIP(hipMemcpy(&flag, reinterpret_cast<char*>(ix->d_small) + 8, 4, hipMemcpyDeviceToHost));
-    if (flag) { set_error("device-side invariant violated (lane stack overflow)"); return GM_ERR_INTERNAL; }
+    GM_HIP(hipMemcpy(&flag, reinterpret_cast<char*>(ix->d_small) + SMALL_ERR_OFF, 4, hipMemcpyDeviceToHost));   // synchronises with the device
+    if (flag) {
+        GM_HIP(hipMemset(reinterpret_cast<char*>(ix->d_small) + SMALL_ERR_OFF, 0, 4));
+        set_error("device-side invariant violated (lane stack overflow) in this or an earlier call on the index");
+        return GM_ERR_INTERNAL;
+    }
     return GM_OK;
 }
 
@@ -776,8 +791,12 @@ int gm_map(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t first_
     void* d_out = nullptr;
     const size_t bytes = (size_t)text_len * (p->value_bits / 8);
     GM_HIP(hipMalloc(&d_out, bytes + 16));
-    if (p->kmer_begin != 0 || p->kmer_end != 0) GM_HIP(hipMemsetAsync(d_out, 0, bytes, nullptr));   // a shard leaves the other positions zero
-    int rc = map_impl(ix, text_begin, text_len, first_seq, n_seq, p, intervals, n_intervals, seq_file_id, d_out, nullptr);
+    int rc = GM_OK;
+    if ((p->flags & GM_MAP_FLAG_RANGE) || p->kmer_begin != 0 || p->kmer_end != 0) {   // a shard leaves the other positions zero
+        hipError_t e = hipMemsetAsync(d_out, 0, bytes, nullptr);
+        if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); hipFree(d_out); return GM_ERR_HIP; }
+    }
+    rc = map_impl(ix, text_begin, text_len, first_seq, n_seq, p, intervals, n_intervals, seq_file_id, d_out, nullptr);
     if (!rc) { hipError_t e = hipMemcpy(out_host, d_out, bytes, hipMemcpyDeviceToHost); if (e != hipSuccess) { set_error("copy back failed: %s", hipGetErrorString(e)); rc = GM_ERR_HIP; } }
     if (!rc) rc = check_device_error(ix);
     hipFree(d_out);
@@ -863,6 +882,43 @@ void gm_runs_free(gm_runs* R)
     free(R->start); free(R->length); free(R->value); free(R);
 }
 
+int gm_index_set_tuning(gm_index* ix, const char* name, int64_t value)
+{
+    if (!ix || !name) return GM_ERR_BAD_ARG;
+    struct { const char* n; int* f; } tab[] = {
+        {"verify_t", &ix->tune.verifyT}, {"lds_stack", &ix->tune.ldsStack}, {"blocks_per_cu", &ix->tune.blocksPerCU}, {"qtable", &ix->tune.qtable},
+        {"sat_min_w", &ix->tune.satMinW}, {"fetch_batch", &ix->tune.fetchBatch}, {"probation", &ix->tune.probation}, {"verify_cost", &ix->tune.verifyCost},
+        {"no_store", &ix->tune.noStore}, {"no_saturate", &ix->tune.noSaturate},
+    };
+    for (auto& t : tab) if (!strcmp(t.n, name)) { *t.f = (int)value; return GM_OK; }
+    set_error("unknown tuning knob '%s'", name);
+    return GM_ERR_BAD_ARG;
+}
+
+int gm_index_sync(gm_index* ix)
+{
+    if (!ix) return GM_ERR_BAD_ARG;
+    GM_HIP(hipSetDevice(ix->device));
+    if (ix->doneValid) GM_HIP(hipEventSynchronize(ix->evDone));
+    return check_device_error(ix);
+}
+
+int gm_map_kernel_times(const gm_index* ix, double* ms, uint32_t n, uint32_t* n_out)
+{
+    if (!ix || !ms || !n_out) return GM_ERR_BAD_ARG;
+    GM_HIP(hipSetDevice(ix->device));
+    const uint32_t have = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(ix->evCount, gm_index::EV_RING), n);
+    for (uint32_t i = 0; i < have; ++i) {
+        const uint32_t slot = (uint32_t)((ix->evCount - have + i) % gm_index::EV_RING);
+        GM_HIP(hipEventSynchronize(ix->evRing[slot][1]));
+        float t = 0;
+        GM_HIP(hipEventElapsedTime(&t, ix->evRing[slot][0], ix->evRing[slot][1]));
+        ms[i] = t;
+    }
+    *n_out = have;
+    return GM_OK;
+}
+
 int gm_last_map_stats(const gm_index* cix, gm_map_stats* out)
 {
     gm_index* ix = const_cast<gm_index*>(cix);
@@ -871,7 +927,7 @@ int gm_last_map_stats(const gm_index* cix, gm_map_stats* out)
     GM_HIP(hipSetDevice(ix->device));
     GM_HIP(hipEventSynchronize(ix->ev[3]));
     float a = 0, b = 0;
-    GM_HIP(hipEventElapsedTime(&a, ix->ev[1], ix->ev[2]));
+    { const uint32_t slot = (uint32_t)((ix->evCount - 1) % gm_index::EV_RING); GM_HIP(hipEventElapsedTime(&a, ix->evRing[slot][0], ix->evRing[slot][1])); }
     GM_HIP(hipEventElapsedTime(&b, ix->ev[0], ix->ev[3]));
     ix->stats.search_ms = a; ix->stats.total_ms = b;
     unsigned long long cnt[17] = {0};

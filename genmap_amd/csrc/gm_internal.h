@@ -18,6 +18,15 @@ int build_sa_bwt(const uint8_t* d_codes, const uint64_t* d_cum, uint32_t nSeq, u
 
 }  // namespace gm
 
+namespace gm {
+// knobs of the search kernel's scheduling; set with gm_index_set_tuning (tests, sweeps), never read from the environment.
+// -1 = "library default for this call" (depends on K, E and the index size, see prepare_search)
+struct Tuning {
+    int verifyT = -1, ldsStack = 4, blocksPerCU = 4, qtable = -1, satMinW = 256, fetchBatch = -1, probation = -1, verifyCost = 3;
+    int noStore = 0, noSaturate = 0;
+};
+}  // namespace gm
+
 struct gm_index {
     int device = 0;
     uint32_t wpp = 3;                 // words per plane of the rank blocks (1, 3, 9)
@@ -50,6 +59,15 @@ struct gm_index {
     uint64_t* d_cumLocal = nullptr; uint64_t cumLocalCap = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool evValid = false;
+    // search-kernel time of the most recent calls (gm_map_kernel_times): begin/end events of the kernel, recorded on the call's stream
+    static constexpr uint32_t EV_RING = 64;
+    hipEvent_t evRing[EV_RING][2] = {};
+    uint64_t evCount = 0;
+    // every call ends by recording evDone on its stream; the next call makes ITS stream wait for it, so calls on
+    // different streams are serialised on the index's shared workspaces instead of racing on them
+    hipEvent_t evDone = nullptr;
+    bool doneValid = false;
+    gm::Tuning tune;
     gm_map_stats stats{};
     int buildRounds[2] = {0, 0};
 };

@@ -96,12 +96,21 @@ typedef struct gm_map_params {
     int32_t  revcompl;        /* 0 with -nc */
     int32_t  value_bits;      /* 8 or 16 */
     int32_t  exclude_pseudo;  /* -ep: count distinct fasta files (needs SA samples) */
-    int32_t  reserved0;
+    int32_t  flags;           /* GM_MAP_FLAG_* */
     uint64_t kmer_begin;      /* shard: compute only k-mer start positions in [kmer_begin, kmer_end) of   */
-    uint64_t kmer_end;        /*        the slice (whole k-mer blocks); both 0 = everything.  gm_map leaves   */
-                              /*        the other positions zero, gm_map_device does not touch them (apart  */
-                              /*        from the boundary reset), so shards can share one device buffer.    */
+    uint64_t kmer_end;        /*        the slice (whole k-mer blocks).  Both 0 without GM_MAP_FLAG_RANGE =   */
+                              /*        everything; with the flag the range is taken literally (an empty    */
+                              /*        range computes nothing).  gm_map leaves the other positions zero,     */
+                              /*        gm_map_device does not touch them (apart from the boundary reset),  */
+                              /*        so shards can share one device buffer.                              */
 } gm_map_params;
+#define GM_MAP_FLAG_RANGE 1   /* [kmer_begin, kmer_end) is a shard even when it is empty or (0,0) */
+
+/* Concurrency: an index owns ONE set of device workspaces (work counter, accumulators, lane stacks, per-call tables).
+ * Calls on the same index may be issued from one host thread at a time, on any streams: every call makes its stream
+ * wait for the end-of-call event of the previous call on that index, so they execute one after the other on the device.
+ * gm_map_device returns without synchronising; device-side invariant violations are reported by the next
+ * synchronising call (gm_map, gm_map_runs, gm_locate, gm_last_map_stats, gm_index_sync). */
 
 /* text_begin/text_len: the slice in sentinel-free global coordinates (src/mappability.hpp:312);
  * first_seq/n_seq: its sequences (for resetLimits, src/algo.hpp:10-22);
@@ -170,6 +179,19 @@ typedef struct gm_map_stats {
     double   total_ms;        /* memset + search + finalize, HIP events on the call's stream */
 } gm_map_stats;
 int gm_last_map_stats(const gm_index *idx, gm_map_stats *stats);
+
+/* search-kernel durations (ms, HIP events recorded on each call's own stream) of the last min(n, 64) gm_map* calls on this
+ * index, oldest first; *n_out = how many were written.  Synchronises with those calls.  (bench.py: roofline denominator
+ * over the timed steps themselves.) */
+int gm_map_kernel_times(const gm_index *idx, double *ms, uint32_t n, uint32_t *n_out);
+
+/* wait until every call issued on this index has finished; GM_ERR_INTERNAL if one of them tripped a device-side check */
+int gm_index_sync(gm_index *idx);
+
+/* scheduling knobs of the search kernel, for sweeps and tests (results never depend on them).  Names: verify_t,
+ * lds_stack, blocks_per_cu, qtable, sat_min_w, fetch_batch, probation, verify_cost, no_store, no_saturate;
+ * value -1 restores the library default where one exists.  Nothing is read from the environment. */
+int gm_index_set_tuning(gm_index *idx, const char *name, int64_t value);
 
 /* reference default of SearchParams.overlap (common-infix length) for (K,E,-xo): src/mappability.hpp:519-543.
  * Returns 0 if -xo is too large. */

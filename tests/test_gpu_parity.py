@@ -153,13 +153,12 @@ def test_gpu_gtest_matrix(E, dna5):
             rc = bool(rng.integers(0, 2))
             triv = ora.trivial(K, E, revcompl=rc, value_bits=8)
             for infix in range(max(minK, nblocks), K + 1):
-                for T in ("0", "1", "4"):   # verification of narrow nodes off / width 1 / width <= 4
-                    os.environ["GM_VERIFY_T"] = T
+                for T in (0, 1, 4):   # verification of narrow nodes off / width 1 / width <= 4
+                    ix.set_tuning(verify_t=T)
                     out = ix.map(K, E, infix=infix, revcompl=rc, value_bits=8)
                     assert np.array_equal(out, triv), (E, dna5, K, infix, T)
     finally:
-        os.environ.pop("GM_VERIFY_T", None)
-    ix.close()
+        ix.close()
 
 
 @pytest.mark.parametrize("K,E", [(30, 0), (30, 1), (30, 2), (100, 1), (24, 1), (50, 3), (36, 4), (128, 0), (150, 2), (250, 1), (255, 0), (255, 4)])
@@ -169,18 +168,15 @@ def test_gpu_baseline_settings_small(K, E):
     lens = [60000, 700, K - 1, 30000, 3]
     codes = _repeat_text(rng, sum(lens), True)
     ora = H.OracleIndex(codes, lens, keep_sa=False)
-    try:
-        for bb in BLOCK_BYTES:
-            ix = g.Index.build(codes, lens, block_bytes=bb, sampling=1)
-            for bits in (8, 16):
-                exp = ora.mappability(K, E, value_bits=bits, threads=8)
-                for T in ("0", "1", "4"):
-                    os.environ["GM_VERIFY_T"] = T
-                    out = ix.map(K, E, value_bits=bits)
-                    assert np.array_equal(out, exp), (K, E, bits, bb, T)
-            ix.close()
-    finally:
-        os.environ.pop("GM_VERIFY_T", None)
+    for bb in BLOCK_BYTES:
+        ix = g.Index.build(codes, lens, block_bytes=bb, sampling=1)
+        for bits in (8, 16):
+            exp = ora.mappability(K, E, value_bits=bits, threads=8)
+            for T in (0, 1, 4):
+                ix.set_tuning(verify_t=T)
+                out = ix.map(K, E, value_bits=bits)
+                assert np.array_equal(out, exp), (K, E, bits, bb, T)
+        ix.close()
 
 
 def test_gpu_shards_and_device_output():
