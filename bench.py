@@ -1,13 +1,21 @@
 #!/usr/bin/env python3
-"""bench.py -- (k,e)-mappability throughput on MI355X.
+"""bench.py -- (k,e)-mappability throughput on MI355X, on BASELINE.json's own configuration.
 
-  python bench.py [--gpus N --steps K --warmup W] [--workload chr1|grch38|ecoli] [--scale f] [--K 30 --E 0]
+  python bench.py [--gpus N --steps K --warmup W] [--workload grch38|chr1|ecoli] [--scale f] [--fasta F.fa] [--K 30 --E 0]
 
-A "step" is one complete computeMappability pass (src/algo.hpp:405-483) over the synthetic genome with the
-index already resident in HBM: memset of the accumulators, the search kernel, finalize/resetLimits, and -- for
-N > 1 -- the RCCL gather of the ranks' shards of the frequency vector to rank 0.  Each rank holds a full index
-replica and computes a disjoint range of k-mer positions (strong scaling: the genome is fixed).
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+Default workload: S3 "grch38-like" (24 sequences with the GRCh38 chromosome lengths, 3,088,269,832 bp, Dna5) -- the
+"3.1 Gbp index" the metric is quoted on (BASELINE.json configs[2]/[3]); it fits one GPU.  --fasta replaces the synthetic
+text by a real FASTA file.  Protocol of /root/reference/benchmarks/bench.sh:24-43: both strands, -fs (8-bit
+frequencies), raw output; the map computation alone is timed, index resident (load / write are reported separately by
+`genmap map -v`).
+
+A "step" is one complete computeMappability pass (src/algo.hpp:405-483) over the text with the index already in HBM:
+clear of the accumulators, the search kernel, finalize/resetLimits, and -- for N > 1 -- the gather of the ranks' chunks of
+the frequency vector to rank 0.  Each rank holds a full index replica and computes interleaved chunks of whole k-mer
+blocks (strong scaling: the genome is fixed).  The headline line is K=30, e=0; the same JSON line carries sub-records
+for (30,1), (30,2) and (100,1) measured in the same run, each with its own roofline (numerator counted in-run by the
+instrumented twin library, denominator = HIP-event time of the search kernel over the timed steps) and CPU baseline.
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -29,38 +37,62 @@ def log(*a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(codes, lens, bwt, K, E, threads):
-    """The oracle (a port of the reference algorithm, kind="port") on this box's host cores, on a bounded
-    sample: whole k-mer blocks from the start of the text, sized so the run takes roughly 10-30 s."""
-    sys.path.insert(0, str(ROOT / "tests"))
-    import helpers as H
-    t0 = time.time()
-    ora = H.OracleIndex(codes, lens, keep_sa=False, bwt=bwt)
-    log(f"cpu_baseline: oracle adopted the GPU-built BWTs in {time.time() - t0:.1f} s")
-    n = len(codes)
-    skip = min(n // 10, 20_000)               # stay clear of the leading N block
-    avail = n - skip - K
-    sample, dt = min(1_000_000, avail), 0.0
-    while True:                                # grow the sample until the timed run takes >= 10 s (or covers the text)
+class CpuBaseline:
+    """The oracle (a port of the reference algorithm, kind="port") on this box's host cores, on a bounded sample:
+    whole k-mer blocks from the start of the text, sized so that the timed run takes roughly 10 s."""
+
+    def __init__(self, codes, lens, bwt, threads):
+        sys.path.insert(0, str(ROOT / "tests"))
+        import helpers as H
         t0 = time.time()
-        ora.mappability(K, E, value_bits=8, threads=threads, intervals=[(skip, skip + sample)])
-        dt = time.time() - t0
-        if dt >= 10.0 or sample >= avail:
-            break
-        sample = int(min(avail, max(sample * 2, sample * 14.0 / max(dt, 1e-3))))
-    return {"value": sample / dt, "unit": "k-mers/s", "cores": threads, "kind": "port",
-            "sample": f"{sample} consecutive k-mer positions from offset {skip} of the same index, K={K} E={E}, both strands, {dt:.1f} s"}
+        self.ora = H.OracleIndex(codes, lens, keep_sa=False, bwt=bwt)
+        self.n, self.threads = len(codes), threads
+        log(f"cpu_baseline: oracle adopted the GPU-built BWTs in {time.time() - t0:.1f} s")
+
+    def run(self, K, E, first_guess):
+        n = self.n
+        skip = min(n // 10, 20_000)               # stay clear of the leading N block
+        avail = n - skip - K
+        sample, dt = min(first_guess, avail), 0.0
+        while True:                                # grow the sample until the timed run takes >= 8 s (or covers the text)
+            t0 = time.time()
+            self.ora.mappability(K, E, value_bits=8, threads=self.threads, intervals=[(skip, skip + sample)])
+            dt = time.time() - t0
+            if dt >= 8.0 or sample >= avail:
+                break
+            sample = int(min(avail, max(sample * 2, sample * 11.0 / max(dt, 1e-3))))
+        return {"value": sample / dt, "unit": "k-mers/s", "cores": self.threads, "kind": "port",
+                "sample": f"{sample} consecutive k-mer positions from offset {skip} of the same index, K={K} E={E}, both strands, {dt:.1f} s"}
+
+
+def read_fasta(path):
+    """FASTA -> (codes, lengths) through the host library's reader (the `genmap index` rules, src/indexing.hpp:209-275)"""
+    import ctypes as C
+    lib = C.CDLL(str(ROOT / "genmap_amd" / "lib" / "libgenmap_host.so"))
+    lib.gmh_read_fasta.restype = C.c_int
+    nseq, total, nb = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    if lib.gmh_read_fasta(str(path).encode(), None, None, None, C.c_uint64(0), C.byref(nseq), C.byref(total), C.byref(nb)):
+        raise SystemExit(f"cannot read {path}")
+    codes = np.empty(total.value, np.uint8)
+    lens = np.empty(nseq.value, np.uint64)
+    names = C.create_string_buffer(nb.value + 1)
+    if lib.gmh_read_fasta(str(path).encode(), codes.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), names, C.c_uint64(nb.value + 1),
+                          C.byref(nseq), C.byref(total), C.byref(nb)):
+        raise SystemExit(f"cannot read {path}")
+    return codes, [int(x) for x in lens]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="chr1")
+    ap.add_argument("--workload", default="grch38")
     ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--fasta", default=None, help="real FASTA file instead of the synthetic workload")
     ap.add_argument("--K", type=int, default=30)
     ap.add_argument("--E", type=int, default=0)
+    ap.add_argument("--sub", default="30,1:2;30,2:1;100,1:2", help="sub-records 'K,E:steps;...' measured after the headline (N=1 only); '' = none")
     ap.add_argument("--block-bytes", type=int, default=0)
     ap.add_argument("--infix", type=int, default=0, help="common-infix length (SearchParams.overlap); 0 = library default")
     ap.add_argument("--sampling", type=int, default=1, help="1: keep the suffix array resident (narrow nodes are verified against the text); 0: rank queries only")
@@ -92,33 +124,23 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     t0 = time.time()
-    codes, lens, desc = synth.workload(args.workload, args.scale)
+    if args.fasta:
+        codes, lens = read_fasta(args.fasta)
+        desc, data = f"{os.path.basename(args.fasta)} {len(codes)} bp in {len(lens)} sequences", "real FASTA"
+    else:
+        codes, lens, desc = synth.workload(args.workload, args.scale)
+        data = "synthetic"
     n = int(len(codes))
-    log(f"workload {desc}: generated in {time.time() - t0:.1f} s")
-    K, E = args.K, args.E
+    log(f"workload {desc}: ready in {time.time() - t0:.1f} s")
     t0 = time.time()
     ix = g.Index.build(codes, lens, sampling=args.sampling, block_bytes=args.block_bytes, device=local_rank)
     t_build = time.time() - t0
     info = ix.info()
     log(f"index built on the GPU in {t_build:.1f} s: {info['n_rows']} rows, {info['block_bytes']}-B blocks, {info['device_bytes'] / 2**30:.2f} GiB")
 
-    infix = args.infix or g.tuned_infix_length(K, E)
-    step_sz = K - infix + 1
-    num_kmers = n - K + 1
-    from genmap_amd.distributed import gather_frequency, max_shard_len, shard_ranges
-    ranges = shard_ranges(num_kmers, step_sz, world)   # contiguous shards of whole k-mer blocks
-    kb, ke = ranges[rank]
-    max_shard = max_shard_len(ranges)
-
-    out = torch.zeros(n + max_shard, dtype=torch.uint8, device=dev)        # -fs: 8-bit frequencies
-    gathered = [torch.empty(max_shard, dtype=torch.uint8, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    from genmap_amd.distributed import ShardPlan, gather_chunks
     stream = torch.cuda.current_stream().cuda_stream
-    search_ms = []
-
-    def one_step():
-        ix.map_device(out.data_ptr(), K, E, infix=args.infix, value_bits=8, kmer_range=(kb, ke) if world > 1 else None, stream=stream)
-        if world > 1:
-            gather_frequency(out, ranges, rank, world, dist, recv_bufs=gathered, stage_on_host=(args.backend != "nccl"))
+    out = None
 
     def sync():
         torch.cuda.synchronize()
@@ -126,91 +148,142 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-        search_ms.append(None)
-    sync()
-    dt = time.perf_counter() - t0
-    st = ix.last_stats()   # HIP events of the last step on the launch stream
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    def measure(K, E, steps, warmup):
+        """W warm-up steps, then exactly `steps` timed steps between barrier + synchronize; returns the record."""
+        nonlocal out
+        infix = args.infix or g.tuned_infix_length(K, E)
+        num_kmers = n - K + 1
+        plan = ShardPlan(num_kmers, K - infix + 1, world)
+        if out is None:
+            out = torch.zeros(plan.padded_len(n), dtype=torch.uint8, device=dev)        # -fs: 8-bit frequencies
+        comm = {"ms": 0.0}
+
+        def one_step():
+            ix.map_device(out.data_ptr(), K, E, infix=args.infix, value_bits=8, chunks=plan.chunk_arg(rank), stream=stream)
+            if world > 1:
+                gather_chunks(out, plan, rank, dist, stage_on_host=(args.backend != "nccl"))
+
+        for _ in range(warmup):
+            one_step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_step()
+        sync()
+        dt = time.perf_counter() - t0
+        kms = ix.kernel_times(steps)   # HIP events around the search kernel of each timed step, on the launch stream
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            if args.backend != "nccl":
+                t = t.cpu()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        return {"K": K, "E": E, "infix": infix, "num_kmers": num_kmers, "steps": steps, "warmup": warmup, "dt": dt,
+                "kernel_ms": float(np.mean(kms)), "kernel_ms_min": float(np.min(kms)), "my_compute_ms": float(np.mean(kms)), "plan": plan}
+
+    def host_rate(K, E):
+        """PCIe-inclusive rate of the drop-in call gm_map (host result vector): never `value`"""
+        t0 = time.perf_counter()
+        ix.map(K, E, infix=args.infix, value_bits=8)
+        return (n - K + 1) / (time.perf_counter() - t0)
+
+    head = measure(args.K, args.E, args.steps, args.warmup)
+    subs = []
+    if world == 1 and args.sub:
+        for item in args.sub.split(";"):
+            ke, st = item.split(":")
+            K, E = map(int, ke.split(","))
+            subs.append(measure(K, E, int(st), 1 if E < 2 else 0))
+            log(f"sub-record K={K} E={E}: {subs[-1]['dt'] / subs[-1]['steps'] * 1e3:.1f} ms/step")
+    value_host = host_rate(args.K, args.E) if world == 1 else None
+
+    # per-rank diagnosis for N > 1: compute ms per rank and shard imbalance (so that a scaling run is readable)
+    per_rank = None
     if world > 1:
-        if args.backend != "nccl":
-            t = t.cpu()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+        mine = torch.tensor([head["my_compute_ms"]], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        allms = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allms, mine)
+        per_rank = [float(x.item()) for x in allms]
 
-    # per-launch kernel time over a few extra (untimed-by-wall) launches, each measured with HIP events
-    kms = []
-    for _ in range(min(args.steps, 5)):
-        ix.map_device(out.data_ptr(), K, E, infix=args.infix, value_bits=8, kmer_range=(kb, ke) if world > 1 else None, stream=stream)
-        kms.append(ix.last_stats()["search_ms"])
-    kernel_ms = float(np.mean(kms))
-
-    result = None
-    if rank == 0:
-        value = num_kmers * args.steps / dt
-        result = {
-            "metric": "k-mers/sec (whole node) for (k,e)-mappability", "value": value, "unit": "k-mers/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32 ranks / u8 counts",
-            "data": "synthetic",
-            "config": {"workload": f"{desc}, K={K} E={E}, both strands, -fs (8-bit), common infix {infix}", "K": K, "E": E,
-                       "text_len": n, "block_bytes": info["block_bytes"], "parallelism": f"text-range shards x{world}, index replicated",
-                       "index_build_s": round(t_build, 2)},
-        }
-    # ---- roofline numerator: count node steps / distinct rank lines with the instrumented twin (untimed) ----
-    lines = steps_cnt = None
-    roots = 0
-    v_items = v_chunks = 0
+    # ---- roofline numerators: count node steps / distinct rank lines with the instrumented twin (untimed) ----
+    counted = {}
     if rank == 0 and world == 1 and not args.no_counters and g.lib_path(True).exists():
         try:
             bf, br = ix.export_bwt()
             ixp = g.Index.from_bwt(bf, br, codes, lens, sa_fwd=(ix.export_sa() if args.sampling == 1 else None), sampling=args.sampling,
                                    block_bytes=info["block_bytes"], device=local_rank, profiling=True)
+            del bf, br
             tmp = torch.zeros(n + 16, dtype=torch.uint8, device=dev)
-            ixp.map_device(tmp.data_ptr(), K, E, infix=args.infix, value_bits=8, stream=stream)
-            sp = ixp.last_stats()
-            lines, steps_cnt, roots = sp["rank_lines"], sp["node_steps"], sp["roots"]
-            v_items, v_chunks = sp["detail"]["verify_items"], sp["detail"]["verify_chunks"]
+            for rec in [head] + subs:
+                ixp.map_device(tmp.data_ptr(), rec["K"], rec["E"], infix=args.infix, value_bits=8, stream=stream)
+                sp = ixp.last_stats()
+                counted[(rec["K"], rec["E"])] = sp
             ixp.close()
             del tmp
         except Exception as e:  # measurement aid only
             log("counter pass failed:", e)
-    if rank == 0:
+
+    def roofline(rec):
         bb = info["block_bytes"]
-        if lines:
-            # rank blocks + one q-mer table entry per root + text read once per strand (4-bit packed) + 8-bit output
-            # + verification (SA entry per row, 8 needle + 8 text symbols per chunk)
-            alg = bb * lines + 16 * roots + n + n + 4 * v_items + 16 * v_chunks
-            ach = alg / (kernel_ms * 1e-3) / 1e9
-            traffic = None
-            tf = ROOT / "profiles" / "pmc_traffic.json"
-            if tf.exists():
-                try:
-                    rec = json.loads(tf.read_text())
-                    if rec.get("workload") == result["config"]["workload"]:
-                        traffic = rec.get("hbm_bytes_per_launch")
-                except Exception:
-                    pass
-            result["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                  "traffic": traffic, "kernel": "search_kernel", "kernel_ms": kernel_ms,
-                                  "algorithmic_bytes": alg, "rank_lines": lines, "roots": roots, "node_steps": steps_cnt,
-                                  "node_steps_per_kmer": steps_cnt / num_kmers,
-                                  "verify_items": v_items, "verify_chunks": v_chunks}
-        else:
-            result["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                                  "kernel": "search_kernel", "kernel_ms": kernel_ms}
+        sp = counted.get((rec["K"], rec["E"]))
+        if not sp or not sp["rank_lines"]:
+            return {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                    "kernel": "search_kernel", "kernel_ms": rec["kernel_ms"]}
+        d = sp["detail"]
+        # rank blocks + one q-mer table entry per root + text read once per strand (4-bit packed) + 8-bit output
+        # + verification (SA entry per row, 8 needle + 8 text symbols per chunk)
+        alg = bb * sp["rank_lines"] + 16 * sp["roots"] + n + n + 4 * d["verify_items"] + 16 * d["verify_chunks"]
+        ach = alg / (rec["kernel_ms"] * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None,   # PMC FETCH_SIZE/WRITE_SIZE need rocprofv3 around the process: tools/profile_round.sh -> profiles/
+                "kernel": "search_kernel", "kernel_ms": rec["kernel_ms"], "algorithmic_bytes": alg, "rank_lines": sp["rank_lines"],
+                "roots": sp["roots"], "node_steps": sp["node_steps"], "node_steps_per_kmer": sp["node_steps"] / rec["num_kmers"],
+                "verify_items": d["verify_items"], "verify_chunks": d["verify_chunks"],
+                "lanes_with_node_per_iteration": d["active_lane_sum"] / max(1, d["wave_iterations"])}
+
+    if rank == 0:
+        cpu = None
         if world == 1 and not args.no_cpu_baseline:
             try:
-                bwt = ix.export_bwt()
-                result["cpu_baseline"] = cpu_baseline(codes, lens, bwt, K, E, os.cpu_count() or 1)
+                cpu = CpuBaseline(codes, lens, ix.export_bwt(), os.cpu_count() or 1)
             except Exception as e:
                 log("cpu baseline failed:", e)
-                result["cpu_baseline"] = None
+
+        def cpu_rec(rec):
+            if cpu is None:
+                return None
+            guess = {0: 100_000_000, 1: 10_000_000}.get(rec["E"], 1_000_000)
+            try:
+                return cpu.run(rec["K"], rec["E"], guess)
+            except Exception as e:
+                log("cpu baseline failed:", e)
+                return None
+
+        def wl(rec):
+            return f"{desc}, K={rec['K']} E={rec['E']}, both strands, -fs (8-bit), common infix {rec['infix']}"
+
+        result = {
+            "metric": "k-mers/sec (whole node) for (k,e)-mappability on 3.1 Gbp index", "value": head["num_kmers"] * head["steps"] / head["dt"], "unit": "k-mers/s",
+            "n_gpus": world, "steps": head["steps"], "warmup": head["warmup"], "ms_per_step": head["dt"] / head["steps"] * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32 ranks / u8 counts", "data": data,
+            "config": {"workload": wl(head), "K": head["K"], "E": head["E"], "text_len": n, "block_bytes": info["block_bytes"],
+                       "parallelism": head["plan"].describe(), "index_build_s": round(t_build, 2), "index_device_gib": round(info["device_bytes"] / 2**30, 2)},
+            "value_host": value_host,   # gm_map with the result vector copied to host memory (PCIe-inclusive); never `value`
+            "roofline": roofline(head),
+        }
+        if per_rank is not None:
+            result["per_rank_search_ms"] = per_rank
+            result["shard_imbalance"] = max(per_rank) / max(1e-9, float(np.mean(per_rank)))
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_rec(head)
+        if subs:
+            result["sub"] = []
+            for rec in subs:
+                r = {"workload": wl(rec), "K": rec["K"], "E": rec["E"], "value": rec["num_kmers"] * rec["steps"] / rec["dt"], "unit": "k-mers/s",
+                     "steps": rec["steps"], "warmup": rec["warmup"], "ms_per_step": rec["dt"] / rec["steps"] * 1e3, "roofline": roofline(rec)}
+                if not args.no_cpu_baseline:
+                    r["cpu_baseline"] = cpu_rec(rec)
+                result["sub"].append(r)
         print(json.dumps(result), flush=True)
     ix.close()
     if world > 1:

@@ -23,7 +23,8 @@ class MapParams(C.Structure):
     """struct gm_map_params"""
     _fields_ = [("K", C.c_uint32), ("E", C.c_uint32), ("overlap", C.c_int32), ("infix", C.c_int32),
                 ("revcompl", C.c_int32), ("value_bits", C.c_int32), ("exclude_pseudo", C.c_int32),
-                ("flags", C.c_int32), ("kmer_begin", C.c_uint64), ("kmer_end", C.c_uint64)]
+                ("flags", C.c_int32), ("kmer_begin", C.c_uint64), ("kmer_end", C.c_uint64),
+                ("chunk_blocks", C.c_uint32), ("chunk_index", C.c_uint32), ("chunk_stride", C.c_uint32), ("reserved1", C.c_uint32)]
 
 
 class IndexInfo(C.Structure):
@@ -199,10 +200,11 @@ class Index:
         _check(self._lib, self._lib.gm_index_export_sa(self._h, _ptr(sa)))
         return sa
 
-    def _params(self, K, E, overlap, infix, revcompl, value_bits, exclude_pseudo, kmer_range):
+    def _params(self, K, E, overlap, infix, revcompl, value_bits, exclude_pseudo, kmer_range, chunks=None):
         kb, ke = kmer_range if kmer_range is not None else (0, 0)
         flags = MAP_FLAG_RANGE if kmer_range is not None else 0   # an explicit range is literal: (b, b) computes nothing
-        return MapParams(K, E, -1 if overlap is None else overlap, infix, int(revcompl), value_bits, int(exclude_pseudo), flags, kb, ke)
+        cb, ci, cs = chunks if chunks is not None else (0, 0, 0)   # (chunk_blocks, chunk_index, chunk_stride): interleaved chunks
+        return MapParams(K, E, -1 if overlap is None else overlap, infix, int(revcompl), value_bits, int(exclude_pseudo), flags, kb, ke, cb, ci, cs, 0)
 
     def _slice(self, first_seq, n_seq):
         if n_seq is None:
@@ -211,10 +213,10 @@ class Index:
         return n_seq, tb, int(self.cum[first_seq + n_seq]) - tb
 
     def map(self, K, E, first_seq=0, n_seq=None, overlap=None, infix=0, revcompl=True, value_bits=16,
-            exclude_pseudo=False, intervals=None, seq_file_id=None, kmer_range=None):
+            exclude_pseudo=False, intervals=None, seq_file_id=None, kmer_range=None, chunks=None):
         """gm_map: computeMappability for the fasta slice made of sequences [first_seq, first_seq+n_seq); host result."""
         n_seq, tb, tl = self._slice(first_seq, n_seq)
-        p = self._params(K, E, overlap, infix, revcompl, value_bits, exclude_pseudo, kmer_range)
+        p = self._params(K, E, overlap, infix, revcompl, value_bits, exclude_pseudo, kmer_range, chunks)
         out = np.zeros(tl, dtype=np.uint8 if value_bits == 8 else np.uint16)
         iv = None if not intervals else np.ascontiguousarray(np.asarray(intervals, dtype=np.uint64).reshape(-1))
         sf = None if seq_file_id is None else np.ascontiguousarray(seq_file_id, dtype=np.uint32)
@@ -222,10 +224,11 @@ class Index:
         return out
 
     def map_device(self, out_ptr, K, E, first_seq=0, n_seq=None, overlap=None, infix=0, revcompl=True, value_bits=16,
-                   exclude_pseudo=False, intervals=None, seq_file_id=None, kmer_range=None, stream=None):
-        """gm_map_device: result written to device memory at out_ptr (e.g. a torch tensor's data_ptr())."""
+                   exclude_pseudo=False, intervals=None, seq_file_id=None, kmer_range=None, chunks=None, stream=None):
+        """gm_map_device: result written to device memory at out_ptr (e.g. a torch tensor's data_ptr()).
+        chunks = (chunk_blocks, chunk_index, chunk_stride): only the interleaved chunks of this shard (ShardPlan.chunk_arg)."""
         n_seq, tb, tl = self._slice(first_seq, n_seq)
-        p = self._params(K, E, overlap, infix, revcompl, value_bits, exclude_pseudo, kmer_range)
+        p = self._params(K, E, overlap, infix, revcompl, value_bits, exclude_pseudo, kmer_range, chunks)
         iv = None if not intervals else np.ascontiguousarray(np.asarray(intervals, dtype=np.uint64).reshape(-1))
         sf = None if seq_file_id is None else np.ascontiguousarray(seq_file_id, dtype=np.uint32)
         _check(self._lib, self._lib.gm_map_device(self._h, tb, tl, first_seq, n_seq, C.byref(p), _ptr(iv), 0 if iv is None else len(iv) // 2,

@@ -99,6 +99,44 @@ __global__ __launch_bounds__(256) void sentinel_text_kernel(const uint8_t* __res
     }
 }
 
+// verification records (gm_kernels.h: CTX_*): one 32-byte record per forward SA row = {SA[row], 56 text symbols around it}
+__global__ __launch_bounds__(256) void ctx_build_kernel(const uint32_t* __restrict__ sa, const uint8_t* __restrict__ textS, uint64_t nRows, uint4* __restrict__ ctx)
+{
+    const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= nRows) return;
+    const uint32_t p0 = sa[row];
+    const uint8_t* p = textS + ((long long)p0 - CTX_LEFT);   // 512 sentinel bytes of padding on both sides of textS
+    uint32_t w[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const uintptr_t u = reinterpret_cast<uintptr_t>(p + 8 * k);
+        const uint64_t* b = reinterpret_cast<const uint64_t*>(u & ~static_cast<uintptr_t>(7));
+        const uint32_t sh = (uint32_t)(u & 7u) * 8u;
+        const uint64_t lo = b[0], hi = b[1];
+        uint64_t v = sh ? (lo >> sh) | (hi << (64u - sh)) : lo;   // 8 symbols, one per byte
+        v = (v | (v >> 4)) & 0x00FF00FF00FF00FFull;              // bytes -> nibbles
+        v = (v | (v >> 8)) & 0x0000FFFF0000FFFFull;
+        v = (v | (v >> 16)) & 0x00000000FFFFFFFFull;
+        w[k] = (uint32_t)v;
+    }
+    ctx[row * 2] = make_uint4(p0, w[0], w[1], w[2]);
+    ctx[row * 2 + 1] = make_uint4(w[3], w[4], w[5], w[6]);
+}
+
+static int make_ctx(gm_index* ix)
+{
+    // 32 B per row (99 GB for a 3.1 Gbp index): only when it leaves the device at least half empty -- the q-mer tables (up to
+    // 17 GB), the per-call workspaces and the caller's own buffers come later.  Without it verification reads SA + text.
+    size_t freeB = 0, totalB = 0;
+    const uint64_t bytes = ix->nRows * 32ull;
+    if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || bytes > freeB || freeB - bytes < totalB / 2) return GM_OK;
+    if (hipMalloc(&ix->d_ctx, bytes) != hipSuccess) { (void)hipGetLastError(); ix->d_ctx = nullptr; return GM_OK; }
+    hipLaunchKernelGGL(ctx_build_kernel, dim3(grid_for(ix->nRows)), dim3(256), 0, 0, ix->d_sa, ix->d_textS, ix->nRows, ix->d_ctx);
+    GM_HIP(hipGetLastError());
+    GM_HIP(hipDeviceSynchronize());
+    return GM_OK;
+}
+
 static int make_sentinel_text(gm_index* ix)
 {
     GM_HIP(hipMalloc(&ix->d_textSAlloc, ix->nRows + 1024));
@@ -244,7 +282,7 @@ void gm_index_free(gm_index* ix)
 {
     if (!ix) return;
     hipSetDevice(ix->device);
-    hipFree(ix->d_blk[0]); hipFree(ix->d_blk[1]); hipFree(ix->d_textAlloc); hipFree(ix->d_text4); hipFree(ix->d_cum); hipFree(ix->d_sa); hipFree(ix->d_textSAlloc); hipFree(ix->d_C);
+    hipFree(ix->d_blk[0]); hipFree(ix->d_blk[1]); hipFree(ix->d_textAlloc); hipFree(ix->d_text4); hipFree(ix->d_cum); hipFree(ix->d_sa); hipFree(ix->d_textSAlloc); hipFree(ix->d_C); hipFree(ix->d_ctx);
     for (auto& kv : ix->qtables) hipFree(kv.second); hipFree(ix->d_seqFile); hipFree(ix->d_bits);
     hipFree(ix->d_acc); hipFree(ix->d_stack); hipFree(ix->d_small); hipFree(ix->d_table); hipFree(ix->d_blocks); hipFree(ix->d_cumLocal);
     for (int i = 0; i < 4; ++i) if (ix->ev[i]) hipEventDestroy(ix->ev[i]);
@@ -274,6 +312,7 @@ int gm_index_build(const uint8_t* codes, const uint64_t* seq_len, uint32_t n_seq
     }
     hipFree(d_sa); hipFree(d_bwt);
     if (!rc && ix->d_sa) rc = make_sentinel_text(ix);
+    if (!rc && ix->d_sa) rc = make_ctx(ix);
     if (rc) { gm_index_free(ix); return rc; }
     *out = ix;
     return GM_OK;
@@ -299,6 +338,7 @@ int gm_index_import(const uint8_t* bwt_fwd, const uint8_t* bwt_rev, const uint32
         if (hipMalloc(&ix->d_sa, ix->nRows * 4) != hipSuccess) rc = GM_ERR_OOM;
         else if (hipMemcpy(ix->d_sa, sa_fwd, ix->nRows * 4, hipMemcpyHostToDevice) != hipSuccess) rc = GM_ERR_HIP;
         if (!rc) rc = make_sentinel_text(ix);
+        if (!rc) rc = make_ctx(ix);
     }
     if (rc) { gm_index_free(ix); return rc; }
     *out = ix;
@@ -338,7 +378,7 @@ int gm_index_get_info(const gm_index* ix, gm_index_info* info)
     info->n_rows = ix->nRows; info->text_len = ix->textLen; info->n_seq = ix->nSeq; info->sampling = ix->sampling;
     info->alphabet_size = ix->alphabet;
     info->block_bytes = ix->wpp == 1 ? 32 : ix->wpp == 3 ? 64 : 128;
-    info->device_bytes = 2 * ix->blkBytes + ix->textLen + (ix->nSeq + 1) * 8ull + (ix->d_sa ? ix->nRows * 5ull : 0ull) + ix->qtableBytes;
+    info->device_bytes = 2 * ix->blkBytes + ix->textLen + (ix->nSeq + 1) * 8ull + (ix->d_sa ? ix->nRows * 5ull : 0ull) + (ix->d_ctx ? ix->nRows * 32ull : 0ull) + ix->qtableBytes;
     if (!ix->d_sa) info->sampling = 0;
     info->device = ix->device;
     return GM_OK;
@@ -367,9 +407,25 @@ template <int WPP, class EnvT>
 static int launch_one(const SearchArgs& A, unsigned blocks, hipStream_t st)
 {
     const size_t lds = search_lds_bytes(A);
-    if (lds > 65536)   // long needle windows (K + n - 1 up to 509 symbols per lane): ask for more than the default 64 KB of LDS
-        GM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&search_kernel<WPP, EnvT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((search_kernel<WPP, EnvT>), dim3(blocks), dim3(256), lds, st, A);
+    constexpr bool CAN_COOP = WPP == 1 || WPP == 3;
+    if constexpr (CAN_COOP) if (A.coop) {
+        if constexpr (WPP == 3) {
+            if (lds > 65536)   // long needle windows (K + n - 1 up to 509 symbols per lane): ask for more than the default 64 KB of LDS
+                GM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&search_kernel_w4<WPP, EnvT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((search_kernel_w4<WPP, EnvT, true>), dim3(blocks), dim3(256), lds, st, A);
+        } else {
+            if (lds > 65536)
+                GM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&search_kernel<WPP, EnvT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((search_kernel<WPP, EnvT, true>), dim3(blocks), dim3(256), lds, st, A);
+        }
+        GM_HIP(hipGetLastError());
+        return GM_OK;
+    }
+    {
+        if (lds > 65536)
+            GM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&search_kernel<WPP, EnvT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((search_kernel<WPP, EnvT, false>), dim3(blocks), dim3(256), lds, st, A);
+    }
     GM_HIP(hipGetLastError());
     return GM_OK;
 }
@@ -397,7 +453,7 @@ static int launch_search(const gm_index* ix, int mode, const SearchArgs& A, unsi
 template <int WPP> static int occupancy_blocks(int* out, size_t ldsBytes)
 {
     int nb = 0;
-    GM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (search_kernel<WPP, CountEnv<WPP>>), 256, ldsBytes));
+    GM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (search_kernel<WPP, CountEnv<WPP>, false>), 256, ldsBytes));
     *out = nb;
     return GM_OK;
 }
@@ -441,6 +497,7 @@ static int get_qtable(gm_index* ix, uint32_t* qio, const uint4** out)
 
 struct SearchSetup {
     MapPlan plan;
+    ChunkSel sel{0, 0, 0};   // interleaved chunks: which positions of [posBase, posEnd) this call owns
     uint64_t blockBegin = 0, blockEnd = 0, numRoots = 0, kmers = 0;
     unsigned blocks = 1;
     uint32_t posBase = 0, posEnd = 0;   // slice positions covered by the selected blocks: [posBase, posEnd)
@@ -482,7 +539,19 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         if (blockEnd < blockBegin) blockEnd = blockBegin;
     }
     const uint32_t rpb = plan.nSearches * plan.nStrands;
-    S->blockBegin = blockBegin; S->blockEnd = blockEnd; S->numRoots = (blockEnd - blockBegin) * rpb;
+    // interleaved chunks of whole blocks: this call owns the chunks c = chunk_index (mod chunk_stride) of the range
+    const bool chunked = p->chunk_blocks > 0 && p->chunk_stride > 1;
+    uint64_t myBlocks = blockEnd - blockBegin;
+    if (chunked) {
+        if (p->chunk_index >= p->chunk_stride) { set_error("chunk_index >= chunk_stride"); return GM_ERR_BAD_ARG; }
+        if (plan.useList) { set_error("interleaved chunks and a selection cannot be combined (shard a selection with kmer_begin/kmer_end)"); return GM_ERR_BAD_ARG; }
+        const uint64_t T = blockEnd - blockBegin, cb = p->chunk_blocks, full = T / cb, rem = T % cb;
+        myBlocks = (full > p->chunk_index ? (full - p->chunk_index + p->chunk_stride - 1) / p->chunk_stride : 0) * cb;
+        if (rem && full % p->chunk_stride == p->chunk_index) myBlocks += rem;
+        if ((uint64_t)cb * plan.stepSize >= (1ull << 32)) { set_error("chunk too long"); return GM_ERR_BAD_ARG; }
+        S->sel = ChunkSel{(uint32_t)(cb * plan.stepSize), p->chunk_stride, p->chunk_index};
+    }
+    S->blockBegin = blockBegin; S->blockEnd = blockEnd; S->numRoots = myBlocks * rpb;
     uint64_t kmers = 0;
     S->posBase = S->posEnd = 0;
     if (blockEnd > blockBegin) {
@@ -492,6 +561,12 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         } else {
             S->posBase = (uint32_t)(blockBegin * plan.stepSize); S->posEnd = (uint32_t)std::min<uint64_t>(blockEnd * plan.stepSize, plan.numKmers);
             kmers = S->posEnd - S->posBase;
+            if (chunked) {   // k-mers of the own chunks (only the very last block of the text can be short)
+                kmers = myBlocks * plan.stepSize;
+                const uint64_t lastBlock = plan.numBlocks - 1, cb = p->chunk_blocks;
+                if (blockEnd == plan.numBlocks && ((lastBlock - blockBegin) / cb) % p->chunk_stride == p->chunk_index)
+                    kmers -= (uint64_t)plan.numBlocks * plan.stepSize - plan.numKmers;
+            }
         }
     }
     S->kmers = kmers;
@@ -591,6 +666,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     A.sa = ix->d_sa; A.cumGlobal = ix->d_cum; A.nSeqGlobal = ix->nSeq;
     A.posBase = S->posBase; A.windowLen = S->posEnd - S->posBase;
     A.textS = ix->d_textS;
+    A.ctx = ix->tune.useCtx ? ix->d_ctx : nullptr;
     A.verifyT = verifyT;
     A.satMinW = (uint32_t)std::max(1, ix->tune.satMinW);   // default 256: narrow nodes finish sooner than the lookup takes (r01h sweep: 128-256 best)
     // profiles/r01e_infix_sweeps.txt (r01h): 16 / 8 / 4 on the 249 Mbp index; beyond 2^30 rows the fetch loads are HBM
@@ -603,6 +679,10 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     A.probation = (p->E == 0 || ix->nRows >= (1ull << 30)) ? 0u : 2u;
     if (ix->tune.probation >= 0) A.probation = (uint32_t)ix->tune.probation;
     A.verifyCost = (uint32_t)std::max(0, ix->tune.verifyCost);
+    A.chunkBlocks = chunked ? p->chunk_blocks : 0u; A.chunkStride = p->chunk_stride; A.chunkIndex = p->chunk_index;
+    A.skipDup = ix->tune.skipDup >= 0 ? (uint32_t)(ix->tune.skipDup != 0) : 1u;   // profiles/r02: +3..8 % on 3.09 Gbp, +1..5 % on 249 Mbp
+    // groups of lanes read the rank blocks (rank2_coop): +4..12 % with 32-byte blocks on 249 Mbp and 3.09 Gbp (profiles/r02)
+    A.coop = ix->tune.coop >= 0 ? (uint32_t)(ix->tune.coop != 0) : (ix->wpp == 1 ? 1u : 0u);
     *Aout = A;
     return GM_OK;
 }
@@ -642,18 +722,25 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
     const uint64_t plane = text_len + 4;
 
     // a shard (kmer_begin/kmer_end) touches only its own positions [r0, r1) of the accumulators and of out
-    const bool sharded = (p->flags & GM_MAP_FLAG_RANGE) || p->kmer_begin != 0 || p->kmer_end != 0;
+    const bool sharded = (p->flags & GM_MAP_FLAG_RANGE) || p->kmer_begin != 0 || p->kmer_end != 0 || S.sel.len != 0;
     const uint64_t r0 = sharded ? std::min<uint64_t>(S.posBase, text_len) : 0;
     const uint64_t r1 = sharded ? std::min<uint64_t>(std::max<uint64_t>(S.posEnd, r0), text_len) : text_len;
     const uint64_t rn = r1 - r0;
     GM_HIP(hipEventRecord(ix->ev[0], st));
+    const ChunkSel sel = S.sel;   // positions are relative to r0 == posBase (a multiple of the block length)
     if (rn > 0) {
         if (ep) GM_HIP(hipMemsetAsync(ix->d_bits + r0 * wordsPerKmer, 0, rn * wordsPerKmer * sizeof(uint32_t), st));
         else if (store) {
             const size_t pb = p->value_bits == 8 ? 1 : 2;   // plane element: as wide as the result
-            GM_HIP(hipMemsetAsync((uint8_t*)ix->d_acc + r0 * pb, 0, rn * pb, st));
-            GM_HIP(hipMemsetAsync((uint8_t*)ix->d_acc + (plane + r0) * pb, 0, rn * pb, st));
-        } else GM_HIP(hipMemsetAsync(ix->d_acc + r0, 0, rn * sizeof(uint32_t), st));
+            if (sel.len) {
+                hipLaunchKernelGGL(clear_chunks_kernel, dim3(grid_for(rn)), dim3(256), 0, st, (uint8_t*)ix->d_acc + r0 * pb, (uint32_t)pb, rn, sel);
+                hipLaunchKernelGGL(clear_chunks_kernel, dim3(grid_for(rn)), dim3(256), 0, st, (uint8_t*)ix->d_acc + (plane + r0) * pb, (uint32_t)pb, rn, sel);
+            } else {
+                GM_HIP(hipMemsetAsync((uint8_t*)ix->d_acc + r0 * pb, 0, rn * pb, st));
+                GM_HIP(hipMemsetAsync((uint8_t*)ix->d_acc + (plane + r0) * pb, 0, rn * pb, st));
+            }
+        } else if (sel.len) hipLaunchKernelGGL(clear_chunks_kernel, dim3(grid_for(rn)), dim3(256), 0, st, (uint8_t*)(ix->d_acc + r0), 4u, rn, sel);
+        else GM_HIP(hipMemsetAsync(ix->d_acc + r0, 0, rn * sizeof(uint32_t), st));
     }
     GM_HIP(hipMemsetAsync(ix->d_small, 0, SMALL_ZEROED, st));
     A.acc = ix->d_acc; A.accPlane = plane; A.fileBits = ix->d_bits;
@@ -671,16 +758,16 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
         if (p->value_bits == 8) {
             uint8_t* o = (uint8_t*)d_out + r0;
             if (rn == 0) {}
-            else if (ep) hipLaunchKernelGGL(finalize_fileset_kernel<uint8_t>, dim3(g1), dim3(256), 0, st, ix->d_bits + r0 * wordsPerKmer, wordsPerKmer, o, rn);
-            else if (store) hipLaunchKernelGGL((finalize2_kernel<uint8_t, uint8_t>), dim3(g1), dim3(256), 0, st, pf8, pf8 + plane, o, rn, 255u);
-            else hipLaunchKernelGGL(finalize_kernel<uint8_t>, dim3(g4), dim3(256), 0, st, ix->d_acc + r0, o, rn, 255u);
+            else if (ep) hipLaunchKernelGGL(finalize_fileset_kernel<uint8_t>, dim3(g1), dim3(256), 0, st, ix->d_bits + r0 * wordsPerKmer, wordsPerKmer, o, rn, sel);
+            else if (store) hipLaunchKernelGGL((finalize2_kernel<uint8_t, uint8_t>), dim3(g1), dim3(256), 0, st, pf8, pf8 + plane, o, rn, 255u, sel);
+            else hipLaunchKernelGGL(finalize_kernel<uint8_t>, dim3(g4), dim3(256), 0, st, ix->d_acc + r0, o, rn, 255u, sel);
             rc = launch_reset_limits(ix, (uint8_t*)d_out, n_seq, p->K, st);
         } else {
             uint16_t* o = (uint16_t*)d_out + r0;
             if (rn == 0) {}
-            else if (ep) hipLaunchKernelGGL(finalize_fileset_kernel<uint16_t>, dim3(g1), dim3(256), 0, st, ix->d_bits + r0 * wordsPerKmer, wordsPerKmer, o, rn);
-            else if (store) hipLaunchKernelGGL((finalize2_kernel<uint16_t, uint16_t>), dim3(g1), dim3(256), 0, st, pf, pf + plane, o, rn, 65535u);
-            else hipLaunchKernelGGL(finalize_kernel<uint16_t>, dim3(g4), dim3(256), 0, st, ix->d_acc + r0, o, rn, 65535u);
+            else if (ep) hipLaunchKernelGGL(finalize_fileset_kernel<uint16_t>, dim3(g1), dim3(256), 0, st, ix->d_bits + r0 * wordsPerKmer, wordsPerKmer, o, rn, sel);
+            else if (store) hipLaunchKernelGGL((finalize2_kernel<uint16_t, uint16_t>), dim3(g1), dim3(256), 0, st, pf, pf + plane, o, rn, 65535u, sel);
+            else hipLaunchKernelGGL(finalize_kernel<uint16_t>, dim3(g4), dim3(256), 0, st, ix->d_acc + r0, o, rn, 65535u, sel);
             rc = launch_reset_limits(ix, (uint16_t*)d_out, n_seq, p->K, st);
         }
         if (rc) return rc;
@@ -703,6 +790,7 @@ static int locate_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uin
     int rc = prepare_search(ix, text_begin, text_len, first_seq, n_seq, p, intervals, n_intervals, st, &S, &A);
     if (rc) return rc;
     if (!ix->d_sa) { set_error("csv output needs an index built with sampling 1"); return GM_ERR_NEED_LOCATE; }
+    if (S.sel.len) { set_error("gm_locate does not take interleaved chunks"); return GM_ERR_BAD_ARG; }
     const uint64_t W = S.posEnd - S.posBase;
     L->pos_begin = S.posBase; L->n_positions = W;
     L->plus_off = (uint64_t*)calloc(W + 1, 8); L->minus_off = (uint64_t*)calloc(W + 1, 8);
@@ -792,7 +880,7 @@ int gm_map(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t first_
     const size_t bytes = (size_t)text_len * (p->value_bits / 8);
     GM_HIP(hipMalloc(&d_out, bytes + 16));
     int rc = GM_OK;
-    if ((p->flags & GM_MAP_FLAG_RANGE) || p->kmer_begin != 0 || p->kmer_end != 0) {   // a shard leaves the other positions zero
+    if ((p->flags & GM_MAP_FLAG_RANGE) || p->kmer_begin != 0 || p->kmer_end != 0 || (p->chunk_blocks > 0 && p->chunk_stride > 1)) {   // a shard leaves the other positions zero
         hipError_t e = hipMemsetAsync(d_out, 0, bytes, nullptr);
         if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); hipFree(d_out); return GM_ERR_HIP; }
     }
@@ -888,7 +976,7 @@ int gm_index_set_tuning(gm_index* ix, const char* name, int64_t value)
     struct { const char* n; int* f; } tab[] = {
         {"verify_t", &ix->tune.verifyT}, {"lds_stack", &ix->tune.ldsStack}, {"blocks_per_cu", &ix->tune.blocksPerCU}, {"qtable", &ix->tune.qtable},
         {"sat_min_w", &ix->tune.satMinW}, {"fetch_batch", &ix->tune.fetchBatch}, {"probation", &ix->tune.probation}, {"verify_cost", &ix->tune.verifyCost},
-        {"no_store", &ix->tune.noStore}, {"no_saturate", &ix->tune.noSaturate},
+        {"no_store", &ix->tune.noStore}, {"no_saturate", &ix->tune.noSaturate}, {"skip_dup", &ix->tune.skipDup}, {"coop", &ix->tune.coop}, {"use_ctx", &ix->tune.useCtx},
     };
     for (auto& t : tab) if (!strcmp(t.n, name)) { *t.f = (int)value; return GM_OK; }
     set_error("unknown tuning knob '%s'", name);

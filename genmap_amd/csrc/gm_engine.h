@@ -136,6 +136,9 @@ GM_HD Post make_post(uint32_t meta, const Plan& pl, const OssRecord& rec, uint32
 //   void note_step(uint32_t mode, uint32_t width)     (statistics hook)
 //   bool any(bool)                                    (true if the predicate holds in any lane of the wavefront)
 // On return `have` tells whether nd holds a node to continue with.
+template <class Env> GM_HD void lane_children(Node& nd, bool& have, const Root& rt, uint32_t K, uint32_t E, Env& env, const Plan& pl,
+                                             const uint32_t rl[NLET], const uint32_t rh[NLET]);
+
 template <class Env>
 GM_HD void lane_step(Node& nd, bool& have, const Root& rt, uint32_t K, uint32_t E, Env& env)
 {
@@ -144,6 +147,15 @@ GM_HD void lane_step(Node& nd, bool& have, const Root& rt, uint32_t K, uint32_t 
     const uint32_t plo = pl.right ? nd.rlo : nd.flo;
     uint32_t rl[NLET], rh[NLET];
     env.rank2(pl.right, plo, plo + nd.w, rl, rh);
+    lane_children(nd, have, rt, K, E, env, pl, rl, rh);
+}
+
+// The part of a step after the two rank vectors are known.  The kernel calls make_plan / rank / lane_children separately
+// when the rank blocks are read cooperatively (gm_kernels.h: rank2_coop runs with every lane of the wavefront enabled).
+template <class Env>
+GM_HD void lane_children(Node& nd, bool& have, const Root& rt, uint32_t K, uint32_t E, Env& env, const Plan& pl,
+                         const uint32_t rl[NLET], const uint32_t rh[NLET])
+{
     const uint32_t tc = env.text_char(rt, pl.pos);
     const Post ps = make_post(nd.meta, pl, rt.rec, K);
     const uint32_t errs = meta_errs(nd.meta);
@@ -220,9 +232,11 @@ GM_HD void lane_step(Node& nd, bool& have, const Root& rt, uint32_t K, uint32_t 
 //     extends to it without leaving the sequence and with at most E mismatches in total (algo.hpp:26-218 explores the
 //     same single path per k-mer; pattern N and text N count as mismatches, a sentinel ends the occurrence).
 // Env additionally supplies:
-//   uint32_t sa(uint32_t row)                                   text position (sentinel text) of a forward SA row
+//   Env::Item item(uint32_t row)                                the candidate location of a forward SA row: item.p0 = its text
+//                                                               position (sentinel text); the kernel's item also carries
+//                                                               the 56 text symbols around p0 (one 32-byte record per row)
 //   uint64_t needle8(const Root&, uint32_t q, bool down)        8 needle symbols, byte j = needle(q + j) or needle(q - j)
-//   uint64_t text8(uint32_t p0, int32_t off, bool down)         8 sentinel-text symbols, byte j = textS[p0 + off +- j];
+//   uint64_t text8(const Item&, int32_t off, bool down)         8 sentinel-text symbols, byte j = textS[p0 + off +- j];
 //                                                               positions outside the text read as sentinels (5)
 //   void leaf_at(const Root&, uint32_t kmer, uint32_t textPos)  one occurrence of k-mer `kmer` at textPos
 // Symbols are compared eight at a time (one 64-bit word per side).
@@ -244,14 +258,14 @@ GM_HD uint32_t ctz64(uint64_t x)
 // Returns how many characters can be taken: the scan stops in front of a sentinel and in front of mismatch number
 // budget + 1.  cnt = mismatches among the taken characters, pos[j] = 1-based offset of mismatch j (j < 4).
 template <class Env>
-GM_HD uint32_t scan_side(Env& env, const Root& rt, uint32_t p0, uint32_t a0, uint32_t q0, bool down, uint32_t need, uint32_t budget,
+GM_HD uint32_t scan_side(Env& env, const Root& rt, const typename Env::Item& it, uint32_t a0, uint32_t q0, bool down, uint32_t need, uint32_t budget,
                          uint32_t& cnt, uint32_t pos[4])
 {
     cnt = 0;
     for (uint32_t i = 0; i < need; i += 8u) {
         const uint32_t q = down ? q0 - i : q0 + i;
         const uint64_t n8 = env.needle8(rt, q, down);
-        const uint64_t t8 = env.text8(p0, (int32_t)q - (int32_t)a0, down);
+        const uint64_t t8 = env.text8(it, (int32_t)q - (int32_t)a0, down);
         env.note_chunk();
         uint64_t ev = bytes_nonzero(n8 ^ t8) | (0x8080808080808080ull & ~bytes_nonzero(n8 ^ 0x0404040404040404ull))   // mismatch, pattern N
                       | (0x8080808080808080ull & ~bytes_nonzero(t8 ^ 0x0505050505050505ull));                           // sentinel
@@ -276,7 +290,8 @@ template <class Env>
 GM_HD void verify_item(uint32_t row, uint32_t meta, const Root& rt, uint32_t K, uint32_t E, Env& env)
 {
     uint32_t a = meta_a(meta), bx = meta_bx(meta), t = meta_t(meta), errs = meta_errs(meta), mode = meta_mode(meta);
-    const uint32_t p0 = env.sa(row);   // aligned with needle coordinate a0 (a changes below, keep the anchor)
+    const typename Env::Item it = env.item(row);
+    const uint32_t p0 = it.p0;   // aligned with needle coordinate a0 (a changes below, keep the anchor)
     env.note_item(mode);
     const uint32_t a0 = a;
     uint32_t scratch[4];
@@ -286,7 +301,7 @@ GM_HD void verify_item(uint32_t row, uint32_t meta, const Root& rt, uint32_t K, 
             const uint32_t right = oss_right(rt.rec, bi), blen = oss_bl(rt.rec, bi), u = oss_u(rt.rec, bi), l = oss_l(rt.rec, bi);
             const uint32_t need = blen - (bx - a);
             uint32_t c = 0;
-            const uint32_t got = scan_side(env, rt, p0, a0, right ? bx : a - 1u, !right, need, u - errs, c, scratch);
+            const uint32_t got = scan_side(env, rt, it, a0, right ? bx : a - 1u, !right, need, u - errs, c, scratch);
             if (got < need) return;            // sentinel, or more than u[b] errors (find2:388,397-401)
             errs += c;
             if (errs < l) return;              // lower bound of the block not met (find2:254-258, :389-392)
@@ -301,8 +316,8 @@ GM_HD void verify_item(uint32_t row, uint32_t meta, const Root& rt, uint32_t K, 
     const uint32_t budget = E - errs;                 // mismatches still allowed
     uint32_t rp[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu}, lp[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
     uint32_t rc = 0, lc = 0;
-    const uint32_t rlim = scan_side(env, rt, p0, a0, bx, false, smax + K - bx, budget, rc, rp);
-    const uint32_t llim = scan_side(env, rt, p0, a0, a - 1u, true, a - smin, budget, lc, lp);
+    const uint32_t rlim = scan_side(env, rt, it, a0, bx, false, smax + K - bx, budget, rc, rp);
+    const uint32_t llim = scan_side(env, rt, it, a0, a - 1u, true, a - smin, budget, lc, lp);
     for (uint32_t s = smin; s <= smax; ++s) {
         const uint32_t lenL = a - s, lenR = s + K - bx;
         if (lenL > llim || lenR > rlim) continue;

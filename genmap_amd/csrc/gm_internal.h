@@ -23,7 +23,7 @@ namespace gm {
 // -1 = "library default for this call" (depends on K, E and the index size, see prepare_search)
 struct Tuning {
     int verifyT = -1, ldsStack = 4, blocksPerCU = 4, qtable = -1, satMinW = 256, fetchBatch = -1, probation = -1, verifyCost = 3;
-    int noStore = 0, noSaturate = 0;
+    int noStore = 0, noSaturate = 0, skipDup = -1, coop = -1, useCtx = 1;
 };
 }  // namespace gm
 
@@ -42,6 +42,7 @@ struct gm_index {
     uint64_t* d_cum = nullptr;
     uint32_t* d_sa = nullptr;         // forward suffix array (kept when sampling == 1): locate = one HBM read
     uint8_t* d_textS = nullptr;       // sentinel text (verification of narrow nodes), present with d_sa
+    uint4* d_ctx = nullptr;           // verification records {SA[row], 56 symbols around it}, 32 B per row, when HBM allows (gm_kernels.h: CTX_*)
     std::map<uint32_t, uint4*> qtables;   // q -> device table of 4^q entries (built on first use)
     uint64_t sig = 0; bool sigValid = false;   // signature of the call whose tables are on the device
     uint32_t qtableCap = 0;               // != 0: longest prefix that fitted the device so far

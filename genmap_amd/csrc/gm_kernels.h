@@ -52,6 +52,7 @@ struct SearchArgs {
     uint64_t* emit;                 // packed (seqNo << 32 | seqPos) per occurrence
     // ---- verification of narrow nodes (gm_engine.h: verify_item) ----
     const uint8_t* textS;           // sentinel text (one code per byte, 5 = sentinel), nRows bytes
+    const uint4* ctx;               // optional: per forward SA row one 32-byte record {SA[row], 56 symbols around it} (CTX_* below)
     uint32_t verifyT;               // nodes with range width <= verifyT are resolved by verification (0 = off)
     uint32_t fetchBatch;            // roots are drawn when this many lanes are idle (or nothing else is left): the fetch code runs per batch
     uint32_t satMinW;               // saturation is looked up (a global read per covered k-mer) only for nodes at least this wide
@@ -69,7 +70,15 @@ struct SearchArgs {
     uint32_t qlenPacked;            // 4 bits per search: table prefix length q_s (0 = no table for that search)
     uint32_t qselMask;              // bit s: search s uses qtabB
     uint32_t startPacked[2];        // 8 bits per search: startPos of the regular block shape (n == stepSize)
+    uint32_t skipDup;               // 1: the range-hi block is not loaded when it is the range-lo block (saves a translation per shared step)
+    uint32_t coop;                  // 1: rank blocks are read by groups of lanes (rank2_coop); 32- and 64-byte blocks
+    uint32_t chunkBlocks, chunkStride, chunkIndex;   // != 0: this call owns the chunks c = chunkIndex (mod chunkStride) of chunkBlocks blocks each
 };
+
+// which positions of a range belong to the calling shard (interleaved chunks of `len` positions); len == 0: all of them
+struct ChunkSel { uint32_t len, stride, index; };
+__device__ __forceinline__ bool chunk_mine(const ChunkSel& c, uint64_t j) { return c.len == 0u || (uint32_t)((j / c.len) % c.stride) == c.index; }
+
 
 // sentinel-text position -> (seqNo, seqPos); sequence s starts at cum[s] + s
 __device__ __forceinline__ uint2 locate_position(const uint64_t* __restrict__ cum, uint32_t nSeq, uint32_t p)
@@ -88,6 +97,11 @@ __device__ __forceinline__ void covered_kmers(uint32_t meta, uint32_t n, uint32_
     else if (md == M_EXT_L) { smin = bx - K; smax = t; }
     else { smin = bx - K; smax = a; }
 }
+
+// Verification record of a suffix-array row (built once per index when HBM allows, gm_api.hip: make_ctx): word 0 = SA[row] = p0,
+// words 1..7 = the 56 symbols textS[p0 - CTX_LEFT .. p0 - CTX_LEFT + 55], 4 bits each (symbol i in bits 4(i%8) of word 1 + i/8).
+// One aligned 32-byte read replaces the dependent pair "SA entry, then text around it" (two to three random requests).
+constexpr int32_t CTX_LEFT = 24, CTX_SYMS = 56;
 
 constexpr uint32_t WORK_CHUNK = 256;   // roots taken from the global counter per atomic
 constexpr uint32_t VERIFY_TMAX = 4;    // widest range resolved by verification
@@ -135,12 +149,97 @@ template <int WPP> struct EnvBase {
         // range lo and range hi usually share a block once the range is narrow: one request instead of two
         // always two loads: when lo and hi share a block the second one is an L1 hit, which is cheaper than a divergent
         // branch around it (r01h: +5..9 %); the miss count (algorithmic lines) is unchanged
+        if (A.skipDup) {   // wave-uniform choice
+            // (the placeholder is opaque to the optimiser: otherwise it turns "placeholder, conditional load, select" into
+            // "copy of the lo block, conditional load", which waits for the first load before it issues the second)
+            const uint32_t z = opaque_zero();
 #pragma unroll
-        for (int j = 0; j < NV; ++j) { uint4 v = ph[j]; wh[4 * j] = v.x; wh[4 * j + 1] = v.y; wh[4 * j + 2] = v.z; wh[4 * j + 3] = v.w; }
+            for (int j = 0; j < NV * 4; ++j) wh[j] = z;
+            if (bl != bh) {   // lanes whose range ends in the block it starts in issue no second request
+#pragma unroll
+                for (int j = 0; j < NV; ++j) { uint4 v = ph[j]; wh[4 * j] = v.x; wh[4 * j + 1] = v.y; wh[4 * j + 2] = v.z; wh[4 * j + 3] = v.w; }
+            }
+            uint32_t same = bl == bh ? 1u : 0u;
+            asm volatile("" : "+v"(same));
+#pragma unroll
+            for (int j = 0; j < NV * 4; ++j) wh[j] = same ? wl[j] : wh[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) { uint4 v = ph[j]; wh[4 * j] = v.x; wh[4 * j + 1] = v.y; wh[4 * j + 2] = v.z; wh[4 * j + 3] = v.w; }
+        }
         block_rank<WPP>(wl, lo - bl * SPB, rl);
         block_rank<WPP>(wh, hi - bh * SPB, rh);
 #ifdef GM_COUNTERS
         steps += 1; lines += 1 + (bl != bh);
+#endif
+    }
+    // ---- cooperative form of rank2: G = BYTES/16 adjacent lanes read ONE block with ONE 16-byte load each ----
+    // Beyond ~4 GiB of randomly read footprint the memory system charges per lane-load (address translation), not per block
+    // or byte (profiles/r02/r02a_gather2_*: 64-B blocks read by one lane 19 G/s, by four lanes 48 G/s).  The lanes of a
+    // group take turns as owner: in round r every lane of the group loads its 16-byte piece of the two blocks owner r asked
+    // for; a butterfly of DPP exchanges then hands every owner the pieces of its own blocks.  Must be called with all 64
+    // lanes enabled; lanes without a query pass lo = hi = 0.
+    static __device__ __forceinline__ uint32_t opaque_zero() { uint32_t z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); return z; }
+    template <int CTRL> static __device__ __forceinline__ uint32_t dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false); }
+    template <int CTRL> static __device__ __forceinline__ uint4 dpp4(const uint4& v) { return make_uint4(dpp<CTRL>(v.x), dpp<CTRL>(v.y), dpp<CTRL>(v.z), dpp<CTRL>(v.w)); }
+    static __device__ __forceinline__ uint4 sel4(bool c, const uint4& a, const uint4& b) { return make_uint4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w); }
+    // exchange step of the transposition: lanes that differ in bit `bit` of their group index swap lo's upper with hi's lower register
+    template <int CTRL> static __device__ __forceinline__ void exchange(bool up, uint4& low, uint4& high)
+    {
+        const uint4 recv = dpp4<CTRL>(sel4(up, low, high));
+        low = sel4(up, recv, low);
+        high = sel4(up, high, recv);
+    }
+    template <int G> static __device__ __forceinline__ void transpose(uint32_t j, uint4 (&V)[G])
+    {
+        static_assert(G == 2 || G == 4, "groups of 2 or 4 lanes");
+        const bool b0 = (j & 1u) != 0u;
+        if (G == 2) { exchange<0xB1>(b0, V[0], V[1]); return; }              // quad_perm [1,0,3,2]
+        exchange<0xB1>(b0, V[0], V[1]); exchange<0xB1>(b0, V[2 % G], V[3 % G]);
+        const bool b1 = (j & 2u) != 0u;
+        exchange<0x4E>(b1, V[0], V[2 % G]); exchange<0x4E>(b1, V[1], V[3 % G]);   // quad_perm [2,3,0,1]
+    }
+    template <int R> __device__ __forceinline__ void coop_round(uint32_t bl, uint32_t bhx, uint32_t j, uint4& L, uint4& H, uint32_t& dup, uint32_t z)
+    {
+        constexpr int G = (5 + 3 * WPP + 3) / 4;
+        constexpr int BC = G == 2 ? (R == 0 ? 0xA0 : 0xF5) : R * 0x55;   // broadcast of lane R of the group: quad_perm [R,R,R,R] / [0,0,2,2] / [1,1,3,3]
+        const uint32_t obl = dpp<BC>(bl), obhx = dpp<BC>(bhx);
+        const uint32_t obh = obhx & 0x7FFFFFFFu;
+        const uint4* pb = reinterpret_cast<const uint4*>((obhx >> 31) ? A.blk[1] : A.blk[0]);
+        L = pb[(size_t)obl * G + j];
+        H = make_uint4(z, z, z, z);                    // opaque placeholder, see rank2
+        if (obl != obh) H = pb[(size_t)obh * G + j];   // group-uniform: nobody touches a block twice
+        uint32_t d = obl == obh ? 1u : 0u;
+        asm volatile("" : "+v"(d));   // opaque: the final select must not be folded into the branch above (see rank2)
+        dup |= d << R;
+    }
+    __device__ __forceinline__ void rank2_coop(uint32_t right, uint32_t lo, uint32_t hi, uint32_t rl[NLET], uint32_t rh[NLET])
+    {
+        constexpr uint32_t SPB = BlockGeom<WPP>::SPB;
+        constexpr int G = (5 + 3 * WPP + 3) / 4;
+        const uint32_t j = threadIdx.x & (uint32_t)(G - 1);
+        const uint32_t bl = lo / SPB, bh = hi / SPB;
+        const uint32_t bhx = bh | right << 31;   // block indexes stay below 2^27
+        uint4 L[G], H[G];
+        uint32_t dup = 0;
+        const uint32_t z = opaque_zero();
+        coop_round<0>(bl, bhx, j, L[0], H[0], dup, z);
+        coop_round<1>(bl, bhx, j, L[1], H[1], dup, z);
+        if (G == 4) { coop_round<2 % G>(bl, bhx, j, L[2 % G], H[2 % G], dup, z); coop_round<3 % G>(bl, bhx, j, L[3 % G], H[3 % G], dup, z); }
+#pragma unroll
+        for (int r = 0; r < G; ++r) H[r] = sel4(((dup >> r) & 1u) != 0u, L[r], H[r]);
+        transpose<G>(j, L);
+        transpose<G>(j, H);
+        uint32_t wl[G * 4], wh[G * 4];
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            wl[4 * k] = L[k].x; wl[4 * k + 1] = L[k].y; wl[4 * k + 2] = L[k].z; wl[4 * k + 3] = L[k].w;
+            wh[4 * k] = H[k].x; wh[4 * k + 1] = H[k].y; wh[4 * k + 2] = H[k].z; wh[4 * k + 3] = H[k].w;
+        }
+        block_rank<WPP>(wl, lo - bl * SPB, rl);
+        block_rank<WPP>(wh, hi - bh * SPB, rh);
+#ifdef GM_COUNTERS
+        if (lo | hi) { steps += 1; lines += 1 + (bl != bh); }
 #endif
     }
     __device__ __forceinline__ uint32_t text_char(const Root& rt, uint32_t pos) const
@@ -168,13 +267,47 @@ template <int WPP> struct EnvBase {
     __device__ __forceinline__ uint32_t C(uint32_t c) const { return A.C[c]; }
     __device__ __forceinline__ bool any(bool b) const { return __ballot(b) != 0ull; }
     __device__ __forceinline__ uint32_t sa(uint32_t row) const { return A.sa[row]; }
+    struct Item { uint32_t p0; uint32_t w[7]; };
+    __device__ __forceinline__ Item item(uint32_t row) const
+    {
+        Item it;
+        if (A.ctx) {   // wave-uniform
+            const uint4 c0 = A.ctx[(size_t)row * 2], c1 = A.ctx[(size_t)row * 2 + 1];
+            it.p0 = c0.x; it.w[0] = c0.y; it.w[1] = c0.z; it.w[2] = c0.w; it.w[3] = c1.x; it.w[4] = c1.y; it.w[5] = c1.z; it.w[6] = c1.w;
+        } else {
+            it.p0 = A.sa[row];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) it.w[k] = 0u;
+        }
+        return it;
+    }
+    // 8 consecutive symbols of the record starting at symbol index s (0 <= s <= 48), one per byte
+    static __device__ __forceinline__ uint64_t ctx8(const Item& it, uint32_t s)
+    {
+        const uint32_t k = s >> 3;
+        // words k and k + 1 (word 7 does not exist: never needed for s <= 48 unless the shift is 0, then its bits are not used)
+        const uint32_t a01 = (k & 1u) ? it.w[1] : it.w[0], a23 = (k & 1u) ? it.w[3] : it.w[2], a45 = (k & 1u) ? it.w[5] : it.w[4], a6 = it.w[6];
+        const uint32_t b01 = (k & 1u) ? it.w[2] : it.w[1], b23 = (k & 1u) ? it.w[4] : it.w[3], b45 = (k & 1u) ? it.w[6] : it.w[5];
+        const uint32_t lo = (k & 4u) ? ((k & 2u) ? a6 : a45) : ((k & 2u) ? a23 : a01);
+        const uint32_t hi = (k & 4u) ? ((k & 2u) ? 0u : b45) : ((k & 2u) ? b23 : b01);
+        const uint32_t sh = (s & 7u) * 4u;
+        const uint32_t v = sh ? (lo >> sh) | (hi << (32u - sh)) : lo;
+        // 8 nibbles -> 8 bytes
+        uint32_t x0 = v & 0xFFFFu, x1 = v >> 16;
+        x0 = (x0 | (x0 << 8)) & 0x00FF00FFu; x0 = (x0 | (x0 << 4)) & 0x0F0F0F0Fu;
+        x1 = (x1 | (x1 << 8)) & 0x00FF00FFu; x1 = (x1 | (x1 << 4)) & 0x0F0F0F0Fu;
+        return (uint64_t)x1 << 32 | x0;
+    }
     // eight consecutive bytes starting at p (any alignment): two aligned 64-bit loads and a funnel shift
     static __device__ __forceinline__ uint64_t load8_up(const uint8_t* p)
     {
         const uintptr_t u = reinterpret_cast<uintptr_t>(p);
-        const uint64_t* b = reinterpret_cast<const uint64_t*>(u & ~static_cast<uintptr_t>(7));
+        // ONE 16-byte load from the 8-aligned address below p (a lane-load is the unit the memory system charges for
+        // beyond the TLB reach, profiles/r02/r02a_gather2_*): two 64-bit halves, funnel-shifted
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2), aligned(8)));
+        const u64x2 v = *reinterpret_cast<const u64x2*>(u & ~static_cast<uintptr_t>(7));
         const uint32_t sh = (uint32_t)(u & 7u) * 8u;
-        const uint64_t lo = b[0], hi = b[1];
+        const uint64_t lo = v.x, hi = v.y;
         return sh ? (lo >> sh) | (hi << (64u - sh)) : lo;
     }
     static __device__ __forceinline__ uint64_t load8_down(const uint8_t* p) { return __builtin_bswap64(load8_up(p - 7)); }   // p[0], p[-1], ..
@@ -189,9 +322,16 @@ template <int WPP> struct EnvBase {
         const uint8_t* p = A.text + (size_t)rt.win + (K + rt.n - 2u - q);   // needle(q) = comp(text[win + W - 1 - q])
         return complement8(down ? load8_up(p) : load8_down(p));
     }
-    __device__ __forceinline__ uint64_t text8(uint32_t p0, int32_t off, bool down) const
+    __device__ __forceinline__ uint64_t text8(const Item& it, int32_t off, bool down) const
     {
-        const uint8_t* p = A.textS + ((long long)p0 + off);   // 512 sentinel bytes of padding on both sides
+        if (A.ctx) {   // wave-uniform: the record holds symbols p0 - CTX_LEFT .. p0 - CTX_LEFT + 55
+            const int32_t s = off + CTX_LEFT - (down ? 7 : 0);
+            if (s >= 0 && s <= CTX_SYMS - 8) {
+                const uint64_t v = ctx8(it, (uint32_t)s);
+                return down ? __builtin_bswap64(v) : v;
+            }
+        }
+        const uint8_t* p = A.textS + ((long long)it.p0 + off);   // 512 sentinel bytes of padding on both sides
         return down ? load8_down(p) : load8_up(p);
     }
 };
@@ -309,8 +449,8 @@ template <int WPP> struct OccEmitEnv : EnvBase<WPP> {
 #else
 #define GM_WAVES_ATTR
 #endif
-template <int WPP, class EnvT>
-__global__ __launch_bounds__(256) GM_WAVES_ATTR void search_kernel(const SearchArgs A)
+template <int WPP, class EnvT, bool COOP>
+__device__ __forceinline__ void search_body(const SearchArgs& A)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const size_t gl = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -419,7 +559,12 @@ __global__ __launch_bounds__(256) GM_WAVES_ATTR void search_kernel(const SearchA
                     const uint32_t off = (uint32_t)(poolCur - poolBase) + rank + poolRem;   // < WORK_CHUNK + rootsPerBlock
                     const uint32_t db = off / A.rootsPerBlock;
                     const uint32_t r = off - db * A.rootsPerBlock;
-                    const unsigned long long gb = A.blockBegin + poolBlock + db;
+                    unsigned long long gb = poolBlock + db;   // ordinal of the block among this call's blocks
+                    if (A.chunkBlocks) {                      // interleaved chunks: ordinal -> (own chunk number, block inside it)
+                        const uint32_t q = (uint32_t)gb / A.chunkBlocks;
+                        gb = (unsigned long long)(q * A.chunkStride + A.chunkIndex) * A.chunkBlocks + ((uint32_t)gb - q * A.chunkBlocks);
+                    }
+                    gb += A.blockBegin;
                     if (A.blockList) { const uint2 e = A.blockList[gb]; frt.win = e.x; frt.n = e.y; }
                     else {
                         frt.win = (uint32_t)gb * A.stepSize;                  // slice positions fit 32 bits
@@ -529,9 +674,25 @@ __global__ __launch_bounds__(256) GM_WAVES_ATTR void search_kernel(const SearchA
                 if (nd.w >= A.satMinW && env.saturated(rt, smin, smax)) { if (leftDone) have = false; else nd = left; }
                 else if (!leftDone) env.push(left);
             }
-            if (have) {
+            if constexpr (!COOP) if (have) {
                 const bool lone = nd.w == 1u;
                 lane_step(nd, have, rt, A.K, A.E, env);
+                w1run = (lone && have && nd.w == 1u) ? w1run + 1u : 0u;
+            }
+        }
+        if constexpr (COOP) {   // the rank blocks are read by groups of lanes: every lane walks through the reads
+            Plan pl; pl.right = pl.exact = pl.minErr = pl.charsLeft = pl.pos = 0;
+            uint32_t plo = 0, phi = 0;
+            if (have) {
+                pl = make_plan(nd.meta, rt.rec, A.E);
+                env.note_step(meta_mode(nd.meta), nd.w);
+                plo = pl.right ? nd.rlo : nd.flo; phi = plo + nd.w;
+            }
+            uint32_t rl[NLET], rh[NLET];
+            env.rank2_coop(pl.right, plo, phi, rl, rh);
+            if (have) {
+                const bool lone = nd.w == 1u;
+                lane_children(nd, have, rt, A.K, A.E, env, pl, rl, rh);
                 w1run = (lone && have && nd.w == 1u) ? w1run + 1u : 0u;
             }
         }
@@ -560,6 +721,13 @@ __global__ __launch_bounds__(256) GM_WAVES_ATTR void search_kernel(const SearchA
 #endif
 }
 
+template <int WPP, class EnvT, bool COOP>
+__global__ __launch_bounds__(256) GM_WAVES_ATTR void search_kernel(const SearchArgs A) { search_body<WPP, EnvT, COOP>(A); }
+// the same kernel compiled for 4 waves per SIMD (at most 128 VGPRs): the cooperative 64-byte variant needs a few registers more
+// than that by itself and loses a wave of occupancy otherwise
+template <int WPP, class EnvT, bool COOP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void search_kernel_w4(const SearchArgs A) { search_body<WPP, EnvT, COOP>(A); }
+
 // SA ranges of every ACGT string of length q in both indexes (right extensions from the root): the top of the search
 // tree, tabulated once per index and q.
 template <int WPP>
@@ -587,20 +755,22 @@ __global__ __launch_bounds__(256) void qmer_table_kernel(const uint32_t* __restr
 
 // store planes -> c[]
 template <typename TValue, typename TPlane>
-__global__ __launch_bounds__(256) void finalize2_kernel(const TPlane* __restrict__ accF, const TPlane* __restrict__ accR, TValue* __restrict__ out, uint64_t n, uint32_t maxVal)
+__global__ __launch_bounds__(256) void finalize2_kernel(const TPlane* __restrict__ accF, const TPlane* __restrict__ accR, TValue* __restrict__ out, uint64_t n, uint32_t maxVal, ChunkSel sel)
 {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
+    if (j >= n || !chunk_mine(sel, j)) return;
     const uint32_t v = (uint32_t)accF[j] + accR[j];   // each plane holds min(count, its own maximum)
     out[j] = (TValue)(v < maxVal ? v : maxVal);
 }
 
 template <typename TValue>
-__global__ __launch_bounds__(256) void finalize_kernel(const uint32_t* __restrict__ acc, TValue* __restrict__ out, uint64_t n, uint32_t maxVal)
+__global__ __launch_bounds__(256) void finalize_kernel(const uint32_t* __restrict__ acc, TValue* __restrict__ out, uint64_t n, uint32_t maxVal, ChunkSel sel)
 {
     const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4ull;
     const bool aligned = ((reinterpret_cast<uintptr_t>(out + i)) & (sizeof(TValue) * 4 - 1)) == 0 && ((reinterpret_cast<uintptr_t>(acc + i)) & 15) == 0;
-    if (i + 4 <= n && aligned) {
+    if (sel.len) {
+        for (uint64_t j = i; j < n && j < i + 4; ++j) if (chunk_mine(sel, j)) { const uint32_t v = acc[j]; out[j] = (TValue)(v < maxVal ? v : maxVal); }
+    } else if (i + 4 <= n && aligned) {
         const uint4 v = *reinterpret_cast<const uint4*>(acc + i);
         TValue r[4] = {(TValue)(v.x < maxVal ? v.x : maxVal), (TValue)(v.y < maxVal ? v.y : maxVal),
                        (TValue)(v.z < maxVal ? v.z : maxVal), (TValue)(v.w < maxVal ? v.w : maxVal)};
@@ -613,10 +783,10 @@ __global__ __launch_bounds__(256) void finalize_kernel(const uint32_t* __restric
 
 // --exclude-pseudo: hits[j] = distinct_sequences.size(), a narrowing store without saturation (algo.hpp:360)
 template <typename TValue>
-__global__ __launch_bounds__(256) void finalize_fileset_kernel(const uint32_t* __restrict__ bits, uint32_t wordsPerKmer, TValue* __restrict__ out, uint64_t n)
+__global__ __launch_bounds__(256) void finalize_fileset_kernel(const uint32_t* __restrict__ bits, uint32_t wordsPerKmer, TValue* __restrict__ out, uint64_t n, ChunkSel sel)
 {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
+    if (j >= n || !chunk_mine(sel, j)) return;
     uint32_t c = 0;
     for (uint32_t w = 0; w < wordsPerKmer; ++w) c += (uint32_t)__popc(bits[j * wordsPerKmer + w]);
     out[j] = (TValue)c;
@@ -639,6 +809,14 @@ __global__ __launch_bounds__(256) void run_values_kernel(const TValue* __restric
 {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r < nRuns) val[r] = (uint16_t)c[starts[r]];
+}
+
+// zero the calling shard's chunks of a workspace (elements of `eb` bytes, positions [0, n) of the range)
+__global__ __launch_bounds__(256) void clear_chunks_kernel(uint8_t* __restrict__ base, uint32_t eb, uint64_t n, ChunkSel sel)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n || !chunk_mine(sel, j)) return;
+    if (eb == 1) base[j] = 0; else if (eb == 2) reinterpret_cast<uint16_t*>(base)[j] = 0; else reinterpret_cast<uint32_t*>(base)[j] = 0;
 }
 
 // resetLimits (algo.hpp:10-22): zero the last K-1 positions of every sequence of the slice.

@@ -1,12 +1,78 @@
 """One-process-per-GPU sharding of a computeMappability call and the gather of its result.
 
-Every rank holds a full index replica (2 BWTs ~ 1.3 B/symbol each: a 3.1 Gbp index is ~4 GB of 288 GB) and
-computes a disjoint, contiguous range of whole k-mer blocks; positions are independent given the read-only
-index (the only coupling in the reference, copying a value to duplicate k-mers at src/algo.hpp:389-396, is
-an optimisation the GPU build drops).  The only collective is ONE gather of the 8/16-bit frequency shards to
-the root over RCCL/xGMI -- no reduction, positions are disjoint.  Works with any torch.distributed backend
-(nccl = RCCL on ROCm; gloo in the CPU tests)."""
+Every rank holds a full index replica (a 3.1 Gbp index is a few GB of the 288) and computes disjoint sets of whole k-mer
+blocks; positions are independent given the read-only index (the only coupling in the reference, copying a value to
+duplicate k-mers at src/algo.hpp:389-396, is an optimisation the GPU build drops).
+
+Load balance: the reference deals >= 50 dynamic chunks per worker because "repeats are slower than unique regions"
+(src/algo.hpp:422-434).  ShardPlan does the static equivalent: the k-mer blocks are cut into fixed chunks -- CHUNKS_PER_RANK
+per rank -- dealt round-robin, so an 18-Mbp N desert or a repeat family is spread over every rank
+(gm_map_params.chunk_blocks / chunk_index / chunk_stride).  The only collective is ONE gather of the ranks' chunks of the
+8/16-bit frequency vector to the root over RCCL/xGMI -- no reduction, positions are disjoint.  Works with any
+torch.distributed backend (nccl = RCCL on ROCm; gloo in the CPU tests).  csv / --exclude-pseudo location lists are
+variable-length and travel as contiguous ranges (shard_ranges + gather_locations)."""
 from typing import List, Tuple
+
+CHUNKS_PER_RANK = 64
+
+
+class ShardPlan:
+    """Interleaved chunks of whole k-mer blocks for `world` ranks over the k-mer positions [0, num_kmers)."""
+
+    def __init__(self, num_kmers: int, step_size: int, world: int, chunks_per_rank: int = CHUNKS_PER_RANK):
+        self.num_kmers, self.step_size, self.world = int(num_kmers), int(step_size), int(world)
+        self.nblocks = (self.num_kmers + step_size - 1) // step_size
+        want = max(1, world * chunks_per_rank)
+        self.chunk_blocks = max(1, -(-self.nblocks // want))            # ceil: at most `want` chunks
+        self.chunk_len = self.chunk_blocks * step_size                   # positions per chunk
+        self.nchunks = -(-self.nblocks // self.chunk_blocks) if self.nblocks else 0
+        self.rows = -(-max(self.nchunks, 1) // world) * world            # chunk slots, a multiple of world
+
+    def chunk_arg(self, rank: int):
+        """(chunk_blocks, chunk_index, chunk_stride) for Index.map_device; None on a single rank"""
+        return None if self.world == 1 else (self.chunk_blocks, rank, self.world)
+
+    def padded_len(self, text_len: int) -> int:
+        """elements a rank's result buffer needs so that it can be viewed as [rows, chunk_len]"""
+        return max(int(text_len), self.rows * self.chunk_len) + 16
+
+    def positions_of(self, rank: int):
+        """[(begin, end)] position ranges owned by `rank` (tests, diagnostics)"""
+        out = []
+        for c in range(rank, self.nchunks, self.world):
+            b = c * self.chunk_len
+            out.append((b, min(b + self.chunk_len, self.num_kmers)))
+        return out
+
+    def describe(self) -> str:
+        if self.world == 1:
+            return "one GPU, whole text"
+        return (f"{self.nchunks} chunks of {self.chunk_blocks} k-mer blocks ({self.chunk_len} positions) dealt round-robin to {self.world} ranks, "
+                f"index replicated, one gather of the 8-bit chunks to rank 0")
+
+
+def gather_chunks(local_full, plan: ShardPlan, rank: int, dist, dst: int = 0, stage_on_host: bool = False):
+    """local_full: this rank's frequency vector (1-D tensor of plan.padded_len(text_len) elements, own chunks filled).
+    After the call the dst rank's local_full holds every rank's chunks.  The rank's chunks are a strided view
+    [rank::world] of the [rows, chunk_len] matrix: packed with one device copy, gathered, unpacked the same way."""
+    world = plan.world
+    if world == 1:
+        return local_full
+    import torch
+    item = local_full.element_size()
+    mat = local_full[:plan.rows * plan.chunk_len].view(torch.uint8).view(plan.rows, plan.chunk_len * item)   # raw bytes: collectives do not take 16-bit unsigned
+    send = mat[rank::world].contiguous()
+    if stage_on_host:   # backends without device-memory collectives (gloo rehearsal): same data path through host buffers
+        send = send.cpu()
+    if rank == dst:
+        recv = [torch.empty_like(send) for _ in range(world)]
+        dist.gather(send, recv, dst=dst)
+        for r in range(world):
+            if r != dst:
+                mat[r::world] = recv[r].to(local_full.device)
+    else:
+        dist.gather(send, None, dst=dst)
+    return local_full
 
 
 def shard_ranges(num_kmers: int, step_size: int, world: int) -> List[Tuple[int, int]]:

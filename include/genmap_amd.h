@@ -103,6 +103,12 @@ typedef struct gm_map_params {
                               /*        range computes nothing).  gm_map leaves the other positions zero,     */
                               /*        gm_map_device does not touch them (apart from the boundary reset),  */
                               /*        so shards can share one device buffer.                              */
+    /* interleaved chunks (multi-GPU load balance; the reference deals >= 50 dynamic chunks per worker because "repeats are
+     * slower than unique regions", src/algo.hpp:422-434): with chunk_blocks > 0 and chunk_stride > 1 the k-mer blocks of the
+     * range are cut into chunks of chunk_blocks whole blocks (a block = K - infix + 1 consecutive k-mers) and this call
+     * computes the chunks whose number is congruent to chunk_index modulo chunk_stride.  gm_map_device touches only the
+     * positions of those chunks.  Not supported by gm_locate. */
+    uint32_t chunk_blocks, chunk_index, chunk_stride, reserved1;
 } gm_map_params;
 #define GM_MAP_FLAG_RANGE 1   /* [kmer_begin, kmer_end) is a shard even when it is empty or (0,0) */
 

@@ -40,7 +40,8 @@ template <int WPP> struct EmuEnv {
     const uint32_t* saArr = nullptr;
     const std::vector<uint8_t>* textSent = nullptr;
     uint64_t verified = 0;
-    uint32_t sa(uint32_t row) const { return saArr[row]; }
+    struct Item { uint32_t p0; };
+    Item item(uint32_t row) const { return Item{saArr[row]}; }
     uint64_t needle8(const Root& rt, uint32_t q, bool down) const
     {
         uint64_t v = 0;
@@ -53,8 +54,9 @@ template <int WPP> struct EmuEnv {
         }
         return v;
     }
-    uint64_t text8(uint32_t p0, int32_t off, bool down) const
+    uint64_t text8(const Item& it, int32_t off, bool down) const
     {
+        const uint32_t p0 = it.p0;
         uint64_t v = 0;
         for (uint32_t j = 0; j < 8; ++j) {
             const int64_t idx = (int64_t)p0 + off + (down ? -(int64_t)j : (int64_t)j);

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from genmap_amd.distributed import gather_frequency, max_shard_len, shard_ranges
+from genmap_amd.distributed import ShardPlan, gather_chunks, gather_frequency, max_shard_len, shard_ranges
 
 
 def test_shard_ranges_cover_and_align():
@@ -19,6 +19,67 @@ def test_shard_ranges_cover_and_align():
             assert b == c and a <= b
         for a, b in r:
             assert a % step == 0 or a == nk
+
+
+def test_shard_plan_partitions_every_position_once():
+    """interleaved chunks: every k-mer position belongs to exactly one rank, chunks are whole blocks, and every rank
+    gets its share of every region (>= 50 chunks per rank on a large text, src/algo.hpp:422-428)"""
+    for nk, step, world in ((1000, 22, 2), (1000, 7, 3), (5, 7, 4), (248956393, 15, 8), (100, 1, 3), (0, 5, 2), (3088269803, 5, 8)):
+        plan = ShardPlan(nk, step, world)
+        assert plan.rows % world == 0 and plan.rows * plan.chunk_len >= nk
+        assert plan.chunk_len % step == 0
+        total = 0
+        prev_end = {}
+        seen = []
+        for r in range(world):
+            for b, e in plan.positions_of(r):
+                assert b % step == 0 and b < e <= nk
+                seen.append((b, e, r))
+                total += e - b
+        assert total == nk
+        seen.sort()
+        for (b0, e0, _), (b1, e1, _) in zip(seen[:-1], seen[1:]):
+            assert e0 == b1
+        if nk > 10**8:
+            for r in range(world):
+                assert len(plan.positions_of(r)) >= 50
+        assert plan.chunk_arg(0) is None if world == 1 else plan.chunk_arg(1) == (plan.chunk_blocks, 1, world)
+
+
+def _chunk_worker(rank, world, port, nk, step, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    plan = ShardPlan(nk, step, world, chunks_per_rank=5)
+    n = nk + 29
+    ok = True
+    for dt, mod in ((torch.uint8, 251), (torch.uint16, 65521)):
+        truth = torch.from_numpy(((np.arange(n, dtype=np.int64) * 977) % mod).astype(np.uint8 if dt == torch.uint8 else np.uint16))
+        truth[nk:] = 0
+        local = torch.zeros(plan.padded_len(n), dtype=dt)
+        for b, e in plan.positions_of(rank):     # what this rank's gm_map_device(chunks=plan.chunk_arg(rank)) would have written
+            local[b:e] = truth[b:e]
+        gather_chunks(local, plan, rank, dist)
+        if rank == 0:
+            ok &= bool(torch.equal(local[:n].view(torch.uint8), truth.view(torch.uint8)))
+    if rank == 0:
+        q.put(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_chunks_reassembles_frequency_vector(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_chunk_worker, args=(r, world, port, 10007, 22, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+    assert ok
 
 
 def _free_port():

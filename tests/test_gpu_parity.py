@@ -173,9 +173,11 @@ def test_gpu_baseline_settings_small(K, E):
         for bits in (8, 16):
             exp = ora.mappability(K, E, value_bits=bits, threads=8)
             for T in (0, 1, 4):
-                ix.set_tuning(verify_t=T)
-                out = ix.map(K, E, value_bits=bits)
-                assert np.array_equal(out, exp), (K, E, bits, bb, T)
+                for coop in ((0, 1) if bb in (32, 64) else (0,)):   # rank blocks read by one lane / by groups of lanes
+                    for ctx in (1, 0):                               # verification from the 32-byte row records / from SA + text
+                        ix.set_tuning(verify_t=T, coop=coop, use_ctx=ctx)
+                        out = ix.map(K, E, value_bits=bits)
+                        assert np.array_equal(out, exp), (K, E, bits, bb, T, coop, ctx)
         ix.close()
 
 
