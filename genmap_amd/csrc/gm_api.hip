@@ -401,7 +401,7 @@ template <typename T> static int grow(T** p, uint64_t* cap, uint64_t need)
 
 enum LeafMode { LEAF_COUNT = 0, LEAF_FILESET = 1, LEAF_OCC_COUNT = 2, LEAF_OCC_EMIT = 3, LEAF_STORE = 4, LEAF_STORE8 = 5 };
 
-static inline size_t search_lds_bytes(const SearchArgs& A) { return (size_t)(4u * A.vqCap + 4u * 64u * (A.ldsDepth + A.winChunks)) * 16u; }
+static inline size_t search_lds_bytes(const SearchArgs& A) { return (size_t)(4u * A.vqCap + 4u * 64u * (A.ldsDepth + A.winChunks)) * 16u + 4u * 128u * 4u; }
 
 template <int WPP, class EnvT>
 static int launch_one(const SearchArgs& A, unsigned blocks, hipStream_t st)
@@ -592,7 +592,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     const uint32_t winChunks = (31u + p->K + plan.stepSize - 1u + 31u) / 32u;
     uint32_t ldsDepth = (uint32_t)std::max(0, ix->tune.ldsStack);
     ldsDepth = std::min(ldsDepth, depth);
-    const size_t ldsBytes = (size_t)(4u * vqCap + 4u * 64u * (ldsDepth + winChunks)) * 16u;
+    const size_t ldsBytes = (size_t)(4u * vqCap + 4u * 64u * (ldsDepth + winChunks)) * 16u + 4u * 128u * 4u;   // == search_lds_bytes
     int perCU = 0;
     switch (ix->wpp) { case 1: rc = occupancy_blocks<1>(&perCU, ldsBytes); break; case 3: rc = occupancy_blocks<3>(&perCU, ldsBytes); break; default: rc = occupancy_blocks<9>(&perCU, ldsBytes); break; }
     if (rc) return rc;
@@ -682,6 +682,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     A.chunkBlocks = chunked ? p->chunk_blocks : 0u; A.chunkStride = p->chunk_stride; A.chunkIndex = p->chunk_index;
     A.skipDup = ix->tune.skipDup >= 0 ? (uint32_t)(ix->tune.skipDup != 0) : 1u;   // profiles/r02: +3..8 % on 3.09 Gbp, +1..5 % on 249 Mbp
     // groups of lanes read the rank blocks (rank2_coop): +4..12 % with 32-byte blocks on 249 Mbp and 3.09 Gbp (profiles/r02)
+    A.steal = ix->tune.steal > 0 ? 1u : 0u;
     A.coop = ix->tune.coop >= 0 ? (uint32_t)(ix->tune.coop != 0) : (ix->wpp == 1 ? 1u : 0u);
     *Aout = A;
     return GM_OK;
@@ -976,7 +977,7 @@ int gm_index_set_tuning(gm_index* ix, const char* name, int64_t value)
     struct { const char* n; int* f; } tab[] = {
         {"verify_t", &ix->tune.verifyT}, {"lds_stack", &ix->tune.ldsStack}, {"blocks_per_cu", &ix->tune.blocksPerCU}, {"qtable", &ix->tune.qtable},
         {"sat_min_w", &ix->tune.satMinW}, {"fetch_batch", &ix->tune.fetchBatch}, {"probation", &ix->tune.probation}, {"verify_cost", &ix->tune.verifyCost},
-        {"no_store", &ix->tune.noStore}, {"no_saturate", &ix->tune.noSaturate}, {"skip_dup", &ix->tune.skipDup}, {"coop", &ix->tune.coop}, {"use_ctx", &ix->tune.useCtx},
+        {"no_store", &ix->tune.noStore}, {"no_saturate", &ix->tune.noSaturate}, {"skip_dup", &ix->tune.skipDup}, {"coop", &ix->tune.coop}, {"use_ctx", &ix->tune.useCtx}, {"steal", &ix->tune.steal},
     };
     for (auto& t : tab) if (!strcmp(t.n, name)) { *t.f = (int)value; return GM_OK; }
     set_error("unknown tuning knob '%s'", name);

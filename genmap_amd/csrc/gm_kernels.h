@@ -72,6 +72,7 @@ struct SearchArgs {
     uint32_t startPacked[2];        // 8 bits per search: startPos of the regular block shape (n == stepSize)
     uint32_t skipDup;               // 1: the range-hi block is not loaded when it is the range-lo block (saves a translation per shared step)
     uint32_t coop;                  // 1: rank blocks are read by groups of lanes (rank2_coop); 32- and 64-byte blocks
+    uint32_t steal;                 // 1: lanes without work take the top of a neighbour's stack (work sharing inside the wavefront)
     uint32_t chunkBlocks, chunkStride, chunkIndex;   // != 0: this call owns the chunks c = chunkIndex (mod chunkStride) of chunkBlocks blocks each
 };
 
@@ -466,6 +467,17 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     env.lstk = smem + 4u * A.vqCap + wv * (A.ldsDepth * 64u) + lane;
     uint4* const wbase = smem + 4u * A.vqCap + 4u * A.ldsDepth * 64u + wv * (A.winChunks * 64u);   // this wavefront's windows
     env.lwin = reinterpret_cast<const uint8_t*>(wbase + lane);
+    // work sharing inside the wavefront: a lane may work on the root of another lane (stolen stack entries); it then reads
+    // that lane's needle window (wlane) and the owner may not stage a new window while users[owner] != 0
+    uint32_t* const users = reinterpret_cast<uint32_t*>(smem + 4u * A.vqCap + 4u * 64u * (A.ldsDepth + A.winChunks)) + wv * 128u;   // [64] users | [64] pairing
+    uint32_t* const pairing = users + 64;
+    uint4* const lstkW = smem + 4u * A.vqCap + wv * (A.ldsDepth * 64u);
+    uint4* const stkW = A.stack + (gl & ~(size_t)63) * A.spillDepth;
+    uint32_t wlane = lane;
+    if (A.steal) { users[lane] = 0u; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+#ifdef GM_COUNTERS
+    uint32_t nSteals = 0;
+#endif
     uint32_t qsize = 0;                             // wave-uniform
 #ifdef GM_COUNTERS
     uint32_t wvIter = 0, wvActive = 0, wvRounds = 0;
@@ -501,6 +513,51 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
             covered_kmers(nd.meta, rt.n, A.K, smin, smax);
             have = !(nd.w >= A.satMinW && env.saturated(rt, smin, smax));   // pending work for k-mers that already reached MAX is dropped
         }
+        // ---- work sharing inside the wavefront: idle lanes take the top of the stack of lanes that have pending nodes ----
+        if (A.steal) {
+            if (wlane != lane && !have && env.sp == 0u) {   // the borrowed root is finished: give its window back
+                atomicSub(&users[wlane], 1u);
+                wlane = lane; env.lwin = reinterpret_cast<const uint8_t*>(wbase + lane);
+            }
+            const bool idle = !have && env.sp == 0u && fs == 0u;
+            const bool rich = have && env.sp >= 1u;
+            const unsigned long long im = __ballot(idle), vm = __ballot(rich);
+            if (im != 0ull && vm != 0ull) {
+                const uint32_t np = min((uint32_t)__popcll(im), (uint32_t)__popcll(vm));
+                const uint32_t ri = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
+                const uint32_t rv = __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0u));
+                const bool robbed = rich && rv < np, thief = idle && ri < np;
+                if (robbed) pairing[rv] = lane;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                uint32_t src = lane;
+                if (thief) src = pairing[ri];
+                const int a4 = (int)(src << 2);
+                // the victim's stack height, root and window (every lane takes part: the victims' registers are the source)
+                const uint32_t vsp = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)env.sp);
+                const uint32_t vwin = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)rt.win);
+                const uint32_t vnss = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)(rt.n | rt.strand << 9 | rt.search << 10));
+                const uint32_t vrx = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)rt.rec.x), vry = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)rt.rec.y);
+                const uint32_t vrz = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)rt.rec.z), vrw = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)rt.rec.w);
+                const uint32_t vwo = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)(env.woff | wlane << 8));
+                if (thief) {
+                    const uint32_t level = vsp - 1u;
+                    const uint4 v = level < A.ldsDepth ? lstkW[level * 64u + src] : stkW[(size_t)(level - A.ldsDepth) * 64u + src];
+                    nd.flo = v.x; nd.rlo = v.y; nd.w = v.z; nd.meta = v.w; have = true; w1run = 0;
+                    rt.win = vwin; rt.n = vnss & 0x1FFu; rt.strand = (vnss >> 9) & 1u; rt.search = vnss >> 10;
+                    rt.rec.x = vrx; rt.rec.y = vry; rt.rec.z = vrz; rt.rec.w = vrw;
+                    env.on_root();
+                    env.woff = vwo & 0xFFu; wlane = vwo >> 8;
+                    env.lwin = reinterpret_cast<const uint8_t*>(wbase + wlane);
+                    atomicAdd(&users[wlane], 1u);
+#ifdef GM_COUNTERS
+                    nSteals++;
+#endif
+                }
+                if (robbed) env.sp -= 1u;
+            }
+        }
         // ---- root fetch, pipelined over iterations so that the wavefront never waits for it ----
         // stage 3: the q-mer table entry has arrived -> the root becomes the lane's node (or turns out empty)
         if (fs == 2u) {
@@ -533,7 +590,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
         // stage 1: lanes without node, stack or fetch in flight draw a root (ballot rank) and issue its loads
 #pragma unroll 1
         for (int round = 0; round < 2; ++round) {
-            const bool need = !have && fs == 0u && env.sp == 0u && !exhausted;
+            const bool need = !have && fs == 0u && env.sp == 0u && !exhausted && (!A.steal || __hip_atomic_load(&users[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == 0u);
             const unsigned long long m = __ballot(need);
             if (m == 0ull) break;
             // the whole wavefront walks through the fetch stages for whoever needs a root: wait until enough lanes do
@@ -657,7 +714,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
         }
         GM_LAP(tVerify);
         if (__ballot(have) == 0ull && qsize == 0u) {
-            if (__ballot(!exhausted || fs != 0u) == 0ull) break;   // nothing in flight, nothing queued, nothing left to draw
+            if (__ballot(!exhausted || fs != 0u || env.sp != 0u) == 0ull) break;   // nothing in flight, nothing queued or stacked, nothing left to draw
             continue;
         }
 

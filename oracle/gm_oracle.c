@@ -170,6 +170,16 @@ gmo_index *gmo_index_from_bwt(const uint8_t *bf, const uint8_t *br, const uint8_
     return ix;
 }
 
+int gmo_index_adopt_sa(gmo_index *ix, const uint32_t *sa)
+{
+    if (!ix || !sa) return -1;
+    free(ix->sa);
+    ix->sa = (uint32_t *)malloc(ix->n * 4);
+    if (!ix->sa) return -1;
+    memcpy(ix->sa, sa, ix->n * 4);
+    return 0;
+}
+
 void gmo_index_free(gmo_index *ix)
 {
     if (!ix) return;

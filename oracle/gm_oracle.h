@@ -39,6 +39,11 @@ gmo_index *gmo_index_build(const uint8_t *codes, const uint64_t *seq_len, uint32
 gmo_index *gmo_index_from_bwt(const uint8_t *bwt_fwd, const uint8_t *bwt_rev,
                               const uint8_t *codes, const uint64_t *seq_len, uint32_t n_seq);
 
+/* Adopt a forward suffix array for an index made by gmo_index_from_bwt (sentinel-text positions, n_total entries) so that
+ * locate (csv, --exclude-pseudo) works without suffix-sorting a large text on the CPU.  The caller vouches for it: the tests
+ * check sa against the adopted BWT (bwt[i] == symbol before sa[i], LF-walk consistency) before using it.  Returns 0. */
+int gmo_index_adopt_sa(gmo_index *, const uint32_t *sa_fwd);
+
 void gmo_index_free(gmo_index *);
 
 /* Accessors used by tests to compare the product's builder against the oracle's. */

@@ -180,6 +180,8 @@ def oracle_lib():
     lib.gmo_index_build.argtypes = [u8p, u64p, C.c_uint32, C.c_int]
     lib.gmo_index_from_bwt.restype = vp
     lib.gmo_index_from_bwt.argtypes = [u8p, u8p, u8p, u64p, C.c_uint32]
+    lib.gmo_index_adopt_sa.restype = C.c_int
+    lib.gmo_index_adopt_sa.argtypes = [vp, vp]
     lib.gmo_index_free.argtypes = [vp]
     lib.gmo_index_size.restype = C.c_uint64
     lib.gmo_index_size.argtypes = [vp]
@@ -209,7 +211,7 @@ def _ptr(a):
 
 
 class OracleIndex:
-    def __init__(self, codes, seq_len, keep_sa=True, bwt=None):
+    def __init__(self, codes, seq_len, keep_sa=True, bwt=None, sa=None):
         self.lib = oracle_lib()
         self.codes = np.ascontiguousarray(codes, dtype=np.uint8)
         self.seq_len = np.ascontiguousarray(seq_len, dtype=np.uint64)
@@ -222,6 +224,10 @@ class OracleIndex:
             self.h = self.lib.gmo_index_from_bwt(_ptr(bf), _ptr(br), _ptr(self.codes), _ptr(self.seq_len), len(self.seq_len))
         if not self.h:
             raise RuntimeError("oracle index build failed")
+        if bwt is not None and sa is not None:   # adopted suffix array (checked by the caller, see check_sa_against_bwt)
+            sa = np.ascontiguousarray(sa, dtype=np.uint32)
+            if self.lib.gmo_index_adopt_sa(self.h, _ptr(sa)) != 0:
+                raise RuntimeError("oracle could not adopt the suffix array")
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -278,6 +284,40 @@ class OracleIndex:
         out = np.zeros(int(self.cum[-1]), dtype=np.uint8 if value_bits == 8 else np.uint16)
         self.lib.gmo_trivial_backtracking(self.h, K, E, int(revcompl), value_bits, _ptr(out))
         return out
+
+
+def check_sa_against_bwt(codes, seq_len, bwt_fwd, sa):
+    """A suffix array handed to the oracle together with an adopted forward BWT is pinned by two properties: it is a
+    permutation of the sentinel-text positions whose preceding symbols are the BWT (sentinel rows wrap to the sequence's
+    own end marker), and following the BWT's LF mapping decrements it (sa[LF(i)] == sa[i] - 1) -- together they
+    determine sa from the BWT, whose own correctness the smaller builder-vs-oracle tests pin."""
+    seq_len = np.asarray(seq_len, dtype=np.int64)
+    n = int(seq_len.sum()) + len(seq_len)
+    sa = np.asarray(sa).astype(np.int64)
+    assert len(sa) == n and len(bwt_fwd) == n
+    textS = np.full(n, 5, dtype=np.uint8)
+    starts = np.concatenate([[0], np.cumsum(seq_len + 1)])[:-1]
+    ends = starts + seq_len                      # position of every sequence's sentinel
+    pos = 0
+    off = 0
+    for s, ln in zip(starts, seq_len):
+        textS[s:s + ln] = codes[off:off + ln]
+        off += int(ln)
+    assert np.array_equal(np.sort(sa), np.arange(n))
+    prev = textS[sa - 1]                         # sa == 0 wraps to textS[-1], the last sentinel
+    assert np.array_equal(prev, np.asarray(bwt_fwd))
+    # LF: row i with symbol c = bwt[i] (a letter) maps to C[c] + rank_c(i)
+    b = np.asarray(bwt_fwd)
+    cnt = np.bincount(b, minlength=6)
+    C = np.zeros(6, dtype=np.int64); C[0] = cnt[5]
+    for c in range(1, 5):
+        C[c] = C[c - 1] + cnt[c - 1]
+    lf = np.full(n, -1, dtype=np.int64)
+    for c in range(5):
+        idx = np.flatnonzero(b == c)
+        lf[idx] = C[c] + np.arange(len(idx))
+    m = lf >= 0
+    assert np.array_equal(sa[lf[m]], sa[m] - 1)
 
 
 def _unpack_locations(L):

@@ -567,24 +567,124 @@ def test_gpu_full_size_chr1_e1_vs_group_and_count():
     ix.close()
 
 
-@pytest.mark.skipif(not os.environ.get("GM_FULL_GRCH38"), reason="opt-in (GM_FULL_GRCH38=1): 3.1 Gbp, ~3 min and ~150 GB of HBM")
-def test_gpu_full_size_grch38_vs_index_free_comparators():
-    """BASELINE config C3's text (24 sequences, 3.1 Gbp): e=0 at every position; e=1 on the first GM_FULL_E1_SCALE of it"""
+def _interval_set(lens, K, n_per=3000):
+    """k-mer ranges that exercise what differs between regions of the S2/S3 texts: the start of the text (leading N block),
+    the edge of the big N block of the first sequence, a stretch inside it, a boundary between two sequences, the middle
+    of a later sequence (planted repeat families are everywhere), the last sequence and the end of the text"""
+    cum = np.concatenate([[0], np.cumsum(np.asarray(lens, dtype=np.int64))])
+    n = int(cum[-1])
+    L0 = int(lens[0])
+    nb0 = int(L0 * 0.49)                                # make_sequence: big N block starts here
+    iv = [(0, n_per), (9000, 9000 + n_per), (nb0 - n_per // 2, nb0 + n_per // 2), (nb0 + 100000, nb0 + 100000 + n_per // 4)]
+    if len(lens) > 1:
+        iv.append((int(cum[1]) - n_per // 2, int(cum[1]) + n_per // 2))                       # sequence boundary
+        mid = len(lens) // 2
+        iv.append((int(cum[mid]) + int(lens[mid]) // 3, int(cum[mid]) + int(lens[mid]) // 3 + n_per))
+        iv.append((int(cum[-2]) + int(lens[-1]) // 4, int(cum[-2]) + int(lens[-1]) // 4 + n_per))   # last sequence
+    iv.append((n - K - n_per, n - K + 1))
+    return [(max(0, a), min(n - K + 1, b)) for a, b in iv]
+
+
+def test_gpu_full_size_grch38_e0_everywhere_e1_e2_k100_on_intervals():
+    """BASELINE configs C3 and C4 on their own text (S3: 24 sequences, 3,088,269,832 bp): K=30 e=0 at every position against
+    the index-free sort-and-count restatement; K=30 e=2 (C3), K=100 e=1 (C4) and K=30 e=1 against the CPU oracle (which
+    adopts the GPU-built BWTs: suffix-sorting 3.1 Gbp on the CPU is not a test) on intervals at the N-block edges, a
+    sequence boundary, inside repeat-bearing sequence, in the last sequence and at the end of the text."""
     import torch
     g = _gm()
     from genmap_amd import synth
-    codes, lens, _ = synth.workload("grch38", 1.0)
-    ix = g.Index.build(codes, lens, sampling=0)
-    exp = _torch_exact_counts(codes, 30, 255, "cuda:0", lens=lens).astype(np.uint8)
+    scale = float(os.environ.get("GM_GRCH38_SCALE", "1.0"))
+    codes, lens, _ = synth.workload("grch38", scale)
+    n = len(codes)
+    exp = _torch_exact_counts(codes, 30, 255, "cuda:0", lens=lens).astype(np.uint8)   # before the index exists: both need > 100 GB
     torch.cuda.empty_cache()
-    assert np.array_equal(ix.map(30, 0, value_bits=8), exp)
-    ix.close()
+    ix = g.Index.build(codes, lens, sampling=1)
+    out0 = ix.map(30, 0, value_bits=8)
+    assert np.array_equal(out0, exp)
     del exp
-    codes, lens, _ = synth.workload("grch38", float(os.environ.get("GM_FULL_E1_SCALE", "0.2")))
-    ix = g.Index.build(codes, lens, sampling=0)
-    exp = _torch_hamming1_counts(codes, 30, 65535, "cuda:0", lens=lens).to(torch.int32).cpu().numpy().astype(np.uint16)
+    bf, br = ix.export_bwt()
+    ora = H.OracleIndex(codes, lens, keep_sa=False, bwt=(bf, br))
+    del bf, br
+    iv = _interval_set(lens, 100)
+    sel = np.zeros(n, bool)
+    for a, b in iv:
+        sel[a:b] = True
+    for K, E, bits in ((30, 2, 16), (100, 1, 16), (30, 1, 8), (30, 0, 16)):
+        got = ix.map(K, E, value_bits=bits, intervals=iv)
+        want = ora.mappability(K, E, value_bits=bits, threads=os.cpu_count() or 8, intervals=iv)
+        assert np.array_equal(got, want), (K, E)
+        assert (got[~sel] == 0).all()
+        if (K, E) == (30, 2):
+            assert (np.minimum(got[sel], 255) >= out0[sel]).all()      # monotone in e
+    ix.close()
+
+
+def test_gpu_24_sequences_62mbp_e1_e2_every_position():
+    """a 24-sequence, 61.8 Mbp slice of the S3 text (GM_SLICE_SCALE): K=30 e=1 and e=2 at EVERY position against the
+    index-free group-and-count restatements (windows with one / every pair of positions blanked)"""
+    import torch
+    g = _gm()
+    from genmap_amd import synth
+    codes, lens, _ = synth.workload("grch38", float(os.environ.get("GM_SLICE_SCALE", "0.02")))
+    assert len(lens) == 24
+    exp2 = _torch_hamming2_counts(codes, 30, 65535, "cuda:0", lens=lens).to(torch.int32).cpu().numpy().astype(np.uint16)
+    exp1 = _torch_hamming1_counts(codes, 30, 65535, "cuda:0", lens=lens).to(torch.int32).cpu().numpy().astype(np.uint16)
     torch.cuda.empty_cache()
-    assert np.array_equal(ix.map(30, 1, value_bits=16), exp)
+    ix = g.Index.build(codes, lens, sampling=1)
+    assert np.array_equal(ix.map(30, 2, value_bits=16), exp2)
+    assert np.array_equal(ix.map(30, 2, value_bits=8), np.minimum(exp2, 255).astype(np.uint8))
+    assert np.array_equal(ix.map(30, 1, value_bits=16), exp1)
+    ix.close()
+
+
+def test_gpu_ecoli_like_full_size_vs_oracle():
+    """BASELINE config C1's text (S1: one 4,641,652 bp Dna4 sequence): K=30 e=0 and e=1 at every position, e=2 on intervals,
+    against the CPU oracle on its OWN index (own suffix sort), and the builder's BWTs against the oracle's"""
+    g = _gm()
+    from genmap_amd import synth
+    codes, lens, _ = synth.workload("ecoli", 1.0)
+    ora = H.OracleIndex(codes, lens, keep_sa=False)
+    ix = g.Index.build(codes, lens, sampling=1)
+    bf, br = ix.export_bwt()
+    assert np.array_equal(bf, ora.bwt(0)) and np.array_equal(br, ora.bwt(1))
+    T = os.cpu_count() or 8
+    for K, E, bits in ((30, 0, 8), (30, 0, 16), (30, 1, 16)):
+        assert np.array_equal(ix.map(K, E, value_bits=bits), ora.mappability(K, E, value_bits=bits, threads=T)), (K, E, bits)
+    iv = _interval_set(lens, 30, 20000)
+    assert np.array_equal(ix.map(30, 2, value_bits=16, intervals=iv), ora.mappability(30, 2, value_bits=16, threads=T, intervals=iv))
+    ix.close()
+
+
+def test_gpu_five_bacteria_full_size_exclude_pseudo_vs_oracle():
+    """BASELINE config C5 at its real size (S5: five related genomes, ~21 Mbp in 10 sequences): K=24 e=1 --exclude-pseudo.
+    The oracle adopts the GPU-built BWTs and suffix array (checked against each other first: check_sa_against_bwt) and
+    computes the distinct-file counts on intervals of every file; the GPU computes every position of every file.  Plus
+    the location lists (csv) of one interval per file."""
+    g = _gm()
+    from genmap_amd import synth
+    files = synth.bacteria5(float(os.environ.get("GM_BACT_SCALE", "1.0")))
+    gen = H.Genome(files)
+    ix = g.Index.build(gen.codes, gen.seq_len, sampling=1)
+    bf, br = ix.export_bwt()
+    sa = ix.export_sa()
+    H.check_sa_against_bwt(gen.codes, gen.seq_len, bf, sa)
+    ora = H.OracleIndex(gen.codes, gen.seq_len, keep_sa=False, bwt=(bf, br), sa=sa)
+    K, E, T = 24, 1, os.cpu_count() or 8
+    nfiles = len(files)
+    for name, first, nseq, tb, tl in gen.file_slices():
+        out = ix.map(K, E, first_seq=first, n_seq=nseq, value_bits=16, exclude_pseudo=True, seq_file_id=gen.seq_file)
+        assert out.max() <= nfiles
+        iv = [(0, 4000), (tl // 3 - 2000, tl // 3 + 2000), (tl * 20 // 21 - 3000, tl * 20 // 21 + 3000), (tl - 5000, tl - K + 1)]   # start, N patch, island edge, end
+        iv = [(max(0, a), min(tl - K + 1, b)) for a, b in iv]
+        want, _, locs = ora.mappability(K, E, first_seq=first, n_seq=nseq, text_begin=tb, text_len=tl, value_bits=16, directory=True,
+                                        exclude_pseudo=True, csv=True, seq_file_id=gen.seq_file, threads=T, intervals=iv)
+        sel = np.zeros(tl, bool)
+        for a, b in iv:
+            sel[a:b] = True
+        assert np.array_equal(out[sel], want[sel]), name
+        # csv location lists of the same intervals
+        loc = ix.locate(K, E, first_seq=first, n_seq=nseq, intervals=iv)
+        assert _csv_entries(gen, first, nseq, K, loc) == locs, name
     ix.close()
 
 
