@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--sampling", type=int, default=1, help="1: keep the suffix array resident (narrow nodes are verified against the text); 0: rank queries only")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the single-GPU rehearsal of the N>1 path)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--comm", default="p2p", choices=["p2p", "collective"], help="N > 1: chunks pushed into the root's vector with peer DMA copies "
+                    "overlapping the search kernel (falls back to the collective when IPC is not available), or one gather collective per step")
+    ap.add_argument("--verify", action="store_true", help="N > 1: after the timed steps rank 0 recomputes the whole vector alone and compares it with the gathered one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true")
     args = ap.parse_args()
@@ -138,7 +141,7 @@ def main():
     info = ix.info()
     log(f"index built on the GPU in {t_build:.1f} s: {info['n_rows']} rows, {info['block_bytes']}-B blocks, {info['device_bytes'] / 2**30:.2f} GiB")
 
-    from genmap_amd.distributed import ShardPlan, gather_chunks
+    from genmap_amd.distributed import PeerGather, ShardPlan, gather_chunks
     stream = torch.cuda.current_stream().cuda_stream
     out = None
 
@@ -156,12 +159,33 @@ def main():
         plan = ShardPlan(num_kmers, K - infix + 1, world)
         if out is None:
             out = torch.zeros(plan.padded_len(n), dtype=torch.uint8, device=dev)        # -fs: 8-bit frequencies
-        comm = {"ms": 0.0}
+        comm = {"wait_s": 0.0, "mode": "none"}
+        pg = None
+        if world > 1 and args.comm == "p2p":
+            pg = PeerGather(plan, n, 1, rank, local_rank, dist)
+            if not pg.ok:
+                log("peer copies not available between these ranks: falling back to the gather collective")
+                pg.close(); pg = None
+        if world > 1:
+            comm["mode"] = "peer DMA copies overlapping compute" if pg else "gather collective"
 
         def one_step():
-            ix.map_device(out.data_ptr(), K, E, infix=args.infix, value_bits=8, chunks=plan.chunk_arg(rank), stream=stream)
-            if world > 1:
-                gather_chunks(out, plan, rank, dist, stage_on_host=(args.backend != "nccl"))
+            if pg is None:
+                ix.map_device(out.data_ptr(), K, E, infix=args.infix, value_bits=8, chunks=plan.chunk_arg(rank), stream=stream)
+                if world > 1:
+                    t1 = time.perf_counter()
+                    gather_chunks(out, plan, rank, dist, stage_on_host=(args.backend != "nccl"))
+                    comm["wait_s"] += time.perf_counter() - t1
+                return
+            for sub in plan.sub_ranges(pg.launches):      # the chunks of one launch travel while the next launch computes
+                ix.map_device(pg.local_ptr, K, E, infix=args.infix, value_bits=8, kmer_range=sub, chunks=plan.chunk_arg(rank), stream=stream)
+                ev = torch.cuda.Event()
+                ev.record()
+                pg.push(sub, ev)
+            t1 = time.perf_counter()
+            torch.cuda.current_stream().synchronize()
+            pg.finish()
+            comm["wait_s"] += time.perf_counter() - t1
 
         for _ in range(warmup):
             one_step()
@@ -171,7 +195,27 @@ def main():
             one_step()
         sync()
         dt = time.perf_counter() - t0
-        kms = ix.kernel_times(steps)   # HIP events around the search kernel of each timed step, on the launch stream
+        launches = pg.launches if pg else 1
+        kms = ix.kernel_times(steps * launches)   # HIP events around the search kernel of each timed launch, on the launch stream
+        kms = [float(np.sum(kms[i * launches:(i + 1) * launches])) for i in range(len(kms) // launches)]
+        if args.verify and world > 1:
+            sync()
+            if rank == 0:
+                got = torch.empty(n, dtype=torch.uint8, device=dev)
+                if pg:
+                    g.push_pieces(local_rank, got.data_ptr(), pg.local_ptr, 0, 0, n, 1, 0, None)
+                else:
+                    got.copy_(out[:n])
+                ref = torch.zeros(n + 16, dtype=torch.uint8, device=dev)
+                ix.map_device(ref.data_ptr(), K, E, infix=args.infix, value_bits=8, stream=stream)
+                torch.cuda.synchronize()
+                same = bool(torch.equal(got, ref[:n]))
+                log(f"verify K={K} E={E}: gathered vector {'==' if same else '!='} single-rank vector ({comm['mode']})")
+                if not same:
+                    raise SystemExit("gathered result differs from the single-rank result")
+            sync()
+        if pg:
+            pg.close()
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         if world > 1:
             if args.backend != "nccl":
@@ -179,7 +223,8 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         return {"K": K, "E": E, "infix": infix, "num_kmers": num_kmers, "steps": steps, "warmup": warmup, "dt": dt,
-                "kernel_ms": float(np.mean(kms)), "kernel_ms_min": float(np.min(kms)), "my_compute_ms": float(np.mean(kms)), "plan": plan}
+                "kernel_ms": float(np.mean(kms)), "kernel_ms_min": float(np.min(kms)), "my_compute_ms": float(np.mean(kms)), "plan": plan,
+                "comm_mode": comm["mode"], "my_comm_wait_ms": comm["wait_s"] / max(1, steps + warmup) * 1e3}
 
     def host_rate(K, E):
         """PCIe-inclusive rate of the drop-in call gm_map (host result vector): never `value`"""
@@ -200,10 +245,10 @@ def main():
     # per-rank diagnosis for N > 1: compute ms per rank and shard imbalance (so that a scaling run is readable)
     per_rank = None
     if world > 1:
-        mine = torch.tensor([head["my_compute_ms"]], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        mine = torch.tensor([head["my_compute_ms"], head["my_comm_wait_ms"]], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         allms = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allms, mine)
-        per_rank = [float(x.item()) for x in allms]
+        per_rank = [[float(v) for v in x.tolist()] for x in allms]
 
     # ---- roofline numerators: count node steps / distinct rank lines with the instrumented twin (untimed) ----
     counted = {}
@@ -272,8 +317,10 @@ def main():
             "roofline": roofline(head),
         }
         if per_rank is not None:
-            result["per_rank_search_ms"] = per_rank
-            result["shard_imbalance"] = max(per_rank) / max(1e-9, float(np.mean(per_rank)))
+            result["per_rank_search_ms"] = [r[0] for r in per_rank]         # search kernel per step, per rank
+            result["per_rank_comm_wait_ms"] = [r[1] for r in per_rank]      # host time per step spent waiting for the gather / the copies
+            result["shard_imbalance"] = max(r[0] for r in per_rank) / max(1e-9, float(np.mean([r[0] for r in per_rank])))
+            result["comm"] = head["comm_mode"]
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_rec(head)
         if subs:

@@ -5,4 +5,5 @@ plus the `genmap` host program.  This package is only the thin ctypes binding us
 bench.py and by the one-process-per-GPU launcher; it contains no compute path of its own and raises if
 the HIP library cannot be loaded or no GPU is present.
 """
-from .capi import (GenmapError, Index, MapParams, default_infix_length, device_count, tuned_infix_length, lib_path, load_library)  # noqa: F401
+from .capi import (GenmapError, Index, MapParams, default_infix_length, device_count, tuned_infix_length, lib_path, load_library,  # noqa: F401
+                   device_alloc, device_free, ipc_export, ipc_open, ipc_close, push_pieces)

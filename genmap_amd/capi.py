@@ -51,7 +51,7 @@ class Locations(C.Structure):
 
 MAP_FLAG_RANGE = 1
 
-EXPORTS = ["gm_index_set_tuning", "gm_index_sync", "gm_map_kernel_times", "gm_map_runs", "gm_runs_free", "gm_tuned_infix_length", "gm_index_export_sa", "gm_locate", "gm_locations_free", "gm_status_string", "gm_last_error", "gm_device_count", "gm_index_build", "gm_index_import",
+EXPORTS = ["gm_device_alloc", "gm_device_free", "gm_ipc_export", "gm_ipc_open", "gm_ipc_close", "gm_push_pieces", "gm_map_shard", "gm_host_pin", "gm_host_unpin", "gm_index_set_tuning", "gm_index_sync", "gm_map_kernel_times", "gm_map_runs", "gm_runs_free", "gm_tuned_infix_length", "gm_index_export_sa", "gm_locate", "gm_locations_free", "gm_status_string", "gm_last_error", "gm_device_count", "gm_index_build", "gm_index_import",
            "gm_index_export_bwt", "gm_index_get_info", "gm_index_free", "gm_map", "gm_map_device",
            "gm_last_map_stats", "gm_default_infix_length"]
 
@@ -95,6 +95,24 @@ def load_library(profiling=False):
     lib.gm_index_free.argtypes = [vp]
     lib.gm_map.restype = C.c_int
     lib.gm_map.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(MapParams), vp, C.c_uint64, vp, vp]
+    lib.gm_map_shard.restype = C.c_int
+    lib.gm_map_shard.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(MapParams), vp, C.c_uint64, vp, vp]
+    lib.gm_host_pin.restype = C.c_int
+    lib.gm_host_pin.argtypes = [vp, C.c_uint64]
+    lib.gm_host_unpin.restype = C.c_int
+    lib.gm_host_unpin.argtypes = [vp]
+    lib.gm_device_alloc.restype = C.c_int
+    lib.gm_device_alloc.argtypes = [C.c_int, C.c_uint64, C.POINTER(vp)]
+    lib.gm_device_free.restype = C.c_int
+    lib.gm_device_free.argtypes = [C.c_int, vp]
+    lib.gm_ipc_export.restype = C.c_int
+    lib.gm_ipc_export.argtypes = [C.c_int, vp, C.c_char_p]
+    lib.gm_ipc_open.restype = C.c_int
+    lib.gm_ipc_open.argtypes = [C.c_int, C.c_char_p, C.POINTER(vp)]
+    lib.gm_ipc_close.restype = C.c_int
+    lib.gm_ipc_close.argtypes = [C.c_int, vp]
+    lib.gm_push_pieces.restype = C.c_int
+    lib.gm_push_pieces.argtypes = [C.c_int, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, vp]
     lib.gm_map_device.restype = C.c_int
     lib.gm_map_device.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(MapParams), vp, C.c_uint64, vp, vp, vp]
     lib.gm_map_runs.restype = C.c_int
@@ -139,6 +157,44 @@ def tuned_infix_length(K, E):
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def device_alloc(device, nbytes):
+    """gm_device_alloc: a zeroed base allocation on `device` (exportable through HIP IPC); returns the device pointer"""
+    lib = load_library()
+    p = C.c_void_p()
+    _check(lib, lib.gm_device_alloc(device, nbytes, C.byref(p)))
+    return p.value
+
+
+def device_free(device, ptr):
+    lib = load_library()
+    _check(lib, lib.gm_device_free(device, C.c_void_p(ptr)))
+
+
+def ipc_export(device, ptr):
+    lib = load_library()
+    buf = C.create_string_buffer(64)
+    _check(lib, lib.gm_ipc_export(device, C.c_void_p(ptr), buf))
+    return bytes(buf.raw)
+
+
+def ipc_open(device, handle):
+    lib = load_library()
+    p = C.c_void_p()
+    _check(lib, lib.gm_ipc_open(device, C.c_char_p(handle) if False else C.create_string_buffer(handle, 64), C.byref(p)))
+    return p.value
+
+
+def ipc_close(device, ptr):
+    lib = load_library()
+    _check(lib, lib.gm_ipc_close(device, C.c_void_p(ptr)))
+
+
+def push_pieces(device, dst, src, first_byte, pitch_bytes, piece_bytes, n_rows, last_piece_bytes=0, stream=None):
+    """gm_push_pieces: this shard's chunks of src -> the same offsets of dst (device-to-device, one async copy per chunk)"""
+    lib = load_library()
+    _check(lib, lib.gm_push_pieces(device, C.c_void_p(dst), C.c_void_p(src), first_byte, pitch_bytes, piece_bytes, n_rows, last_piece_bytes, C.c_void_p(stream or 0)))
 
 
 class Index:
@@ -222,6 +278,17 @@ class Index:
         sf = None if seq_file_id is None else np.ascontiguousarray(seq_file_id, dtype=np.uint32)
         _check(self._lib, self._lib.gm_map(self._h, tb, tl, first_seq, n_seq, C.byref(p), _ptr(iv), 0 if iv is None else len(iv) // 2, _ptr(sf), _ptr(out)))
         return out
+
+    def map_shard(self, out, K, E, first_seq=0, n_seq=None, overlap=None, infix=0, revcompl=True, value_bits=16,
+                  exclude_pseudo=False, intervals=None, seq_file_id=None, kmer_range=None, chunks=None):
+        """gm_map_shard: this device's share (interleaved chunks or a k-mer range) written into the shared host vector `out`
+        (numpy array of the slice's length); other positions are not touched."""
+        n_seq, tb, tl = self._slice(first_seq, n_seq)
+        assert out.size == tl and out.dtype == (np.uint8 if value_bits == 8 else np.uint16) and out.flags.c_contiguous
+        p = self._params(K, E, overlap, infix, revcompl, value_bits, exclude_pseudo, kmer_range, chunks)
+        iv = None if not intervals else np.ascontiguousarray(np.asarray(intervals, dtype=np.uint64).reshape(-1))
+        sf = None if seq_file_id is None else np.ascontiguousarray(seq_file_id, dtype=np.uint32)
+        _check(self._lib, self._lib.gm_map_shard(self._h, tb, tl, first_seq, n_seq, C.byref(p), _ptr(iv), 0 if iv is None else len(iv) // 2, _ptr(sf), _ptr(out)))
 
     def map_device(self, out_ptr, K, E, first_seq=0, n_seq=None, overlap=None, infix=0, revcompl=True, value_bits=16,
                    exclude_pseudo=False, intervals=None, seq_file_id=None, kmer_range=None, chunks=None, stream=None):

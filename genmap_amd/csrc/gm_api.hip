@@ -288,6 +288,10 @@ void gm_index_free(gm_index* ix)
     for (int i = 0; i < 4; ++i) if (ix->ev[i]) hipEventDestroy(ix->ev[i]);
     for (uint32_t i = 0; i < gm_index::EV_RING; ++i) for (int j = 0; j < 2; ++j) if (ix->evRing[i][j]) hipEventDestroy(ix->evRing[i][j]);
     if (ix->evDone) hipEventDestroy(ix->evDone);
+    hipFree(ix->d_shardOut);
+    if (ix->stCompute) hipStreamDestroy(ix->stCompute);
+    if (ix->stCopy) hipStreamDestroy(ix->stCopy);
+    for (auto& e : ix->evShard) if (e) hipEventDestroy(e);
     delete ix;
 }
 
@@ -587,7 +591,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         if (ix->tune.verifyT >= 0) t = ix->tune.verifyT;
         verifyT = (uint32_t)std::max(0, std::min(t, (int)VERIFY_TMAX));
     }
-    const uint32_t depth = stack_bound(p->E, plan.stepSize);
+    const uint32_t depth = stack_bound(p->E, plan.stepSize) + (ix->tune.steal > 0 ? STEAL_LEVELS : 0u);
     const uint32_t vqCap = verifyT ? 64u + 64u * verifyT : 1u;
     const uint32_t winChunks = (31u + p->K + plan.stepSize - 1u + 31u) / 32u;
     uint32_t ldsDepth = (uint32_t)std::max(0, ix->tune.ldsStack);
@@ -890,6 +894,136 @@ int gm_map(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t first_
     if (!rc) rc = check_device_error(ix);
     hipFree(d_out);
     return rc;
+}
+
+int gm_host_pin(void* host, uint64_t bytes)
+{
+    if (!host) return GM_ERR_BAD_ARG;
+    GM_HIP(hipHostRegister(host, bytes, hipHostRegisterDefault));
+    return GM_OK;
+}
+int gm_host_unpin(void* host)
+{
+    if (!host) return GM_ERR_BAD_ARG;
+    GM_HIP(hipHostUnregister(host));
+    return GM_OK;
+}
+
+int gm_device_alloc(int device, uint64_t bytes, void** dptr)
+{
+    if (!dptr) return GM_ERR_BAD_ARG;
+    int rc = select_device(device); if (rc) return rc;
+    GM_HIP(hipMalloc(dptr, bytes));
+    GM_HIP(hipMemset(*dptr, 0, bytes));
+    return GM_OK;
+}
+int gm_device_free(int device, void* dptr) { GM_HIP(hipSetDevice(device)); GM_HIP(hipFree(dptr)); return GM_OK; }
+int gm_ipc_export(int device, void* dptr, uint8_t handle[64])
+{
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    if (!dptr || !handle) return GM_ERR_BAD_ARG;
+    GM_HIP(hipSetDevice(device));
+    hipIpcMemHandle_t h;
+    GM_HIP(hipIpcGetMemHandle(&h, dptr));
+    memcpy(handle, &h, 64);
+    return GM_OK;
+}
+int gm_ipc_open(int device, const uint8_t handle[64], void** dptr)
+{
+    if (!dptr || !handle) return GM_ERR_BAD_ARG;
+    GM_HIP(hipSetDevice(device));
+    hipIpcMemHandle_t h; memcpy(&h, handle, 64);
+    GM_HIP(hipIpcOpenMemHandle(dptr, h, hipIpcMemLazyEnablePeerAccess));
+    return GM_OK;
+}
+int gm_ipc_close(int device, void* dptr) { GM_HIP(hipSetDevice(device)); GM_HIP(hipIpcCloseMemHandle(dptr)); return GM_OK; }
+int gm_push_pieces(int device, void* dst, const void* src, uint64_t first_byte, uint64_t pitch_bytes, uint64_t piece_bytes, uint64_t n_rows,
+                   uint64_t last_piece_bytes, void* stream)
+{
+    if (!dst || !src) return GM_ERR_BAD_ARG;
+    GM_HIP(hipSetDevice(device));
+    for (uint64_t i = 0; i < n_rows; ++i) {
+        const uint64_t off = first_byte + i * pitch_bytes, len = (i + 1 == n_rows && last_piece_bytes) ? last_piece_bytes : piece_bytes;
+        GM_HIP(hipMemcpyAsync((uint8_t*)dst + off, (const uint8_t*)src + off, len, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
+    return GM_OK;
+}
+
+int gm_map_shard(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t first_seq, uint32_t n_seq, const gm_map_params* p,
+                 const uint64_t* intervals, uint64_t n_intervals, const uint32_t* seq_file_id, void* out_host)
+{
+    if (!ix || !p || !out_host) { set_error("null argument"); return GM_ERR_BAD_ARG; }
+    if (p->value_bits != 8 && p->value_bits != 16) return GM_ERR_BAD_VALUE_BITS;
+    if (p->K < 1 || p->K > MAX_K) return GM_ERR_BAD_K;
+    GM_HIP(hipSetDevice(ix->device));
+    const size_t eb = p->value_bits / 8;
+    if (!ix->stCompute) {
+        GM_HIP(hipStreamCreateWithFlags(&ix->stCompute, hipStreamNonBlocking));
+        GM_HIP(hipStreamCreateWithFlags(&ix->stCopy, hipStreamNonBlocking));
+        for (auto& e : ix->evShard) GM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    if (ix->shardOutCap < text_len * eb + 16) {
+        hipFree(ix->d_shardOut); ix->d_shardOut = nullptr; ix->shardOutCap = 0;
+        GM_HIP(hipMalloc(&ix->d_shardOut, text_len * eb + 16));
+        ix->shardOutCap = text_len * eb + 16;
+    }
+    uint8_t* d_out = (uint8_t*)ix->d_shardOut;
+    uint8_t* h_out = (uint8_t*)out_host;
+    const uint64_t numKmers = text_len >= p->K ? text_len - p->K + 1 : 0;
+    const bool ranged = (p->flags & GM_MAP_FLAG_RANGE) || p->kmer_begin != 0 || p->kmer_end != 0;
+    const uint64_t kb = ranged ? std::min<uint64_t>(p->kmer_begin, numKmers) : 0, ke = ranged ? std::min<uint64_t>(p->kmer_end, numKmers) : numKmers;
+    const bool chunked = p->chunk_blocks > 0 && p->chunk_stride > 1;
+    if (n_intervals > 0 || !chunked) {
+        // a selection, or a plain contiguous share: one launch, then the positions of the range (a selection is small)
+        int rc = map_impl(ix, text_begin, text_len, first_seq, n_seq, p, intervals, n_intervals, seq_file_id, d_out, ix->stCompute);
+        if (rc) return rc;
+        // whole blocks: the share ends where the next one begins; the tail past the last k-mer is all zeros (resetLimits)
+        const uint32_t infix = p->infix > 0 ? (uint32_t)p->infix : (p->overlap >= 0 ? default_infix_length(p->K, p->E, p->overlap) : tuned_infix_length(p->K, p->E));
+        const uint64_t step = p->K - infix + 1;
+        const uint64_t b = (kb + step - 1) / step * step, e = ke >= numKmers ? text_len : (ke + step - 1) / step * step;
+        if (e > b) GM_HIP(hipMemcpyAsync(h_out + b * eb, d_out + b * eb, (e - b) * eb, hipMemcpyDeviceToHost, ix->stCompute));
+        GM_HIP(hipStreamSynchronize(ix->stCompute));
+        return check_device_error(ix);
+    }
+    const uint32_t infix = p->infix > 0 ? (uint32_t)p->infix : (p->overlap >= 0 ? default_infix_length(p->K, p->E, p->overlap) : tuned_infix_length(p->K, p->E));
+    if (infix == 0 || infix > p->K) return GM_ERR_BAD_OVERLAP;
+    const uint64_t step = p->K - infix + 1, chunkLen = (uint64_t)p->chunk_blocks * step, rowLen = chunkLen * p->chunk_stride;
+    const uint64_t base = (kb + step - 1) / step * step;                       // first block of the range
+    const uint64_t span = ke > base ? ke - base : 0;
+    const uint64_t rows = (span + rowLen - 1) / rowLen;                        // one chunk of every shard per row
+    const uint32_t S = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(rows, 1), 4);   // launches: copy of launch s overlaps compute of s + 1
+    for (uint32_t s = 0; s < S; ++s) {
+        const uint64_t r0 = rows * s / S, r1 = rows * (s + 1) / S;
+        if (r1 <= r0) continue;
+        gm_map_params q = *p;
+        q.flags |= GM_MAP_FLAG_RANGE;
+        q.kmer_begin = base + r0 * rowLen; q.kmer_end = std::min<uint64_t>(base + r1 * rowLen, ke);   // rows start at multiples of the row length: chunk numbers keep their residue
+        int rc = map_impl(ix, text_begin, text_len, first_seq, n_seq, &q, nullptr, 0, seq_file_id, d_out, ix->stCompute);
+        if (rc) return rc;
+        GM_HIP(hipEventRecord(ix->evShard[s], ix->stCompute));
+        GM_HIP(hipStreamWaitEvent(ix->stCopy, ix->evShard[s], 0));
+        // own chunks of rows [r0, r1): a strided copy; the last row may hold a short (or no) chunk of this shard
+        const uint64_t first = base + r0 * rowLen + (uint64_t)p->chunk_index * chunkLen;
+        uint64_t full = r1 - r0;
+        const uint64_t lastBegin = first + (full - 1) * rowLen;
+        const uint64_t limit = ke >= numKmers ? text_len : ke;                 // the final shard also delivers the zeroed tail
+        uint64_t lastLen = lastBegin >= limit ? 0 : std::min<uint64_t>(chunkLen, limit - lastBegin);
+        if (lastLen < chunkLen) full -= 1; else lastLen = 0;
+        if (full > 0) GM_HIP(hipMemcpy2DAsync(h_out + first * eb, rowLen * eb, d_out + first * eb, rowLen * eb, chunkLen * eb, full, hipMemcpyDeviceToHost, ix->stCopy));
+        if (lastLen > 0) GM_HIP(hipMemcpyAsync(h_out + lastBegin * eb, d_out + lastBegin * eb, lastLen * eb, hipMemcpyDeviceToHost, ix->stCopy));
+    }
+    // the tail past the last k-mer (K - 1 zeros) belongs to the chunk that holds position numKmers - 1 when that chunk is short;
+    // otherwise it lies in later chunk slots nobody owns: the shard owning the LAST chunk delivers it
+    if (ke >= numKmers && numKmers > 0) {
+        const uint64_t lastChunk = (numKmers - 1 - base) / chunkLen;
+        if (lastChunk % p->chunk_stride == p->chunk_index) {
+            const uint64_t from = base + (lastChunk + 1) * chunkLen;
+            if (from < text_len) GM_HIP(hipMemcpyAsync(h_out + from * eb, d_out + from * eb, (text_len - from) * eb, hipMemcpyDeviceToHost, ix->stCopy));
+        }
+    }
+    GM_HIP(hipStreamSynchronize(ix->stCopy));
+    GM_HIP(hipStreamSynchronize(ix->stCompute));
+    return check_device_error(ix);
 }
 
 int gm_locate(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t first_seq, uint32_t n_seq, const gm_map_params* p,

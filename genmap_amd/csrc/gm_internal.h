@@ -68,6 +68,10 @@ struct gm_index {
     // different streams are serialised on the index's shared workspaces instead of racing on them
     hipEvent_t evDone = nullptr;
     bool doneValid = false;
+    // gm_map_shard: result buffer kept between calls, compute and copy streams, one event per launch of a share
+    void* d_shardOut = nullptr; uint64_t shardOutCap = 0;
+    hipStream_t stCompute = nullptr, stCopy = nullptr;
+    hipEvent_t evShard[8] = {};
     gm::Tuning tune;
     gm_map_stats stats{};
     int buildRounds[2] = {0, 0};

@@ -104,6 +104,8 @@ __device__ __forceinline__ void covered_kmers(uint32_t meta, uint32_t n, uint32_
 // One aligned 32-byte read replaces the dependent pair "SA entry, then text around it" (two to three random requests).
 constexpr int32_t CTX_LEFT = 24, CTX_SYMS = 56;
 
+constexpr uint32_t STEAL_LEVELS = 16;  // a lane gives away at most this many bottom entries before its stack has run empty once
+
 constexpr uint32_t WORK_CHUNK = 256;   // roots taken from the global counter per atomic
 constexpr uint32_t VERIFY_TMAX = 4;    // widest range resolved by verification
 
@@ -113,7 +115,8 @@ template <int WPP> struct EnvBase {
     uint4* lstk;         // LDS: [depth][lane] of this wavefront, already offset by the lane
     const uint8_t* lwin; // LDS: [chunk][lane] 16-byte chunks of this lane's packed window, already offset by the lane
     uint32_t woff;       // nibble offset of the window inside its first chunk
-    uint32_t sp;
+    uint32_t sp;         // entries on the lane's stack; they live at levels [sbase, sbase + sp)
+    uint32_t sbase;      // raised when a neighbour takes the bottom entry (work sharing), back to 0 when the stack runs empty
     uint32_t K;
 #ifdef GM_COUNTERS
     uint32_t steps = 0, lines = 0, stOss = 0, stExt = 0, stExtW1 = 0, stExtW4 = 0, stOssW1 = 0, pushes = 0, vItems = 0, vItemsOss = 0, vChunks = 0;
@@ -128,11 +131,14 @@ template <int WPP> struct EnvBase {
     __device__ __forceinline__ void note_chunk() {}
     __device__ __forceinline__ void note_item(uint32_t) {}
 #endif
-    __device__ __forceinline__ EnvBase(const SearchArgs& a, uint4* s, uint32_t k) : A(a), stk(s), lstk(nullptr), lwin(nullptr), woff(0), sp(0), K(k) {}
+    __device__ __forceinline__ EnvBase(const SearchArgs& a, uint4* s, uint32_t k) : A(a), stk(s), lstk(nullptr), lwin(nullptr), woff(0), sp(0), sbase(0), K(k) {}
     __device__ __forceinline__ uint4 pop()
     {
         --sp;
-        return sp < A.ldsDepth ? lstk[sp * 64u] : stk[(size_t)(sp - A.ldsDepth) * 64u];
+        const uint32_t lv = sbase + sp;
+        const uint4 v = lv < A.ldsDepth ? lstk[lv * 64u] : stk[(size_t)(lv - A.ldsDepth) * 64u];
+        if (sp == 0u) sbase = 0u;
+        return v;
     }
     __device__ __forceinline__ uint32_t slice_pos(const Root& rt, uint32_t kmer) const { return rt.win + (rt.strand ? rt.n - 1u - kmer : kmer); }
 
@@ -257,13 +263,16 @@ template <int WPP> struct EnvBase {
         pushes++;
 #endif
         const uint4 v = make_uint4(nd.flo, nd.rlo, nd.w, nd.meta);
+        const uint32_t lv = sbase + sp;
         // wave-uniform fast path (scalar branch, no exec-mask juggling): nobody in the wavefront is past the LDS levels
-        if (__ballot(sp >= A.ldsDepth) == 0ull) { lstk[sp * 64u] = v; ++sp; return; }
-        if (sp < A.ldsDepth) { lstk[sp * 64u] = v; ++sp; }
-        else if (sp < A.stackDepth) { stk[(size_t)(sp - A.ldsDepth) * 64u] = v; ++sp; }
-        else *A.errorFlag = 1u;   // never expected: depth = stack_bound(E, stepSize)
+        if (__ballot(lv >= A.ldsDepth) == 0ull) { lstk[lv * 64u] = v; ++sp; return; }
+        if (lv < A.ldsDepth) { lstk[lv * 64u] = v; ++sp; }
+        else if (lv < A.stackDepth) { stk[(size_t)(lv - A.ldsDepth) * 64u] = v; ++sp; }
+        else *A.errorFlag = 1u;   // never expected: depth = stack_bound(E, stepSize) (+ STEAL_LEVELS with work sharing)
     }
     __device__ __forceinline__ void on_root() {}
+    __device__ __forceinline__ uint32_t root_hits() const { return 0u; }     // travels with stolen work (CountEnv: gate of the saturation check)
+    __device__ __forceinline__ void set_root_hits(uint32_t) {}
     __device__ __forceinline__ bool saturated(const Root&, uint32_t, uint32_t) const { return false; }
     __device__ __forceinline__ uint32_t C(uint32_t c) const { return A.C[c]; }
     __device__ __forceinline__ bool any(bool b) const { return __ballot(b) != 0ull; }
@@ -344,6 +353,8 @@ template <int WPP> struct CountEnv : EnvBase<WPP> {
     uint32_t rootHits = 0;   // hits this lane has added for its current root (gates the saturation check)
     __device__ __forceinline__ CountEnv(const SearchArgs& a, uint4* s, uint32_t k) : EnvBase<WPP>(a, s, k) {}
     __device__ __forceinline__ void on_root() { rootHits = 0; }
+    __device__ __forceinline__ uint32_t root_hits() const { return rootHits; }
+    __device__ __forceinline__ void set_root_hits(uint32_t v) { rootHits = v; }
     // c[] = min(total, MAX) (algo.hpp:36,48,191): once every k-mer a node still covers has reached MAX, nothing below the
     // node can change the result.  Checked only after this lane alone has produced MAX hits for the root (repeats).
     __device__ __forceinline__ bool saturated(const Root& rt, uint32_t smin, uint32_t smax) const
@@ -520,7 +531,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                 wlane = lane; env.lwin = reinterpret_cast<const uint8_t*>(wbase + lane);
             }
             const bool idle = !have && env.sp == 0u && fs == 0u;
-            const bool rich = have && env.sp >= 1u;
+            const bool rich = have && env.sp >= 1u && env.sbase < STEAL_LEVELS;
             const unsigned long long im = __ballot(idle), vm = __ballot(rich);
             if (im != 0ull && vm != 0ull) {
                 const uint32_t np = min((uint32_t)__popcll(im), (uint32_t)__popcll(vm));
@@ -535,27 +546,28 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                 if (thief) src = pairing[ri];
                 const int a4 = (int)(src << 2);
                 // the victim's stack height, root and window (every lane takes part: the victims' registers are the source)
-                const uint32_t vsp = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)env.sp);
+                const uint32_t vsb = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)env.sbase);   // the BOTTOM entry: the oldest, i.e. the largest pending subtree
                 const uint32_t vwin = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)rt.win);
                 const uint32_t vnss = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)(rt.n | rt.strand << 9 | rt.search << 10));
                 const uint32_t vrx = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)rt.rec.x), vry = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)rt.rec.y);
                 const uint32_t vrz = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)rt.rec.z), vrw = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)rt.rec.w);
                 const uint32_t vwo = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)(env.woff | wlane << 8));
+                const uint32_t vrh = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)env.root_hits());
                 if (thief) {
-                    const uint32_t level = vsp - 1u;
+                    const uint32_t level = vsb;
                     const uint4 v = level < A.ldsDepth ? lstkW[level * 64u + src] : stkW[(size_t)(level - A.ldsDepth) * 64u + src];
                     nd.flo = v.x; nd.rlo = v.y; nd.w = v.z; nd.meta = v.w; have = true; w1run = 0;
                     rt.win = vwin; rt.n = vnss & 0x1FFu; rt.strand = (vnss >> 9) & 1u; rt.search = vnss >> 10;
                     rt.rec.x = vrx; rt.rec.y = vry; rt.rec.z = vrz; rt.rec.w = vrw;
-                    env.on_root();
+                    env.set_root_hits(vrh);   // a root that saturates its k-mers keeps doing so in the thief's hands
                     env.woff = vwo & 0xFFu; wlane = vwo >> 8;
                     env.lwin = reinterpret_cast<const uint8_t*>(wbase + wlane);
-                    atomicAdd(&users[wlane], 1u);
+                    if (wlane != lane) atomicAdd(&users[wlane], 1u);   // (stealing back work of one's own root needs no reference)
 #ifdef GM_COUNTERS
                     nSteals++;
 #endif
                 }
-                if (robbed) env.sp -= 1u;
+                if (robbed) { env.sp -= 1u; env.sbase = env.sp ? env.sbase + 1u : 0u; }
             }
         }
         // ---- root fetch, pipelined over iterations so that the wavefront never waits for it ----

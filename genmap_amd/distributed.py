@@ -44,11 +44,109 @@ class ShardPlan:
             out.append((b, min(b + self.chunk_len, self.num_kmers)))
         return out
 
+    def sub_ranges(self, launches: int):
+        """the k-mer positions cut into `launches` row-aligned ranges (a row = one chunk of every rank): the pieces of a pass
+        whose results travel while the next piece is computed"""
+        row_len = self.chunk_len * self.world
+        rows = self.rows // self.world if self.world else 0
+        rows = max(rows, 1)
+        out = []
+        for s in range(launches):
+            b, e = rows * s // launches * row_len, rows * (s + 1) // launches * row_len
+            b, e = min(b, self.num_kmers), min(e, self.num_kmers)
+            if e > b:
+                out.append((b, e))
+        return out or [(0, self.num_kmers)]
+
     def describe(self) -> str:
         if self.world == 1:
             return "one GPU, whole text"
         return (f"{self.nchunks} chunks of {self.chunk_blocks} k-mer blocks ({self.chunk_len} positions) dealt round-robin to {self.world} ranks, "
                 f"index replicated, one gather of the 8-bit chunks to rank 0")
+
+
+class PeerGather:
+    """The root's result vector shared through a HIP IPC handle; every other rank pushes its finished chunks into it with
+    device-to-device copies (xGMI, DMA engines) on a copy stream of its own while its search kernel works on the next chunks.
+
+      pg = PeerGather(plan, text_len, item_bytes, rank, local_device, dist)      # collective; pg.ok False -> use gather_chunks
+      for sub in plan.sub_ranges(pg.launches):                                    # every step
+          ix.map_device(pg.local_ptr, ..., kmer_range=sub, chunks=plan.chunk_arg(rank), stream=compute)
+          pg.push(sub, compute_stream_event)                                      # rank != root: async copies of the chunks just computed
+      pg.finish()                                                                 # wait for this rank's copies
+
+    The root computes straight into the shared vector.  Setup ends with a pattern exchange: if any rank's test chunk does not
+    arrive, every rank falls back to the RCCL gather (ok == False on all ranks)."""
+
+    def __init__(self, plan: ShardPlan, text_len: int, item_bytes: int, rank: int, device: int, dist, launches: int = 4):
+        import torch
+        from . import capi
+        self.plan, self.rank, self.device, self.item, self.dist = plan, rank, device, item_bytes, dist
+        self.launches = max(1, min(launches, plan.rows // plan.world if plan.world else 1))
+        self.nbytes = plan.padded_len(text_len) * item_bytes
+        self.ok = False
+        self.local_ptr = capi.device_alloc(device, self.nbytes)      # rank 0: the shared result; others: their own staging vector
+        self.remote_ptr = None
+        self.copy_stream = torch.cuda.Stream(device=device)
+        handle = [capi.ipc_export(device, self.local_ptr) if rank == 0 else None]
+        good = 1
+        try:
+            dist.broadcast_object_list(handle, src=0)
+            if rank != 0:
+                self.remote_ptr = capi.ipc_open(device, handle[0])
+        except Exception:
+            good = 0
+        # pattern exchange: rank r writes r + 1 into the first bytes of its first chunk
+        if good and rank != 0 and plan.nchunks > rank:
+            t = torch.full((min(64, plan.chunk_len * item_bytes),), rank + 1, dtype=torch.uint8, device=f"cuda:{device}")
+            try:
+                capi.push_pieces(device, self.remote_ptr + rank * plan.chunk_len * item_bytes, t.data_ptr(), 0, 0, t.numel(), 1, 0, self.copy_stream.cuda_stream)
+                self.copy_stream.synchronize()
+            except Exception:
+                good = 0
+        flag = torch.tensor([good], dtype=torch.int32)
+        cpu_ok = dist.get_backend() != "nccl"
+        flag = flag if cpu_ok else flag.to(f"cuda:{device}")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        dist.barrier()
+        if int(flag.item()) == 1 and rank == 0:
+            for r in range(1, plan.world):
+                if plan.nchunks <= r:
+                    continue
+                probe = torch.empty(1, dtype=torch.uint8, device=f"cuda:{device}")
+                capi.push_pieces(device, probe.data_ptr(), self.local_ptr + r * plan.chunk_len * item_bytes, 0, 0, 1, 1, 0, None)
+                torch.cuda.synchronize()
+                if int(probe.item()) != r + 1:
+                    flag[0] = 0
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        self.ok = int(flag.item()) == 1
+
+    def push(self, sub_range, after_event):
+        """rank != root: copy this rank's chunks inside sub_range (row-aligned k-mer range) to the root, after `after_event`"""
+        if self.rank == 0:
+            return
+        from . import capi
+        plan, item = self.plan, self.item
+        row_len = plan.chunk_len * plan.world
+        r0, r1 = sub_range[0] // row_len, -(-sub_range[1] // row_len)
+        rows = [c for c in range(r0, r1) if c * plan.world + self.rank < plan.nchunks]
+        if not rows:
+            return
+        self.copy_stream.wait_event(after_event)
+        first = (rows[0] * plan.world + self.rank) * plan.chunk_len * item
+        capi.push_pieces(self.device, self.remote_ptr, self.local_ptr, first, row_len * item, plan.chunk_len * item, len(rows), 0, self.copy_stream.cuda_stream)
+
+    def finish(self):
+        self.copy_stream.synchronize()
+
+    def close(self):
+        from . import capi
+        try:
+            if self.remote_ptr:
+                capi.ipc_close(self.device, self.remote_ptr)
+        finally:
+            self.dist.barrier()
+            capi.device_free(self.device, self.local_ptr)
 
 
 def gather_chunks(local_full, plan: ShardPlan, rank: int, dist, dst: int = 0, stage_on_host: bool = False):

@@ -290,22 +290,26 @@ int map_main(int argc, const char** argv)
                 if (replicas.size() == 1) {
                     rc = gm_map(ix, textBegin, textLen, firstSeq, nSeq, &p, ivp, intervals.size() / 2, seqFile.data(), c.data());
                 } else {
-                    // shards of k-mer positions; every device returns a full-length vector that is zero outside its shard
+                    // every device computes interleaved chunks of whole k-mer blocks (>= 64 per device: repeats and N deserts are
+                    // spread over all of them, cf. the dynamic chunks of src/algo.hpp:422-434) and copies exactly its chunks
+                    // into the one result vector -- nothing is merged on the CPU (gm_map_shard).  A selection is small: contiguous shares.
                     const uint64_t numKmers = textLen >= K ? textLen - K + 1 : 0;
                     const size_t nd = replicas.size();
-                    std::vector<std::vector<uint8_t>> part(nd);
+                    const uint32_t tuned = gm_tuned_infix_length(K, E);
+                    const uint64_t stepSize = K - (xo >= 0 ? infix : tuned) + 1, nBlocks = (numKmers + stepSize - 1) / stepSize;
+                    const uint32_t chunkBlocks = (uint32_t)std::max<uint64_t>(1, (nBlocks + nd * 64 - 1) / (nd * 64));
+                    const bool pinned = gm_host_pin(c.data(), c.size()) == GM_OK;
                     std::vector<std::thread> th;
                     for (size_t d = 0; d < nd; ++d)
                         th.emplace_back([&, d] {
                             gm_map_params q = p;
-                            q.kmer_begin = numKmers * d / nd; q.kmer_end = numKmers * (d + 1) / nd;
-                            if (q.kmer_end == 0 && d + 1 == nd) q.kmer_end = 1;   // (0,0) means "everything" in the ABI
-                            part[d].assign((size_t)textLen * width + 16, 0);
-                            rcs[d] = (q.kmer_begin == q.kmer_end) ? 0 : gm_map(replicas[d], textBegin, textLen, firstSeq, nSeq, &q, ivp, intervals.size() / 2, seqFile.data(), part[d].data());
+                            if (ivp) { q.flags |= GM_MAP_FLAG_RANGE; q.kmer_begin = numKmers * d / nd; q.kmer_end = numKmers * (d + 1) / nd; }
+                            else { q.chunk_blocks = chunkBlocks; q.chunk_index = (uint32_t)d; q.chunk_stride = (uint32_t)nd; }
+                            rcs[d] = gm_map_shard(replicas[d], textBegin, textLen, firstSeq, nSeq, &q, ivp, intervals.size() / 2, seqFile.data(), c.data());
                         });
                     for (auto& t : th) t.join();
+                    if (pinned) gm_host_unpin(c.data());
                     for (size_t d = 0; d < nd && !rc; ++d) rc = rcs[d];
-                    if (!rc) for (size_t d = 0; d < nd; ++d) for (size_t i = 0; i < (size_t)textLen * width; ++i) c[i] |= part[d][i];   // shards are disjoint
                 }
                 if (rc) { for (auto* r : replicas) gm_index_free(r); return fail_gm("computeMappability failed", rc); }
             }

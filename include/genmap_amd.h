@@ -133,6 +133,36 @@ int gm_map_device(gm_index *idx, uint64_t text_begin, uint64_t text_len, uint32_
                   const gm_map_params *params, const uint64_t *intervals, uint64_t n_intervals,
                   const uint32_t *seq_file_id, void *out_device, void *stream);
 
+/* One device's share of a computeMappability call whose result is assembled in HOST memory by several devices (the
+ * `genmap map -D 0,1,..` path: one index replica and one host thread per GPU).  Computes the interleaved chunks selected by
+ * params->chunk_blocks / chunk_index / chunk_stride (all of the k-mer range when chunk_stride <= 1) and copies exactly
+ * those chunks' positions into out_host -- the other bytes are not touched, so the devices fill one vector concurrently
+ * and nothing is merged on the CPU.  The share is processed in a few launches; the copy of one launch's chunks
+ * (device -> host over PCIe, DMA engines) runs while the next launch computes.  out_host should be pinned
+ * (gm_host_pin) for the copies to be asynchronous; pageable memory works but is staged by the runtime. */
+int gm_map_shard(gm_index *idx, uint64_t text_begin, uint64_t text_len, uint32_t first_seq, uint32_t n_seq,
+                 const gm_map_params *params, const uint64_t *intervals, uint64_t n_intervals,
+                 const uint32_t *seq_file_id, void *out_host);
+int gm_host_pin(void *host, uint64_t bytes);      /* hipHostRegister / hipHostUnregister */
+int gm_host_unpin(void *host);
+
+/* One process per GPU (torch.distributed launchers): the root's result vector is shared with the other ranks through a HIP IPC
+ * handle and every rank pushes its finished chunks straight into it -- device-to-device copies over xGMI by the DMA engines,
+ * on their own stream, while the rank's search kernel works on its next chunks (the persistent kernel holds every CU, a
+ * collective's kernel could not run beside it).  gm_device_alloc returns a base allocation (IPC handles name allocations, not
+ * pointers inside a framework's caching allocator).  handle = 64 bytes (hipIpcMemHandle_t). */
+int gm_device_alloc(int device, uint64_t bytes, void **dptr);
+int gm_device_free(int device, void *dptr);
+int gm_ipc_export(int device, void *dptr, uint8_t handle[64]);
+int gm_ipc_open(int device, const uint8_t handle[64], void **dptr);
+int gm_ipc_close(int device, void *dptr);
+/* copy n_rows pieces of piece_bytes each, pitch_bytes apart (the chunks of one shard), from src to the same offsets of dst:
+ * dst + first_byte + i * pitch_bytes <- src + first_byte + i * pitch_bytes.  One asynchronous copy per piece on `stream`
+ * (1-D copies go to the DMA engines; a 2-D copy would be a blit kernel that waits for free CUs).  The last piece may be
+ * shortened with last_piece_bytes (0 = full). */
+int gm_push_pieces(int device, void *dst, const void *src, uint64_t first_byte, uint64_t pitch_bytes, uint64_t piece_bytes,
+                   uint64_t n_rows, uint64_t last_piece_bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Locations for csv output  (the `locations` map filled by src/algo.hpp:311-387 and consumed by
  * saveCsv, src/output.hpp:189-288).  For every slice position j in [pos_begin, pos_begin + n_positions):

@@ -154,7 +154,7 @@ def test_gpu_gtest_matrix(E, dna5):
             triv = ora.trivial(K, E, revcompl=rc, value_bits=8)
             for infix in range(max(minK, nblocks), K + 1):
                 for T in (0, 1, 4):   # verification of narrow nodes off / width 1 / width <= 4
-                    ix.set_tuning(verify_t=T)
+                    ix.set_tuning(verify_t=T, steal=T & 1, coop=(T + 1) & 1)
                     out = ix.map(K, E, infix=infix, revcompl=rc, value_bits=8)
                     assert np.array_equal(out, triv), (E, dna5, K, infix, T)
     finally:
@@ -173,11 +173,12 @@ def test_gpu_baseline_settings_small(K, E):
         for bits in (8, 16):
             exp = ora.mappability(K, E, value_bits=bits, threads=8)
             for T in (0, 1, 4):
-                for coop in ((0, 1) if bb in (32, 64) else (0,)):   # rank blocks read by one lane / by groups of lanes
-                    for ctx in (1, 0):                               # verification from the 32-byte row records / from SA + text
-                        ix.set_tuning(verify_t=T, coop=coop, use_ctx=ctx)
-                        out = ix.map(K, E, value_bits=bits)
-                        assert np.array_equal(out, exp), (K, E, bits, bb, T, coop, ctx)
+                # rank blocks read by one lane / by groups of lanes; verification from the 32-byte row records / from SA + text;
+                # idle lanes steal from their neighbours' stacks or not
+                for coop, ctx, steal in (((1, 1, 0), (0, 0, 0), (1, 0, 1), (0, 1, 1)) if bb in (32, 64) else ((0, 1, 0), (0, 0, 1))):
+                    ix.set_tuning(verify_t=T, coop=coop, use_ctx=ctx, steal=steal)
+                    out = ix.map(K, E, value_bits=bits)
+                    assert np.array_equal(out, exp), (K, E, bits, bb, T, coop, ctx, steal)
         ix.close()
 
 
@@ -203,6 +204,40 @@ def test_gpu_shards_and_device_output():
     got = acc.cpu().numpy()
     # positions zeroed by resetLimits are zero in every shard; other positions are non-zero in exactly one
     assert np.array_equal(got, full)
+    ix.close()
+
+
+def test_gpu_interleaved_chunk_shards_fill_one_vector():
+    """the multi-GPU data path on one device: every "rank" computes its interleaved chunks of whole k-mer blocks
+    (gm_map_params.chunk_*), (a) into one host vector through gm_map_shard -- what `genmap map -D` does, no merge on the CPU --
+    and (b) into a device buffer through gm_map_device -- what bench.py's ranks do before the gather"""
+    g = _gm()
+    import torch
+    from genmap_amd.distributed import ShardPlan
+    rng = np.random.default_rng(77)
+    lens = [300000, 41, 250000, 7]
+    codes = _repeat_text(rng, sum(lens), True)
+    n = sum(lens)
+    ix = g.Index.build(codes, lens, sampling=1)
+    for K, E, bits, world, cpr in ((30, 0, 8, 3, 7), (30, 1, 16, 4, 5), (100, 1, 8, 2, 64), (24, 2, 16, 8, 3)):
+        full = ix.map(K, E, value_bits=bits)
+        plan = ShardPlan(n - K + 1, K - g.tuned_infix_length(K, E) + 1, world, chunks_per_rank=cpr)
+        host = np.full(n, 0xEE if bits == 8 else 0xEEEE, dtype=full.dtype)     # every byte must be delivered by exactly one shard
+        dev = torch.zeros(plan.padded_len(n), dtype=torch.uint8 if bits == 8 else torch.uint16, device="cuda:0")
+        for r in range(world):
+            ix.map_shard(host, K, E, value_bits=bits, chunks=plan.chunk_arg(r))
+            ix.map_device(dev.data_ptr(), K, E, value_bits=bits, chunks=plan.chunk_arg(r), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(host, full), (K, E, bits, world)
+        got = dev[:n].cpu().numpy() if bits == 8 else dev[:n].view(torch.int16).cpu().numpy().view(np.uint16)
+        assert np.array_equal(got, full), (K, E, bits, world)
+        # contiguous shares (what a selection or csv uses) through the same entry point
+        host[:] = 0xEE if bits == 8 else 0xEEEE
+        nk = n - K + 1
+        cuts = [0, nk // 3, nk // 3, nk * 2 // 3, nk]            # one share is empty
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            ix.map_shard(host, K, E, value_bits=bits, kmer_range=(a, b))
+        assert np.array_equal(host, full), (K, E, bits, "ranges")
     ix.close()
 
 
