@@ -251,13 +251,23 @@ def main():
         per_rank = [[float(v) for v in x.tolist()] for x in allms]
 
     # ---- roofline numerators: count node steps / distinct rank lines with the instrumented twin (untimed) ----
+    # The timed index is released first: the twin needs the same HBM (verification records included) to run the same schedule.
     counted = {}
+    bwt_host = None
+    if rank == 0 and world == 1 and (not args.no_cpu_baseline or not args.no_counters):
+        bwt_host = ix.export_bwt()
     if rank == 0 and world == 1 and not args.no_counters and g.lib_path(True).exists():
         try:
-            bf, br = ix.export_bwt()
-            ixp = g.Index.from_bwt(bf, br, codes, lens, sa_fwd=(ix.export_sa() if args.sampling == 1 else None), sampling=args.sampling,
+            bf, br = bwt_host
+            sa_host = ix.export_sa() if args.sampling == 1 else None
+            ix.close()
+            out = None
+            torch.cuda.empty_cache()
+            ixp = g.Index.from_bwt(bf, br, codes, lens, sa_fwd=sa_host, sampling=args.sampling,
                                    block_bytes=info["block_bytes"], device=local_rank, profiling=True)
-            del bf, br
+            del sa_host
+            if ixp.info()["verify_records"] != info["verify_records"]:
+                log("warning: the instrumented twin did not get the same verification records as the timed index")
             tmp = torch.zeros(n + 16, dtype=torch.uint8, device=dev)
             for rec in [head] + subs:
                 ixp.map_device(tmp.data_ptr(), rec["K"], rec["E"], infix=args.infix, value_bits=8, stream=stream)
@@ -276,8 +286,10 @@ def main():
                     "kernel": "search_kernel", "kernel_ms": rec["kernel_ms"]}
         d = sp["detail"]
         # rank blocks + one q-mer table entry per root + text read once per strand (4-bit packed) + 8-bit output
-        # + verification (SA entry per row, 8 needle + 8 text symbols per chunk)
-        alg = bb * sp["rank_lines"] + 16 * sp["roots"] + n + n + 4 * d["verify_items"] + 16 * d["verify_chunks"]
+        # + verification: one 32-byte record per row and 8 needle symbols per chunk -- or, without the records, the SA entry
+        # per row and 8 needle + 8 text symbols per chunk
+        ver = 32 * d["verify_items"] + 8 * d["verify_chunks"] if info["verify_records"] else 4 * d["verify_items"] + 16 * d["verify_chunks"]
+        alg = bb * sp["rank_lines"] + 16 * sp["roots"] + n + n + ver
         ach = alg / (rec["kernel_ms"] * 1e-3) / 1e9
         return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": None,   # PMC FETCH_SIZE/WRITE_SIZE need rocprofv3 around the process: tools/profile_round.sh -> profiles/
@@ -290,7 +302,7 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             try:
-                cpu = CpuBaseline(codes, lens, ix.export_bwt(), os.cpu_count() or 1)
+                cpu = CpuBaseline(codes, lens, bwt_host, os.cpu_count() or 1)
             except Exception as e:
                 log("cpu baseline failed:", e)
 

@@ -30,7 +30,7 @@ class MapParams(C.Structure):
 class IndexInfo(C.Structure):
     _fields_ = [("n_rows", C.c_uint64), ("text_len", C.c_uint64), ("n_seq", C.c_uint32), ("sampling", C.c_uint32),
                 ("alphabet_size", C.c_uint32), ("block_bytes", C.c_uint32), ("device_bytes", C.c_uint64),
-                ("device", C.c_int32)]
+                ("device", C.c_int32), ("verify_records", C.c_uint32)]
 
 
 class MapStats(C.Structure):

@@ -385,6 +385,7 @@ int gm_index_get_info(const gm_index* ix, gm_index_info* info)
     info->device_bytes = 2 * ix->blkBytes + ix->textLen + (ix->nSeq + 1) * 8ull + (ix->d_sa ? ix->nRows * 5ull : 0ull) + (ix->d_ctx ? ix->nRows * 32ull : 0ull) + ix->qtableBytes;
     if (!ix->d_sa) info->sampling = 0;
     info->device = ix->device;
+    info->verify_records = ix->d_ctx ? 1u : 0u;
     return GM_OK;
 }
 
@@ -588,10 +589,13 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     if (ix->d_sa && ix->d_textS) {   // narrow nodes are resolved against the text when the SA is resident
         int t = 1;
         if (plan.stepSize >= 32) t = 4;   // long blocks (e.g. K=100): a narrow node still covers many k-mers (profiles/r01c)
+        // long k-mers with errors: a two-row node has a long way to go by rank steps; with the 32-byte row records two reads
+        // settle it (K=100 e=1: +8 % on 3.09 Gbp, +12 % on 249 Mbp; K=30: -20 %, profiles/r02/sweep_*_steal_verify.txt)
+        else if (p->K >= 64 && p->E >= 1 && ix->d_ctx && ix->tune.useCtx) t = 2;
         if (ix->tune.verifyT >= 0) t = ix->tune.verifyT;
         verifyT = (uint32_t)std::max(0, std::min(t, (int)VERIFY_TMAX));
     }
-    const uint32_t depth = stack_bound(p->E, plan.stepSize) + (ix->tune.steal > 0 ? STEAL_LEVELS : 0u);
+    const uint32_t depth = stack_bound(p->E, plan.stepSize) + STEAL_LEVELS;   // room for the levels work sharing may vacate at the bottom
     const uint32_t vqCap = verifyT ? 64u + 64u * verifyT : 1u;
     const uint32_t winChunks = (31u + p->K + plan.stepSize - 1u + 31u) / 32u;
     uint32_t ldsDepth = (uint32_t)std::max(0, ix->tune.ldsStack);
@@ -686,7 +690,11 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     A.chunkBlocks = chunked ? p->chunk_blocks : 0u; A.chunkStride = p->chunk_stride; A.chunkIndex = p->chunk_index;
     A.skipDup = ix->tune.skipDup >= 0 ? (uint32_t)(ix->tune.skipDup != 0) : 1u;   // profiles/r02: +3..8 % on 3.09 Gbp, +1..5 % on 249 Mbp
     // groups of lanes read the rank blocks (rank2_coop): +4..12 % with 32-byte blocks on 249 Mbp and 3.09 Gbp (profiles/r02)
-    A.steal = ix->tune.steal > 0 ? 1u : 0u;
+    // work sharing inside the wavefront pays where lanes run dry often and pruning by saturation is rare: e <= 1 on large
+    // indexes (3.09 Gbp: e=1 +8 %, e=0 +1 %), small calls (tail of the kernel); it costs 30 % at e = 2, where stolen subtrees
+    // are searched before the counters that would have pruned them saturate (profiles/r02/sweep_chr1_steal_*.txt)
+    const bool stealDefault = (p->E <= 1 && p->K < 64 && ix->nRows >= (1ull << 30)) || S->numRoots < 64ull * 4ull * 1024ull;
+    A.steal = ix->tune.steal >= 0 ? (uint32_t)(ix->tune.steal != 0) : (stealDefault ? 1u : 0u);
     A.coop = ix->tune.coop >= 0 ? (uint32_t)(ix->tune.coop != 0) : (ix->wpp == 1 ? 1u : 0u);
     *Aout = A;
     return GM_OK;

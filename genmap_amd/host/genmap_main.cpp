@@ -120,7 +120,9 @@ int index_main(int argc, const char** argv)
     if (seqLen.size() <= 0xFFFFull && maxLen <= 0xFFFFFFFFull) { meta.seqNoBits = 16; meta.seqPosBits = 32; meta.bwtBits = total <= 0xFFFFFFFFull ? 32 : 64; }
     else if (seqLen.size() <= 0xFFFFFFFFull && maxLen <= 0xFFFFull) { meta.seqNoBits = 32; meta.seqPosBits = 16; meta.bwtBits = 64; }
     else { meta.seqNoBits = 64; meta.seqPosBits = 64; meta.bwtBits = 64; }
-    meta.sampling = 1;   // this build keeps the whole suffix array (HBM is large); -S is accepted for compatibility
+    meta.sampling = 1;   // this build keeps the whole suffix array (4 B/row of 288 GB: locate is one read, no LF walk)
+    if (a.has("sampling") && sampling != 1)
+        std::cerr << "WARNING: -S " << sampling << " is not honoured: this build always stores the full suffix array (index.info says sampling_rate:1).\n";
     if (verbose)
         std::cout << "Index will be constructed using " << (dna5 ? "dna5/rna5" : "dna4/rna4") << " alphabet.\n"
                   << "- The BWT is represented by " << meta.bwtBits << " bit values.\n"
@@ -211,9 +213,22 @@ int map_main(int argc, const char** argv)
     if (haveSelection) {
         FILE* f = fopen(a.get("selection").c_str(), "r");
         if (!f) { std::cerr << "ERROR: cannot open " << a.get("selection") << "\n"; return 1; }
-        char name[4096]; unsigned long long b, e; char line[8192];
-        while (fgets(line, sizeof line, f))
-            if (sscanf(line, "%4095s %llu %llu", name, &b, &e) == 3) selection[name].push_back({b, e});
+        // BED3 rows: ref <TAB> begin <TAB> end; the ref field runs to the first TAB (ids may contain spaces when the shortened
+        // ids are not unique, src/indexing.hpp:36-61); rows without tabs fall back to blanks as separators
+        std::string row; int ch;
+        auto flush = [&]() {
+            if (row.empty() || row[0] == '#') { row.clear(); return; }
+            size_t t1 = row.find('\t'), t2 = t1 == std::string::npos ? t1 : row.find('\t', t1 + 1);
+            if (t2 == std::string::npos) { t1 = row.find_first_of(" \t"); t2 = t1 == std::string::npos ? t1 : row.find_first_of(" \t", row.find_first_not_of(" \t", t1)); }
+            if (t1 != std::string::npos && t2 != std::string::npos) {
+                char* endp = nullptr;
+                const unsigned long long b = strtoull(row.c_str() + t1 + 1, &endp, 10), e = strtoull(row.c_str() + t2 + 1, nullptr, 10);
+                if (endp != row.c_str() + t1 + 1) selection[row.substr(0, t1)].push_back({b, e});
+            }
+            row.clear();
+        };
+        while ((ch = fgetc(f)) != EOF) { if (ch == '\n') flush(); else if (ch != '\r') row.push_back((char)ch); }
+        flush();
         fclose(f);
     }
 
@@ -322,25 +337,27 @@ int map_main(int argc, const char** argv)
                 t = wall();
                 // windows of k-mer positions, halved whenever one holds too many occurrences for a single gm_locate call
                 const uint64_t numKmers = textLen >= K ? textLen - K + 1 : 0;
-                uint64_t begin = 0, window = std::max<uint64_t>(numKmers, 1); bool first = true;
+                // (a gm_locate call holds (4+8) B x 2W on the device and 16 B x W on the host for a window of W positions)
+                uint64_t begin = 0, window = std::max<uint64_t>(std::min<uint64_t>(numKmers, 1ull << 26), 1); bool first = true;
                 if (numKmers == 0) { gmh::CsvInput in; uint64_t z[1] = {0}; in.plusOff = in.minusOff = z; ok = gmh::save_csv(stem, in, seqs, K, revCompl, fileNames, seqsPerFile, false, err); }
                 // every device of -D takes one contiguous range per round (its own halving windows inside); a round's
                 // results are written in position order
                 const size_t nd = replicas.size();
-                if (nd > 1) window = std::max<uint64_t>(1, (numKmers + nd - 1) / nd);
+                if (nd > 1) window = std::max<uint64_t>(1, std::min<uint64_t>((numKmers + nd - 1) / nd, 1ull << 26));
                 while (ok && begin < numKmers) {
                     std::vector<std::vector<gm_locations*>> got(nd);
                     std::vector<int> lrc(nd, 0);
                     std::vector<uint64_t> ends(nd, begin);
                     auto work = [&](size_t d, uint64_t rb, uint64_t re) {
-                        uint64_t b2 = rb, w2 = std::max<uint64_t>(re - rb, 1);
+                        uint64_t b2 = rb, w2 = std::max<uint64_t>(re - rb, 1), okRun = 0;
                         while (b2 < re) {
                             gm_map_params q = p;
                             q.kmer_begin = b2; q.kmer_end = std::min(re, b2 + w2);
                             gm_locations* L = nullptr;
                             int r2 = gm_locate(replicas[d], textBegin, textLen, firstSeq, nSeq, &q, ivp, intervals.size() / 2, &L);
-                            if (r2 == GM_ERR_TOO_LONG && w2 > 1) { w2 = std::max<uint64_t>(1, w2 / 2); continue; }
+                            if (r2 == GM_ERR_TOO_LONG && w2 > 1) { w2 = std::max<uint64_t>(1, w2 / 2); okRun = 0; continue; }
                             if (r2) { lrc[d] = r2; return; }
+                            if (++okRun >= 4 && w2 < re - rb) { w2 *= 2; okRun = 0; }   // past the repeat that forced small windows: grow again
                             got[d].push_back(L);
                             // the window is rounded to whole k-mer blocks by the library: continue after what it covered
                             b2 = std::max<uint64_t>(q.kmer_end, L->n_positions ? L->pos_begin + L->n_positions : q.kmer_end);

@@ -58,6 +58,8 @@ typedef struct gm_index_info {
     uint32_t block_bytes;     /* rank block size of this index: 32, 64 or 128 */
     uint64_t device_bytes;    /* HBM held by the index */
     int32_t  device;
+    uint32_t verify_records;  /* 1: the index holds one 32-byte record {SA[row], 56 text symbols around it} per row (built with
+                                 sampling 1 when HBM allows): a narrow search node is verified with ONE read */
 } gm_index_info;
 
 /* Build both FM indexes ON THE GPU from host sequences (concatenated codes, no sentinels).
