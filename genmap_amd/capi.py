@@ -30,7 +30,7 @@ class MapParams(C.Structure):
 class IndexInfo(C.Structure):
     _fields_ = [("n_rows", C.c_uint64), ("text_len", C.c_uint64), ("n_seq", C.c_uint32), ("sampling", C.c_uint32),
                 ("alphabet_size", C.c_uint32), ("block_bytes", C.c_uint32), ("device_bytes", C.c_uint64),
-                ("device", C.c_int32), ("verify_records", C.c_uint32)]
+                ("device", C.c_int32), ("row_bits", C.c_uint32), ("verify_records", C.c_uint32)]
 
 
 class MapStats(C.Structure):
@@ -50,6 +50,7 @@ class Locations(C.Structure):
 
 
 MAP_FLAG_RANGE = 1
+WIDE_ROWS = 0x10000   # GM_BLOCK_WIDE_ROWS: OR into block_bytes to force 64-bit rows
 
 EXPORTS = ["gm_device_alloc", "gm_device_free", "gm_ipc_export", "gm_ipc_open", "gm_ipc_close", "gm_push_pieces", "gm_map_shard", "gm_host_pin", "gm_host_unpin", "gm_index_set_tuning", "gm_index_sync", "gm_map_kernel_times", "gm_map_runs", "gm_runs_free", "gm_tuned_infix_length", "gm_index_export_sa", "gm_locate", "gm_locations_free", "gm_status_string", "gm_last_error", "gm_device_count", "gm_index_build", "gm_index_import",
            "gm_index_export_bwt", "gm_index_get_info", "gm_index_free", "gm_map", "gm_map_device",
@@ -224,7 +225,8 @@ class Index:
         br = np.ascontiguousarray(bwt_rev, dtype=np.uint8)
         codes = np.ascontiguousarray(codes, dtype=np.uint8)
         sl = np.ascontiguousarray(seq_len, dtype=np.uint64)
-        sa = None if sa_fwd is None else np.ascontiguousarray(sa_fwd, dtype=np.uint32)
+        wide = bool(block_bytes & WIDE_ROWS) or len(bf) >= 0xFFFFFFFF
+        sa = None if sa_fwd is None else np.ascontiguousarray(sa_fwd, dtype=np.uint64 if wide else np.uint32)
         h = C.c_void_p()
         _check(lib, lib.gm_index_import(_ptr(bf), _ptr(br), _ptr(sa), _ptr(codes), _ptr(sl), len(sl), sampling, block_bytes, device, C.byref(h)))
         return cls(h, lib, codes, sl)
@@ -252,7 +254,8 @@ class Index:
         return bf, br
 
     def export_sa(self):
-        sa = np.empty(self.info()["n_rows"], np.uint32)
+        i = self.info()
+        sa = np.empty(i["n_rows"], np.uint64 if i["row_bits"] == 64 else np.uint32)
         _check(self._lib, self._lib.gm_index_export_sa(self._h, _ptr(sa)))
         return sa
 

@@ -34,7 +34,7 @@ constexpr size_t SMALL_BYTES = 512, SMALL_ZEROED = 256, SMALL_ERR_OFF = 256;
 // ---- rank block construction -------------------------------------------------------------------------------
 // cnt[c * (nb + 1) + q] = letters c in block q; entry nb is zero so that the exclusive scan leaves the total there.
 template <int WPP>
-__global__ __launch_bounds__(256) void count_blocks_kernel(const uint8_t* __restrict__ bwt, uint64_t n, uint64_t nb, uint32_t* __restrict__ cnt)
+__global__ __launch_bounds__(256) void count_blocks_kernel(const uint8_t* __restrict__ bwt, uint64_t n, uint64_t nb, typename BlockGeom<WPP>::row_t* __restrict__ cnt)
 {
     const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q > nb) return;
@@ -50,14 +50,17 @@ __global__ __launch_bounds__(256) void count_blocks_kernel(const uint8_t* __rest
 }
 
 template <int WPP>
-__global__ __launch_bounds__(256) void pack_blocks_kernel(const uint8_t* __restrict__ bwt, uint64_t n, uint64_t nb, const uint32_t* __restrict__ cum, uint32_t* __restrict__ blk)
+__global__ __launch_bounds__(256) void pack_blocks_kernel(const uint8_t* __restrict__ bwt, uint64_t n, uint64_t nb, const typename BlockGeom<WPP>::row_t* __restrict__ cum, uint32_t* __restrict__ blk)
 {
     const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nb) return;
     constexpr uint32_t WPB = BlockGeom<WPP>::WPB;
     uint32_t w[WPB];
     for (uint32_t i = 0; i < WPB; ++i) w[i] = 0;
-    for (uint32_t s = 0; s < NLET; ++s) w[s] = cum[s * (nb + 1) + q];
+    for (uint32_t s = 0; s < NLET; ++s) {
+        const uint64_t c = cum[s * (nb + 1) + q];
+        if (BlockGeom<WPP>::HDRW == 5u) w[s] = (uint32_t)c; else { w[2 * s] = (uint32_t)c; w[2 * s + 1] = (uint32_t)(c >> 32); }
+    }
     pack_planes<WPP>(bwt, n, q, w);
     uint32_t* dst = blk + q * WPB;
     for (uint32_t i = 0; i < WPB; ++i) dst[i] = w[i];
@@ -71,7 +74,8 @@ __global__ __launch_bounds__(256) void unpack_blocks_kernel(const uint32_t* __re
     constexpr uint32_t SPB = BlockGeom<WPP>::SPB, WPB = BlockGeom<WPP>::WPB;
     const uint64_t q = i / SPB; const uint32_t off = (uint32_t)(i - q * SPB), w = off >> 5, t = off & 31u;
     const uint32_t* b = blk + q * WPB;
-    bwt[i] = (uint8_t)(((b[5 + w] >> t) & 1u) | (((b[5 + WPP + w] >> t) & 1u) << 1) | (((b[5 + 2 * WPP + w] >> t) & 1u) << 2));
+    constexpr uint32_t H = BlockGeom<WPP>::HDRW;
+    bwt[i] = (uint8_t)(((b[H + w] >> t) & 1u) | (((b[H + WPP + w] >> t) & 1u) << 1) | (((b[H + 2 * WPP + w] >> t) & 1u) << 2));
 }
 
 // 4-bit packed copy of the text: chunk c holds symbols [32c, 32c + 32), symbol i in nibble (i & 1) of byte (i >> 1)
@@ -127,11 +131,12 @@ static int make_ctx(gm_index* ix)
 {
     // 32 B per row (99 GB for a 3.1 Gbp index): only when it leaves the device at least half empty -- the q-mer tables (up to
     // 17 GB), the per-call workspaces and the caller's own buffers come later.  Without it verification reads SA + text.
+    if (ix->wide) return GM_OK;   // the record holds a 32-bit position
     size_t freeB = 0, totalB = 0;
     const uint64_t bytes = ix->nRows * 32ull;
     if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || bytes > freeB || freeB - bytes < totalB / 2) return GM_OK;
     if (hipMalloc(&ix->d_ctx, bytes) != hipSuccess) { (void)hipGetLastError(); ix->d_ctx = nullptr; return GM_OK; }
-    hipLaunchKernelGGL(ctx_build_kernel, dim3(grid_for(ix->nRows)), dim3(256), 0, 0, ix->d_sa, ix->d_textS, ix->nRows, ix->d_ctx);
+    hipLaunchKernelGGL(ctx_build_kernel, dim3(grid_for(ix->nRows)), dim3(256), 0, 0, (const uint32_t*)ix->d_sa, ix->d_textS, ix->nRows, ix->d_ctx);
     GM_HIP(hipGetLastError());
     GM_HIP(hipDeviceSynchronize());
     return GM_OK;
@@ -151,28 +156,29 @@ static int make_sentinel_text(gm_index* ix)
 template <int WPP>
 static int pack_direction(gm_index* ix, int d, const uint8_t* d_bwt)
 {
+    typedef typename BlockGeom<WPP>::row_t row_t;
     const uint64_t n = ix->nRows, nb = num_blocks<WPP>(n);
-    uint32_t* d_cnt = nullptr; void* d_tmp = nullptr; size_t tmpBytes = 0;
-    GM_HIP(hipMalloc(&d_cnt, (nb + 1) * NLET * sizeof(uint32_t)));
+    row_t* d_cnt = nullptr; void* d_tmp = nullptr; size_t tmpBytes = 0;
+    GM_HIP(hipMalloc(&d_cnt, (nb + 1) * NLET * sizeof(row_t)));
     hipLaunchKernelGGL(count_blocks_kernel<WPP>, dim3(grid_for(nb + 1)), dim3(256), 0, 0, d_bwt, n, nb, d_cnt);
-    GM_HIP(rocprim::exclusive_scan(nullptr, tmpBytes, d_cnt, d_cnt, 0u, nb + 1, rocprim::plus<uint32_t>()));
+    GM_HIP(rocprim::exclusive_scan(nullptr, tmpBytes, d_cnt, d_cnt, (row_t)0, nb + 1, rocprim::plus<row_t>()));
     GM_HIP(hipMalloc(&d_tmp, tmpBytes ? tmpBytes : 16));
     for (uint32_t s = 0; s < NLET; ++s) {
         size_t tb = tmpBytes;
-        GM_HIP(rocprim::exclusive_scan(d_tmp, tb, d_cnt + s * (nb + 1), d_cnt + s * (nb + 1), 0u, nb + 1, rocprim::plus<uint32_t>()));
+        GM_HIP(rocprim::exclusive_scan(d_tmp, tb, d_cnt + s * (nb + 1), d_cnt + s * (nb + 1), (row_t)0, nb + 1, rocprim::plus<row_t>()));
     }
     ix->blkBytes = nb * BlockGeom<WPP>::BYTES;
     GM_HIP(hipMalloc(&ix->d_blk[d], ix->blkBytes));
     hipLaunchKernelGGL(pack_blocks_kernel<WPP>, dim3(grid_for(nb)), dim3(256), 0, 0, d_bwt, n, nb, d_cnt, ix->d_blk[d]);
     GM_HIP(hipGetLastError());
     if (d == 0) {
-        uint32_t tot[NLET];
-        for (uint32_t s = 0; s < NLET; ++s) GM_HIP(hipMemcpy(&tot[s], d_cnt + s * (nb + 1) + nb, 4, hipMemcpyDeviceToHost));
-        uint32_t acc = ix->nSeq;   // sentinel suffixes occupy rows [0, nSeq)
+        row_t tot[NLET];
+        for (uint32_t s = 0; s < NLET; ++s) GM_HIP(hipMemcpy(&tot[s], d_cnt + s * (nb + 1) + nb, sizeof(row_t), hipMemcpyDeviceToHost));
+        uint64_t acc = ix->nSeq;   // sentinel suffixes occupy rows [0, nSeq)
         for (uint32_t s = 0; s < NLET; ++s) { ix->C[s] = acc; acc += tot[s]; }
         ix->C[NLET] = acc;
         ix->alphabet = tot[SYM_N] ? 5 : 4;
-        if (acc != ix->nRows) { set_error("BWT letter counts (%u) do not add up to the row count (%llu)", acc, (unsigned long long)ix->nRows); return GM_ERR_BAD_ARG; }
+        if (acc != ix->nRows) { set_error("BWT letter counts (%llu) do not add up to the row count (%llu)", (unsigned long long)acc, (unsigned long long)ix->nRows); return GM_ERR_BAD_ARG; }
     }
     GM_HIP(hipDeviceSynchronize());
     hipFree(d_cnt); hipFree(d_tmp);
@@ -183,6 +189,7 @@ static int pack_dispatch(gm_index* ix, int d, const uint8_t* d_bwt)
 {
     switch (ix->wpp) {
         case 1: return pack_direction<1>(ix, d, d_bwt);
+        case 2: return pack_direction<2>(ix, d, d_bwt);
         case 3: return pack_direction<3>(ix, d, d_bwt);
         case 9: return pack_direction<9>(ix, d, d_bwt);
     }
@@ -208,6 +215,8 @@ static int index_common_setup(gm_index* ix, const uint8_t* codes, const uint64_t
 {
     ix->device = device; ix->nSeq = n_seq; ix->sampling = sampling;
     if (sampling > 1) { set_error("this build keeps the full suffix array in HBM (sampling 1) or none (0); sampled SA + LF walk is not implemented"); return GM_ERR_BAD_ARG; }
+    const bool forceWide = (block_bytes & GM_BLOCK_WIDE_ROWS) != 0;
+    block_bytes &= ~(uint32_t)GM_BLOCK_WIDE_ROWS;
     ix->wpp = wpp_of_block_bytes(block_bytes);
     if (!ix->wpp) { set_error("block_bytes must be 32, 64 or 128"); return GM_ERR_BAD_ARG; }
     ix->cum.assign((size_t)n_seq + 1, 0);
@@ -217,7 +226,10 @@ static int index_common_setup(gm_index* ix, const uint8_t* codes, const uint64_t
     }
     ix->textLen = ix->cum[n_seq];
     ix->nRows = ix->textLen + n_seq;
-    if (ix->nRows >= 0xFFFFFFFFull) { set_error("index of %llu rows needs 64-bit positions (not in this build)", (unsigned long long)ix->nRows); return GM_ERR_TOO_LONG; }
+    // 2^32 - 1 rows or more: 64-bit rows, ranges and text positions (the reference's 64-bit BWT variants, src/indexing.hpp:158-169)
+    ix->wide = forceWide || ix->nRows >= 0xFFFFFFFFull;
+    if (ix->wide) ix->wpp = WPP_WIDE;
+    if (ix->nRows >= (1ull << 40)) { set_error("index of %llu rows is beyond this build (2^40 rows)", (unsigned long long)ix->nRows); return GM_ERR_TOO_LONG; }
     hipDeviceProp_t prop;
     GM_HIP(hipGetDeviceProperties(&prop, device));
     ix->numCU = prop.multiProcessorCount;
@@ -303,15 +315,17 @@ int gm_index_build(const uint8_t* codes, const uint64_t* seq_len, uint32_t n_seq
     gm_index* ix = new (std::nothrow) gm_index();
     if (!ix) return GM_ERR_OOM;
     rc = index_common_setup(ix, codes, seq_len, n_seq, sampling, block_bytes, device);
-    uint32_t* d_sa = nullptr; uint8_t* d_bwt = nullptr;
-    if (!rc && hipMalloc(&d_sa, ix->nRows * 4) != hipSuccess) rc = GM_ERR_OOM;
+    void* d_sa = nullptr; uint8_t* d_bwt = nullptr;
+    const size_t rb = ix->wide ? 8 : 4;   // bytes per suffix-array entry
+    if (!rc && hipMalloc(&d_sa, ix->nRows * rb) != hipSuccess) rc = GM_ERR_OOM;
     if (!rc && hipMalloc(&d_bwt, ix->nRows) != hipSuccess) rc = GM_ERR_OOM;
     for (int d = 0; d < 2 && !rc; ++d) {
-        rc = build_sa_bwt(ix->d_text, ix->d_cum, n_seq, ix->textLen, d, d_sa, d_bwt, &ix->buildRounds[d]);
+        rc = ix->wide ? build_sa_bwt_wide(ix->d_text, ix->d_cum, n_seq, ix->textLen, d, (uint64_t*)d_sa, d_bwt, &ix->buildRounds[d])
+                      : build_sa_bwt(ix->d_text, ix->d_cum, n_seq, ix->textLen, d, (uint32_t*)d_sa, d_bwt, &ix->buildRounds[d]);
         if (!rc) rc = pack_dispatch(ix, d, d_bwt);
-        if (!rc && d == 0 && sampling == 1) {   // the forward SA stays resident: 4 B/row of 288 GB buys locate without LF walks
+        if (!rc && d == 0 && sampling == 1) {   // the forward SA stays resident: 4 (8) B/row of 288 GB buys locate without LF walks
             ix->d_sa = d_sa; d_sa = nullptr;
-            if (hipMalloc(&d_sa, ix->nRows * 4) != hipSuccess) rc = GM_ERR_OOM;
+            if (hipMalloc(&d_sa, ix->nRows * rb) != hipSuccess) rc = GM_ERR_OOM;
         }
     }
     hipFree(d_sa); hipFree(d_bwt);
@@ -339,8 +353,9 @@ int gm_index_import(const uint8_t* bwt_fwd, const uint8_t* bwt_rev, const uint32
     }
     hipFree(d_bwt);
     if (!rc && sa_fwd && sampling == 1) {
-        if (hipMalloc(&ix->d_sa, ix->nRows * 4) != hipSuccess) rc = GM_ERR_OOM;
-        else if (hipMemcpy(ix->d_sa, sa_fwd, ix->nRows * 4, hipMemcpyHostToDevice) != hipSuccess) rc = GM_ERR_HIP;
+        const size_t rb = ix->wide ? 8 : 4;   // sa_fwd is an array of uint64_t for wide indexes
+        if (hipMalloc(&ix->d_sa, ix->nRows * rb) != hipSuccess) rc = GM_ERR_OOM;
+        else if (hipMemcpy(ix->d_sa, sa_fwd, ix->nRows * rb, hipMemcpyHostToDevice) != hipSuccess) rc = GM_ERR_HIP;
         if (!rc) rc = make_sentinel_text(ix);
         if (!rc) rc = make_ctx(ix);
     }
@@ -358,6 +373,7 @@ int gm_index_export_bwt(const gm_index* ix, uint8_t* bwt_fwd, uint8_t* bwt_rev)
     for (int d = 0; d < 2; ++d) {
         switch (ix->wpp) {
             case 1: hipLaunchKernelGGL(unpack_blocks_kernel<1>, dim3(grid_for(ix->nRows)), dim3(256), 0, 0, ix->d_blk[d], ix->nRows, d_bwt); break;
+            case 2: hipLaunchKernelGGL(unpack_blocks_kernel<2>, dim3(grid_for(ix->nRows)), dim3(256), 0, 0, ix->d_blk[d], ix->nRows, d_bwt); break;
             case 3: hipLaunchKernelGGL(unpack_blocks_kernel<3>, dim3(grid_for(ix->nRows)), dim3(256), 0, 0, ix->d_blk[d], ix->nRows, d_bwt); break;
             default: hipLaunchKernelGGL(unpack_blocks_kernel<9>, dim3(grid_for(ix->nRows)), dim3(256), 0, 0, ix->d_blk[d], ix->nRows, d_bwt); break;
         }
@@ -372,7 +388,7 @@ int gm_index_export_sa(const gm_index* ix, uint32_t* sa)
     if (!ix || !sa) return GM_ERR_BAD_ARG;
     if (!ix->d_sa) { set_error("index holds no suffix array (built with sampling 0)"); return GM_ERR_NEED_LOCATE; }
     GM_HIP(hipSetDevice(ix->device));
-    GM_HIP(hipMemcpy(sa, ix->d_sa, ix->nRows * 4, hipMemcpyDeviceToHost));
+    GM_HIP(hipMemcpy(sa, ix->d_sa, ix->nRows * (ix->wide ? 8 : 4), hipMemcpyDeviceToHost));
     return GM_OK;
 }
 
@@ -381,8 +397,9 @@ int gm_index_get_info(const gm_index* ix, gm_index_info* info)
     if (!ix || !info) return GM_ERR_BAD_ARG;
     info->n_rows = ix->nRows; info->text_len = ix->textLen; info->n_seq = ix->nSeq; info->sampling = ix->sampling;
     info->alphabet_size = ix->alphabet;
-    info->block_bytes = ix->wpp == 1 ? 32 : ix->wpp == 3 ? 64 : 128;
-    info->device_bytes = 2 * ix->blkBytes + ix->textLen + (ix->nSeq + 1) * 8ull + (ix->d_sa ? ix->nRows * 5ull : 0ull) + (ix->d_ctx ? ix->nRows * 32ull : 0ull) + ix->qtableBytes;
+    info->block_bytes = ix->wpp == 1 ? 32 : (ix->wpp == 3 || ix->wpp == 2) ? 64 : 128;
+    info->row_bits = ix->wide ? 64 : 32;
+    info->device_bytes = 2 * ix->blkBytes + ix->textLen + (ix->nSeq + 1) * 8ull + (ix->d_sa ? ix->nRows * (ix->wide ? 9ull : 5ull) : 0ull) + (ix->d_ctx ? ix->nRows * 32ull : 0ull) + ix->qtableBytes;
     if (!ix->d_sa) info->sampling = 0;
     info->device = ix->device;
     info->verify_records = ix->d_ctx ? 1u : 0u;
@@ -406,31 +423,27 @@ template <typename T> static int grow(T** p, uint64_t* cap, uint64_t need)
 
 enum LeafMode { LEAF_COUNT = 0, LEAF_FILESET = 1, LEAF_OCC_COUNT = 2, LEAF_OCC_EMIT = 3, LEAF_STORE = 4, LEAF_STORE8 = 5 };
 
-static inline size_t search_lds_bytes(const SearchArgs& A) { return (size_t)(4u * A.vqCap + 4u * 64u * (A.ldsDepth + A.winChunks)) * 16u + 4u * 128u * 4u; }
+// nu = 16-byte units per stored node / queue entry: 1, or 2 with 64-bit rows (gm_kernels.h: NodeIO)
+static inline size_t search_lds_bytes(const SearchArgs& A, uint32_t nu) { return (size_t)(4u * A.vqCap * nu + 4u * 64u * (A.ldsDepth * nu + A.winChunks)) * 16u + 4u * 128u * 4u; }
 
 template <int WPP, class EnvT>
 static int launch_one(const SearchArgs& A, unsigned blocks, hipStream_t st)
 {
-    const size_t lds = search_lds_bytes(A);
+    const size_t lds = search_lds_bytes(A, NodeIO<typename BlockGeom<WPP>::row_t>::NU);
     constexpr bool CAN_COOP = WPP == 1 || WPP == 3;
-    if constexpr (CAN_COOP) if (A.coop) {
-        if constexpr (WPP == 3) {
-            if (lds > 65536)   // long needle windows (K + n - 1 up to 509 symbols per lane): ask for more than the default 64 KB of LDS
-                GM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&search_kernel_w4<WPP, EnvT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((search_kernel_w4<WPP, EnvT, true>), dim3(blocks), dim3(256), lds, st, A);
-        } else {
-            if (lds > 65536)
-                GM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&search_kernel<WPP, EnvT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((search_kernel<WPP, EnvT, true>), dim3(blocks), dim3(256), lds, st, A);
-        }
-        GM_HIP(hipGetLastError());
-        return GM_OK;
-    }
-    {
-        if (lds > 65536)
-            GM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&search_kernel<WPP, EnvT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((search_kernel<WPP, EnvT, false>), dim3(blocks), dim3(256), lds, st, A);
-    }
+    // 32- and 64-byte blocks with 32-bit rows are compiled for 4 waves per SIMD (at most 128 VGPRs: the kernels sit within a
+    // register or two of that limit); the 128-byte and the wide geometries take what they need
+    constexpr bool W4 = WPP == 1 || WPP == 3;
+    const void* fn;
+    if constexpr (CAN_COOP) fn = A.coop ? reinterpret_cast<const void*>(&search_kernel_w4<WPP, EnvT, true>) : reinterpret_cast<const void*>(&search_kernel_w4<WPP, EnvT, false>);
+    else fn = reinterpret_cast<const void*>(&search_kernel<WPP, EnvT, false>);
+    if (lds > 65536)   // long needle windows (K + n - 1 up to 509 symbols per lane): ask for more than the default 64 KB of LDS
+        GM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if constexpr (CAN_COOP) {
+        static_assert(W4, "");
+        if (A.coop) hipLaunchKernelGGL((search_kernel_w4<WPP, EnvT, true>), dim3(blocks), dim3(256), lds, st, A);
+        else hipLaunchKernelGGL((search_kernel_w4<WPP, EnvT, false>), dim3(blocks), dim3(256), lds, st, A);
+    } else hipLaunchKernelGGL((search_kernel<WPP, EnvT, false>), dim3(blocks), dim3(256), lds, st, A);
     GM_HIP(hipGetLastError());
     return GM_OK;
 }
@@ -450,6 +463,7 @@ static int launch_search(const gm_index* ix, int mode, const SearchArgs& A, unsi
 {
     switch (ix->wpp) {
         case 1: return launch_mode<1>(mode, A, blocks, st);
+        case 2: return launch_mode<2>(mode, A, blocks, st);
         case 3: return launch_mode<3>(mode, A, blocks, st);
         default: return launch_mode<9>(mode, A, blocks, st);
     }
@@ -458,7 +472,8 @@ static int launch_search(const gm_index* ix, int mode, const SearchArgs& A, unsi
 template <int WPP> static int occupancy_blocks(int* out, size_t ldsBytes)
 {
     int nb = 0;
-    GM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (search_kernel<WPP, CountEnv<WPP>, false>), 256, ldsBytes));
+    if constexpr (WPP == 1 || WPP == 3) GM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (search_kernel_w4<WPP, CountEnv<WPP>, false>), 256, ldsBytes));
+    else GM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (search_kernel<WPP, CountEnv<WPP>, false>), 256, ldsBytes));
     *out = nb;
     return GM_OK;
 }
@@ -478,7 +493,7 @@ static int get_qtable(gm_index* ix, uint32_t* qio, const uint4** out)
     for (;; --q) {   // shorter prefixes when the device is short of memory (the table is an accelerator, not a requirement)
         if (q == 0) { *qio = 0; *out = nullptr; return GM_OK; }
         size_t freeB = 0, totalB = 0;
-        const uint64_t bytes = (1ull << (2 * q)) * sizeof(uint4);
+        const uint64_t bytes = (1ull << (2 * q)) * sizeof(uint4) * (ix->wide ? 2 : 1);
         if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && bytes > freeB / 2) { ix->qtableCap = q - 1; continue; }
         if (hipMalloc(&d, bytes) == hipSuccess) break;
         (void)hipGetLastError();
@@ -487,14 +502,15 @@ static int get_qtable(gm_index* ix, uint32_t* qio, const uint4** out)
     const uint64_t n = 1ull << (2 * q);
     if (!ix->d_C) { GM_HIP(hipMalloc(&ix->d_C, sizeof(ix->C))); GM_HIP(hipMemcpy(ix->d_C, ix->C, sizeof(ix->C), hipMemcpyHostToDevice)); }
     switch (ix->wpp) {
-        case 1: hipLaunchKernelGGL(qmer_table_kernel<1>, dim3(grid_for(n)), dim3(256), 0, 0, ix->d_blk[1], ix->d_C, (uint32_t)ix->nRows, q, d); break;
-        case 3: hipLaunchKernelGGL(qmer_table_kernel<3>, dim3(grid_for(n)), dim3(256), 0, 0, ix->d_blk[1], ix->d_C, (uint32_t)ix->nRows, q, d); break;
-        default: hipLaunchKernelGGL(qmer_table_kernel<9>, dim3(grid_for(n)), dim3(256), 0, 0, ix->d_blk[1], ix->d_C, (uint32_t)ix->nRows, q, d); break;
+        case 1: hipLaunchKernelGGL(qmer_table_kernel<1>, dim3(grid_for(n)), dim3(256), 0, 0, ix->d_blk[1], ix->d_C, ix->nRows, q, d); break;
+        case 2: hipLaunchKernelGGL(qmer_table_kernel<2>, dim3(grid_for(n)), dim3(256), 0, 0, ix->d_blk[1], ix->d_C, ix->nRows, q, d); break;
+        case 3: hipLaunchKernelGGL(qmer_table_kernel<3>, dim3(grid_for(n)), dim3(256), 0, 0, ix->d_blk[1], ix->d_C, ix->nRows, q, d); break;
+        default: hipLaunchKernelGGL(qmer_table_kernel<9>, dim3(grid_for(n)), dim3(256), 0, 0, ix->d_blk[1], ix->d_C, ix->nRows, q, d); break;
     }
     GM_HIP(hipGetLastError());
     GM_HIP(hipDeviceSynchronize());
     ix->qtables[q] = d;
-    ix->qtableBytes += n * sizeof(uint4);
+    ix->qtableBytes += n * sizeof(uint4) * (ix->wide ? 2 : 1);
     *qio = q;
     *out = d;
     return GM_OK;
@@ -505,7 +521,7 @@ struct SearchSetup {
     ChunkSel sel{0, 0, 0};   // interleaved chunks: which positions of [posBase, posEnd) this call owns
     uint64_t blockBegin = 0, blockEnd = 0, numRoots = 0, kmers = 0;
     unsigned blocks = 1;
-    uint32_t posBase = 0, posEnd = 0;   // slice positions covered by the selected blocks: [posBase, posEnd)
+    uint64_t posBase = 0, posEnd = 0;   // slice positions covered by the selected blocks: [posBase, posEnd)
 };
 
 // validation, planning, workspace, uploads; fills every SearchArgs field that does not depend on the leaf policy
@@ -564,7 +580,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
             for (uint64_t b = blockBegin; b < blockEnd; ++b) kmers += plan.blocks[b].second;
             S->posBase = plan.blocks[blockBegin].first; S->posEnd = plan.blocks[blockEnd - 1].first + plan.blocks[blockEnd - 1].second;
         } else {
-            S->posBase = (uint32_t)(blockBegin * plan.stepSize); S->posEnd = (uint32_t)std::min<uint64_t>(blockEnd * plan.stepSize, plan.numKmers);
+            S->posBase = blockBegin * plan.stepSize; S->posEnd = std::min<uint64_t>(blockEnd * plan.stepSize, plan.numKmers);
             kmers = S->posEnd - S->posBase;
             if (chunked) {   // k-mers of the own chunks (only the very last block of the text can be short)
                 kmers = myBlocks * plan.stepSize;
@@ -598,11 +614,12 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     const uint32_t depth = stack_bound(p->E, plan.stepSize) + STEAL_LEVELS;   // room for the levels work sharing may vacate at the bottom
     const uint32_t vqCap = verifyT ? 64u + 64u * verifyT : 1u;
     const uint32_t winChunks = (31u + p->K + plan.stepSize - 1u + 31u) / 32u;
-    uint32_t ldsDepth = (uint32_t)std::max(0, ix->tune.ldsStack);
+    const uint32_t nu = ix->wide ? 2u : 1u;
+    uint32_t ldsDepth = (uint32_t)std::max(0, ix->tune.ldsStack) / nu;   // the same LDS for the stack tops of wide nodes
     ldsDepth = std::min(ldsDepth, depth);
-    const size_t ldsBytes = (size_t)(4u * vqCap + 4u * 64u * (ldsDepth + winChunks)) * 16u + 4u * 128u * 4u;   // == search_lds_bytes
+    const size_t ldsBytes = (size_t)(4u * vqCap * nu + 4u * 64u * (ldsDepth * nu + winChunks)) * 16u + 4u * 128u * 4u;   // == search_lds_bytes
     int perCU = 0;
-    switch (ix->wpp) { case 1: rc = occupancy_blocks<1>(&perCU, ldsBytes); break; case 3: rc = occupancy_blocks<3>(&perCU, ldsBytes); break; default: rc = occupancy_blocks<9>(&perCU, ldsBytes); break; }
+    switch (ix->wpp) { case 1: rc = occupancy_blocks<1>(&perCU, ldsBytes); break; case 2: rc = occupancy_blocks<2>(&perCU, ldsBytes); break; case 3: rc = occupancy_blocks<3>(&perCU, ldsBytes); break; default: rc = occupancy_blocks<9>(&perCU, ldsBytes); break; }
     if (rc) return rc;
     const int wantPerCU = std::max(1, ix->tune.blocksPerCU);   // default 4 = 4 waves/SIMD, what the kernel's VGPR count allows
     perCU = std::max(1, std::min(perCU, wantPerCU));
@@ -610,7 +627,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     const uint64_t useful = (S->numRoots + 255) / 256;
     if (blocks > useful) blocks = std::max<uint64_t>(useful, 1);
     S->blocks = (unsigned)blocks;
-    rc = grow(&ix->d_stack, &ix->stackCap, blocks * 256ull * std::max<uint32_t>(depth - ldsDepth, 1u)); if (rc) return rc;
+    rc = grow(&ix->d_stack, &ix->stackCap, blocks * 256ull * std::max<uint32_t>(depth - ldsDepth, 1u) * nu); if (rc) return rc;
 
     {   // the call's small device-side tables (OSS records, block list, local sequence limits) are uploaded only when the
         // call differs from the previous one on this index: a loop over shards or repeated passes launches without any
@@ -634,11 +651,11 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     SearchArgs A; memset(&A, 0, sizeof(A));
     A.blk[0] = ix->d_blk[0]; A.blk[1] = ix->d_blk[1];
     for (uint32_t c = 0; c <= NLET; ++c) A.C[c] = ix->C[c];
-    A.nRows = (uint32_t)ix->nRows;
+    A.nRows = ix->nRows;
     A.text = ix->d_text + text_begin;
     A.K = p->K; A.E = p->E;
     A.stepSize = plan.stepSize; A.nSearches = plan.nSearches; A.rootsPerBlock = rpb;
-    A.numKmers = (uint32_t)plan.numKmers;
+    A.numKmers = plan.numKmers;
     A.blockBegin = blockBegin; A.numRoots = S->numRoots;
     A.blockList = plan.useList ? ix->d_blocks : nullptr;
     A.table = ix->d_table;
@@ -650,6 +667,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         // (profiles/r01h_qtable_sweep.txt: e=0 +27 % on 249 Mbp, +30 % on 3.1 Gbp going from 12 to 15).
         uint32_t qmax = 1;
         while (qmax < 15 && (1ull << (2 * qmax)) < 4ull * ix->nRows) ++qmax;
+        if (ix->wide) qmax = std::min(qmax, 14u);   // 32-byte entries
         if (ix->tune.qtable >= 0) qmax = (uint32_t)std::min(ix->tune.qtable, 15);
         A.qtabA = A.qtabB = nullptr; A.qlenPacked = 0; A.qselMask = 0; A.startPacked[0] = A.startPacked[1] = 0;
         uint32_t qA = 0, qB = 0;
@@ -696,6 +714,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     const bool stealDefault = (p->E <= 1 && p->K < 64 && ix->nRows >= (1ull << 30)) || S->numRoots < 64ull * 4ull * 1024ull;
     A.steal = ix->tune.steal >= 0 ? (uint32_t)(ix->tune.steal != 0) : (stealDefault ? 1u : 0u);
     A.coop = ix->tune.coop >= 0 ? (uint32_t)(ix->tune.coop != 0) : (ix->wpp == 1 ? 1u : 0u);
+    if (ix->wide) A.coop = 0u;
     *Aout = A;
     return GM_OK;
 }

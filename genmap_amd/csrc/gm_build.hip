@@ -147,4 +147,124 @@ done:
     return rc;
 }
 
+// ---- 64-bit rows ---------------------------------------------------------------------------------------------
+// Same prefix doubling; ranks need more than 32 bits, so the (rank[i], rank[i+h]) key of a round no longer fits one 64-bit
+// radix key: every round sorts twice, stably, LSD fashion -- by rank[i+h], then by rank[i].
+__global__ __launch_bounds__(256) void make_symbols_wide_kernel(const uint8_t* __restrict__ codes, const uint64_t* __restrict__ cum,
+                                                                uint32_t nSeq, uint64_t textLen, int rev,
+                                                                uint8_t* __restrict__ sym, uint64_t* __restrict__ key, uint64_t* __restrict__ sa)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < textLen) {
+        uint32_t lo = 0, hi = nSeq;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cum[mid] <= i) lo = mid; else hi = mid; }
+        const uint64_t b = cum[lo], e = cum[lo + 1];
+        const uint64_t p = (rev ? (b + (e - 1 - i)) : i) + lo;
+        const uint32_t c = codes[i];
+        sym[p] = (uint8_t)c; key[p] = (uint64_t)nSeq + c; sa[p] = p;
+    } else if (i < textLen + nSeq) {
+        const uint32_t s = (uint32_t)(i - textLen);
+        const uint64_t p = cum[s + 1] + s;
+        sym[p] = (uint8_t)SYM_SENT; key[p] = s; sa[p] = p;
+    }
+}
+// flag[j] = 1 when suffix sa[j] starts a new group: its (first, second) rank pair differs from its predecessor's
+__global__ __launch_bounds__(256) void head_flags_pair_kernel(const uint64_t* __restrict__ sa, const uint64_t* __restrict__ rank, uint64_t* __restrict__ flag, uint64_t n, uint64_t h)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    if (j == 0) { flag[0] = 0; return; }
+    const uint64_t p = sa[j], q = sa[j - 1];
+    const uint64_t p2 = p + h < n ? rank[p + h] + 1 : 0, q2 = q + h < n ? rank[q + h] + 1 : 0;
+    flag[j] = (rank[p] != rank[q] || p2 != q2) ? 1ull : 0ull;
+}
+__global__ __launch_bounds__(256) void head_flags_key_kernel(const uint64_t* __restrict__ keys, uint64_t* __restrict__ flag, uint64_t n)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) flag[j] = (j > 0 && keys[j] != keys[j - 1]) ? 1ull : 0ull;
+}
+__global__ __launch_bounds__(256) void scatter_rank_wide_kernel(const uint64_t* __restrict__ sa, const uint64_t* __restrict__ dense, uint64_t* __restrict__ rank, uint64_t n)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) rank[sa[j]] = dense[j];
+}
+// key of a suffix for one of the two passes: which = 1 -> rank[i + h] (0 for suffixes shorter than h, they sort first), which = 0 -> rank[i]
+__global__ __launch_bounds__(256) void make_key_wide_kernel(const uint64_t* __restrict__ sa, const uint64_t* __restrict__ rank, uint64_t* __restrict__ keys, uint64_t n, uint64_t h, int which)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint64_t p = sa[j];
+    keys[j] = which ? (p + h < n ? rank[p + h] + 1 : 0ull) : rank[p];
+}
+__global__ __launch_bounds__(256) void bwt_wide_kernel(const uint64_t* __restrict__ sa, const uint8_t* __restrict__ sym, uint8_t* __restrict__ bwt, uint64_t n)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) { const uint64_t p = sa[j]; bwt[j] = p ? sym[p - 1] : sym[n - 1]; }
+}
+
+int build_sa_bwt_wide(const uint8_t* d_codes, const uint64_t* d_cum, uint32_t nSeq, uint64_t textLen, int rev,
+                      uint64_t* d_sa_out, uint8_t* d_bwt, int* roundsOut)
+{
+    const uint64_t n = textLen + nSeq;
+    uint8_t* d_sym = nullptr;
+    uint64_t *d_own = nullptr, *d_rank = nullptr, *d_flag = nullptr, *d_keyA = nullptr, *d_keyB = nullptr;
+    void* d_tmp = nullptr;
+    size_t tmpBytes = 0;
+    int rc = GM_OK;
+#define HC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); rc = (e_ == hipErrorOutOfMemory ? GM_ERR_OOM : GM_ERR_HIP); goto done; } } while (0)
+    {
+        uint64_t* cur = d_sa_out;
+        uint64_t* alt = nullptr;
+        HC(hipMalloc(&d_sym, n));
+        HC(hipMalloc(&d_own, n * 8)); HC(hipMalloc(&d_rank, n * 8)); HC(hipMalloc(&d_flag, n * 8));
+        HC(hipMalloc(&d_keyA, n * 8)); HC(hipMalloc(&d_keyB, n * 8));
+        alt = d_own;
+        hipLaunchKernelGGL(make_symbols_wide_kernel, dim3(grid_for(n)), dim3(256), 0, 0, d_codes, d_cum, nSeq, textLen, rev, d_sym, d_keyA, cur);
+        HC(hipGetLastError());
+        unsigned keyBits = 1; while ((1ull << keyBits) < (uint64_t)nSeq + NLET) ++keyBits;
+        unsigned rbits = 1; while ((1ull << rbits) < n + 1) ++rbits;
+        size_t t1 = 0, t2 = 0;
+        HC(rocprim::radix_sort_pairs(nullptr, t1, d_keyA, d_keyB, cur, alt, n, 0, std::max(keyBits, rbits)));
+        HC(rocprim::inclusive_scan(nullptr, t2, d_flag, d_keyA, n, rocprim::plus<uint64_t>()));
+        tmpBytes = std::max(t1, t2);
+        HC(hipMalloc(&d_tmp, tmpBytes ? tmpBytes : 16));
+        // round 0: order by first symbol
+        size_t tb = tmpBytes;
+        HC(rocprim::radix_sort_pairs(d_tmp, tb, d_keyA, d_keyB, cur, alt, n, 0, keyBits));
+        std::swap(cur, alt);
+        hipLaunchKernelGGL(head_flags_key_kernel, dim3(grid_for(n)), dim3(256), 0, 0, d_keyB, d_flag, n);
+        tb = tmpBytes;
+        HC(rocprim::inclusive_scan(d_tmp, tb, d_flag, d_keyA, n, rocprim::plus<uint64_t>()));   // dense ranks in d_keyA
+        hipLaunchKernelGGL(scatter_rank_wide_kernel, dim3(grid_for(n)), dim3(256), 0, 0, cur, d_keyA, d_rank, n);
+        uint64_t maxRank = 0;
+        HC(hipMemcpy(&maxRank, d_keyA + (n - 1), 8, hipMemcpyDeviceToHost));
+        int rounds = 0;
+        for (uint64_t h = 1; maxRank != n - 1; h <<= 1) {
+            if (h >= n) { set_error("prefix doubling did not converge"); rc = GM_ERR_INTERNAL; goto done; }
+            for (int which = 1; which >= 0; --which) {   // stable LSD: second key first
+                hipLaunchKernelGGL(make_key_wide_kernel, dim3(grid_for(n)), dim3(256), 0, 0, cur, d_rank, d_keyA, n, h, which);
+                tb = tmpBytes;
+                HC(rocprim::radix_sort_pairs(d_tmp, tb, d_keyA, d_keyB, cur, alt, n, 0, rbits));
+                std::swap(cur, alt);
+            }
+            hipLaunchKernelGGL(head_flags_pair_kernel, dim3(grid_for(n)), dim3(256), 0, 0, cur, d_rank, d_flag, n, h);
+            tb = tmpBytes;
+            HC(rocprim::inclusive_scan(d_tmp, tb, d_flag, d_keyA, n, rocprim::plus<uint64_t>()));
+            hipLaunchKernelGGL(scatter_rank_wide_kernel, dim3(grid_for(n)), dim3(256), 0, 0, cur, d_keyA, d_keyB, n);   // new ranks in d_keyB ...
+            HC(hipMemcpyAsync(d_rank, d_keyB, n * 8, hipMemcpyDeviceToDevice, 0));                                          // ... (the flags read the old ones)
+            HC(hipMemcpy(&maxRank, d_keyA + (n - 1), 8, hipMemcpyDeviceToHost));
+            ++rounds;
+        }
+        if (roundsOut) *roundsOut = rounds;
+        if (cur != d_sa_out) HC(hipMemcpy(d_sa_out, cur, n * 8, hipMemcpyDeviceToDevice));
+        hipLaunchKernelGGL(bwt_wide_kernel, dim3(grid_for(n)), dim3(256), 0, 0, d_sa_out, d_sym, d_bwt, n);
+        HC(hipGetLastError());
+        HC(hipDeviceSynchronize());
+    }
+done:
+    hipFree(d_sym); hipFree(d_own); hipFree(d_rank); hipFree(d_flag); hipFree(d_keyA); hipFree(d_keyB); hipFree(d_tmp);
+#undef HC
+    return rc;
+}
+
 }  // namespace gm

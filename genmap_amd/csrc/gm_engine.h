@@ -28,7 +28,9 @@ namespace gm {
 enum : uint32_t { M_OSS = 0, M_EXT_R = 1, M_EXT_L = 2, M_SPLIT = 3 };
 
 // meta: a (9 bits) | bx<<9 (9) | t<<18 (9) | errs<<27 (3) | mode<<30 (2): window coordinates reach 2K-1 <= 509 (K <= MAX_K)
-struct Node { uint32_t flo, rlo, w, meta; };
+// R = row type: uint32_t, or uint64_t for indexes of 2^32 - 1 rows or more (gm_rank.h: BlockGeom<2>)
+template <typename R> struct NodeT { R flo, rlo, w; uint32_t meta; };
+typedef NodeT<uint32_t> Node;
 constexpr uint32_t META_ERRS_SHIFT = 27;
 
 GM_HD uint32_t meta_pack(uint32_t a, uint32_t bx, uint32_t t, uint32_t errs, uint32_t mode)
@@ -42,24 +44,25 @@ GM_HD uint32_t meta_errs(uint32_t m) { return (m >> META_ERRS_SHIFT) & 7u; }
 GM_HD uint32_t meta_mode(uint32_t m) { return m >> 30; }
 
 // the root a lane is currently working on: one (k-mer block, strand, search) triple
-struct Root {
-    uint32_t win;      // slice-relative text offset of the block's window = position of its first k-mer
+template <typename R> struct RootT {
+    R win;             // slice-relative text offset of the block's window = position of its first k-mer
     uint32_t n;        // k-mers in the block; window length W = K + n - 1; common infix = [n-1, K)
     uint32_t strand;   // 1: the window is read reverse-complemented (algo.hpp:286-287)
     uint32_t search;   // index of the OSS search inside the scheme (selects rec)
     OssRecord rec;
 };
+typedef RootT<uint32_t> Root;
 
-GM_HD Node root_node(const Root& rt, uint32_t nRows)
+template <typename R> GM_HD NodeT<R> root_node(const RootT<R>& rt, R nRows)
 {
     // _optimalSearchSchemeGM(..., s.startPos, s.startPos + 1, 0, s, 0, Rev()) find2_index_approx.hpp:441
     uint32_t a = (rt.n - 1u) + oss_start(rt.rec);
-    Node nd; nd.flo = 0; nd.rlo = 0; nd.w = nRows; nd.meta = meta_pack(a, a, 0, 0, M_OSS);
+    NodeT<R> nd; nd.flo = 0; nd.rlo = 0; nd.w = nRows; nd.meta = meta_pack(a, a, 0, 0, M_OSS);
     return nd;
 }
 
 // SPLIT -> (EXT_R kept, EXT_L returned through `left`).  algo.hpp:53-56 and :68-71 (same in :196-211).
-GM_HD void split_node(Node& nd, Node& left, uint32_t K)
+template <typename R> GM_HD void split_node(NodeT<R>& nd, NodeT<R>& left, uint32_t K)
 {
     uint32_t m = nd.meta, a = meta_a(m), bx = meta_bx(m), errs = meta_errs(m);
     uint32_t alm = bx - K;                                 // b + 1 - length  (>= 0)
@@ -136,16 +139,17 @@ GM_HD Post make_post(uint32_t meta, const Plan& pl, const OssRecord& rec, uint32
 //   void note_step(uint32_t mode, uint32_t width)     (statistics hook)
 //   bool any(bool)                                    (true if the predicate holds in any lane of the wavefront)
 // On return `have` tells whether nd holds a node to continue with.
-template <class Env> GM_HD void lane_children(Node& nd, bool& have, const Root& rt, uint32_t K, uint32_t E, Env& env, const Plan& pl,
-                                             const uint32_t rl[NLET], const uint32_t rh[NLET]);
+template <class Env> GM_HD void lane_children(NodeT<typename Env::row_t>& nd, bool& have, const RootT<typename Env::row_t>& rt, uint32_t K, uint32_t E, Env& env, const Plan& pl,
+                                             const typename Env::row_t rl[NLET], const typename Env::row_t rh[NLET]);
 
 template <class Env>
-GM_HD void lane_step(Node& nd, bool& have, const Root& rt, uint32_t K, uint32_t E, Env& env)
+GM_HD void lane_step(NodeT<typename Env::row_t>& nd, bool& have, const RootT<typename Env::row_t>& rt, uint32_t K, uint32_t E, Env& env)
 {
+    typedef typename Env::row_t R;
     const Plan pl = make_plan(nd.meta, rt.rec, E);
     env.note_step(meta_mode(nd.meta), nd.w);   // instrumentation hook (empty unless GM_COUNTERS)
-    const uint32_t plo = pl.right ? nd.rlo : nd.flo;
-    uint32_t rl[NLET], rh[NLET];
+    const R plo = pl.right ? nd.rlo : nd.flo;
+    R rl[NLET], rh[NLET];
     env.rank2(pl.right, plo, plo + nd.w, rl, rh);
     lane_children(nd, have, rt, K, E, env, pl, rl, rh);
 }
@@ -153,19 +157,21 @@ GM_HD void lane_step(Node& nd, bool& have, const Root& rt, uint32_t K, uint32_t 
 // The part of a step after the two rank vectors are known.  The kernel calls make_plan / rank / lane_children separately
 // when the rank blocks are read cooperatively (gm_kernels.h: rank2_coop runs with every lane of the wavefront enabled).
 template <class Env>
-GM_HD void lane_children(Node& nd, bool& have, const Root& rt, uint32_t K, uint32_t E, Env& env, const Plan& pl,
-                         const uint32_t rl[NLET], const uint32_t rh[NLET])
+GM_HD void lane_children(NodeT<typename Env::row_t>& nd, bool& have, const RootT<typename Env::row_t>& rt, uint32_t K, uint32_t E, Env& env, const Plan& pl,
+                         const typename Env::row_t rl[NLET], const typename Env::row_t rh[NLET])
 {
+    typedef typename Env::row_t R;
+    typedef NodeT<R> Node;
     const uint32_t tc = env.text_char(rt, pl.pos);
     const Post ps = make_post(nd.meta, pl, rt.rec, K);
     const uint32_t errs = meta_errs(nd.meta);
-    const uint32_t olo = pl.right ? nd.flo : nd.rlo;
+    const R olo = pl.right ? nd.flo : nd.rlo;
 
     // per letter: occurrences, rows below it inside the range, first row of the child; validity as a bit mask
-    uint32_t cnt[NLET], sm[NLET], pn[NLET], tot = 0;
+    R cnt[NLET], sm[NLET], pn[NLET], tot = 0;
 #pragma unroll
     for (int x = 0; x < (int)NLET; ++x) { cnt[x] = rh[x] - rl[x]; tot += cnt[x]; pn[x] = env.C((uint32_t)x) + rl[x]; }
-    uint32_t run = nd.w - tot;   // sentinels in BWT[lo,hi) sort before every letter
+    R run = nd.w - tot;   // sentinels in BWT[lo,hi) sort before every letter
     uint32_t valid = 0;
 #pragma unroll
     for (int x = 0; x < (int)NLET; ++x) {
@@ -184,9 +190,9 @@ GM_HD void lane_children(Node& nd, bool& have, const Root& rt, uint32_t K, uint3
     // matching child needs a lane-dependent register pick; the mismatch rounds index cnt/pn/sm statically.
     const bool hasMatch = tc < SYM_N && ((valid >> tc) & 1u) != 0u;
     if (hasMatch) {
-        const uint32_t cx = tc == 0 ? cnt[0] : tc == 1 ? cnt[1] : tc == 2 ? cnt[2] : cnt[3];
-        const uint32_t pnew = tc == 0 ? pn[0] : tc == 1 ? pn[1] : tc == 2 ? pn[2] : pn[3];
-        const uint32_t onew = olo + (tc == 0 ? sm[0] : tc == 1 ? sm[1] : tc == 2 ? sm[2] : sm[3]);
+        const R cx = tc == 0 ? cnt[0] : tc == 1 ? cnt[1] : tc == 2 ? cnt[2] : cnt[3];
+        const R pnew = tc == 0 ? pn[0] : tc == 1 ? pn[1] : tc == 2 ? pn[2] : pn[3];
+        const R onew = olo + (tc == 0 ? sm[0] : tc == 1 ? sm[1] : tc == 2 ? sm[2] : sm[3]);
         if (ps.leaf) env.leaf(rt, ps.kmer, pl.right ? onew : pnew, cx);
         else {
             keep.flo = pl.right ? onew : pnew;
@@ -203,7 +209,7 @@ GM_HD void lane_children(Node& nd, bool& have, const Root& rt, uint32_t K, uint3
             const bool on = ((miss >> x) & 1u) != 0u;
             if (!env.any(on)) continue;
             if (on) {
-                const uint32_t pnew = pn[x], onew = olo + sm[x];
+                const R pnew = pn[x], onew = olo + sm[x];
                 if (ps.leaf) env.leaf(rt, ps.kmer, pl.right ? onew : pnew, cnt[x]);
                 else {
                     if (haveKeep) env.push(keep);
@@ -258,7 +264,7 @@ GM_HD uint32_t ctz64(uint64_t x)
 // Returns how many characters can be taken: the scan stops in front of a sentinel and in front of mismatch number
 // budget + 1.  cnt = mismatches among the taken characters, pos[j] = 1-based offset of mismatch j (j < 4).
 template <class Env>
-GM_HD uint32_t scan_side(Env& env, const Root& rt, const typename Env::Item& it, uint32_t a0, uint32_t q0, bool down, uint32_t need, uint32_t budget,
+GM_HD uint32_t scan_side(Env& env, const RootT<typename Env::row_t>& rt, const typename Env::Item& it, uint32_t a0, uint32_t q0, bool down, uint32_t need, uint32_t budget,
                          uint32_t& cnt, uint32_t pos[4])
 {
     cnt = 0;
@@ -287,11 +293,12 @@ GM_HD uint32_t scan_side(Env& env, const Root& rt, const typename Env::Item& it,
 }
 
 template <class Env>
-GM_HD void verify_item(uint32_t row, uint32_t meta, const Root& rt, uint32_t K, uint32_t E, Env& env)
+GM_HD void verify_item(typename Env::row_t row, uint32_t meta, const RootT<typename Env::row_t>& rt, uint32_t K, uint32_t E, Env& env)
 {
+    typedef typename Env::row_t R;
     uint32_t a = meta_a(meta), bx = meta_bx(meta), t = meta_t(meta), errs = meta_errs(meta), mode = meta_mode(meta);
     const typename Env::Item it = env.item(row);
-    const uint32_t p0 = it.p0;   // aligned with needle coordinate a0 (a changes below, keep the anchor)
+    const R p0 = it.p0;   // aligned with needle coordinate a0 (a changes below, keep the anchor)
     env.note_item(mode);
     const uint32_t a0 = a;
     uint32_t scratch[4];

@@ -79,7 +79,8 @@ inline int make_map_plan(uint32_t K, uint32_t E, uint32_t infix, int revcompl, u
     if (E > MAX_ERRORS) return PLAN_BAD_E;
     if (K < 1 || K > MAX_K) return PLAN_BAD_K;
     if (infix < 1 || infix > K) return PLAN_BAD_OVERLAP;
-    if (textLen >= 0xFFFFFFFFull) return PLAN_TOO_LONG;
+    if (textLen >= (1ull << 40)) return PLAN_TOO_LONG;
+    if (nIntervals != 0 && textLen >= 0xFFFFFFFFull) return PLAN_TOO_LONG;   // block lists address 32-bit slice positions
     p.K = K; p.E = E; p.infix = infix; p.stepSize = K - infix + 1;   // algo.hpp:416
     p.nSearches = oss_scheme(E).ns; p.nStrands = revcompl ? 2 : 1;
     p.textLen = textLen;

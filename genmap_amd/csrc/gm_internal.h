@@ -15,6 +15,9 @@ void set_error(const char* fmt, ...);
 // gm_build.hip
 int build_sa_bwt(const uint8_t* d_codes, const uint64_t* d_cum, uint32_t nSeq, uint64_t textLen, int rev,
                  uint32_t* d_sa_out, uint8_t* d_bwt, int* roundsOut);
+// the same for 64-bit rows (two stable sorting passes per doubling round: the (rank, rank) key no longer fits 64 bits)
+int build_sa_bwt_wide(const uint8_t* d_codes, const uint64_t* d_cum, uint32_t nSeq, uint64_t textLen, int rev,
+                      uint64_t* d_sa_out, uint8_t* d_bwt, int* roundsOut);
 
 }  // namespace gm
 
@@ -29,25 +32,26 @@ struct Tuning {
 
 struct gm_index {
     int device = 0;
-    uint32_t wpp = 3;                 // words per plane of the rank blocks (1, 3, 9)
+    uint32_t wpp = 3;                 // words per plane of the rank blocks (1, 3, 9; 2 = the wide geometry, 64-bit rows)
+    bool wide = false;                // rows / ranges / text positions are 64-bit (d_sa, C, q-mer tables, nodes)
     uint64_t nRows = 0, textLen = 0;
     uint32_t nSeq = 0, sampling = 0, alphabet = 4;
     uint32_t* d_blk[2] = {nullptr, nullptr};
     uint64_t blkBytes = 0;            // per direction
-    uint32_t C[gm::NLET + 1] = {0, 0, 0, 0, 0, 0};
+    uint64_t C[gm::NLET + 1] = {0, 0, 0, 0, 0, 0};
     uint8_t* d_text = nullptr;        // sentinel-free codes, one byte each (= d_textAlloc + 16: readers may touch a few bytes around)
     uint8_t* d_textAlloc = nullptr; uint8_t* d_textSAlloc = nullptr;
     uint4* d_text4 = nullptr;         // the text at 4 bits per symbol: needle windows are staged into LDS from it
     std::vector<uint64_t> cum;        // nSeq + 1
     uint64_t* d_cum = nullptr;
-    uint32_t* d_sa = nullptr;         // forward suffix array (kept when sampling == 1): locate = one HBM read
+    void* d_sa = nullptr;             // forward suffix array, uint32_t or (wide) uint64_t per row (kept when sampling == 1): locate = one HBM read
     uint8_t* d_textS = nullptr;       // sentinel text (verification of narrow nodes), present with d_sa
     uint4* d_ctx = nullptr;           // verification records {SA[row], 56 symbols around it}, 32 B per row, when HBM allows (gm_kernels.h: CTX_*)
     std::map<uint32_t, uint4*> qtables;   // q -> device table of 4^q entries (built on first use)
     uint64_t sig = 0; bool sigValid = false;   // signature of the call whose tables are on the device
     uint32_t qtableCap = 0;               // != 0: longest prefix that fitted the device so far
     uint64_t qtableBytes = 0;
-    uint32_t* d_C = nullptr;
+    uint64_t* d_C = nullptr;
     uint32_t* d_seqFile = nullptr; uint64_t seqFileCap = 0;
     uint32_t* d_bits = nullptr; uint64_t bitsCap = 0;
     int numCU = 0;

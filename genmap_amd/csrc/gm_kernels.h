@@ -19,15 +19,15 @@ namespace gm {
 
 struct SearchArgs {
     const uint32_t* blk[2];     // rank blocks: [0] forward BWT (extend left), [1] reverse BWT (extend right)
-    uint32_t C[NLET + 1];
-    uint32_t nRows;
+    uint64_t C[NLET + 1];       // (rows are row_t = uint32_t, or uint64_t in the wide geometry WPP = 2; the arguments carry 64 bits)
+    uint64_t nRows;
     const uint8_t* text;        // slice base, one code per byte
     uint32_t* acc;              // per slice position, zeroed by the caller (two planes of accPlane entries with StoreEnv)
     uint64_t accPlane;
     uint32_t maxVal;            // 255 or 65535: the result is min(total, maxVal), so saturated k-mers need no further hits
     uint32_t K, E;
     uint32_t stepSize, nSearches, rootsPerBlock;
-    uint32_t numKmers;
+    uint64_t numKmers;
     uint64_t blockBegin;        // first block of this shard
     uint64_t numRoots;          // roots of this shard
     const uint2* blockList;     // (first k-mer, count) per block, or nullptr for the arithmetic partition
@@ -39,14 +39,14 @@ struct SearchArgs {
     uint32_t* errorFlag;
     unsigned long long* counters;   // [0] node steps, [1] distinct rank lines (only with GM_COUNTERS)
     // ---- locate path (csv, --exclude-pseudo; /root/reference/src/algo.hpp:311-387) ----
-    const uint32_t* sa;             // forward suffix array (sentinel-text positions), sampling rate 1
+    const void* sa;                 // forward suffix array (sentinel-text positions, row_t each), sampling rate 1
     const uint64_t* cumGlobal;      // sentinel-free cumulative sequence lengths of the WHOLE index, nSeqGlobal + 1
     uint32_t nSeqGlobal;
     const uint32_t* seqFile;        // fasta id per global sequence (mappingSeqIdFile, src/mappability.hpp:230-248)
     uint32_t* fileBits;             // [pos * wordsPerKmer + w]: set of fasta ids seen for the k-mer at pos
     uint32_t wordsPerKmer;
-    uint32_t posBase;               // window origin of cnt2 / offs / emit arrays (slice position)
-    uint32_t windowLen;
+    uint64_t posBase;               // window origin of cnt2 / offs / emit arrays (slice position)
+    uint64_t windowLen;
     uint32_t* cnt2;                 // [strand * windowLen + pos - posBase]: occurrences (pass 1) / cursor (pass 2)
     const uint64_t* offs;           // exclusive scan of cnt2 (pass 2)
     uint64_t* emit;                 // packed (seqNo << 32 | seqPos) per occurrence
@@ -82,12 +82,57 @@ __device__ __forceinline__ bool chunk_mine(const ChunkSel& c, uint64_t j) { retu
 
 
 // sentinel-text position -> (seqNo, seqPos); sequence s starts at cum[s] + s
-__device__ __forceinline__ uint2 locate_position(const uint64_t* __restrict__ cum, uint32_t nSeq, uint32_t p)
+// (seqPos is reported in 32 bits: csv / --exclude-pseudo need every single sequence to be shorter than 2^32, gm_api.hip checks)
+__device__ __forceinline__ uint2 locate_position(const uint64_t* __restrict__ cum, uint32_t nSeq, uint64_t p)
 {
     uint32_t lo = 0, hi = nSeq;
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cum[mid] + mid <= (uint64_t)p) lo = mid; else hi = mid; }
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cum[mid] + mid <= p) lo = mid; else hi = mid; }
     return make_uint2(lo, (uint32_t)(p - (cum[lo] + lo)));
 }
+
+// search nodes and queue entries in memory: one 16-byte unit for 32-bit rows, two for 64-bit rows
+template <typename R> struct NodeIO;
+template <> struct NodeIO<uint32_t> {
+    static constexpr uint32_t NU = 1;
+    static __device__ __forceinline__ void store(uint4* p, uint32_t stride, const NodeT<uint32_t>& nd) { p[0] = make_uint4(nd.flo, nd.rlo, nd.w, nd.meta); (void)stride; }
+    static __device__ __forceinline__ NodeT<uint32_t> load(const uint4* p, uint32_t stride) { (void)stride; const uint4 v = p[0]; NodeT<uint32_t> nd; nd.flo = v.x; nd.rlo = v.y; nd.w = v.z; nd.meta = v.w; return nd; }
+    // verification queue entry: row, meta, window origin, n | strand << 8 | search << 9
+    static __device__ __forceinline__ void store_item(uint4* p, uint32_t row, uint32_t meta, uint32_t win, uint32_t nss) { p[0] = make_uint4(row, meta, win, nss); }
+    static __device__ __forceinline__ void load_item(const uint4* p, uint32_t& row, uint32_t& meta, uint32_t& win, uint32_t& nss) { const uint4 v = p[0]; row = v.x; meta = v.y; win = v.z; nss = v.w; }
+    // q-mer table entry {fwd lo, rev lo, width}
+    static __device__ __forceinline__ void load_qentry(const uint4* tab, uint32_t idx, uint32_t& flo, uint32_t& rlo, uint32_t& w) { const uint4 v = tab[idx]; flo = v.x; rlo = v.y; w = v.z; }
+    static __device__ __forceinline__ void store_qentry(uint4* tab, uint32_t idx, uint32_t flo, uint32_t rlo, uint32_t w) { tab[idx] = make_uint4(flo, rlo, w, 0u); }
+};
+template <> struct NodeIO<uint64_t> {
+    static constexpr uint32_t NU = 2;
+    static __device__ __forceinline__ void store(uint4* p, uint32_t stride, const NodeT<uint64_t>& nd)
+    {
+        p[0] = make_uint4((uint32_t)nd.flo, (uint32_t)(nd.flo >> 32), (uint32_t)nd.rlo, (uint32_t)(nd.rlo >> 32));
+        p[stride] = make_uint4((uint32_t)nd.w, (uint32_t)(nd.w >> 32), nd.meta, 0u);
+    }
+    static __device__ __forceinline__ NodeT<uint64_t> load(const uint4* p, uint32_t stride)
+    {
+        const uint4 a = p[0], b = p[stride];
+        NodeT<uint64_t> nd; nd.flo = (uint64_t)a.y << 32 | a.x; nd.rlo = (uint64_t)a.w << 32 | a.z; nd.w = (uint64_t)b.y << 32 | b.x; nd.meta = b.z; return nd;
+    }
+    static __device__ __forceinline__ void store_item(uint4* p, uint64_t row, uint32_t meta, uint64_t win, uint32_t nss)
+    {
+        p[0] = make_uint4((uint32_t)row, (uint32_t)(row >> 32), meta, nss); p[1] = make_uint4((uint32_t)win, (uint32_t)(win >> 32), 0u, 0u);
+    }
+    static __device__ __forceinline__ void load_item(const uint4* p, uint64_t& row, uint32_t& meta, uint64_t& win, uint32_t& nss)
+    {
+        const uint4 a = p[0], b = p[1]; row = (uint64_t)a.y << 32 | a.x; meta = a.z; nss = a.w; win = (uint64_t)b.y << 32 | b.x;
+    }
+    static __device__ __forceinline__ void load_qentry(const uint4* tab, uint32_t idx, uint64_t& flo, uint64_t& rlo, uint64_t& w)
+    {
+        const uint4 a = tab[2 * (size_t)idx], b = tab[2 * (size_t)idx + 1]; flo = (uint64_t)a.y << 32 | a.x; rlo = (uint64_t)a.w << 32 | a.z; w = (uint64_t)b.y << 32 | b.x;
+    }
+    static __device__ __forceinline__ void store_qentry(uint4* tab, uint32_t idx, uint64_t flo, uint64_t rlo, uint64_t w)
+    {
+        tab[2 * (size_t)idx] = make_uint4((uint32_t)flo, (uint32_t)(flo >> 32), (uint32_t)rlo, (uint32_t)(rlo >> 32));
+        tab[2 * (size_t)idx + 1] = make_uint4((uint32_t)w, (uint32_t)(w >> 32), 0u, 0u);
+    }
+};
 
 // k-mer starts (block coordinates) still covered by a node
 __device__ __forceinline__ void covered_kmers(uint32_t meta, uint32_t n, uint32_t K, uint32_t& smin, uint32_t& smax)
@@ -110,6 +155,10 @@ constexpr uint32_t WORK_CHUNK = 256;   // roots taken from the global counter pe
 constexpr uint32_t VERIFY_TMAX = 4;    // widest range resolved by verification
 
 template <int WPP> struct EnvBase {
+    typedef typename BlockGeom<WPP>::row_t row_t;
+    typedef NodeT<row_t> Node;
+    typedef RootT<row_t> Root;
+    typedef NodeIO<row_t> IO;
     const SearchArgs& A;
     uint4* stk;          // global spill area of this lane
     uint4* lstk;         // LDS: [depth][lane] of this wavefront, already offset by the lane
@@ -122,32 +171,32 @@ template <int WPP> struct EnvBase {
     uint32_t steps = 0, lines = 0, stOss = 0, stExt = 0, stExtW1 = 0, stExtW4 = 0, stOssW1 = 0, pushes = 0, vItems = 0, vItemsOss = 0, vChunks = 0;
     __device__ __forceinline__ void note_chunk() { vChunks++; }
     __device__ __forceinline__ void note_item(uint32_t mode) { vItems++; vItemsOss += (mode == M_OSS); }
-    __device__ __forceinline__ void note_step(uint32_t mode, uint32_t w)
+    __device__ __forceinline__ void note_step(uint32_t mode, row_t w)
     {
         if (mode == M_OSS) { stOss++; stOssW1 += (w == 1u); } else { stExt++; stExtW1 += (w == 1u); stExtW4 += (w > 1u && w <= 4u); }
     }
 #else
-    __device__ __forceinline__ void note_step(uint32_t, uint32_t) {}
+    __device__ __forceinline__ void note_step(uint32_t, row_t) {}
     __device__ __forceinline__ void note_chunk() {}
     __device__ __forceinline__ void note_item(uint32_t) {}
 #endif
     __device__ __forceinline__ EnvBase(const SearchArgs& a, uint4* s, uint32_t k) : A(a), stk(s), lstk(nullptr), lwin(nullptr), woff(0), sp(0), sbase(0), K(k) {}
-    __device__ __forceinline__ uint4 pop()
+    __device__ __forceinline__ Node pop()
     {
         --sp;
         const uint32_t lv = sbase + sp;
-        const uint4 v = lv < A.ldsDepth ? lstk[lv * 64u] : stk[(size_t)(lv - A.ldsDepth) * 64u];
+        const Node nd = lv < A.ldsDepth ? IO::load(lstk + (size_t)lv * IO::NU * 64u, 64u) : IO::load(stk + (size_t)(lv - A.ldsDepth) * IO::NU * 64u, 64u);
         if (sp == 0u) sbase = 0u;
-        return v;
+        return nd;
     }
-    __device__ __forceinline__ uint32_t slice_pos(const Root& rt, uint32_t kmer) const { return rt.win + (rt.strand ? rt.n - 1u - kmer : kmer); }
+    __device__ __forceinline__ row_t slice_pos(const Root& rt, uint32_t kmer) const { return rt.win + (rt.strand ? rt.n - 1u - kmer : kmer); }
 
-    __device__ __forceinline__ void rank2(uint32_t right, uint32_t lo, uint32_t hi, uint32_t rl[NLET], uint32_t rh[NLET])
+    __device__ __forceinline__ void rank2(uint32_t right, row_t lo, row_t hi, row_t rl[NLET], row_t rh[NLET])
     {
         constexpr uint32_t SPB = BlockGeom<WPP>::SPB, WPB = BlockGeom<WPP>::WPB;
-        constexpr int NV = (5 + 3 * WPP + 3) / 4;   // uint4 loads that cover header + planes
+        constexpr int NV = (BlockGeom<WPP>::HDRW + 3 * WPP + 3) / 4;   // uint4 loads that cover header + planes
         const uint32_t* base = right ? A.blk[1] : A.blk[0];
-        const uint32_t bl = lo / SPB, bh = hi / SPB;
+        const row_t bl = lo / SPB, bh = hi / SPB;
         const uint4* pl = reinterpret_cast<const uint4*>(base + (size_t)bl * WPB);
         const uint4* ph = reinterpret_cast<const uint4*>(base + (size_t)bh * WPB);
         uint32_t wl[NV * 4], wh[NV * 4];
@@ -174,8 +223,8 @@ template <int WPP> struct EnvBase {
 #pragma unroll
             for (int j = 0; j < NV; ++j) { uint4 v = ph[j]; wh[4 * j] = v.x; wh[4 * j + 1] = v.y; wh[4 * j + 2] = v.z; wh[4 * j + 3] = v.w; }
         }
-        block_rank<WPP>(wl, lo - bl * SPB, rl);
-        block_rank<WPP>(wh, hi - bh * SPB, rh);
+        block_rank<WPP>(wl, (uint32_t)(lo - bl * SPB), rl);
+        block_rank<WPP>(wh, (uint32_t)(hi - bh * SPB), rh);
 #ifdef GM_COUNTERS
         steps += 1; lines += 1 + (bl != bh);
 #endif
@@ -220,7 +269,7 @@ template <int WPP> struct EnvBase {
         asm volatile("" : "+v"(d));   // opaque: the final select must not be folded into the branch above (see rank2)
         dup |= d << R;
     }
-    __device__ __forceinline__ void rank2_coop(uint32_t right, uint32_t lo, uint32_t hi, uint32_t rl[NLET], uint32_t rh[NLET])
+    __device__ __forceinline__ void rank2_coop(uint32_t right, uint32_t lo, uint32_t hi, uint32_t rl[NLET], uint32_t rh[NLET])   // 32-bit rows only
     {
         constexpr uint32_t SPB = BlockGeom<WPP>::SPB;
         constexpr int G = (5 + 3 * WPP + 3) / 4;
@@ -262,30 +311,29 @@ template <int WPP> struct EnvBase {
 #ifdef GM_COUNTERS
         pushes++;
 #endif
-        const uint4 v = make_uint4(nd.flo, nd.rlo, nd.w, nd.meta);
         const uint32_t lv = sbase + sp;
         // wave-uniform fast path (scalar branch, no exec-mask juggling): nobody in the wavefront is past the LDS levels
-        if (__ballot(lv >= A.ldsDepth) == 0ull) { lstk[lv * 64u] = v; ++sp; return; }
-        if (lv < A.ldsDepth) { lstk[lv * 64u] = v; ++sp; }
-        else if (lv < A.stackDepth) { stk[(size_t)(lv - A.ldsDepth) * 64u] = v; ++sp; }
+        if (__ballot(lv >= A.ldsDepth) == 0ull) { IO::store(lstk + (size_t)lv * IO::NU * 64u, 64u, nd); ++sp; return; }
+        if (lv < A.ldsDepth) { IO::store(lstk + (size_t)lv * IO::NU * 64u, 64u, nd); ++sp; }
+        else if (lv < A.stackDepth) { IO::store(stk + (size_t)(lv - A.ldsDepth) * IO::NU * 64u, 64u, nd); ++sp; }
         else *A.errorFlag = 1u;   // never expected: depth = stack_bound(E, stepSize) (+ STEAL_LEVELS with work sharing)
     }
     __device__ __forceinline__ void on_root() {}
     __device__ __forceinline__ uint32_t root_hits() const { return 0u; }     // travels with stolen work (CountEnv: gate of the saturation check)
     __device__ __forceinline__ void set_root_hits(uint32_t) {}
     __device__ __forceinline__ bool saturated(const Root&, uint32_t, uint32_t) const { return false; }
-    __device__ __forceinline__ uint32_t C(uint32_t c) const { return A.C[c]; }
+    __device__ __forceinline__ row_t C(uint32_t c) const { return (row_t)A.C[c]; }
     __device__ __forceinline__ bool any(bool b) const { return __ballot(b) != 0ull; }
-    __device__ __forceinline__ uint32_t sa(uint32_t row) const { return A.sa[row]; }
-    struct Item { uint32_t p0; uint32_t w[7]; };
-    __device__ __forceinline__ Item item(uint32_t row) const
+    __device__ __forceinline__ row_t sa(row_t row) const { return reinterpret_cast<const row_t*>(A.sa)[row]; }
+    struct Item { row_t p0; uint32_t w[7]; };
+    __device__ __forceinline__ Item item(row_t row) const
     {
         Item it;
         if (A.ctx) {   // wave-uniform
             const uint4 c0 = A.ctx[(size_t)row * 2], c1 = A.ctx[(size_t)row * 2 + 1];
             it.p0 = c0.x; it.w[0] = c0.y; it.w[1] = c0.z; it.w[2] = c0.w; it.w[3] = c1.x; it.w[4] = c1.y; it.w[5] = c1.z; it.w[6] = c1.w;
         } else {
-            it.p0 = A.sa[row];
+            it.p0 = sa(row);
 #pragma unroll
             for (int k = 0; k < 7; ++k) it.w[k] = 0u;
         }
@@ -349,6 +397,8 @@ template <int WPP> struct EnvBase {
 // leaf policy 1: frequency only -- hits[a-ab] = min(countOccurrences(it) + hits[a-ab], max) (algo.hpp:48,191)
 template <int WPP> struct CountEnv : EnvBase<WPP> {
     using EnvBase<WPP>::A;
+    typedef typename EnvBase<WPP>::row_t row_t;
+    typedef typename EnvBase<WPP>::Root Root;
     uint32_t leafSum = 0;
     uint32_t rootHits = 0;   // hits this lane has added for its current root (gates the saturation check)
     __device__ __forceinline__ CountEnv(const SearchArgs& a, uint4* s, uint32_t k) : EnvBase<WPP>(a, s, k) {}
@@ -360,22 +410,23 @@ template <int WPP> struct CountEnv : EnvBase<WPP> {
     __device__ __forceinline__ bool saturated(const Root& rt, uint32_t smin, uint32_t smax) const
     {
         if (rootHits < A.maxVal) return false;
-        const uint32_t lo = rt.win + (rt.strand ? rt.n - 1u - smax : smin), cnt = smax - smin + 1u;
+        const row_t lo = rt.win + (rt.strand ? rt.n - 1u - smax : smin);
+        const uint32_t cnt = smax - smin + 1u;
         for (uint32_t i = 0; i < cnt; ++i) if (__hip_atomic_load(&A.acc[lo + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < A.maxVal) return false;
         return true;
     }
-    __device__ __forceinline__ void leaf(const Root&, uint32_t, uint32_t, uint32_t w) { leafSum += w; }
+    __device__ __forceinline__ void leaf(const Root&, uint32_t, row_t, row_t w) { leafSum = (row_t)leafSum + w > 0xFFFFFFFFull ? 0xFFFFFFFFu : leafSum + (uint32_t)w; }
     __device__ __forceinline__ void leaf_flush(const Root& rt, uint32_t kmer)
     {
         const uint32_t count = leafSum; leafSum = 0;
         if (!count) return;
         rootHits = rootHits + count < rootHits ? 0xFFFFFFFFu : rootHits + count;
-        const uint32_t pos = this->slice_pos(rt, kmer);
+        const row_t pos = this->slice_pos(rt, kmer);
         const uint32_t add = count < 0xFFFFu ? count : 0xFFFFu;   // every add is <= MAX of the widest value type
         const uint32_t old = atomicAdd(&A.acc[pos], add);
         if (old > 0xFFFFFFFFu - add) atomicOr(&A.acc[pos], 0x80000000u);   // sticky saturation on (theoretical) wrap
     }
-    __device__ __forceinline__ void leaf_at(const Root& rt, uint32_t kmer, uint32_t)
+    __device__ __forceinline__ void leaf_at(const Root& rt, uint32_t kmer, row_t)
     {
         uint32_t* p = &A.acc[this->slice_pos(rt, kmer)];
         if (atomicAdd(p, 1u) == 0xFFFFFFFFu) atomicOr(p, 0x80000000u);
@@ -388,14 +439,16 @@ template <int WPP> struct CountEnv : EnvBase<WPP> {
 // pos], counts clamp at 65535) instead of a device-scope atomic (which is a fabric transaction on a multi-XCD part); finalize adds the planes.
 template <int WPP, typename TPlane> struct StoreEnv : EnvBase<WPP> {
     using EnvBase<WPP>::A;
+    typedef typename EnvBase<WPP>::row_t row_t;
+    typedef typename EnvBase<WPP>::Root Root;
     static constexpr uint32_t CAP = sizeof(TPlane) == 1 ? 0xFFu : 0xFFFFu;   // min(MAX, f + r) == min(MAX, min(MAX, f) + min(MAX, r))
     __device__ __forceinline__ StoreEnv(const SearchArgs& a, uint4* s, uint32_t k) : EnvBase<WPP>(a, s, k) {}
-    __device__ __forceinline__ void leaf(const Root& rt, uint32_t kmer, uint32_t, uint32_t w)
+    __device__ __forceinline__ void leaf(const Root& rt, uint32_t kmer, row_t, row_t w)
     {
         reinterpret_cast<TPlane*>(A.acc)[(size_t)rt.strand * A.accPlane + this->slice_pos(rt, kmer)] = (TPlane)(w < CAP ? w : CAP);
     }
     __device__ __forceinline__ void leaf_flush(const Root&, uint32_t) {}
-    __device__ __forceinline__ void leaf_at(const Root& rt, uint32_t kmer, uint32_t)
+    __device__ __forceinline__ void leaf_at(const Root& rt, uint32_t kmer, row_t)
     {
         reinterpret_cast<TPlane*>(A.acc)[(size_t)rt.strand * A.accPlane + this->slice_pos(rt, kmer)] = (TPlane)1u;
     }
@@ -404,18 +457,20 @@ template <int WPP, typename TPlane> struct StoreEnv : EnvBase<WPP> {
 // leaf policy 2: --exclude-pseudo -- the set of fasta files that contain the k-mer (algo.hpp:351-364)
 template <int WPP> struct FileSetEnv : EnvBase<WPP> {
     using EnvBase<WPP>::A;
+    typedef typename EnvBase<WPP>::row_t row_t;
+    typedef typename EnvBase<WPP>::Root Root;
     __device__ __forceinline__ FileSetEnv(const SearchArgs& a, uint4* s, uint32_t k) : EnvBase<WPP>(a, s, k) {}
-    __device__ __forceinline__ void leaf(const Root& rt, uint32_t kmer, uint32_t flo, uint32_t w)
+    __device__ __forceinline__ void leaf(const Root& rt, uint32_t kmer, row_t flo, row_t w)
     {
         uint32_t* bits = A.fileBits + (size_t)this->slice_pos(rt, kmer) * A.wordsPerKmer;
-        for (uint32_t r = 0; r < w; ++r) {
-            const uint2 sp = locate_position(A.cumGlobal, A.nSeqGlobal, A.sa[flo + r]);
+        for (row_t r = 0; r < w; ++r) {
+            const uint2 sp = locate_position(A.cumGlobal, A.nSeqGlobal, this->sa(flo + r));
             const uint32_t f = A.seqFile[sp.x];
             atomicOr(&bits[f >> 5], 1u << (f & 31u));
         }
     }
     __device__ __forceinline__ void leaf_flush(const Root&, uint32_t) {}
-    __device__ __forceinline__ void leaf_at(const Root& rt, uint32_t kmer, uint32_t textPos)
+    __device__ __forceinline__ void leaf_at(const Root& rt, uint32_t kmer, row_t textPos)
     {
         const uint32_t f = A.seqFile[locate_position(A.cumGlobal, A.nSeqGlobal, textPos).x];
         atomicOr(&A.fileBits[(size_t)this->slice_pos(rt, kmer) * A.wordsPerKmer + (f >> 5)], 1u << (f & 31u));
@@ -425,30 +480,34 @@ template <int WPP> struct FileSetEnv : EnvBase<WPP> {
 // leaf policy 3: csv pass 1 -- occurrences per (k-mer, strand)
 template <int WPP> struct OccCountEnv : EnvBase<WPP> {
     using EnvBase<WPP>::A;
+    typedef typename EnvBase<WPP>::row_t row_t;
+    typedef typename EnvBase<WPP>::Root Root;
     __device__ __forceinline__ OccCountEnv(const SearchArgs& a, uint4* s, uint32_t k) : EnvBase<WPP>(a, s, k) {}
-    __device__ __forceinline__ void leaf(const Root& rt, uint32_t kmer, uint32_t, uint32_t w)
+    __device__ __forceinline__ void leaf(const Root& rt, uint32_t kmer, row_t, row_t w)
     {
-        atomicAdd(&A.cnt2[(size_t)rt.strand * A.windowLen + (this->slice_pos(rt, kmer) - A.posBase)], w);
+        atomicAdd(&A.cnt2[(size_t)rt.strand * A.windowLen + (this->slice_pos(rt, kmer) - A.posBase)], (uint32_t)w);   // windows hold < 2^31 occurrences
     }
     __device__ __forceinline__ void leaf_flush(const Root&, uint32_t) {}
-    __device__ __forceinline__ void leaf_at(const Root& rt, uint32_t kmer, uint32_t) { leaf(rt, kmer, 0u, 1u); }
+    __device__ __forceinline__ void leaf_at(const Root& rt, uint32_t kmer, row_t) { leaf(rt, kmer, 0u, 1u); }
 };
 
 // leaf policy 4: csv pass 2 -- getOccurrences(iterator) of every leaf (algo.hpp:328-345), unsorted
 template <int WPP> struct OccEmitEnv : EnvBase<WPP> {
     using EnvBase<WPP>::A;
+    typedef typename EnvBase<WPP>::row_t row_t;
+    typedef typename EnvBase<WPP>::Root Root;
     __device__ __forceinline__ OccEmitEnv(const SearchArgs& a, uint4* s, uint32_t k) : EnvBase<WPP>(a, s, k) {}
-    __device__ __forceinline__ void leaf(const Root& rt, uint32_t kmer, uint32_t flo, uint32_t w)
+    __device__ __forceinline__ void leaf(const Root& rt, uint32_t kmer, row_t flo, row_t w)
     {
         const size_t slot = (size_t)rt.strand * A.windowLen + (this->slice_pos(rt, kmer) - A.posBase);
-        const uint64_t base = A.offs[slot] + atomicAdd(&A.cnt2[slot], w);
-        for (uint32_t r = 0; r < w; ++r) {
-            const uint2 sp = locate_position(A.cumGlobal, A.nSeqGlobal, A.sa[flo + r]);
+        const uint64_t base = A.offs[slot] + atomicAdd(&A.cnt2[slot], (uint32_t)w);
+        for (row_t r = 0; r < w; ++r) {
+            const uint2 sp = locate_position(A.cumGlobal, A.nSeqGlobal, this->sa(flo + r));
             A.emit[base + r] = (uint64_t)sp.x << 32 | sp.y;
         }
     }
     __device__ __forceinline__ void leaf_flush(const Root&, uint32_t) {}
-    __device__ __forceinline__ void leaf_at(const Root& rt, uint32_t kmer, uint32_t textPos)
+    __device__ __forceinline__ void leaf_at(const Root& rt, uint32_t kmer, row_t textPos)
     {
         const size_t slot = (size_t)rt.strand * A.windowLen + (this->slice_pos(rt, kmer) - A.posBase);
         const uint2 sp = locate_position(A.cumGlobal, A.nSeqGlobal, textPos);
@@ -464,26 +523,32 @@ template <int WPP> struct OccEmitEnv : EnvBase<WPP> {
 template <int WPP, class EnvT, bool COOP>
 __device__ __forceinline__ void search_body(const SearchArgs& A)
 {
+    typedef typename BlockGeom<WPP>::row_t row_t;
+    typedef NodeT<row_t> Node;
+    typedef RootT<row_t> Root;
+    typedef NodeIO<row_t> IO;
+    constexpr uint32_t NU = IO::NU;   // 16-byte units per stored node / queue entry
     const uint32_t lane = threadIdx.x & 63u;
     const size_t gl = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     // spilled stack levels: wavefront-interleaved (level i of the 64 lanes is one contiguous KiB), like the LDS levels
-    EnvT env(A, A.stack + (gl & ~(size_t)63) * A.spillDepth + lane, A.K);
-    Node nd; nd.flo = nd.rlo = nd.w = nd.meta = 0;
+    EnvT env(A, A.stack + (gl & ~(size_t)63) * A.spillDepth * NU + lane, A.K);
+    Node nd; nd.flo = nd.rlo = nd.w = 0; nd.meta = 0;
     Root rt; rt.win = 0; rt.n = 1; rt.strand = 0; rt.search = 0; rt.rec = OssRecord{0, 0, 0, 0};
     // per-wavefront queue of narrow nodes awaiting verification: filled by ballot rank, drained 64 at a time so that a
     // verification round keeps every lane busy with the same kind of loop
     extern __shared__ uint4 smem[];
     const uint32_t wv = threadIdx.x >> 6;
-    uint4* vq = smem + wv * A.vqCap;
-    env.lstk = smem + 4u * A.vqCap + wv * (A.ldsDepth * 64u) + lane;
-    uint4* const wbase = smem + 4u * A.vqCap + 4u * A.ldsDepth * 64u + wv * (A.winChunks * 64u);   // this wavefront's windows
+    // LDS per block of 4 wavefronts: [4 x vqCap x NU] queue | [4 x ldsDepth x NU x 64] stack tops | [4 x winChunks x 64] windows | users/pairing
+    uint4* vq = smem + wv * A.vqCap * NU;
+    env.lstk = smem + 4u * A.vqCap * NU + wv * (A.ldsDepth * NU * 64u) + lane;
+    uint4* const wbase = smem + 4u * A.vqCap * NU + 4u * A.ldsDepth * NU * 64u + wv * (A.winChunks * 64u);   // this wavefront's windows
     env.lwin = reinterpret_cast<const uint8_t*>(wbase + lane);
     // work sharing inside the wavefront: a lane may work on the root of another lane (stolen stack entries); it then reads
     // that lane's needle window (wlane) and the owner may not stage a new window while users[owner] != 0
-    uint32_t* const users = reinterpret_cast<uint32_t*>(smem + 4u * A.vqCap + 4u * 64u * (A.ldsDepth + A.winChunks)) + wv * 128u;   // [64] users | [64] pairing
+    uint32_t* const users = reinterpret_cast<uint32_t*>(smem + 4u * A.vqCap * NU + 4u * 64u * (A.ldsDepth * NU + A.winChunks)) + wv * 128u;   // [64] users | [64] pairing
     uint32_t* const pairing = users + 64;
-    uint4* const lstkW = smem + 4u * A.vqCap + wv * (A.ldsDepth * 64u);
-    uint4* const stkW = A.stack + (gl & ~(size_t)63) * A.spillDepth;
+    uint4* const lstkW = smem + 4u * A.vqCap * NU + wv * (A.ldsDepth * NU * 64u);
+    uint4* const stkW = A.stack + (gl & ~(size_t)63) * A.spillDepth * NU;
     uint32_t wlane = lane;
     if (A.steal) { users[lane] = 0u; __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 #ifdef GM_COUNTERS
@@ -498,7 +563,8 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     // root fetch pipeline of this lane: 0 idle, 1 window/record loads in flight, 2 q-mer table lookup in flight
     uint32_t fs = 0, fa0 = 0, fql = 0, fwoff = 0, fnch = 0, fshift = 0;
     Root frt; frt.win = 0; frt.n = 1; frt.strand = 0; frt.search = 0; frt.rec = OssRecord{0, 0, 0, 0};
-    uint4 frec = make_uint4(0, 0, 0, 0), ftab = frec;
+    uint4 frec = make_uint4(0, 0, 0, 0);
+    row_t ftFlo = 0, ftRlo = 0, ftW = 0;
     unsigned long long fx0 = 0, fx1 = 0;
     const uint4* fsrc = A.text4;
     unsigned long long poolCur = 0, poolEnd = 0, poolBase = 0, poolBlock = 0;   // wave-uniform
@@ -518,8 +584,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
 #pragma unroll 1
         for (int tries = 0; tries < 4 && !have && env.sp > 0; ++tries) {
 #endif
-            const uint4 v = env.pop();
-            nd.flo = v.x; nd.rlo = v.y; nd.w = v.z; nd.meta = v.w; w1run = 0;
+            nd = env.pop(); w1run = 0;
             uint32_t smin, smax;
             covered_kmers(nd.meta, rt.n, A.K, smin, smax);
             have = !(nd.w >= A.satMinW && env.saturated(rt, smin, smax));   // pending work for k-mers that already reached MAX is dropped
@@ -547,7 +612,8 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                 const int a4 = (int)(src << 2);
                 // the victim's stack height, root and window (every lane takes part: the victims' registers are the source)
                 const uint32_t vsb = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)env.sbase);   // the BOTTOM entry: the oldest, i.e. the largest pending subtree
-                const uint32_t vwin = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)rt.win);
+                uint32_t vwin = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)(uint32_t)rt.win), vwinHi = 0u;
+                if (sizeof(row_t) == 8) vwinHi = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)(uint32_t)((uint64_t)rt.win >> 32));
                 const uint32_t vnss = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)(rt.n | rt.strand << 9 | rt.search << 10));
                 const uint32_t vrx = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)rt.rec.x), vry = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)rt.rec.y);
                 const uint32_t vrz = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)rt.rec.z), vrw = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)rt.rec.w);
@@ -555,9 +621,9 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                 const uint32_t vrh = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)env.root_hits());
                 if (thief) {
                     const uint32_t level = vsb;
-                    const uint4 v = level < A.ldsDepth ? lstkW[level * 64u + src] : stkW[(size_t)(level - A.ldsDepth) * 64u + src];
-                    nd.flo = v.x; nd.rlo = v.y; nd.w = v.z; nd.meta = v.w; have = true; w1run = 0;
-                    rt.win = vwin; rt.n = vnss & 0x1FFu; rt.strand = (vnss >> 9) & 1u; rt.search = vnss >> 10;
+                    nd = level < A.ldsDepth ? IO::load(lstkW + (size_t)level * NU * 64u + src, 64u) : IO::load(stkW + (size_t)(level - A.ldsDepth) * NU * 64u + src, 64u);
+                    have = true; w1run = 0;
+                    rt.win = (row_t)((uint64_t)vwinHi << 32 | vwin); rt.n = vnss & 0x1FFu; rt.strand = (vnss >> 9) & 1u; rt.search = vnss >> 10;
                     rt.rec.x = vrx; rt.rec.y = vry; rt.rec.z = vrz; rt.rec.w = vrw;
                     env.set_root_hits(vrh);   // a root that saturates its k-mers keeps doing so in the thief's hands
                     env.woff = vwo & 0xFFu; wlane = vwo >> 8;
@@ -574,9 +640,9 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
         // stage 3: the q-mer table entry has arrived -> the root becomes the lane's node (or turns out empty)
         if (fs == 2u) {
             fs = 0u;
-            if (ftab.z != 0u) {
+            if (ftW != 0u) {
                 rt = frt; env.on_root();
-                nd.flo = ftab.x; nd.rlo = ftab.y; nd.w = ftab.z; nd.meta = meta_pack(fa0, fa0 + fql, 0, 0, M_OSS);
+                nd.flo = ftFlo; nd.rlo = ftRlo; nd.w = ftW; nd.meta = meta_pack(fa0, fa0 + fql, 0, 0, M_OSS);
                 have = true; w1run = 0;
             }
         }
@@ -584,7 +650,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
         if (fs == 1u) {
             env.woff = fwoff;   // the window itself went from HBM straight into this lane's LDS slots (stage 1)
             frt.rec.x = frec.x; frt.rec.y = frec.y; frt.rec.z = frec.z; frt.rec.w = frec.w;
-            if (fql == 0u) { rt = frt; env.on_root(); nd = root_node(rt, A.nRows); have = true; fs = 0u; w1run = 0; }
+            if (fql == 0u) { rt = frt; env.on_root(); nd = root_node(rt, (row_t)A.nRows); have = true; fs = 0u; w1run = 0; }
             else {
                 // 16 symbols starting at the lowest text position of the q-mer, 4 bits each
                 const unsigned long long v = fshift ? (fx0 >> fshift) | (fx1 << (64u - fshift)) : fx0;
@@ -596,7 +662,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                     idx |= frt.strand ? (3u - (c & 3u)) << (2u * i) : (c & 3u) << (2u * (fql - 1u - i));
                 }
                 if (bad) fs = 0u;   // a pattern N never matches in an exact block (find2:330): this root finds nothing
-                else { ftab = (((A.qselMask >> frt.search) & 1u) ? A.qtabB : A.qtabA)[idx]; fs = 2u; }
+                else { IO::load_qentry(((A.qselMask >> frt.search) & 1u) ? A.qtabB : A.qtabA, idx, ftFlo, ftRlo, ftW); fs = 2u; }
             }
         }
         // stage 1: lanes without node, stack or fetch in flight draw a root (ballot rank) and issue its loads
@@ -634,11 +700,11 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                         gb = (unsigned long long)(q * A.chunkStride + A.chunkIndex) * A.chunkBlocks + ((uint32_t)gb - q * A.chunkBlocks);
                     }
                     gb += A.blockBegin;
-                    if (A.blockList) { const uint2 e = A.blockList[gb]; frt.win = e.x; frt.n = e.y; }
+                    if (A.blockList) { const uint2 e = A.blockList[gb]; frt.win = e.x; frt.n = e.y; }   // (selections address 32-bit slice positions)
                     else {
-                        frt.win = (uint32_t)gb * A.stepSize;                  // slice positions fit 32 bits
-                        const uint32_t left = A.numKmers - frt.win;
-                        frt.n = left < A.stepSize ? left : A.stepSize;
+                        frt.win = (row_t)gb * A.stepSize;
+                        const row_t left = (row_t)A.numKmers - frt.win;
+                        frt.n = left < A.stepSize ? (uint32_t)left : A.stepSize;
                     }
                     frt.strand = r >= A.nSearches ? 1u : 0u;
                     frt.search = r - frt.strand * A.nSearches;
@@ -697,7 +763,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                 if (m == 0ull) break;
                 if (e) {
                     const uint32_t slot = qsize + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    vq[slot] = make_uint4(nd.flo + r, nd.meta, rt.win, rt.n | rt.strand << 8 | rt.search << 9);
+                    IO::store_item(vq + (size_t)slot * NU, nd.flo + r, nd.meta, rt.win, rt.n | rt.strand << 8 | rt.search << 9);
                 }
                 qsize += (uint32_t)__popcll(m);
             }
@@ -713,11 +779,12 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
 #endif
                 const uint32_t take = qsize < 64u ? qsize : 64u;
                 if (lane < take) {
-                    const uint4 it = vq[qsize - 1u - lane];
-                    Root vr; vr.win = it.z; vr.n = it.w & 0xFFu; vr.strand = (it.w >> 8) & 1u; vr.search = it.w >> 9;
+                    row_t irow, iwin; uint32_t imeta, inss;
+                    IO::load_item(vq + (size_t)(qsize - 1u - lane) * NU, irow, imeta, iwin, inss);
+                    Root vr; vr.win = iwin; vr.n = inss & 0xFFu; vr.strand = (inss >> 8) & 1u; vr.search = inss >> 9;
                     const uint4 q = A.table[(size_t)(vr.n - 1u) * 8u + vr.search];
                     vr.rec.x = q.x; vr.rec.y = q.y; vr.rec.z = q.z; vr.rec.w = q.w;
-                    verify_item(it.x, it.y, vr, A.K, A.E, env);
+                    verify_item(irow, imeta, vr, A.K, A.E, env);
                 }
                 qsize -= take;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -751,13 +818,13 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
         }
         if constexpr (COOP) {   // the rank blocks are read by groups of lanes: every lane walks through the reads
             Plan pl; pl.right = pl.exact = pl.minErr = pl.charsLeft = pl.pos = 0;
-            uint32_t plo = 0, phi = 0;
+            row_t plo = 0, phi = 0;
             if (have) {
                 pl = make_plan(nd.meta, rt.rec, A.E);
                 env.note_step(meta_mode(nd.meta), nd.w);
                 plo = pl.right ? nd.rlo : nd.flo; phi = plo + nd.w;
             }
-            uint32_t rl[NLET], rh[NLET];
+            row_t rl[NLET], rh[NLET];
             env.rank2_coop(pl.right, plo, phi, rl, rh);
             if (have) {
                 const bool lone = nd.w == 1u;
@@ -800,26 +867,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // SA ranges of every ACGT string of length q in both indexes (right extensions from the root): the top of the search
 // tree, tabulated once per index and q.
 template <int WPP>
-__global__ __launch_bounds__(256) void qmer_table_kernel(const uint32_t* __restrict__ blkRev, const uint32_t* __restrict__ Cin, uint32_t nRows, uint32_t q,
+__global__ __launch_bounds__(256) void qmer_table_kernel(const uint32_t* __restrict__ blkRev, const uint64_t* __restrict__ Cin, uint64_t nRows, uint32_t q,
                                                          uint4* __restrict__ out)
 {
+    typedef typename BlockGeom<WPP>::row_t row_t;
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (1u << (2u * q))) return;
     constexpr uint32_t SPB = BlockGeom<WPP>::SPB, WPB = BlockGeom<WPP>::WPB;
-    uint32_t flo = 0, rlo = 0, w = nRows;
+    row_t flo = 0, rlo = 0, w = (row_t)nRows;
     for (uint32_t i = 0; i < q && w; ++i) {
         const uint32_t c = (idx >> (2u * (q - 1u - i))) & 3u;
-        uint32_t rl[NLET], rh[NLET];
-        const uint32_t lo = rlo, hi = rlo + w;
-        block_rank<WPP>(blkRev + (size_t)(lo / SPB) * WPB, lo % SPB, rl);
-        block_rank<WPP>(blkRev + (size_t)(hi / SPB) * WPB, hi % SPB, rh);
-        uint32_t tot = 0, below = 0;
-        for (uint32_t x = 0; x < NLET; ++x) { const uint32_t cx = rh[x] - rl[x]; tot += cx; if (x < c) below += cx; }
+        row_t rl[NLET], rh[NLET];
+        const row_t lo = rlo, hi = rlo + w;
+        block_rank<WPP>(blkRev + (size_t)(lo / SPB) * WPB, (uint32_t)(lo % SPB), rl);
+        block_rank<WPP>(blkRev + (size_t)(hi / SPB) * WPB, (uint32_t)(hi % SPB), rh);
+        row_t tot = 0, below = 0;
+        for (uint32_t x = 0; x < NLET; ++x) { const row_t cx = rh[x] - rl[x]; tot += cx; if (x < c) below += cx; }
         flo += (w - tot) + below;           // sentinels sort before every letter
-        rlo = Cin[c] + rl[c];
+        rlo = (row_t)Cin[c] + rl[c];
         w = rh[c] - rl[c];
     }
-    out[idx] = make_uint4(flo, rlo, w, 0u);
+    NodeIO<row_t>::store_qentry(out, idx, flo, rlo, w);
 }
 
 // store planes -> c[]

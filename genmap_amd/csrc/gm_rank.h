@@ -19,6 +19,11 @@
 //   WPP=3 ->  64 B blocks,  96 symbols (5.3 bit/symbol)   [2 spare words]
 //   WPP=9 -> 128 B blocks, 288 symbols (3.6 bit/symbol)
 // Which one is fastest is a measured property of the memory system (profiles/), not a guess.
+//
+// Indexes of 2^32 - 1 rows or more (the reference's 64-bit BWT variants, /root/reference/src/indexing.hpp:158-169,
+// src/mappability.hpp:373-385) use the WIDE geometry, selected by WPP = 2 throughout the templates:
+//   WPP=2 ->  64 B blocks,  64 symbols: [0..9] five 64-bit cumulative counts, [10 + 2j + w] word w of plane j.
+// Rows, ranges and text positions are then uint64_t (BlockGeom<2>::row_t); everything else is the same code.
 #pragma once
 #include "gm_common.h"
 
@@ -26,10 +31,17 @@ namespace gm {
 
 template <int WPP> struct BlockGeom {
     static_assert(WPP == 1 || WPP == 3 || WPP == 9, "supported block shapes");
+    typedef uint32_t row_t;                                          // SA rows, range widths, text positions
     static constexpr uint32_t SPB = 32u * WPP;                       // symbols per block
     static constexpr uint32_t WPB = (WPP == 1) ? 8u : (WPP == 3) ? 16u : 32u;  // words per block
+    static constexpr uint32_t HDRW = 5u;                             // words of cumulative counts
     static constexpr uint32_t BYTES = WPB * 4u;
 };
+template <> struct BlockGeom<2> {                                    // the wide geometry: 64-bit rows
+    typedef uint64_t row_t;
+    static constexpr uint32_t SPB = 64u, WPB = 16u, HDRW = 10u, BYTES = 64u;
+};
+constexpr int WPP_WIDE = 2;
 
 GM_HD uint32_t popc32(uint32_t x)
 {
@@ -45,14 +57,15 @@ template <int WPP> GM_HD uint64_t num_blocks(uint64_t n) { return n / BlockGeom<
 
 // In-block letter counts of the first `off` symbols of block words blk[0..WPB), added to the header.
 // out[c] = rank_c(position) for c = A,C,G,T,N.
-template <int WPP> GM_HD void block_rank(const uint32_t* blk, uint32_t off, uint32_t out[NLET])
+template <int WPP> GM_HD void block_rank(const uint32_t* blk, uint32_t off, typename BlockGeom<WPP>::row_t out[NLET])
 {
+    constexpr uint32_t H = BlockGeom<WPP>::HDRW;
     uint32_t cA = 0, cC = 0, cG = 0, cT = 0, cN = 0;
 #pragma unroll
     for (int w = 0; w < WPP; ++w) {
         int rem = (int)off - 32 * w;
         uint32_t m = rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << rem) - 1u));
-        uint32_t p0 = blk[5 + w], p1 = blk[5 + WPP + w], p2 = blk[5 + 2 * WPP + w];
+        uint32_t p0 = blk[H + w], p1 = blk[H + WPP + w], p2 = blk[H + 2 * WPP + w];
         uint32_t let = ~p2 & m;
         cA += popc32(let & ~p1 & ~p0);
         cC += popc32(let & ~p1 & p0);
@@ -60,7 +73,12 @@ template <int WPP> GM_HD void block_rank(const uint32_t* blk, uint32_t off, uint
         cT += popc32(let & p1 & p0);
         cN += popc32(p2 & ~p0 & m);
     }
-    out[0] = blk[0] + cA; out[1] = blk[1] + cC; out[2] = blk[2] + cG; out[3] = blk[3] + cT; out[4] = blk[4] + cN;
+    if (H == 5u) { out[0] = blk[0] + cA; out[1] = blk[1] + cC; out[2] = blk[2] + cG; out[3] = blk[3] + cT; out[4] = blk[4] + cN; }
+    else {
+        typedef typename BlockGeom<WPP>::row_t R;
+        out[0] = (R)((uint64_t)blk[1] << 32 | blk[0]) + cA; out[1] = (R)((uint64_t)blk[3] << 32 | blk[2]) + cC; out[2] = (R)((uint64_t)blk[5] << 32 | blk[4]) + cG;
+        out[3] = (R)((uint64_t)blk[7] << 32 | blk[6]) + cT; out[4] = (R)((uint64_t)blk[9] << 32 | blk[8]) + cN;
+    }
 }
 
 // Pack the planes of one block from symbol codes (positions past n are padded with the sentinel code,
@@ -77,7 +95,7 @@ template <int WPP> GM_HD void pack_planes(const uint8_t* bwt, uint64_t n, uint64
             p1 |= ((c >> 1) & 1u) << t;
             p2 |= ((c >> 2) & 1u) << t;
         }
-        blk[5 + w] = p0; blk[5 + WPP + w] = p1; blk[5 + 2 * WPP + w] = p2;
+        blk[BlockGeom<WPP>::HDRW + w] = p0; blk[BlockGeom<WPP>::HDRW + WPP + w] = p1; blk[BlockGeom<WPP>::HDRW + 2 * WPP + w] = p2;
     }
 }
 

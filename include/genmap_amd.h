@@ -30,7 +30,7 @@ typedef enum gm_status {
     GM_ERR_NEED_LOCATE = -4,   /* csv / --exclude-pseudo requested on an index without SA samples */
     GM_ERR_BAD_OVERLAP = -5,   /* -xo larger than min(K-1, K-E-2), src/mappability.hpp:528-540; or infix < #blocks */
     GM_ERR_BAD_K = -6,         /* K < 1 or K > 255 (this build's node encoding) */
-    GM_ERR_TOO_LONG = -7,      /* total index length >= 2^32 - 1 (32-bit BWT positions, src/indexing.hpp:159-162) */
+    GM_ERR_TOO_LONG = -7,      /* beyond the build's limits: 2^40 rows; a gm_locate window of 2^31 occurrences */
     GM_ERR_BAD_ARG = -8,
     GM_ERR_HIP = -9,           /* a HIP call failed; gm_last_error() has the text */
     GM_ERR_IO = -10,
@@ -58,6 +58,7 @@ typedef struct gm_index_info {
     uint32_t block_bytes;     /* rank block size of this index: 32, 64 or 128 */
     uint64_t device_bytes;    /* HBM held by the index */
     int32_t  device;
+    uint32_t row_bits;        /* 32, or 64 for indexes of 2^32 - 1 rows or more (and with GM_BLOCK_WIDE_ROWS) */
     uint32_t verify_records;  /* 1: the index holds one 32-byte record {SA[row], 56 text symbols around it} per row (built with
                                  sampling 1 when HBM allows): a narrow search node is verified with ONE read */
 } gm_index_info;
@@ -65,6 +66,11 @@ typedef struct gm_index_info {
 /* Build both FM indexes ON THE GPU from host sequences (concatenated codes, no sentinels).
  * block_bytes: 32, 64 or 128 (0 = library default).  sampling: keep SA[i] where the in-sequence offset
  * is a multiple of `sampling` (src/seqan_libdivsufsort.h:129-143); 0 = none. */
+/* OR this into block_bytes to force 64-bit rows on a small index (tests).  Indexes of 2^32 - 1 rows or more get them by
+ * themselves (the reference's 64-bit BWT variants, src/indexing.hpp:158-169, src/mappability.hpp:373-385): 64-byte rank blocks
+ * of 64 symbols with 64-bit counts, 64-bit suffix array, 32-byte search nodes; sa_fwd of gm_index_import / gm_index_export_sa is
+ * then an array of uint64_t.  csv / --exclude-pseudo additionally need every single sequence to be shorter than 2^32. */
+#define GM_BLOCK_WIDE_ROWS 0x10000u
 int gm_index_build(const uint8_t *codes, const uint64_t *seq_len, uint32_t n_seq,
                    uint32_t sampling, uint32_t block_bytes, int device, gm_index **out);
 

@@ -10,7 +10,8 @@ import helpers as H
 
 pytestmark = pytest.mark.gpu
 
-BLOCK_BYTES = (32, 64, 128)
+WIDE = 64 | 0x10000          # GM_BLOCK_WIDE_ROWS: 64-bit rows forced on a small index (what >= 2^32 - 1 rows get by themselves)
+BLOCK_BYTES = (32, 64, 128, WIDE)
 
 
 def _gm():
@@ -50,7 +51,7 @@ def test_gpu_builder_matches_oracle_bwt(dna5):
         assert np.array_equal(bf, ora.bwt(0)), bb
         assert np.array_equal(br, ora.bwt(1)), bb
         info = ix.info()
-        assert info["alphabet_size"] == (5 if dna5 else 4) and info["block_bytes"] == bb
+        assert info["alphabet_size"] == (5 if dna5 else 4) and info["block_bytes"] == (bb & 0xFFFF) and info["row_bits"] == (64 if bb == WIDE else 32)
         ix.close()
 
 
@@ -100,9 +101,10 @@ def test_gpu_csv_locations_match_reference_fixtures(case):
     g = _gm()
     d = H.CASES_DIR / f"case_{case}"
     gen, directory, fl, bed = H.load_case(case)
-    ix = g.Index.build(gen.codes, gen.seq_len, sampling=1)
     rc = not fl.get("nc", False)
-    for xo in H.xo_variants(case):
+    for bb in (0, WIDE):
+      ix = g.Index.build(gen.codes, gen.seq_len, sampling=1, block_bytes=bb)
+      for xo in H.xo_variants(case):
         for name, first, nseq, tb, tl in gen.file_slices():
             iv = civ = None
             if bed is not None:
@@ -113,8 +115,8 @@ def test_gpu_csv_locations_match_reference_fixtures(case):
             loc = ix.locate(fl["K"], fl["E"], first_seq=first, n_seq=nseq, overlap=xo, revcompl=rc, intervals=iv)
             txt = H.format_csv(gen, _csv_entries(gen, first, nseq, fl["K"], loc), rc, civ)
             exp = (d / "csv" / (name.rsplit(".", 1)[0] + ".genmap.csv")).read_text()
-            assert txt == exp, (case, xo, name)
-    ix.close()
+            assert txt == exp, (case, xo, name, bb)
+      ix.close()
 
 
 def test_gpu_exclude_pseudo_and_locations_vs_oracle():
@@ -136,16 +138,17 @@ def test_gpu_exclude_pseudo_and_locations_vs_oracle():
     ix.close()
 
 
+@pytest.mark.parametrize("wide", [False, True])
 @pytest.mark.parametrize("dna5", [False, True])
 @pytest.mark.parametrize("E", [0, 1, 2, 3, 4])
-def test_gpu_gtest_matrix(E, dna5):
+def test_gpu_gtest_matrix(E, dna5, wide):
     """tests/tests.cpp:133-260 with a portable PRNG: every K, every infix length, vs trivial backtracking."""
     g = _gm()
     rng = np.random.default_rng(3000 + 10 * E + dna5)
     nseq, ln = 3, (1000 if E < 3 else 300)
     codes = rng.integers(0, 5 if dna5 else 4, size=nseq * ln, dtype=np.uint8)
     ora = H.OracleIndex(codes, [ln] * nseq, keep_sa=False)
-    ix = g.Index.build(codes, [ln] * nseq, sampling=1)
+    ix = g.Index.build(codes, [ln] * nseq, sampling=1, block_bytes=WIDE if wide else 0)
     minK = E + 1 + (E >= 2)
     nblocks = [1, 2, 4, 5, 6][E]
     try:
@@ -156,7 +159,7 @@ def test_gpu_gtest_matrix(E, dna5):
                 for T in (0, 1, 4):   # verification of narrow nodes off / width 1 / width <= 4
                     ix.set_tuning(verify_t=T, steal=T & 1, coop=(T + 1) & 1)
                     out = ix.map(K, E, infix=infix, revcompl=rc, value_bits=8)
-                    assert np.array_equal(out, triv), (E, dna5, K, infix, T)
+                    assert np.array_equal(out, triv), (E, dna5, K, infix, T, wide)
     finally:
         ix.close()
 
@@ -250,11 +253,12 @@ def test_gpu_many_short_sequences_and_extremes():
     codes = rng.integers(0, 4, size=sum(lens), dtype=np.uint8)
     codes[rng.integers(0, len(codes), size=300)] = 4
     ora = H.OracleIndex(codes, lens, keep_sa=False)
-    ix = g.Index.build(codes, lens, sampling=1)
-    for K, E in ((30, 0), (30, 1), (50, 2), (100, 1), (1, 0), (2, 1), (128, 1), (150, 0), (250, 1), (255, 2)):
-        exp = ora.mappability(K, E, value_bits=16, threads=8)
-        assert np.array_equal(ix.map(K, E, value_bits=16), exp), (K, E)
-    ix.close()
+    for bb in (0, WIDE):
+        ix = g.Index.build(codes, lens, sampling=1, block_bytes=bb)
+        for K, E in ((30, 0), (30, 1), (50, 2), (100, 1), (1, 0), (2, 1), (128, 1), (150, 0), (250, 1), (255, 2)):
+            exp = ora.mappability(K, E, value_bits=16, threads=8)
+            assert np.array_equal(ix.map(K, E, value_bits=16), exp), (K, E, bb)
+        ix.close()
     # low complexity: counts far above 255 / 65535
     codes = np.zeros(70000, dtype=np.uint8); codes[::7] = 1
     ora = H.OracleIndex(codes, [70000], keep_sa=False)
