@@ -25,7 +25,9 @@ void set_error(const char* fmt, ...)
 
 #define GM_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { gm::set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); return (e_ == hipErrorOutOfMemory) ? GM_ERR_OOM : GM_ERR_HIP; } } while (0)
 
-static inline unsigned grid_for(uint64_t n, unsigned bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+// every kernel launched over rows or text positions is a grid-stride loop: a dispatch holds fewer than 2^32 work-items per
+// dimension and wide indexes have more rows than that
+static inline unsigned grid_for(uint64_t n, unsigned bs = 256) { return (unsigned)std::min<uint64_t>((n + bs - 1) / bs, 1u << 22); }
 
 // d_small: work counter (8 B) | pad | statistics counters (17 x 8 B at +16), zeroed by every call  ||  +256: sticky error flag
 // (set by a device-side invariant check, surfaced and cleared by the next host-side check: gm_map, gm_index_sync, gm_last_map_stats)
@@ -36,24 +38,23 @@ constexpr size_t SMALL_BYTES = 512, SMALL_ZEROED = 256, SMALL_ERR_OFF = 256;
 template <int WPP>
 __global__ __launch_bounds__(256) void count_blocks_kernel(const uint8_t* __restrict__ bwt, uint64_t n, uint64_t nb, typename BlockGeom<WPP>::row_t* __restrict__ cnt)
 {
-    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q > nb) return;
-    uint32_t c[NLET] = {0, 0, 0, 0, 0};
-    if (q < nb) {
-        constexpr uint32_t SPB = BlockGeom<WPP>::SPB;
-        for (uint32_t t = 0; t < SPB; ++t) {
-            const uint64_t i = q * SPB + t;
-            if (i < n) { const uint32_t s = bwt[i]; if (s < NLET) c[s]++; }
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q <= nb; q += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t c[NLET] = {0, 0, 0, 0, 0};
+        if (q < nb) {
+            constexpr uint32_t SPB = BlockGeom<WPP>::SPB;
+            for (uint32_t t = 0; t < SPB; ++t) {
+                const uint64_t i = q * SPB + t;
+                if (i < n) { const uint32_t s = bwt[i]; if (s < NLET) c[s]++; }
+            }
         }
+        for (uint32_t s = 0; s < NLET; ++s) cnt[s * (nb + 1) + q] = c[s];
     }
-    for (uint32_t s = 0; s < NLET; ++s) cnt[s * (nb + 1) + q] = c[s];
 }
 
 template <int WPP>
 __global__ __launch_bounds__(256) void pack_blocks_kernel(const uint8_t* __restrict__ bwt, uint64_t n, uint64_t nb, const typename BlockGeom<WPP>::row_t* __restrict__ cum, uint32_t* __restrict__ blk)
 {
-    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nb) return;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nb; q += (uint64_t)gridDim.x * blockDim.x) {
     constexpr uint32_t WPB = BlockGeom<WPP>::WPB;
     uint32_t w[WPB];
     for (uint32_t i = 0; i < WPB; ++i) w[i] = 0;
@@ -64,50 +65,51 @@ __global__ __launch_bounds__(256) void pack_blocks_kernel(const uint8_t* __restr
     pack_planes<WPP>(bwt, n, q, w);
     uint32_t* dst = blk + q * WPB;
     for (uint32_t i = 0; i < WPB; ++i) dst[i] = w[i];
+    }
 }
 
 template <int WPP>
 __global__ __launch_bounds__(256) void unpack_blocks_kernel(const uint32_t* __restrict__ blk, uint64_t n, uint8_t* __restrict__ bwt)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     constexpr uint32_t SPB = BlockGeom<WPP>::SPB, WPB = BlockGeom<WPP>::WPB;
     const uint64_t q = i / SPB; const uint32_t off = (uint32_t)(i - q * SPB), w = off >> 5, t = off & 31u;
     const uint32_t* b = blk + q * WPB;
     constexpr uint32_t H = BlockGeom<WPP>::HDRW;
     bwt[i] = (uint8_t)(((b[H + w] >> t) & 1u) | (((b[H + WPP + w] >> t) & 1u) << 1) | (((b[H + 2 * WPP + w] >> t) & 1u) << 2));
+    }
 }
 
 // 4-bit packed copy of the text: chunk c holds symbols [32c, 32c + 32), symbol i in nibble (i & 1) of byte (i >> 1)
 __global__ __launch_bounds__(256) void pack_text4_kernel(const uint8_t* __restrict__ codes, uint64_t textLen, uint32_t* __restrict__ out, uint64_t nWords)
 {
-    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= nWords) return;
-    uint32_t v = 0;
-    for (uint32_t j = 0; j < 8; ++j) { const uint64_t i = w * 8 + j; const uint32_t c = i < textLen ? codes[i] : 0u; v |= (c & 15u) << (4u * j); }
-    out[w] = v;
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nWords; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t v = 0;
+        for (uint32_t j = 0; j < 8; ++j) { const uint64_t i = w * 8 + j; const uint32_t c = i < textLen ? codes[i] : 0u; v |= (c & 15u) << (4u * j); }
+        out[w] = v;
+    }
 }
 
 // sentinel text: sequence s occupies [cum[s] + s, cum[s+1] + s), its sentinel follows
 __global__ __launch_bounds__(256) void sentinel_text_kernel(const uint8_t* __restrict__ codes, const uint64_t* __restrict__ cum, uint32_t nSeq, uint64_t textLen,
                                                             uint8_t* __restrict__ out)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < textLen) {
-        uint32_t lo = 0, hi = nSeq;
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cum[mid] <= i) lo = mid; else hi = mid; }
-        out[i + lo] = codes[i];
-    } else if (i < textLen + nSeq) {
-        const uint32_t s = (uint32_t)(i - textLen);
-        out[cum[s + 1] + s] = (uint8_t)SYM_SENT;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < textLen + nSeq; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (i < textLen) {
+            uint32_t lo = 0, hi = nSeq;
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cum[mid] <= i) lo = mid; else hi = mid; }
+            out[i + lo] = codes[i];
+        } else {
+            const uint32_t s = (uint32_t)(i - textLen);
+            out[cum[s + 1] + s] = (uint8_t)SYM_SENT;
+        }
     }
 }
 
 // verification records (gm_kernels.h: CTX_*): one 32-byte record per forward SA row = {SA[row], 56 text symbols around it}
 __global__ __launch_bounds__(256) void ctx_build_kernel(const uint32_t* __restrict__ sa, const uint8_t* __restrict__ textS, uint64_t nRows, uint4* __restrict__ ctx)
 {
-    const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= nRows) return;
+    for (uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; row < nRows; row += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t p0 = sa[row];
     const uint8_t* p = textS + ((long long)p0 - CTX_LEFT);   // 512 sentinel bytes of padding on both sides of textS
     uint32_t w[7];
@@ -125,6 +127,7 @@ __global__ __launch_bounds__(256) void ctx_build_kernel(const uint32_t* __restri
     }
     ctx[row * 2] = make_uint4(p0, w[0], w[1], w[2]);
     ctx[row * 2 + 1] = make_uint4(w[3], w[4], w[5], w[6]);
+    }
 }
 
 static int make_ctx(gm_index* ix)
@@ -908,6 +911,8 @@ int gm_map(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t first_
     if (!ix || !p || !out_host) { set_error("null argument"); return GM_ERR_BAD_ARG; }
     if (p->value_bits != 8 && p->value_bits != 16) return GM_ERR_BAD_VALUE_BITS;
     GM_HIP(hipSetDevice(ix->device));
+    if (!((p->flags & GM_MAP_FLAG_RANGE) || p->kmer_begin != 0 || p->kmer_end != 0 || (p->chunk_blocks > 0 && p->chunk_stride > 1)))
+        return gm_map_shard(ix, text_begin, text_len, first_seq, n_seq, p, intervals, n_intervals, seq_file_id, out_host);   // every position is delivered
     void* d_out = nullptr;
     const size_t bytes = (size_t)text_len * (p->value_bits / 8);
     GM_HIP(hipMalloc(&d_out, bytes + 16));
@@ -1001,14 +1006,29 @@ int gm_map_shard(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t 
     const uint64_t kb = ranged ? std::min<uint64_t>(p->kmer_begin, numKmers) : 0, ke = ranged ? std::min<uint64_t>(p->kmer_end, numKmers) : numKmers;
     const bool chunked = p->chunk_blocks > 0 && p->chunk_stride > 1;
     if (n_intervals > 0 || !chunked) {
-        // a selection, or a plain contiguous share: one launch, then the positions of the range (a selection is small)
-        int rc = map_impl(ix, text_begin, text_len, first_seq, n_seq, p, intervals, n_intervals, seq_file_id, d_out, ix->stCompute);
-        if (rc) return rc;
-        // whole blocks: the share ends where the next one begins; the tail past the last k-mer is all zeros (resetLimits)
+        // a selection, or a plain contiguous share (gm_map is the share "everything")
         const uint32_t infix = p->infix > 0 ? (uint32_t)p->infix : (p->overlap >= 0 ? default_infix_length(p->K, p->E, p->overlap) : tuned_infix_length(p->K, p->E));
+        if (infix == 0 || infix > p->K) return GM_ERR_BAD_OVERLAP;
         const uint64_t step = p->K - infix + 1;
+        // whole blocks: the share ends where the next one begins; the tail past the last k-mer is all zeros (resetLimits)
         const uint64_t b = (kb + step - 1) / step * step, e = ke >= numKmers ? text_len : (ke + step - 1) / step * step;
-        if (e > b) GM_HIP(hipMemcpyAsync(h_out + b * eb, d_out + b * eb, (e - b) * eb, hipMemcpyDeviceToHost, ix->stCompute));
+        // large shares without a selection go in a few launches so that the copy of one piece overlaps the search of the next
+        const uint32_t S = (n_intervals == 0 && e > b && e - b >= (1ull << 26)) ? 4u : 1u;
+        for (uint32_t s2 = 0; s2 < S; ++s2) {
+            gm_map_params q = *p;
+            uint64_t pb = b, pe = e;
+            if (S > 1) {
+                pb = b + (e - b) * s2 / S / step * step; pe = s2 + 1 == S ? e : b + (e - b) * (s2 + 1) / S / step * step;
+                q.flags |= GM_MAP_FLAG_RANGE; q.kmer_begin = pb; q.kmer_end = std::min<uint64_t>(pe, ke);
+                if (pe <= pb) continue;
+            }
+            int rc = map_impl(ix, text_begin, text_len, first_seq, n_seq, &q, intervals, n_intervals, seq_file_id, d_out, ix->stCompute);
+            if (rc) return rc;
+            GM_HIP(hipEventRecord(ix->evShard[s2], ix->stCompute));
+            GM_HIP(hipStreamWaitEvent(ix->stCopy, ix->evShard[s2], 0));
+            if (pe > pb) GM_HIP(hipMemcpyAsync(h_out + pb * eb, d_out + pb * eb, (pe - pb) * eb, hipMemcpyDeviceToHost, ix->stCopy));
+        }
+        GM_HIP(hipStreamSynchronize(ix->stCopy));
         GM_HIP(hipStreamSynchronize(ix->stCompute));
         return check_device_error(ix);
     }
@@ -1077,6 +1097,7 @@ int gm_map_runs(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t f
     if (!ix || !p || !out) { set_error("null argument"); return GM_ERR_BAD_ARG; }
     if (p->value_bits != 8 && p->value_bits != 16) return GM_ERR_BAD_VALUE_BITS;
     GM_HIP(hipSetDevice(ix->device));
+    if (text_len >= 0xFFFFFFFFull) { set_error("gm_map_runs addresses 32-bit slice positions: split the file or use gm_map"); return GM_ERR_TOO_LONG; }
     gm_runs* R = (gm_runs*)calloc(1, sizeof(gm_runs));
     if (!R) return GM_ERR_OOM;
     void* d_c = nullptr; uint8_t* d_head = nullptr; uint32_t *d_starts = nullptr, *d_count = nullptr; uint16_t* d_val = nullptr; void* d_tmp = nullptr;

@@ -74,6 +74,8 @@ __global__ __launch_bounds__(256) void bwt_kernel(const uint32_t* __restrict__ s
 }
 
 static inline unsigned grid_for(uint64_t n, unsigned bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+// for grid-stride kernels: at most 2^30 work-items per launch (a dispatch holds fewer than 2^32 per dimension)
+static inline unsigned grid_cap(uint64_t n, unsigned bs = 256) { return (unsigned)std::min<uint64_t>((n + bs - 1) / bs, 1u << 22); }
 
 // Suffix array of the sentinel text (forward or reversed) in d_sa_out (n x u32), its BWT in d_bwt (n x u8).
 // Both are caller-provided device buffers; everything else is allocated and freed here.
@@ -154,52 +156,52 @@ __global__ __launch_bounds__(256) void make_symbols_wide_kernel(const uint8_t* _
                                                                 uint32_t nSeq, uint64_t textLen, int rev,
                                                                 uint8_t* __restrict__ sym, uint64_t* __restrict__ key, uint64_t* __restrict__ sa)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < textLen) {
-        uint32_t lo = 0, hi = nSeq;
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cum[mid] <= i) lo = mid; else hi = mid; }
-        const uint64_t b = cum[lo], e = cum[lo + 1];
-        const uint64_t p = (rev ? (b + (e - 1 - i)) : i) + lo;
-        const uint32_t c = codes[i];
-        sym[p] = (uint8_t)c; key[p] = (uint64_t)nSeq + c; sa[p] = p;
-    } else if (i < textLen + nSeq) {
-        const uint32_t s = (uint32_t)(i - textLen);
-        const uint64_t p = cum[s + 1] + s;
-        sym[p] = (uint8_t)SYM_SENT; key[p] = s; sa[p] = p;
+    // grid-stride: a launch holds fewer than 2^32 work-items per dimension, these texts have more symbols than that
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < textLen + nSeq; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (i < textLen) {
+            uint32_t lo = 0, hi = nSeq;
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cum[mid] <= i) lo = mid; else hi = mid; }
+            const uint64_t b = cum[lo], e = cum[lo + 1];
+            const uint64_t p = (rev ? (b + (e - 1 - i)) : i) + lo;
+            const uint32_t c = codes[i];
+            sym[p] = (uint8_t)c; key[p] = (uint64_t)nSeq + c; sa[p] = p;
+        } else {
+            const uint32_t s = (uint32_t)(i - textLen);
+            const uint64_t p = cum[s + 1] + s;
+            sym[p] = (uint8_t)SYM_SENT; key[p] = s; sa[p] = p;
+        }
     }
 }
 // flag[j] = 1 when suffix sa[j] starts a new group: its (first, second) rank pair differs from its predecessor's
 __global__ __launch_bounds__(256) void head_flags_pair_kernel(const uint64_t* __restrict__ sa, const uint64_t* __restrict__ rank, uint64_t* __restrict__ flag, uint64_t n, uint64_t h)
 {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    if (j == 0) { flag[0] = 0; return; }
-    const uint64_t p = sa[j], q = sa[j - 1];
-    const uint64_t p2 = p + h < n ? rank[p + h] + 1 : 0, q2 = q + h < n ? rank[q + h] + 1 : 0;
-    flag[j] = (rank[p] != rank[q] || p2 != q2) ? 1ull : 0ull;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+        if (j == 0) { flag[0] = 0; continue; }
+        const uint64_t p = sa[j], q = sa[j - 1];
+        const uint64_t p2 = p + h < n ? rank[p + h] + 1 : 0, q2 = q + h < n ? rank[q + h] + 1 : 0;
+        flag[j] = (rank[p] != rank[q] || p2 != q2) ? 1ull : 0ull;
+    }
 }
 __global__ __launch_bounds__(256) void head_flags_key_kernel(const uint64_t* __restrict__ keys, uint64_t* __restrict__ flag, uint64_t n)
 {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n) flag[j] = (j > 0 && keys[j] != keys[j - 1]) ? 1ull : 0ull;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x)
+        flag[j] = (j > 0 && keys[j] != keys[j - 1]) ? 1ull : 0ull;
 }
 __global__ __launch_bounds__(256) void scatter_rank_wide_kernel(const uint64_t* __restrict__ sa, const uint64_t* __restrict__ dense, uint64_t* __restrict__ rank, uint64_t n)
 {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n) rank[sa[j]] = dense[j];
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) rank[sa[j]] = dense[j];
 }
 // key of a suffix for one of the two passes: which = 1 -> rank[i + h] (0 for suffixes shorter than h, they sort first), which = 0 -> rank[i]
 __global__ __launch_bounds__(256) void make_key_wide_kernel(const uint64_t* __restrict__ sa, const uint64_t* __restrict__ rank, uint64_t* __restrict__ keys, uint64_t n, uint64_t h, int which)
 {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const uint64_t p = sa[j];
-    keys[j] = which ? (p + h < n ? rank[p + h] + 1 : 0ull) : rank[p];
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t p = sa[j];
+        keys[j] = which ? (p + h < n ? rank[p + h] + 1 : 0ull) : rank[p];
+    }
 }
 __global__ __launch_bounds__(256) void bwt_wide_kernel(const uint64_t* __restrict__ sa, const uint8_t* __restrict__ sym, uint8_t* __restrict__ bwt, uint64_t n)
 {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n) { const uint64_t p = sa[j]; bwt[j] = p ? sym[p - 1] : sym[n - 1]; }
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) { const uint64_t p = sa[j]; bwt[j] = p ? sym[p - 1] : sym[n - 1]; }
 }
 
 int build_sa_bwt_wide(const uint8_t* d_codes, const uint64_t* d_cum, uint32_t nSeq, uint64_t textLen, int rev,
@@ -219,7 +221,7 @@ int build_sa_bwt_wide(const uint8_t* d_codes, const uint64_t* d_cum, uint32_t nS
         HC(hipMalloc(&d_own, n * 8)); HC(hipMalloc(&d_rank, n * 8)); HC(hipMalloc(&d_flag, n * 8));
         HC(hipMalloc(&d_keyA, n * 8)); HC(hipMalloc(&d_keyB, n * 8));
         alt = d_own;
-        hipLaunchKernelGGL(make_symbols_wide_kernel, dim3(grid_for(n)), dim3(256), 0, 0, d_codes, d_cum, nSeq, textLen, rev, d_sym, d_keyA, cur);
+        hipLaunchKernelGGL(make_symbols_wide_kernel, dim3(grid_cap(n)), dim3(256), 0, 0, d_codes, d_cum, nSeq, textLen, rev, d_sym, d_keyA, cur);
         HC(hipGetLastError());
         unsigned keyBits = 1; while ((1ull << keyBits) < (uint64_t)nSeq + NLET) ++keyBits;
         unsigned rbits = 1; while ((1ull << rbits) < n + 1) ++rbits;
@@ -232,32 +234,33 @@ int build_sa_bwt_wide(const uint8_t* d_codes, const uint64_t* d_cum, uint32_t nS
         size_t tb = tmpBytes;
         HC(rocprim::radix_sort_pairs(d_tmp, tb, d_keyA, d_keyB, cur, alt, n, 0, keyBits));
         std::swap(cur, alt);
-        hipLaunchKernelGGL(head_flags_key_kernel, dim3(grid_for(n)), dim3(256), 0, 0, d_keyB, d_flag, n);
+        hipLaunchKernelGGL(head_flags_key_kernel, dim3(grid_cap(n)), dim3(256), 0, 0, d_keyB, d_flag, n);
         tb = tmpBytes;
         HC(rocprim::inclusive_scan(d_tmp, tb, d_flag, d_keyA, n, rocprim::plus<uint64_t>()));   // dense ranks in d_keyA
-        hipLaunchKernelGGL(scatter_rank_wide_kernel, dim3(grid_for(n)), dim3(256), 0, 0, cur, d_keyA, d_rank, n);
+        hipLaunchKernelGGL(scatter_rank_wide_kernel, dim3(grid_cap(n)), dim3(256), 0, 0, cur, d_keyA, d_rank, n);
         uint64_t maxRank = 0;
         HC(hipMemcpy(&maxRank, d_keyA + (n - 1), 8, hipMemcpyDeviceToHost));
         int rounds = 0;
         for (uint64_t h = 1; maxRank != n - 1; h <<= 1) {
             if (h >= n) { set_error("prefix doubling did not converge"); rc = GM_ERR_INTERNAL; goto done; }
             for (int which = 1; which >= 0; --which) {   // stable LSD: second key first
-                hipLaunchKernelGGL(make_key_wide_kernel, dim3(grid_for(n)), dim3(256), 0, 0, cur, d_rank, d_keyA, n, h, which);
+                hipLaunchKernelGGL(make_key_wide_kernel, dim3(grid_cap(n)), dim3(256), 0, 0, cur, d_rank, d_keyA, n, h, which);
                 tb = tmpBytes;
                 HC(rocprim::radix_sort_pairs(d_tmp, tb, d_keyA, d_keyB, cur, alt, n, 0, rbits));
                 std::swap(cur, alt);
             }
-            hipLaunchKernelGGL(head_flags_pair_kernel, dim3(grid_for(n)), dim3(256), 0, 0, cur, d_rank, d_flag, n, h);
+            hipLaunchKernelGGL(head_flags_pair_kernel, dim3(grid_cap(n)), dim3(256), 0, 0, cur, d_rank, d_flag, n, h);
             tb = tmpBytes;
             HC(rocprim::inclusive_scan(d_tmp, tb, d_flag, d_keyA, n, rocprim::plus<uint64_t>()));
-            hipLaunchKernelGGL(scatter_rank_wide_kernel, dim3(grid_for(n)), dim3(256), 0, 0, cur, d_keyA, d_keyB, n);   // new ranks in d_keyB ...
+            hipLaunchKernelGGL(scatter_rank_wide_kernel, dim3(grid_cap(n)), dim3(256), 0, 0, cur, d_keyA, d_keyB, n);   // new ranks in d_keyB ...
             HC(hipMemcpyAsync(d_rank, d_keyB, n * 8, hipMemcpyDeviceToDevice, 0));                                          // ... (the flags read the old ones)
             HC(hipMemcpy(&maxRank, d_keyA + (n - 1), 8, hipMemcpyDeviceToHost));
+            HC(hipGetLastError());
             ++rounds;
         }
         if (roundsOut) *roundsOut = rounds;
         if (cur != d_sa_out) HC(hipMemcpy(d_sa_out, cur, n * 8, hipMemcpyDeviceToDevice));
-        hipLaunchKernelGGL(bwt_wide_kernel, dim3(grid_for(n)), dim3(256), 0, 0, d_sa_out, d_sym, d_bwt, n);
+        hipLaunchKernelGGL(bwt_wide_kernel, dim3(grid_cap(n)), dim3(256), 0, 0, d_sa_out, d_sym, d_bwt, n);
         HC(hipGetLastError());
         HC(hipDeviceSynchronize());
     }

@@ -894,16 +894,17 @@ __global__ __launch_bounds__(256) void qmer_table_kernel(const uint32_t* __restr
 template <typename TValue, typename TPlane>
 __global__ __launch_bounds__(256) void finalize2_kernel(const TPlane* __restrict__ accF, const TPlane* __restrict__ accR, TValue* __restrict__ out, uint64_t n, uint32_t maxVal, ChunkSel sel)
 {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n || !chunk_mine(sel, j)) return;
-    const uint32_t v = (uint32_t)accF[j] + accR[j];   // each plane holds min(count, its own maximum)
-    out[j] = (TValue)(v < maxVal ? v : maxVal);
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {   // (grid-stride: n may exceed 2^32)
+        if (!chunk_mine(sel, j)) continue;
+        const uint32_t v = (uint32_t)accF[j] + accR[j];   // each plane holds min(count, its own maximum)
+        out[j] = (TValue)(v < maxVal ? v : maxVal);
+    }
 }
 
 template <typename TValue>
 __global__ __launch_bounds__(256) void finalize_kernel(const uint32_t* __restrict__ acc, TValue* __restrict__ out, uint64_t n, uint32_t maxVal, ChunkSel sel)
 {
-    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4ull;
+    for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4ull; i < n; i += (uint64_t)gridDim.x * blockDim.x * 4ull) {
     const bool aligned = ((reinterpret_cast<uintptr_t>(out + i)) & (sizeof(TValue) * 4 - 1)) == 0 && ((reinterpret_cast<uintptr_t>(acc + i)) & 15) == 0;
     if (sel.len) {
         for (uint64_t j = i; j < n && j < i + 4; ++j) if (chunk_mine(sel, j)) { const uint32_t v = acc[j]; out[j] = (TValue)(v < maxVal ? v : maxVal); }
@@ -916,25 +917,26 @@ __global__ __launch_bounds__(256) void finalize_kernel(const uint32_t* __restric
     } else {
         for (uint64_t j = i; j < n && j < i + 4; ++j) { const uint32_t v = acc[j]; out[j] = (TValue)(v < maxVal ? v : maxVal); }
     }
+    }
 }
 
 // --exclude-pseudo: hits[j] = distinct_sequences.size(), a narrowing store without saturation (algo.hpp:360)
 template <typename TValue>
 __global__ __launch_bounds__(256) void finalize_fileset_kernel(const uint32_t* __restrict__ bits, uint32_t wordsPerKmer, TValue* __restrict__ out, uint64_t n, ChunkSel sel)
 {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n || !chunk_mine(sel, j)) return;
-    uint32_t c = 0;
-    for (uint32_t w = 0; w < wordsPerKmer; ++w) c += (uint32_t)__popc(bits[j * wordsPerKmer + w]);
-    out[j] = (TValue)c;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+        if (!chunk_mine(sel, j)) continue;
+        uint32_t c = 0;
+        for (uint32_t w = 0; w < wordsPerKmer; ++w) c += (uint32_t)__popc(bits[j * wordsPerKmer + w]);
+        out[j] = (TValue)c;
+    }
 }
 
 // ---- run-length form of c[] (saveWig / saveBedGraph scans, src/output.hpp:74-187) --------------------------------
 template <typename TValue>
 __global__ __launch_bounds__(256) void run_heads_kernel(const TValue* __restrict__ c, uint64_t n, uint8_t* __restrict__ head)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) head[i] = (i == 0 || c[i] != c[i - 1]) ? 1 : 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) head[i] = (i == 0 || c[i] != c[i - 1]) ? 1 : 0;
 }
 __global__ void seq_heads_kernel(const uint64_t* __restrict__ cumLocal, uint32_t nSeq, uint64_t n, uint8_t* __restrict__ head)
 {
@@ -944,16 +946,16 @@ __global__ void seq_heads_kernel(const uint64_t* __restrict__ cumLocal, uint32_t
 template <typename TValue>
 __global__ __launch_bounds__(256) void run_values_kernel(const TValue* __restrict__ c, const uint32_t* __restrict__ starts, uint64_t nRuns, uint16_t* __restrict__ val)
 {
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < nRuns) val[r] = (uint16_t)c[starts[r]];
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nRuns; r += (uint64_t)gridDim.x * blockDim.x) val[r] = (uint16_t)c[starts[r]];
 }
 
 // zero the calling shard's chunks of a workspace (elements of `eb` bytes, positions [0, n) of the range)
 __global__ __launch_bounds__(256) void clear_chunks_kernel(uint8_t* __restrict__ base, uint32_t eb, uint64_t n, ChunkSel sel)
 {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n || !chunk_mine(sel, j)) return;
-    if (eb == 1) base[j] = 0; else if (eb == 2) reinterpret_cast<uint16_t*>(base)[j] = 0; else reinterpret_cast<uint32_t*>(base)[j] = 0;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+        if (!chunk_mine(sel, j)) continue;
+        if (eb == 1) base[j] = 0; else if (eb == 2) reinterpret_cast<uint16_t*>(base)[j] = 0; else reinterpret_cast<uint32_t*>(base)[j] = 0;
+    }
 }
 
 // resetLimits (algo.hpp:10-22): zero the last K-1 positions of every sequence of the slice.

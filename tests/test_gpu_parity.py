@@ -749,3 +749,15 @@ def test_gpu_rccl_collectives_next_to_the_library():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_one_rank_check.py")], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gpu_multi_rank_rehearsal_on_one_device(world):
+    """tools/multi_check.py under torchrun: `world` processes share cuda:0 -- interleaved chunks + collective gather, the IPC
+    peer-copy gather (what travels over xGMI between GPUs), and the -ep / csv shares; every gathered result == unsharded"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29600 + world), os.path.join(root, "tools", "multi_check.py")], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and "MULTI_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
