@@ -553,8 +553,8 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     uint64_t blockBegin = 0, blockEnd = plan.numBlocks;
     if ((p->flags & GM_MAP_FLAG_RANGE) || p->kmer_begin != 0 || p->kmer_end != 0) {
         if (plan.useList) {
-            auto lo = std::lower_bound(plan.blocks.begin(), plan.blocks.end(), p->kmer_begin, [](const std::pair<uint32_t, uint32_t>& b, uint64_t v) { return b.first < v; });
-            auto hi = std::lower_bound(plan.blocks.begin(), plan.blocks.end(), p->kmer_end, [](const std::pair<uint32_t, uint32_t>& b, uint64_t v) { return b.first < v; });
+            auto lo = std::lower_bound(plan.blocks.begin(), plan.blocks.end(), p->kmer_begin, [](const std::pair<uint32_t, uint32_t>& b, uint64_t v) { return MapPlan::block_pos(b) < v; });
+            auto hi = std::lower_bound(plan.blocks.begin(), plan.blocks.end(), p->kmer_end, [](const std::pair<uint32_t, uint32_t>& b, uint64_t v) { return MapPlan::block_pos(b) < v; });
             blockBegin = lo - plan.blocks.begin(); blockEnd = hi - plan.blocks.begin();
         } else {
             blockBegin = std::min<uint64_t>((p->kmer_begin + plan.stepSize - 1) / plan.stepSize, plan.numBlocks);
@@ -580,8 +580,8 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     S->posBase = S->posEnd = 0;
     if (blockEnd > blockBegin) {
         if (plan.useList) {
-            for (uint64_t b = blockBegin; b < blockEnd; ++b) kmers += plan.blocks[b].second;
-            S->posBase = plan.blocks[blockBegin].first; S->posEnd = plan.blocks[blockEnd - 1].first + plan.blocks[blockEnd - 1].second;
+            for (uint64_t b = blockBegin; b < blockEnd; ++b) kmers += MapPlan::block_n(plan.blocks[b]);
+            S->posBase = MapPlan::block_pos(plan.blocks[blockBegin]); S->posEnd = MapPlan::block_pos(plan.blocks[blockEnd - 1]) + MapPlan::block_n(plan.blocks[blockEnd - 1]);
         } else {
             S->posBase = blockBegin * plan.stepSize; S->posEnd = std::min<uint64_t>(blockEnd * plan.stepSize, plan.numKmers);
             kmers = S->posEnd - S->posBase;
@@ -947,6 +947,7 @@ int gm_device_alloc(int device, uint64_t bytes, void** dptr)
     int rc = select_device(device); if (rc) return rc;
     GM_HIP(hipMalloc(dptr, bytes));
     GM_HIP(hipMemset(*dptr, 0, bytes));
+    GM_HIP(hipDeviceSynchronize());   // the clear is finished before the handle can reach another process
     return GM_OK;
 }
 int gm_device_free(int device, void* dptr) { GM_HIP(hipSetDevice(device)); GM_HIP(hipFree(dptr)); return GM_OK; }

@@ -61,7 +61,10 @@ struct MapPlan {
     uint32_t K = 0, E = 0, infix = 0, stepSize = 0, nSearches = 0, nStrands = 0;
     uint64_t textLen = 0, numKmers = 0;
     bool useList = false;
-    std::vector<std::pair<uint32_t, uint32_t>> blocks;   // (first k-mer position, k-mers) when useList
+    // when useList: (low 32 bits of the first k-mer position, k-mers | high bits of the position << 8) -- block_pos / block_n
+    std::vector<std::pair<uint32_t, uint32_t>> blocks;
+    static uint64_t block_pos(const std::pair<uint32_t, uint32_t>& b) { return (uint64_t)(b.second >> 8) << 32 | b.first; }
+    static uint32_t block_n(const std::pair<uint32_t, uint32_t>& b) { return b.second & 0xFFu; }
     uint64_t numBlocks = 0;
     std::vector<OssRecord> table;                        // [(n-1)*8 + s], n = 1..stepSize
     uint64_t numRoots() const { return numBlocks * nSearches * nStrands; }
@@ -80,7 +83,6 @@ inline int make_map_plan(uint32_t K, uint32_t E, uint32_t infix, int revcompl, u
     if (K < 1 || K > MAX_K) return PLAN_BAD_K;
     if (infix < 1 || infix > K) return PLAN_BAD_OVERLAP;
     if (textLen >= (1ull << 40)) return PLAN_TOO_LONG;
-    if (nIntervals != 0 && textLen >= 0xFFFFFFFFull) return PLAN_TOO_LONG;   // block lists address 32-bit slice positions
     p.K = K; p.E = E; p.infix = infix; p.stepSize = K - infix + 1;   // algo.hpp:416
     p.nSearches = oss_scheme(E).ns; p.nStrands = revcompl ? 2 : 1;
     p.textLen = textLen;
@@ -108,7 +110,7 @@ inline int make_map_plan(uint32_t K, uint32_t E, uint32_t infix, int revcompl, u
         }
         for (auto& x : mg)
             for (uint64_t i = x.first; i < x.second; i += p.stepSize)                          // algo.hpp:448-451
-                p.blocks.emplace_back((uint32_t)i, (uint32_t)std::min<uint64_t>(p.stepSize, x.second - i));
+                p.blocks.emplace_back((uint32_t)i, (uint32_t)std::min<uint64_t>(p.stepSize, x.second - i) | (uint32_t)(i >> 32) << 8);
         p.numBlocks = p.blocks.size();
     }
     return PLAN_OK;

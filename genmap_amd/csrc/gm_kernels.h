@@ -700,7 +700,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                         gb = (unsigned long long)(q * A.chunkStride + A.chunkIndex) * A.chunkBlocks + ((uint32_t)gb - q * A.chunkBlocks);
                     }
                     gb += A.blockBegin;
-                    if (A.blockList) { const uint2 e = A.blockList[gb]; frt.win = e.x; frt.n = e.y; }   // (selections address 32-bit slice positions)
+                    if (A.blockList) { const uint2 e = A.blockList[gb]; frt.win = (row_t)((uint64_t)(e.y >> 8) << 32 | e.x); frt.n = e.y & 0xFFu; }
                     else {
                         frt.win = (row_t)gb * A.stepSize;
                         const row_t left = (row_t)A.numKmers - frt.win;

@@ -133,7 +133,7 @@ static int run(const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nse
     for (uint64_t id = 0; id < roots; ++id) {
         uint64_t b = id / rpb; uint32_t r = (uint32_t)(id % rpb);
         Root rt;
-        if (plan.useList) { rt.win = plan.blocks[b].first; rt.n = plan.blocks[b].second; }
+        if (plan.useList) { rt.win = (uint32_t)MapPlan::block_pos(plan.blocks[b]); rt.n = MapPlan::block_n(plan.blocks[b]); }
         else { rt.win = (uint32_t)(b * plan.stepSize); rt.n = (uint32_t)std::min<uint64_t>(plan.stepSize, plan.numKmers - rt.win); }
         rt.strand = r / plan.nSearches;
         rt.search = r % plan.nSearches;
