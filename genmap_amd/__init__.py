@@ -6,4 +6,4 @@ bench.py and by the one-process-per-GPU launcher; it contains no compute path of
 the HIP library cannot be loaded or no GPU is present.
 """
 from .capi import (GenmapError, Index, MapParams, default_infix_length, device_count, tuned_infix_length, lib_path, load_library,  # noqa: F401
-                   device_alloc, device_free, ipc_export, ipc_open, ipc_close, push_pieces)
+                   device_alloc, device_free, ipc_export, ipc_open, ipc_close, push_pieces, host_pin, host_unpin)

@@ -173,6 +173,17 @@ def device_free(device, ptr):
     _check(lib, lib.gm_device_free(device, C.c_void_p(ptr)))
 
 
+def host_pin(arr):
+    """gm_host_pin: page-lock a numpy array so that device-to-host copies into it are asynchronous DMA transfers"""
+    lib = load_library()
+    _check(lib, lib.gm_host_pin(_ptr(arr), arr.nbytes))
+
+
+def host_unpin(arr):
+    lib = load_library()
+    _check(lib, lib.gm_host_unpin(_ptr(arr)))
+
+
 def ipc_export(device, ptr):
     lib = load_library()
     buf = C.create_string_buffer(64)
@@ -272,11 +283,14 @@ class Index:
         return n_seq, tb, int(self.cum[first_seq + n_seq]) - tb
 
     def map(self, K, E, first_seq=0, n_seq=None, overlap=None, infix=0, revcompl=True, value_bits=16,
-            exclude_pseudo=False, intervals=None, seq_file_id=None, kmer_range=None, chunks=None):
-        """gm_map: computeMappability for the fasta slice made of sequences [first_seq, first_seq+n_seq); host result."""
+            exclude_pseudo=False, intervals=None, seq_file_id=None, kmer_range=None, chunks=None, out=None):
+        """gm_map: computeMappability for the fasta slice made of sequences [first_seq, first_seq+n_seq); host result
+        (a new array, or `out` -- e.g. a page-locked one, host_pin)."""
         n_seq, tb, tl = self._slice(first_seq, n_seq)
         p = self._params(K, E, overlap, infix, revcompl, value_bits, exclude_pseudo, kmer_range, chunks)
-        out = np.zeros(tl, dtype=np.uint8 if value_bits == 8 else np.uint16)
+        if out is None:
+            out = np.zeros(tl, dtype=np.uint8 if value_bits == 8 else np.uint16)
+        assert out.size == tl and out.dtype == (np.uint8 if value_bits == 8 else np.uint16) and out.flags.c_contiguous
         iv = None if not intervals else np.ascontiguousarray(np.asarray(intervals, dtype=np.uint64).reshape(-1))
         sf = None if seq_file_id is None else np.ascontiguousarray(seq_file_id, dtype=np.uint32)
         _check(self._lib, self._lib.gm_map(self._h, tb, tl, first_seq, n_seq, C.byref(p), _ptr(iv), 0 if iv is None else len(iv) // 2, _ptr(sf), _ptr(out)))

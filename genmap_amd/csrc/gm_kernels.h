@@ -654,13 +654,22 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
             else {
                 // 16 symbols starting at the lowest text position of the q-mer, 4 bits each
                 const unsigned long long v = fshift ? (fx0 >> fshift) | (fx1 << (64u - fshift)) : fx0;
-                uint32_t idx = 0, bad = 0;
-                for (uint32_t i = 0; i < fql; ++i) {
-                    const uint32_t c = (uint32_t)(v >> (4u * i)) & 15u;
-                    bad |= c > 3u ? 1u : 0u;
-                    // forward strand: symbol i is needle(a0 + i), most significant first; reverse strand: needle(a0 + q-1-i) = 3 - c
-                    idx |= frt.strand ? (3u - (c & 3u)) << (2u * i) : (c & 3u) << (2u * (fql - 1u - i));
-                }
+                // the table index without a loop over the symbols: nibbles -> 2-bit symbols (symbol i at bits 2i); a code above 3
+                // (N) anywhere in the q-mer makes the root empty
+                const unsigned long long qmask = fql >= 16u ? ~0ull : ((1ull << (4u * fql)) - 1ull);
+                const uint32_t bad = (v & qmask & 0xCCCCCCCCCCCCCCCCull) != 0ull ? 1u : 0u;
+                unsigned long long t = v & qmask & 0x3333333333333333ull;
+                t = (t | (t >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+                t = (t | (t >> 4)) & 0x00FF00FF00FF00FFull;
+                t = (t | (t >> 8)) & 0x0000FFFF0000FFFFull;
+                t = (t | (t >> 16)) & 0x00000000FFFFFFFFull;
+                const uint32_t lo2 = (uint32_t)t;                                   // sum of c_i << 2i
+                const uint32_t m2 = fql >= 16u ? 0xFFFFFFFFu : ((1u << (2u * fql)) - 1u);
+                // reverse strand: needle(a0 + q-1-i) = 3 - c_i, i.e. the complement of every 2-bit group, same order
+                // forward strand: symbol i is needle(a0 + i), most significant first: reverse the order of the groups
+                uint32_t r = __builtin_bitreverse32(lo2);
+                r = ((r & 0xAAAAAAAAu) >> 1) | ((r & 0x55555555u) << 1);
+                const uint32_t idx = frt.strand ? (~lo2 & m2) : (fql ? r >> (32u - 2u * fql) : 0u);
                 if (bad) fs = 0u;   // a pattern N never matches in an exact block (find2:330): this root finds nothing
                 else { IO::load_qentry(((A.qselMask >> frt.search) & 1u) ? A.qtabB : A.qtabA, idx, ftFlo, ftRlo, ftW); fs = 2u; }
             }

@@ -177,7 +177,9 @@ int map_main(int argc, const char** argv)
 
     std::string indexPath = a.get("index");
     gmh::IndexMeta meta; std::vector<uint8_t> text, bf, br; std::vector<uint32_t> sa;
+    const double tRead = wall();
     if (!gmh::read_index_dir(indexPath, meta, text, bf, br, sa, err)) { std::cout << err << (err.empty() || err.back() != '\n' ? "\n" : ""); return 1; }
+    const double readSeconds = wall() - tRead;
 
     // output path: directory, or a file name for single-fasta indices (src/mappability.hpp:562-619)
     std::string outputPath = a.get("output");
@@ -245,6 +247,7 @@ int map_main(int argc, const char** argv)
     if (devices.empty()) devices.push_back(0);
     std::vector<gm_index*> replicas(devices.size(), nullptr);
     std::vector<int> rcs(devices.size(), 0);
+    const double tLoad = wall();
     {
         std::vector<std::thread> th;
         const uint32_t bb = (uint32_t)std::atoi(a.get("block-bytes", "0").c_str());
@@ -256,6 +259,9 @@ int map_main(int argc, const char** argv)
     for (size_t d = 0; d < devices.size(); ++d) if (rcs[d]) { for (auto* r : replicas) gm_index_free(r); return fail_gm("cannot load the index onto the GPU", rcs[d]); }
     gm_index* ix = replicas[0];
     int rc = 0;
+    if (verbose)   // load, compute and write are reported separately
+        std::cout << "- Index files read in " << (std::round(readSeconds * 100.0) / 100.0) << " seconds, loaded onto " << devices.size() << " GPU(s) in "
+                  << (std::round((wall() - tLoad) * 100.0) / 100.0) << " seconds\n" << std::flush;
     { std::vector<uint8_t>().swap(bf); std::vector<uint8_t>().swap(br); std::vector<uint32_t>().swap(sa); }
 
     const double start = wall();
@@ -287,6 +293,9 @@ int map_main(int argc, const char** argv)
             std::string stem = outputPath;
             if (!outputIncludesFilename) stem += fileNames[fi].substr(0, fileNames[fi].find_last_of('.')) + ".genmap";   // src/mappability.hpp:76-78
             bool ok = true; double t;
+            const double tCompute = wall();
+            bool computeReported = false;
+            auto computed = [&]() { if (verbose && !computeReported) { computeReported = true; std::cout << "- " << fileNames[fi] << ": computed in " << (std::round((wall() - tCompute) * 1000.0) / 1000.0) << " seconds\n"; } };
             auto report = [&](const char* what) { if (verbose) std::cout << "- " << what << " written in " << (std::round((wall() - t) * 100.0) / 100.0) << " seconds\n"; };
             const uint64_t* ivp = intervals.empty() ? nullptr : intervals.data();
             if (!raw && !txt && !csv && replicas.size() == 1) {
@@ -294,6 +303,7 @@ int map_main(int argc, const char** argv)
                 gm_runs* R = nullptr;
                 rc = gm_map_runs(ix, textBegin, textLen, firstSeq, nSeq, &p, ivp, intervals.size() / 2, seqFile.data(), &R);
                 if (rc) { for (auto* r : replicas) gm_index_free(r); return fail_gm("computeMappability failed", rc); }
+                computed();
                 gmh::RunsInput ri; ri.n = R->n_runs; ri.start = R->start; ri.length = R->length; ri.value = R->value;
                 if (wig) { t = wall(); ok = ok && gmh::save_wig_runs(ri, stem, seqs, mappability, err); report("WIG file"); }
                 if (bg) { t = wall(); ok = ok && gmh::save_bedgraph_runs(ri, stem, seqs, true, mappability, err); report("bedgraph file"); }
@@ -327,6 +337,7 @@ int map_main(int argc, const char** argv)
                     for (size_t d = 0; d < nd && !rc; ++d) rc = rcs[d];
                 }
                 if (rc) { for (auto* r : replicas) gm_index_free(r); return fail_gm("computeMappability failed", rc); }
+                computed();
             }
             if (raw) { t = wall(); ok = ok && gmh::save_raw(c.data(), textLen, width, stem, kind, err); report("RAW file"); }
             if (txt) { t = wall(); ok = ok && gmh::save_txt(c.data(), textLen, width, stem, seqs, mappability, err); report("TXT file"); }

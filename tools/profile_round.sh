@@ -8,7 +8,7 @@ R=${1:-r02}; O=gpurun_out/$R; mkdir -p $O
 export TMPDIR=/tmp
 echo "== bench default"; timeout 1700 python bench.py > $O/bench_default.json 2> $O/bench_default.log; tail -c 1500 $O/bench_default.json; echo
 echo "== rocprofv3 kernel stats (headline launch only)"
-timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o p --output-format csv -- python bench.py --no-cpu-baseline --no-counters --sub "" > $O/prof.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o p --output-format csv -- python bench.py --no-cpu-baseline --no-counters --no-host-rate --sub "" > $O/prof.log 2>&1
 python - $O <<'PY'
 import csv, glob, sys
 O = sys.argv[1]
@@ -24,7 +24,7 @@ PY
 rm -rf $O/prof
 echo "== PMC traffic (FETCH_SIZE, WRITE_SIZE in separate passes)"
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $C --kernel-trace -d $O/pmc_$C -o p --output-format csv -- python bench.py --no-cpu-baseline --no-counters --sub "" --steps 2 --warmup 1 > $O/pmc_$C.log 2>&1
+  timeout 900 rocprofv3 --pmc $C --kernel-trace -d $O/pmc_$C -o p --output-format csv -- python bench.py --no-cpu-baseline --no-counters --no-host-rate --sub "" --steps 2 --warmup 1 > $O/pmc_$C.log 2>&1
   python - $C $O <<'PY'
 import csv, glob, sys
 c, O = sys.argv[1], sys.argv[2]; vals = []
