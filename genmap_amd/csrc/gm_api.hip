@@ -304,6 +304,8 @@ void gm_index_free(gm_index* ix)
     for (uint32_t i = 0; i < gm_index::EV_RING; ++i) for (int j = 0; j < 2; ++j) if (ix->evRing[i][j]) hipEventDestroy(ix->evRing[i][j]);
     if (ix->evDone) hipEventDestroy(ix->evDone);
     hipFree(ix->d_shardOut);
+    if (ix->h_stage) hipHostFree(ix->h_stage);
+    for (auto& e : ix->evStage) if (e) hipEventDestroy(e);
     if (ix->stCompute) hipStreamDestroy(ix->stCompute);
     if (ix->stCopy) hipStreamDestroy(ix->stCopy);
     for (auto& e : ix->evShard) if (e) hipEventDestroy(e);
@@ -982,6 +984,52 @@ int gm_push_pieces(int device, void* dst, const void* src, uint64_t first_byte, 
     return GM_OK;
 }
 
+}  // extern "C"
+
+namespace gm {
+// Device -> pageable host memory at more than the runtime's staging rate: DMA into a page-locked ring of four 64-MiB slots
+// on `st` (the source must be ready on that stream), and while the next slots fill, host threads copy a finished slot to
+// its destination.  Blocks until everything has arrived.
+static int staged_copy_to_host(gm_index* ix, uint8_t* h_dst, const uint8_t* d_src, uint64_t bytes, hipStream_t st)
+{
+    constexpr uint64_t SLOT = 64ull << 20;
+    constexpr int NS = 4;
+    if (!ix->h_stage) {
+        GM_HIP(hipHostMalloc(&ix->h_stage, SLOT * NS, hipHostMallocDefault));
+        for (auto& e : ix->evStage) GM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const int64_t nsub = (int64_t)((bytes + SLOT - 1) / SLOT);
+    auto len_of = [&](int64_t k) { return std::min<uint64_t>(SLOT, bytes - (uint64_t)k * SLOT); };
+    for (int64_t k = 0; k < nsub + NS - 1; ++k) {
+        if (k < nsub) {
+            GM_HIP(hipMemcpyAsync(ix->h_stage + (k % NS) * SLOT, d_src + (uint64_t)k * SLOT, len_of(k), hipMemcpyDeviceToHost, st));
+            GM_HIP(hipEventRecord(ix->evStage[k % NS], st));
+        }
+        const int64_t j = k - (NS - 1);   // the slot that must be free before issue k + 1 reuses it
+        if (j >= 0 && j < nsub) {
+            GM_HIP(hipEventSynchronize(ix->evStage[j % NS]));
+            const uint8_t* src = ix->h_stage + (j % NS) * SLOT;
+            uint8_t* dst = h_dst + (uint64_t)j * SLOT;
+            const uint64_t len = len_of(j);
+            constexpr int T = 4;
+            std::thread th[T - 1];
+            for (int t = 1; t < T; ++t) th[t - 1] = std::thread([=] { memcpy(dst + len * t / T, src + len * t / T, len * (t + 1) / T - len * t / T); });
+            memcpy(dst, src, len / T);
+            for (auto& x : th) x.join();
+        }
+    }
+    return GM_OK;
+}
+static bool host_memory_is_pinned(const void* p)
+{
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeHost;
+}
+}  // namespace gm
+
+extern "C" {
+
 int gm_map_shard(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t first_seq, uint32_t n_seq, const gm_map_params* p,
                  const uint64_t* intervals, uint64_t n_intervals, const uint32_t* seq_file_id, void* out_host)
 {
@@ -1015,7 +1063,9 @@ int gm_map_shard(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t 
         const uint64_t b = (kb + step - 1) / step * step, e = ke >= numKmers ? text_len : (ke + step - 1) / step * step;
         // large shares without a selection go in a few launches so that the copy of one piece overlaps the search of the next
         const uint32_t S = (n_intervals == 0 && e > b && e - b >= (1ull << 26)) ? 4u : 1u;
-        for (uint32_t s2 = 0; s2 < S; ++s2) {
+        const bool pinned = S > 1 && host_memory_is_pinned(h_out);
+        uint64_t pbs[4] = {0, 0, 0, 0}, pes[4] = {0, 0, 0, 0};
+        for (uint32_t s2 = 0; s2 < S; ++s2) {   // every launch is queued before the first piece is collected
             gm_map_params q = *p;
             uint64_t pb = b, pe = e;
             if (S > 1) {
@@ -1023,11 +1073,16 @@ int gm_map_shard(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t 
                 q.flags |= GM_MAP_FLAG_RANGE; q.kmer_begin = pb; q.kmer_end = std::min<uint64_t>(pe, ke);
                 if (pe <= pb) continue;
             }
+            pbs[s2] = pb; pes[s2] = pe;
             int rc = map_impl(ix, text_begin, text_len, first_seq, n_seq, &q, intervals, n_intervals, seq_file_id, d_out, ix->stCompute);
             if (rc) return rc;
             GM_HIP(hipEventRecord(ix->evShard[s2], ix->stCompute));
+        }
+        for (uint32_t s2 = 0; s2 < S; ++s2) {
+            if (pes[s2] <= pbs[s2]) continue;
             GM_HIP(hipStreamWaitEvent(ix->stCopy, ix->evShard[s2], 0));
-            if (pe > pb) GM_HIP(hipMemcpyAsync(h_out + pb * eb, d_out + pb * eb, (pe - pb) * eb, hipMemcpyDeviceToHost, ix->stCopy));
+            if (pinned || S == 1) GM_HIP(hipMemcpyAsync(h_out + pbs[s2] * eb, d_out + pbs[s2] * eb, (pes[s2] - pbs[s2]) * eb, hipMemcpyDeviceToHost, ix->stCopy));
+            else { int rc = staged_copy_to_host(ix, h_out + pbs[s2] * eb, d_out + pbs[s2] * eb, (pes[s2] - pbs[s2]) * eb, ix->stCopy); if (rc) return rc; }
         }
         GM_HIP(hipStreamSynchronize(ix->stCopy));
         GM_HIP(hipStreamSynchronize(ix->stCompute));

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <vector>
 #include <map>
+#include <thread>
 #include "../../include/genmap_amd.h"
 #include "gm_common.h"
 
@@ -76,6 +77,9 @@ struct gm_index {
     void* d_shardOut = nullptr; uint64_t shardOutCap = 0;
     hipStream_t stCompute = nullptr, stCopy = nullptr;
     hipEvent_t evShard[8] = {};
+    // results that go to ordinary (pageable) host memory are staged: DMA into this page-locked ring, then host threads copy
+    uint8_t* h_stage = nullptr;
+    hipEvent_t evStage[4] = {};
     gm::Tuning tune;
     gm_map_stats stats{};
     int buildRounds[2] = {0, 0};
