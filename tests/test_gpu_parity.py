@@ -301,6 +301,36 @@ def test_gpu_run_length_form_matches_vector():
     ix.close()
 
 
+def test_gpu_run_length_form_vs_oracle_vector():
+    """gm_map_runs against an independent run-length encoding (numpy) of the ORACLE's vector: many sequences (some shorter
+    than K, some whole-sequence repeats), long constant runs (a unique stretch, a two-copy stretch, poly-A, N blocks) and
+    runs that end exactly at sequence boundaries -- the scans of saveWig / saveBedGraph (src/output.hpp:74-187)"""
+    g = _gm()
+    rng = np.random.default_rng(31)
+    uniq = rng.integers(0, 4, size=20000, dtype=np.uint8)
+    rep = rng.integers(0, 4, size=3000, dtype=np.uint8)
+    seqs = [uniq[:9000], rep, np.concatenate([uniq[9000:12000], rep[:1500]]), rep, np.zeros(500, np.uint8), np.full(700, 4, np.uint8),
+            uniq[12000:12010], rep[100:131], uniq[12010:20000], np.concatenate([rep, rep])]
+    lens = [len(x) for x in seqs]
+    codes = np.concatenate(seqs)
+    ora = H.OracleIndex(codes, lens, keep_sa=False)
+    ix = g.Index.build(codes, lens, sampling=1)
+    cum = np.concatenate([[0], np.cumsum(lens)])
+    for K, E, bits in ((30, 0, 8), (30, 1, 16), (31, 0, 16), (16, 2, 8)):
+        vec = ora.mappability(K, E, value_bits=bits, threads=8)
+        head = np.ones(len(vec), bool)
+        head[1:] = vec[1:] != vec[:-1]
+        head[cum[:-1]] = True                                   # a run never crosses a sequence boundary
+        st_all = np.flatnonzero(head)
+        ln_all = np.diff(np.concatenate([st_all, [len(vec)]]))
+        keep = vec[st_all] != 0                                  # runs of 0 are never written (src/output.hpp:98,152)
+        st, ln, va = ix.map_runs(K, E, value_bits=bits)
+        assert np.array_equal(st, st_all[keep].astype(np.uint64)) and np.array_equal(ln, ln_all[keep].astype(np.uint64)), (K, E, bits)
+        assert np.array_equal(va, vec[st_all[keep]].astype(np.uint16)), (K, E, bits)
+        assert ln.max() > 1000                                   # the text does produce long runs
+    ix.close()
+
+
 def test_gpu_midsize_vs_oracle_and_properties():
     """4 Mbp chr1-like text: GPU-built index; oracle adopts the exported BWTs (its own suffix sort is the slow
     part) and checks e=0 everywhere and e=1/2 on selected intervals; plus size-independent properties."""
