@@ -718,6 +718,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     // are searched before the counters that would have pruned them saturate (profiles/r02/sweep_chr1_steal_*.txt)
     const bool stealDefault = (p->E <= 1 && p->K < 64 && ix->nRows >= (1ull << 30)) || S->numRoots < 64ull * 4ull * 1024ull;
     A.steal = ix->tune.steal >= 0 ? (uint32_t)(ix->tune.steal != 0) : (stealDefault ? 1u : 0u);
+    A.stealMaxHits = ix->tune.stealMaxHits > 0 ? (uint32_t)ix->tune.stealMaxHits : 0xFFFFFFFFu;
     A.coop = ix->tune.coop >= 0 ? (uint32_t)(ix->tune.coop != 0) : (ix->wpp == 1 ? 1u : 0u);
     if (ix->wide) A.coop = 0u;
     *Aout = A;
@@ -1215,7 +1216,7 @@ int gm_index_set_tuning(gm_index* ix, const char* name, int64_t value)
     struct { const char* n; int* f; } tab[] = {
         {"verify_t", &ix->tune.verifyT}, {"lds_stack", &ix->tune.ldsStack}, {"blocks_per_cu", &ix->tune.blocksPerCU}, {"qtable", &ix->tune.qtable},
         {"sat_min_w", &ix->tune.satMinW}, {"fetch_batch", &ix->tune.fetchBatch}, {"probation", &ix->tune.probation}, {"verify_cost", &ix->tune.verifyCost},
-        {"no_store", &ix->tune.noStore}, {"no_saturate", &ix->tune.noSaturate}, {"skip_dup", &ix->tune.skipDup}, {"coop", &ix->tune.coop}, {"use_ctx", &ix->tune.useCtx}, {"steal", &ix->tune.steal},
+        {"no_store", &ix->tune.noStore}, {"no_saturate", &ix->tune.noSaturate}, {"skip_dup", &ix->tune.skipDup}, {"coop", &ix->tune.coop}, {"use_ctx", &ix->tune.useCtx}, {"steal", &ix->tune.steal}, {"steal_max_hits", &ix->tune.stealMaxHits},
     };
     for (auto& t : tab) if (!strcmp(t.n, name)) { *t.f = (int)value; return GM_OK; }
     set_error("unknown tuning knob '%s'", name);
@@ -1257,10 +1258,10 @@ int gm_last_map_stats(const gm_index* cix, gm_map_stats* out)
     { const uint32_t slot = (uint32_t)((ix->evCount - 1) % gm_index::EV_RING); GM_HIP(hipEventElapsedTime(&a, ix->evRing[slot][0], ix->evRing[slot][1])); }
     GM_HIP(hipEventElapsedTime(&b, ix->ev[0], ix->ev[3]));
     ix->stats.search_ms = a; ix->stats.total_ms = b;
-    unsigned long long cnt[17] = {0};
-    GM_HIP(hipMemcpy(cnt, reinterpret_cast<char*>(ix->d_small) + 16, 136, hipMemcpyDeviceToHost));
+    unsigned long long cnt[22] = {0};
+    GM_HIP(hipMemcpy(cnt, reinterpret_cast<char*>(ix->d_small) + 16, sizeof(cnt), hipMemcpyDeviceToHost));
     ix->stats.node_steps = cnt[0]; ix->stats.rank_lines = cnt[1];
-    for (int i = 0; i < 15; ++i) ix->stats.detail[i] = cnt[2 + i];
+    for (int i = 0; i < 20; ++i) ix->stats.detail[i] = cnt[2 + i];
     int rc = check_device_error(ix);
     *out = ix->stats;
     return rc;

@@ -72,7 +72,9 @@ struct SearchArgs {
     uint32_t startPacked[2];        // 8 bits per search: startPos of the regular block shape (n == stepSize)
     uint32_t skipDup;               // 1: the range-hi block is not loaded when it is the range-lo block (saves a translation per shared step)
     uint32_t coop;                  // 1: rank blocks are read by groups of lanes (rank2_coop); 32- and 64-byte blocks
-    uint32_t steal;                 // 1: lanes without work take the top of a neighbour's stack (work sharing inside the wavefront)
+    uint32_t steal;                 // 1: lanes without work take the bottom of a neighbour's stack (work sharing inside the wavefront)
+    uint32_t stealMaxHits;          // ... but only from roots that have produced fewer hits than this: a root on its way to saturating
+                                    // its k-mers prunes its own pending subtrees soon (CountEnv::saturated) -- sharing them would search them first
     uint32_t chunkBlocks, chunkStride, chunkIndex;   // != 0: this call owns the chunks c = chunkIndex (mod chunkStride) of chunkBlocks blocks each
 };
 
@@ -572,10 +574,12 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     bool globalDone = false;                        // wave-uniform
 
 #ifdef GM_COUNTERS
-    unsigned long long tFetch = 0, tVerify = 0, tStep = 0, tMark = __builtin_amdgcn_s_memtime();
+    unsigned long long tFetch = 0, tVerify = 0, tStep = 0, tPop = 0, tShare = 0, tSt32 = 0, tSt1 = 0, tMark = __builtin_amdgcn_s_memtime();
+#define GM_LAP2(acc) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tMark; tFetch += now_ - tMark; tMark = now_; } while (0)
 #define GM_LAP(acc) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tMark; tMark = now_; } while (0)
 #else
 #define GM_LAP(acc) do { } while (0)
+#define GM_LAP2(acc) do { } while (0)
 #endif
     for (;;) {
 #ifndef GM_POP_LOOP
@@ -589,14 +593,15 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
             covered_kmers(nd.meta, rt.n, A.K, smin, smax);
             have = !(nd.w >= A.satMinW && env.saturated(rt, smin, smax));   // pending work for k-mers that already reached MAX is dropped
         }
-        // ---- work sharing inside the wavefront: idle lanes take the top of the stack of lanes that have pending nodes ----
+        GM_LAP2(tPop);
+        // ---- work sharing inside the wavefront: idle lanes take the bottom of the stack of lanes that have pending nodes ----
         if (A.steal) {
             if (wlane != lane && !have && env.sp == 0u) {   // the borrowed root is finished: give its window back
                 atomicSub(&users[wlane], 1u);
                 wlane = lane; env.lwin = reinterpret_cast<const uint8_t*>(wbase + lane);
             }
             const bool idle = !have && env.sp == 0u && fs == 0u;
-            const bool rich = have && env.sp >= 1u && env.sbase < STEAL_LEVELS;
+            const bool rich = have && env.sp >= 1u && env.sbase < STEAL_LEVELS && env.root_hits() < A.stealMaxHits;
             const unsigned long long im = __ballot(idle), vm = __ballot(rich);
             if (im != 0ull && vm != 0ull) {
                 const uint32_t np = min((uint32_t)__popcll(im), (uint32_t)__popcll(vm));
@@ -636,6 +641,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                 if (robbed) { env.sp -= 1u; env.sbase = env.sp ? env.sbase + 1u : 0u; }
             }
         }
+        GM_LAP2(tShare);
         // ---- root fetch, pipelined over iterations so that the wavefront never waits for it ----
         // stage 3: the q-mer table entry has arrived -> the root becomes the lane's node (or turns out empty)
         if (fs == 2u) {
@@ -674,6 +680,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                 else { IO::load_qentry(((A.qselMask >> frt.search) & 1u) ? A.qtabB : A.qtabA, idx, ftFlo, ftRlo, ftW); fs = 2u; }
             }
         }
+        GM_LAP2(tSt32);
         // stage 1: lanes without node, stack or fetch in flight draw a root (ballot rank) and issue its loads
 #pragma unroll 1
         for (int round = 0; round < 2; ++round) {
@@ -748,7 +755,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
             }
             poolCur += want < avail ? want : avail;
         }
-        GM_LAP(tFetch);
+        GM_LAP2(tSt1);
         // ---- defer narrow nodes: one queue entry per SA row ----
         if (A.verifyT) {
             bool narrow = have && nd.w <= A.verifyT;
@@ -855,6 +862,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     atomicAdd(&A.counters[8], (unsigned long long)env.vItems);
     atomicAdd(&A.counters[9], (unsigned long long)env.vItemsOss);
     atomicAdd(&A.counters[10], (unsigned long long)env.vChunks);
+    atomicAdd(&A.counters[21], (unsigned long long)nSteals);
     if (lane == 0) {
         atomicAdd(&A.counters[11], (unsigned long long)wvIter);
         atomicAdd(&A.counters[12], (unsigned long long)wvActive);
@@ -862,6 +870,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
         atomicAdd(&A.counters[14], tFetch);
         atomicAdd(&A.counters[15], tVerify);
         atomicAdd(&A.counters[16], tStep);
+        atomicAdd(&A.counters[17], tPop); atomicAdd(&A.counters[18], tShare); atomicAdd(&A.counters[19], tSt32); atomicAdd(&A.counters[20], tSt1);
     }
 #endif
 }

@@ -327,7 +327,8 @@ def test_gpu_run_length_form_vs_oracle_vector():
         st, ln, va = ix.map_runs(K, E, value_bits=bits)
         assert np.array_equal(st, st_all[keep].astype(np.uint64)) and np.array_equal(ln, ln_all[keep].astype(np.uint64)), (K, E, bits)
         assert np.array_equal(va, vec[st_all[keep]].astype(np.uint16)), (K, E, bits)
-        assert ln.max() > 1000                                   # the text does produce long runs
+        if (K, E) == (30, 0):
+            assert ln.max() > 1000                               # the unique stretches are long runs of 1
     ix.close()
 
 
