@@ -622,6 +622,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     const uint32_t nu = ix->wide ? 2u : 1u;
     uint32_t ldsDepth = (uint32_t)std::max(0, ix->tune.ldsStack) / nu;   // the same LDS for the stack tops of wide nodes
     ldsDepth = std::min(ldsDepth, depth);
+    while (ldsDepth & (ldsDepth - 1u)) ldsDepth &= ldsDepth - 1u;   // a power of two (or 0): the ring slot of a level is level & (ldsDepth - 1)
     const size_t ldsBytes = (size_t)(4u * vqCap * nu + 4u * 64u * (ldsDepth * nu + winChunks)) * 16u + 4u * 128u * 4u;   // == search_lds_bytes
     int perCU = 0;
     switch (ix->wpp) { case 1: rc = occupancy_blocks<1>(&perCU, ldsBytes); break; case 2: rc = occupancy_blocks<2>(&perCU, ldsBytes); break; case 3: rc = occupancy_blocks<3>(&perCU, ldsBytes); break; default: rc = occupancy_blocks<9>(&perCU, ldsBytes); break; }
@@ -632,7 +633,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     const uint64_t useful = (S->numRoots + 255) / 256;
     if (blocks > useful) blocks = std::max<uint64_t>(useful, 1);
     S->blocks = (unsigned)blocks;
-    rc = grow(&ix->d_stack, &ix->stackCap, blocks * 256ull * std::max<uint32_t>(depth - ldsDepth, 1u) * nu); if (rc) return rc;
+    rc = grow(&ix->d_stack, &ix->stackCap, blocks * 256ull * depth * nu); if (rc) return rc;   // HBM holds level L at index L (the LDS ring only caches the top)
 
     {   // the call's small device-side tables (OSS records, block list, local sequence limits) are uploaded only when the
         // call differs from the previous one on this index: a loop over shards or repeated passes launches without any
@@ -664,7 +665,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     A.blockBegin = blockBegin; A.numRoots = S->numRoots;
     A.blockList = plan.useList ? ix->d_blocks : nullptr;
     A.table = ix->d_table;
-    A.stack = ix->d_stack; A.stackDepth = depth; A.spillDepth = std::max<uint32_t>(depth - ldsDepth, 1u);
+    A.stack = ix->d_stack; A.stackDepth = depth; A.spillDepth = depth;
     {   // q-mer tables for the first block of every search: q = min(Qmax, length of that block - 1) for the regular block shape
         // Longest tabulated prefix: one more symbol than it takes a random string to become unique in this text
         // (ceil(log4 rows) + 1), at most 15: 4^15 entries x 16 B = 17 GB of the 288 GB -- every tabulated symbol

@@ -202,8 +202,10 @@ GM_HD void lane_children(NodeT<typename Env::row_t>& nd, bool& have, const RootT
             haveKeep = true;
         }
     }
-    const uint32_t miss = hasMatch ? valid & ~(1u << tc) : valid;   // pattern N: every child is a mismatch (find2:250)
-    if (env.any(miss != 0u)) {
+    // Env::EXACT_ONLY: the kernel was compiled for E = 0 (every segment is exact, pl.exact holds everywhere): no mismatching
+    // child exists, so none of the code below -- nor the registers it keeps alive -- is generated
+    const uint32_t miss = Env::EXACT_ONLY ? 0u : (hasMatch ? valid & ~(1u << tc) : valid);   // pattern N: every child is a mismatch (find2:250)
+    if (!Env::EXACT_ONLY && env.any(miss != 0u)) {
 #pragma unroll
         for (int x = 0; x < (int)NLET; ++x) {
             const bool on = ((miss >> x) & 1u) != 0u;

@@ -38,6 +38,7 @@ template <int WPP> struct HostIndex {
 
 template <int WPP> struct EmuEnv {
     typedef uint32_t row_t;
+    static constexpr bool EXACT_ONLY = false;
     const uint32_t* saArr = nullptr;
     const std::vector<uint8_t>* textSent = nullptr;
     uint64_t verified = 0;
