@@ -622,7 +622,6 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     const uint32_t nu = ix->wide ? 2u : 1u;
     uint32_t ldsDepth = (uint32_t)std::max(0, ix->tune.ldsStack) / nu;   // the same LDS for the stack tops of wide nodes
     ldsDepth = std::min(ldsDepth, depth);
-    while (ldsDepth & (ldsDepth - 1u)) ldsDepth &= ldsDepth - 1u;   // a power of two (or 0): the ring slot of a level is level & (ldsDepth - 1)
     const size_t ldsBytes = (size_t)(4u * vqCap * nu + 4u * 64u * (ldsDepth * nu + winChunks)) * 16u + 4u * 128u * 4u;   // == search_lds_bytes
     int perCU = 0;
     switch (ix->wpp) { case 1: rc = occupancy_blocks<1>(&perCU, ldsBytes); break; case 2: rc = occupancy_blocks<2>(&perCU, ldsBytes); break; case 3: rc = occupancy_blocks<3>(&perCU, ldsBytes); break; default: rc = occupancy_blocks<9>(&perCU, ldsBytes); break; }
@@ -633,7 +632,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     const uint64_t useful = (S->numRoots + 255) / 256;
     if (blocks > useful) blocks = std::max<uint64_t>(useful, 1);
     S->blocks = (unsigned)blocks;
-    rc = grow(&ix->d_stack, &ix->stackCap, blocks * 256ull * depth * nu); if (rc) return rc;   // HBM holds level L at index L (the LDS ring only caches the top)
+    rc = grow(&ix->d_stack, &ix->stackCap, blocks * 256ull * std::max<uint32_t>(depth - ldsDepth, 1u) * nu); if (rc) return rc;
 
     {   // the call's small device-side tables (OSS records, block list, local sequence limits) are uploaded only when the
         // call differs from the previous one on this index: a loop over shards or repeated passes launches without any
@@ -665,7 +664,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     A.blockBegin = blockBegin; A.numRoots = S->numRoots;
     A.blockList = plan.useList ? ix->d_blocks : nullptr;
     A.table = ix->d_table;
-    A.stack = ix->d_stack; A.stackDepth = depth; A.spillDepth = depth;
+    A.stack = ix->d_stack; A.stackDepth = depth; A.spillDepth = std::max<uint32_t>(depth - ldsDepth, 1u);
     {   // q-mer tables for the first block of every search: q = min(Qmax, length of that block - 1) for the regular block shape
         // Longest tabulated prefix: one more symbol than it takes a random string to become unique in this text
         // (ceil(log4 rows) + 1), at most 15: 4^15 entries x 16 B = 17 GB of the 288 GB -- every tabulated symbol
@@ -719,7 +718,6 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     // are searched before the counters that would have pruned them saturate (profiles/r02/sweep_chr1_steal_*.txt)
     const bool stealDefault = (p->E <= 1 && p->K < 64 && ix->nRows >= (1ull << 30)) || S->numRoots < 64ull * 4ull * 1024ull;
     A.steal = ix->tune.steal >= 0 ? (uint32_t)(ix->tune.steal != 0) : (stealDefault ? 1u : 0u);
-    A.stealMaxHits = ix->tune.stealMaxHits > 0 ? (uint32_t)ix->tune.stealMaxHits : 0xFFFFFFFFu;
     A.coop = ix->tune.coop >= 0 ? (uint32_t)(ix->tune.coop != 0) : (ix->wpp == 1 ? 1u : 0u);
     if (ix->wide) A.coop = 0u;
     *Aout = A;
@@ -1217,7 +1215,7 @@ int gm_index_set_tuning(gm_index* ix, const char* name, int64_t value)
     struct { const char* n; int* f; } tab[] = {
         {"verify_t", &ix->tune.verifyT}, {"lds_stack", &ix->tune.ldsStack}, {"blocks_per_cu", &ix->tune.blocksPerCU}, {"qtable", &ix->tune.qtable},
         {"sat_min_w", &ix->tune.satMinW}, {"fetch_batch", &ix->tune.fetchBatch}, {"probation", &ix->tune.probation}, {"verify_cost", &ix->tune.verifyCost},
-        {"no_store", &ix->tune.noStore}, {"no_saturate", &ix->tune.noSaturate}, {"skip_dup", &ix->tune.skipDup}, {"coop", &ix->tune.coop}, {"use_ctx", &ix->tune.useCtx}, {"steal", &ix->tune.steal}, {"steal_max_hits", &ix->tune.stealMaxHits},
+        {"no_store", &ix->tune.noStore}, {"no_saturate", &ix->tune.noSaturate}, {"skip_dup", &ix->tune.skipDup}, {"coop", &ix->tune.coop}, {"use_ctx", &ix->tune.useCtx}, {"steal", &ix->tune.steal},
     };
     for (auto& t : tab) if (!strcmp(t.n, name)) { *t.f = (int)value; return GM_OK; }
     set_error("unknown tuning knob '%s'", name);

@@ -73,8 +73,6 @@ struct SearchArgs {
     uint32_t skipDup;               // 1: the range-hi block is not loaded when it is the range-lo block (saves a translation per shared step)
     uint32_t coop;                  // 1: rank blocks are read by groups of lanes (rank2_coop); 32- and 64-byte blocks
     uint32_t steal;                 // 1: lanes without work take the bottom of a neighbour's stack (work sharing inside the wavefront)
-    uint32_t stealMaxHits;          // ... but only from roots that have produced fewer hits than this: a root on its way to saturating
-                                    // its k-mers prunes its own pending subtrees soon (CountEnv::saturated) -- sharing them would search them first
     uint32_t chunkBlocks, chunkStride, chunkIndex;   // != 0: this call owns the chunks c = chunkIndex (mod chunkStride) of chunkBlocks blocks each
 };
 
@@ -167,12 +165,8 @@ template <int WPP> struct EnvBase {
     uint4* lstk;         // LDS: [depth][lane] of this wavefront, already offset by the lane
     const uint8_t* lwin; // LDS: [chunk][lane] 16-byte chunks of this lane's packed window, already offset by the lane
     uint32_t woff;       // nibble offset of the window inside its first chunk
-    // The lane's stack: sp entries at levels [sbase, sbase + sp).  The TOP lw levels (lw <= ldsDepth) live in LDS, level L in ring
-    // slot L % ldsDepth; the levels below them live in HBM at index L (wavefront-interleaved).  A push onto a full ring spills the
-    // ring's oldest level to HBM (a store nobody waits for); a pop finds its node in LDS unless the ring has run empty.
-    uint32_t sp;
+    uint32_t sp;         // entries on the lane's stack; they live at levels [sbase, sbase + sp)
     uint32_t sbase;      // raised when a neighbour takes the bottom entry (work sharing), back to 0 when the stack runs empty
-    uint32_t lw;
     uint32_t K;
 #ifdef GM_COUNTERS
     uint32_t steps = 0, lines = 0, stOss = 0, stExt = 0, stExtW1 = 0, stExtW4 = 0, stOssW1 = 0, pushes = 0, vItems = 0, vItemsOss = 0, vChunks = 0;
@@ -187,14 +181,12 @@ template <int WPP> struct EnvBase {
     __device__ __forceinline__ void note_chunk() {}
     __device__ __forceinline__ void note_item(uint32_t) {}
 #endif
-    __device__ __forceinline__ EnvBase(const SearchArgs& a, uint4* s, uint32_t k) : A(a), stk(s), lstk(nullptr), lwin(nullptr), woff(0), sp(0), sbase(0), lw(0), K(k) {}
+    __device__ __forceinline__ EnvBase(const SearchArgs& a, uint4* s, uint32_t k) : A(a), stk(s), lstk(nullptr), lwin(nullptr), woff(0), sp(0), sbase(0), K(k) {}
     __device__ __forceinline__ Node pop()
     {
         --sp;
-        const uint32_t lv = sbase + sp;   // the top level
-        Node nd;
-        if (lw > 0u) { nd = IO::load(lstk + (size_t)(lv & (A.ldsDepth - 1u)) * IO::NU * 64u, 64u); --lw; }   // ldsDepth is a power of two
-        else nd = IO::load(stk + (size_t)lv * IO::NU * 64u, 64u);
+        const uint32_t lv = sbase + sp;
+        const Node nd = lv < A.ldsDepth ? IO::load(lstk + (size_t)lv * IO::NU * 64u, 64u) : IO::load(stk + (size_t)(lv - A.ldsDepth) * IO::NU * 64u, 64u);
         if (sp == 0u) sbase = 0u;
         return nd;
     }
@@ -320,19 +312,12 @@ template <int WPP> struct EnvBase {
 #ifdef GM_COUNTERS
         pushes++;
 #endif
-        const uint32_t lv = sbase + sp;   // the new top level
-        if (lv >= A.stackDepth) { *A.errorFlag = 1u; return; }   // never expected: depth = stack_bound(E, stepSize) + STEAL_LEVELS
-        if (A.ldsDepth == 0u) { IO::store(stk + (size_t)lv * IO::NU * 64u, 64u, nd); ++sp; return; }
-        uint4* slot = lstk + (size_t)(lv & (A.ldsDepth - 1u)) * IO::NU * 64u;
-        // wave-uniform fast path (scalar branch, no exec-mask juggling): nobody's ring is full
-        if (__ballot(lw == A.ldsDepth) != 0ull) {
-            if (lw == A.ldsDepth) {   // the slot holds level lv - ldsDepth, the ring's oldest: it moves to HBM
-                IO::store(stk + (size_t)(lv - A.ldsDepth) * IO::NU * 64u, 64u, IO::load(slot, 64u));
-                --lw;
-            }
-        }
-        IO::store(slot, 64u, nd);
-        ++sp; ++lw;
+        const uint32_t lv = sbase + sp;
+        // wave-uniform fast path (scalar branch, no exec-mask juggling): nobody in the wavefront is past the LDS levels
+        if (__ballot(lv >= A.ldsDepth) == 0ull) { IO::store(lstk + (size_t)lv * IO::NU * 64u, 64u, nd); ++sp; return; }
+        if (lv < A.ldsDepth) { IO::store(lstk + (size_t)lv * IO::NU * 64u, 64u, nd); ++sp; }
+        else if (lv < A.stackDepth) { IO::store(stk + (size_t)(lv - A.ldsDepth) * IO::NU * 64u, 64u, nd); ++sp; }
+        else *A.errorFlag = 1u;   // never expected: depth = stack_bound(E, stepSize) (+ STEAL_LEVELS with work sharing)
     }
     __device__ __forceinline__ void on_root() {}
     __device__ __forceinline__ uint32_t root_hits() const { return 0u; }     // travels with stolen work (CountEnv: gate of the saturation check)
@@ -616,8 +601,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                 wlane = lane; env.lwin = reinterpret_cast<const uint8_t*>(wbase + lane);
             }
             const bool idle = !have && env.sp == 0u && fs == 0u;
-            const bool rich = have && env.sp >= 1u && env.sbase < STEAL_LEVELS && env.root_hits() < A.stealMaxHits;
-            // (the bottom entry sits in LDS only while the whole stack does: lw == sp)
+            const bool rich = have && env.sp >= 1u && env.sbase < STEAL_LEVELS;
             const unsigned long long im = __ballot(idle), vm = __ballot(rich);
             if (im != 0ull && vm != 0ull) {
                 const uint32_t np = min((uint32_t)__popcll(im), (uint32_t)__popcll(vm));
@@ -632,7 +616,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                 if (thief) src = pairing[ri];
                 const int a4 = (int)(src << 2);
                 // the victim's stack height, root and window (every lane takes part: the victims' registers are the source)
-                const uint32_t vsb3 = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)(env.sbase | env.sp << 8 | env.lw << 16));   // the BOTTOM entry: the oldest, i.e. the largest pending subtree
+                const uint32_t vsb = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)env.sbase);   // the BOTTOM entry: the oldest, i.e. the largest pending subtree
                 uint32_t vwin = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)(uint32_t)rt.win), vwinHi = 0u;
                 if (sizeof(row_t) == 8) vwinHi = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)(uint32_t)((uint64_t)rt.win >> 32));
                 const uint32_t vnss = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)(rt.n | rt.strand << 9 | rt.search << 10));
@@ -641,8 +625,8 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                 const uint32_t vwo = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)(env.woff | wlane << 8));
                 const uint32_t vrh = (uint32_t)__builtin_amdgcn_ds_bpermute(a4, (int)env.root_hits());
                 if (thief) {
-                    const uint32_t level = vsb3 & 0xFFu, vsp = (vsb3 >> 8) & 0xFFu, vlw = vsb3 >> 16;
-                    nd = vlw == vsp ? IO::load(lstkW + (size_t)(level & (A.ldsDepth - 1u)) * NU * 64u + src, 64u) : IO::load(stkW + (size_t)level * NU * 64u + src, 64u);
+                    const uint32_t level = vsb;
+                    nd = level < A.ldsDepth ? IO::load(lstkW + (size_t)level * NU * 64u + src, 64u) : IO::load(stkW + (size_t)(level - A.ldsDepth) * NU * 64u + src, 64u);
                     have = true; w1run = 0;
                     rt.win = (row_t)((uint64_t)vwinHi << 32 | vwin); rt.n = vnss & 0x1FFu; rt.strand = (vnss >> 9) & 1u; rt.search = vnss >> 10;
                     rt.rec.x = vrx; rt.rec.y = vry; rt.rec.z = vrz; rt.rec.w = vrw;
@@ -654,7 +638,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                     nSteals++;
 #endif
                 }
-                if (robbed) { if (env.lw == env.sp) env.lw -= 1u; env.sp -= 1u; env.sbase = env.sp ? env.sbase + 1u : 0u; }
+                if (robbed) { env.sp -= 1u; env.sbase = env.sp ? env.sbase + 1u : 0u; }
             }
         }
         GM_LAP2(tShare);
