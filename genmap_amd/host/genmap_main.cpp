@@ -234,6 +234,13 @@ int map_main(int argc, const char** argv)
         fclose(f);
     }
 
+    if (haveSelection) {   // a BED row whose reference names no indexed sequence selects nothing: say so
+        for (auto& kv : selection) {
+            bool known = false;
+            for (auto& r : meta.ids) if (r.name == kv.first) { known = true; break; }
+            if (!known) std::cerr << "WARNING: the selection names \"" << kv.first << "\", which is not a sequence of this index; its " << kv.second.size() << " interval(s) are ignored.\n";
+        }
+    }
     // sequences and files of the index (src/mappability.hpp:225-250)
     std::vector<uint64_t> seqLen; std::vector<uint32_t> seqFile; std::vector<std::string> fileNames; std::vector<uint64_t> seqsPerFile;
     for (auto& r : meta.ids) {
