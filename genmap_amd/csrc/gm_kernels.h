@@ -879,8 +879,13 @@ template <int WPP, class EnvT, bool COOP>
 __global__ __launch_bounds__(256) GM_WAVES_ATTR void search_kernel(const SearchArgs A) { search_body<WPP, EnvT, COOP>(A); }
 // the same kernel compiled for 4 waves per SIMD (at most 128 VGPRs): the cooperative 64-byte variant needs a few registers more
 // than that by itself and loses a wave of occupancy otherwise
+#ifndef GM_COUNTERS
 template <int WPP, class EnvT, bool COOP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void search_kernel_w4(const SearchArgs A) { search_body<WPP, EnvT, COOP>(A); }
+#else   // the instrumented twin keeps ~20 counters in registers: capped at 128 VGPRs it spills and its cycle attribution is skewed
+template <int WPP, class EnvT, bool COOP>
+__global__ __launch_bounds__(256) void search_kernel_w4(const SearchArgs A) { search_body<WPP, EnvT, COOP>(A); }
+#endif
 
 // SA ranges of every ACGT string of length q in both indexes (right extensions from the root): the top of the search
 // tree, tabulated once per index and q.
