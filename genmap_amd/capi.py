@@ -52,7 +52,7 @@ class Locations(C.Structure):
 MAP_FLAG_RANGE = 1
 WIDE_ROWS = 0x10000   # GM_BLOCK_WIDE_ROWS: OR into block_bytes to force 64-bit rows
 
-EXPORTS = ["gm_device_alloc", "gm_device_free", "gm_ipc_export", "gm_ipc_open", "gm_ipc_close", "gm_push_pieces", "gm_map_shard", "gm_host_pin", "gm_host_unpin", "gm_index_set_tuning", "gm_index_sync", "gm_map_kernel_times", "gm_map_runs", "gm_runs_free", "gm_tuned_infix_length", "gm_index_export_sa", "gm_locate", "gm_locations_free", "gm_status_string", "gm_last_error", "gm_device_count", "gm_index_build", "gm_index_import",
+EXPORTS = ["gm_device_alloc", "gm_device_free", "gm_ipc_export", "gm_ipc_open", "gm_ipc_close", "gm_push_pieces", "gm_map_shard", "gm_host_pin", "gm_host_unpin", "gm_index_set_tuning", "gm_index_sync", "gm_map_kernel_times", "gm_map_runs", "gm_runs_free", "gm_tuned_infix_length", "gm_index_export_sa", "gm_locate", "gm_locations_free", "gm_status_string", "gm_last_error", "gm_device_count", "gm_index_build", "gm_index_import", "gm_index_import_sampled", "gm_index_export_sa_sampled",
            "gm_index_export_bwt", "gm_index_get_info", "gm_index_free", "gm_map", "gm_map_device",
            "gm_last_map_stats", "gm_default_infix_length"]
 
@@ -89,6 +89,10 @@ def load_library(profiling=False):
     lib.gm_index_import.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)]
     lib.gm_index_export_bwt.restype = C.c_int
     lib.gm_index_export_bwt.argtypes = [vp, vp, vp]
+    lib.gm_index_import_sampled.restype = C.c_int
+    lib.gm_index_import_sampled.argtypes = [vp, vp, vp, vp, C.c_uint64, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)]
+    lib.gm_index_export_sa_sampled.restype = C.c_int
+    lib.gm_index_export_sa_sampled.argtypes = [vp, vp, vp, C.POINTER(C.c_uint64)]
     lib.gm_index_export_sa.restype = C.c_int
     lib.gm_index_export_sa.argtypes = [vp, vp]
     lib.gm_index_get_info.restype = C.c_int
@@ -242,6 +246,22 @@ class Index:
         _check(lib, lib.gm_index_import(_ptr(bf), _ptr(br), _ptr(sa), _ptr(codes), _ptr(sl), len(sl), sampling, block_bytes, device, C.byref(h)))
         return cls(h, lib, codes, sl)
 
+    @classmethod
+    def from_sampled(cls, bwt_fwd, bwt_rev, mark_words, samples, codes, seq_len, sampling, block_bytes=0, device=0, profiling=False):
+        """gm_index_import_sampled: the sampled suffix array as an index directory holds it"""
+        lib = load_library(profiling)
+        bf = np.ascontiguousarray(bwt_fwd, dtype=np.uint8)
+        br = np.ascontiguousarray(bwt_rev, dtype=np.uint8)
+        mk = np.ascontiguousarray(mark_words, dtype=np.uint32)
+        sm = np.ascontiguousarray(samples, dtype=np.uint32)
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        sl = np.ascontiguousarray(seq_len, dtype=np.uint64)
+        if len(mk) != (len(bf) + 31) // 32:
+            raise ValueError("mark_words: one bit per row")
+        h = C.c_void_p()
+        _check(lib, lib.gm_index_import_sampled(_ptr(bf), _ptr(br), _ptr(mk), _ptr(sm), len(sm), _ptr(codes), _ptr(sl), len(sl), sampling, block_bytes, device, C.byref(h)))
+        return cls(h, lib, codes, sl)
+
     def close(self):
         if self._h:
             self._lib.gm_index_free(self._h)
@@ -269,6 +289,15 @@ class Index:
         sa = np.empty(i["n_rows"], np.uint64 if i["row_bits"] == 64 else np.uint32)
         _check(self._lib, self._lib.gm_index_export_sa(self._h, _ptr(sa)))
         return sa
+
+    def export_sa_sampled(self):
+        """(mark_words, samples): one bit per row, and SA[row] of the marked rows in row order"""
+        n = C.c_uint64(0)
+        _check(self._lib, self._lib.gm_index_export_sa_sampled(self._h, None, None, C.byref(n)))
+        mk = np.empty((self.info()["n_rows"] + 31) // 32, np.uint32)
+        sm = np.empty(n.value, np.uint32)
+        _check(self._lib, self._lib.gm_index_export_sa_sampled(self._h, _ptr(mk), _ptr(sm), C.byref(n)))
+        return mk, sm
 
     def _params(self, K, E, overlap, infix, revcompl, value_bits, exclude_pseudo, kmer_range, chunks=None):
         kb, ke = kmer_range if kmer_range is not None else (0, 0)

@@ -217,7 +217,7 @@ static uint32_t wpp_of_block_bytes(uint32_t bb)
 static int index_common_setup(gm_index* ix, const uint8_t* codes, const uint64_t* seq_len, uint32_t n_seq, uint32_t sampling, uint32_t block_bytes, int device)
 {
     ix->device = device; ix->nSeq = n_seq; ix->sampling = sampling;
-    if (sampling > 1) { set_error("this build keeps the full suffix array in HBM (sampling 1) or none (0); sampled SA + LF walk is not implemented"); return GM_ERR_BAD_ARG; }
+    if (sampling > 64) { set_error("sampling rate %u: 0 (no suffix array), 1 (all of it) or 2..64", sampling); return GM_ERR_BAD_ARG; }
     const bool forceWide = (block_bytes & GM_BLOCK_WIDE_ROWS) != 0;
     block_bytes &= ~(uint32_t)GM_BLOCK_WIDE_ROWS;
     ix->wpp = wpp_of_block_bytes(block_bytes);
@@ -232,6 +232,7 @@ static int index_common_setup(gm_index* ix, const uint8_t* codes, const uint64_t
     // 2^32 - 1 rows or more: 64-bit rows, ranges and text positions (the reference's 64-bit BWT variants, src/indexing.hpp:158-169)
     ix->wide = forceWide || ix->nRows >= 0xFFFFFFFFull;
     if (ix->wide) ix->wpp = WPP_WIDE;
+    if (ix->wide && sampling > 1) { set_error("a sampled suffix array is kept for 32-bit rows only; use sampling 1 (or 0) for this index"); return GM_ERR_BAD_ARG; }
     if (ix->nRows >= (1ull << 40)) { set_error("index of %llu rows is beyond this build (2^40 rows)", (unsigned long long)ix->nRows); return GM_ERR_TOO_LONG; }
     hipDeviceProp_t prop;
     GM_HIP(hipGetDeviceProperties(&prop, device));
@@ -253,6 +254,37 @@ static int index_common_setup(gm_index* ix, const uint8_t* codes, const uint64_t
     for (int i = 0; i < 4; ++i) GM_HIP(hipEventCreate(&ix->ev[i]));
     for (uint32_t i = 0; i < gm_index::EV_RING; ++i) for (int j = 0; j < 2; ++j) GM_HIP(hipEventCreate(&ix->evRing[i][j]));
     GM_HIP(hipEventCreateWithFlags(&ix->evDone, hipEventDisableTiming));
+    return GM_OK;
+}
+
+// the sampled form of a full forward suffix array (device): marks + "samples before this word" per 32 rows, and the kept values
+static int sample_sa(gm_index* ix, const uint32_t* d_saFull)
+{
+    const uint64_t n = ix->nRows, words = (n + 31) / 32;
+    GM_HIP(hipMalloc(&ix->d_saMark, words * sizeof(uint2)));
+    hipLaunchKernelGGL(sa_mark_kernel, dim3(grid_for(words)), dim3(256), 0, 0, d_saFull, ix->d_cum, ix->nSeq, n, ix->sampling, ix->d_saMark);
+    GM_HIP(hipGetLastError());
+    uint32_t *d_cnt = nullptr, *d_before = nullptr; void* d_tmp = nullptr; size_t tmpBytes = 0;
+    int rc = GM_OK;
+    if (hipMalloc(&d_cnt, words * 4) != hipSuccess || hipMalloc(&d_before, words * 4) != hipSuccess) rc = GM_ERR_OOM;
+    if (!rc) {
+        hipLaunchKernelGGL(sa_mark_counts_kernel, dim3(grid_for(words)), dim3(256), 0, 0, ix->d_saMark, words, d_cnt);
+        if (rocprim::exclusive_scan(nullptr, tmpBytes, d_cnt, d_before, 0u, words, rocprim::plus<uint32_t>()) != hipSuccess) rc = GM_ERR_HIP;
+    }
+    if (!rc && hipMalloc(&d_tmp, tmpBytes ? tmpBytes : 16) != hipSuccess) rc = GM_ERR_OOM;
+    if (!rc && rocprim::exclusive_scan(d_tmp, tmpBytes, d_cnt, d_before, 0u, words, rocprim::plus<uint32_t>()) != hipSuccess) rc = GM_ERR_HIP;
+    uint32_t last[2] = {0, 0};
+    if (!rc) {
+        hipLaunchKernelGGL(sa_mark_offsets_kernel, dim3(grid_for(words)), dim3(256), 0, 0, ix->d_saMark, words, d_before);
+        if (hipMemcpy(&last[0], d_before + (words - 1), 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&last[1], d_cnt + (words - 1), 4, hipMemcpyDeviceToHost) != hipSuccess) rc = GM_ERR_HIP;
+    }
+    hipFree(d_cnt); hipFree(d_before); hipFree(d_tmp);
+    if (rc) return rc;
+    ix->nSamples = (uint64_t)last[0] + last[1];
+    GM_HIP(hipMalloc(&ix->d_saSamples, std::max<uint64_t>(ix->nSamples, 1) * 4));
+    hipLaunchKernelGGL(sa_compact_kernel, dim3(grid_for(n)), dim3(256), 0, 0, d_saFull, ix->d_saMark, n, ix->d_saSamples);
+    GM_HIP(hipGetLastError());
+    GM_HIP(hipDeviceSynchronize());
     return GM_OK;
 }
 
@@ -298,6 +330,7 @@ void gm_index_free(gm_index* ix)
     if (!ix) return;
     hipSetDevice(ix->device);
     hipFree(ix->d_blk[0]); hipFree(ix->d_blk[1]); hipFree(ix->d_textAlloc); hipFree(ix->d_text4); hipFree(ix->d_cum); hipFree(ix->d_sa); hipFree(ix->d_textSAlloc); hipFree(ix->d_C); hipFree(ix->d_ctx);
+    hipFree(ix->d_saMark); hipFree(ix->d_saSamples);
     for (auto& kv : ix->qtables) hipFree(kv.second); hipFree(ix->d_seqFile); hipFree(ix->d_bits);
     hipFree(ix->d_acc); hipFree(ix->d_stack); hipFree(ix->d_small); hipFree(ix->d_table); hipFree(ix->d_blocks); hipFree(ix->d_cumLocal);
     for (int i = 0; i < 4; ++i) if (ix->ev[i]) hipEventDestroy(ix->ev[i]);
@@ -332,6 +365,7 @@ int gm_index_build(const uint8_t* codes, const uint64_t* seq_len, uint32_t n_seq
             ix->d_sa = d_sa; d_sa = nullptr;
             if (hipMalloc(&d_sa, ix->nRows * rb) != hipSuccess) rc = GM_ERR_OOM;
         }
+        if (!rc && d == 0 && sampling > 1) rc = sample_sa(ix, (const uint32_t*)d_sa);   // -S: keep 1/s of it, locate walks the LF mapping
     }
     hipFree(d_sa); hipFree(d_bwt);
     if (!rc && ix->d_sa) rc = make_sentinel_text(ix);
@@ -364,8 +398,56 @@ int gm_index_import(const uint8_t* bwt_fwd, const uint8_t* bwt_rev, const uint32
         if (!rc) rc = make_sentinel_text(ix);
         if (!rc) rc = make_ctx(ix);
     }
+    if (!rc && sa_fwd && sampling > 1) {   // the caller holds the full array: sample it on the device
+        uint32_t* d_full = nullptr;
+        if (hipMalloc(&d_full, ix->nRows * 4) != hipSuccess) rc = GM_ERR_OOM;
+        else if (hipMemcpy(d_full, sa_fwd, ix->nRows * 4, hipMemcpyHostToDevice) != hipSuccess) rc = GM_ERR_HIP;
+        if (!rc) rc = sample_sa(ix, d_full);
+        hipFree(d_full);
+    }
     if (rc) { gm_index_free(ix); return rc; }
     *out = ix;
+    return GM_OK;
+}
+
+int gm_index_import_sampled(const uint8_t* bwt_fwd, const uint8_t* bwt_rev, const uint32_t* mark_words, const uint32_t* samples, uint64_t n_samples,
+                            const uint8_t* codes, const uint64_t* seq_len, uint32_t n_seq, uint32_t sampling, uint32_t block_bytes, int device, gm_index** out)
+{
+    if (!mark_words || !samples || sampling < 2) { set_error("gm_index_import_sampled: marks, samples and a sampling rate of 2..64"); return GM_ERR_BAD_ARG; }
+    gm_index* ix = nullptr;
+    int rc = gm_index_import(bwt_fwd, bwt_rev, nullptr, codes, seq_len, n_seq, sampling, block_bytes, device, &ix);
+    if (rc) return rc;
+    const uint64_t words = (ix->nRows + 31) / 32;
+    // "samples before this word" is recomputed here; a file whose marks and sample count disagree is rejected
+    std::vector<uint2> mk(words);
+    uint64_t run = 0;
+    for (uint64_t w = 0; w < words; ++w) { mk[w] = make_uint2(mark_words[w], (uint32_t)run); run += (uint64_t)__builtin_popcount(mark_words[w]); }
+    if (run != n_samples || ((ix->nRows & 31u) && (mark_words[words - 1] >> (ix->nRows & 31u)))) {
+        set_error("sampled suffix array: %llu marks for %llu samples", (unsigned long long)run, (unsigned long long)n_samples);
+        gm_index_free(ix); return GM_ERR_BAD_ARG;
+    }
+    if (hipMalloc(&ix->d_saMark, words * sizeof(uint2)) != hipSuccess || hipMalloc(&ix->d_saSamples, std::max<uint64_t>(n_samples, 1) * 4) != hipSuccess) rc = GM_ERR_OOM;
+    if (!rc && (hipMemcpy(ix->d_saMark, mk.data(), words * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(ix->d_saSamples, samples, n_samples * 4, hipMemcpyHostToDevice) != hipSuccess)) rc = GM_ERR_HIP;
+    if (rc) { gm_index_free(ix); return rc; }
+    ix->nSamples = n_samples;
+    *out = ix;
+    return GM_OK;
+}
+
+int gm_index_export_sa_sampled(const gm_index* ix, uint32_t* mark_words, uint32_t* samples, uint64_t* n_samples)
+{
+    if (!ix || !n_samples) return GM_ERR_BAD_ARG;
+    if (!ix->d_saMark) { set_error("index holds no sampled suffix array (sampling %u)", ix->sampling); return GM_ERR_NEED_LOCATE; }
+    *n_samples = ix->nSamples;
+    if (!samples && !mark_words) return GM_OK;
+    if (!samples || !mark_words) return GM_ERR_BAD_ARG;
+    GM_HIP(hipSetDevice(ix->device));
+    const uint64_t words = (ix->nRows + 31) / 32;
+    std::vector<uint2> mk(words);
+    GM_HIP(hipMemcpy(mk.data(), ix->d_saMark, words * sizeof(uint2), hipMemcpyDeviceToHost));
+    for (uint64_t w = 0; w < words; ++w) mark_words[w] = mk[w].x;
+    GM_HIP(hipMemcpy(samples, ix->d_saSamples, ix->nSamples * 4, hipMemcpyDeviceToHost));
     return GM_OK;
 }
 
@@ -391,7 +473,7 @@ int gm_index_export_bwt(const gm_index* ix, uint8_t* bwt_fwd, uint8_t* bwt_rev)
 int gm_index_export_sa(const gm_index* ix, uint32_t* sa)
 {
     if (!ix || !sa) return GM_ERR_BAD_ARG;
-    if (!ix->d_sa) { set_error("index holds no suffix array (built with sampling 0)"); return GM_ERR_NEED_LOCATE; }
+    if (!ix->d_sa) { set_error("index holds no full suffix array (sampling %u)", ix->d_saMark ? ix->sampling : 0u); return GM_ERR_NEED_LOCATE; }
     GM_HIP(hipSetDevice(ix->device));
     GM_HIP(hipMemcpy(sa, ix->d_sa, ix->nRows * (ix->wide ? 8 : 4), hipMemcpyDeviceToHost));
     return GM_OK;
@@ -404,8 +486,9 @@ int gm_index_get_info(const gm_index* ix, gm_index_info* info)
     info->alphabet_size = ix->alphabet;
     info->block_bytes = ix->wpp == 1 ? 32 : (ix->wpp == 3 || ix->wpp == 2) ? 64 : 128;
     info->row_bits = ix->wide ? 64 : 32;
-    info->device_bytes = 2 * ix->blkBytes + ix->textLen + (ix->nSeq + 1) * 8ull + (ix->d_sa ? ix->nRows * (ix->wide ? 9ull : 5ull) : 0ull) + (ix->d_ctx ? ix->nRows * 32ull : 0ull) + ix->qtableBytes;
-    if (!ix->d_sa) info->sampling = 0;
+    info->device_bytes = 2 * ix->blkBytes + ix->textLen + (ix->nSeq + 1) * 8ull + (ix->d_sa ? ix->nRows * (ix->wide ? 9ull : 5ull) : 0ull) + (ix->d_ctx ? ix->nRows * 32ull : 0ull) + ix->qtableBytes
+                       + (ix->d_saMark ? (ix->nRows + 31) / 32 * 8ull + ix->nSamples * 4ull : 0ull);
+    if (!ix->d_sa && !ix->d_saMark) info->sampling = 0;
     info->device = ix->device;
     info->verify_records = ix->d_ctx ? 1u : 0u;
     return GM_OK;
@@ -694,7 +777,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     A.workCounter = reinterpret_cast<unsigned long long*>(ix->d_small);
     A.errorFlag = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ix->d_small) + SMALL_ERR_OFF);
     A.counters = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ix->d_small) + 16);
-    A.sa = ix->d_sa; A.cumGlobal = ix->d_cum; A.nSeqGlobal = ix->nSeq;
+    A.sa = ix->d_sa; A.saMark = ix->d_saMark; A.saSamples = ix->d_saSamples; A.cumGlobal = ix->d_cum; A.nSeqGlobal = ix->nSeq;
     A.posBase = S->posBase; A.windowLen = S->posEnd - S->posBase;
     A.textS = ix->d_textS;
     A.ctx = ix->tune.useCtx ? ix->d_ctx : nullptr;
@@ -742,7 +825,7 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
     const bool ep = p->exclude_pseudo != 0;
     uint32_t wordsPerKmer = 0;
     if (ep) {
-        if (!ix->d_sa) { set_error("--exclude-pseudo needs an index built with sampling 1"); return GM_ERR_NEED_LOCATE; }
+        if (!ix->d_sa && !ix->d_saMark) { set_error("--exclude-pseudo needs an index with suffix array samples (sampling >= 1)"); return GM_ERR_NEED_LOCATE; }
         if (!seq_file_id) { set_error("--exclude-pseudo needs seq_file_id"); return GM_ERR_BAD_ARG; }
         uint32_t nFiles = 0;
         for (uint32_t s = 0; s < ix->nSeq; ++s) nFiles = std::max(nFiles, seq_file_id[s] + 1);
@@ -826,7 +909,7 @@ static int locate_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uin
     SearchSetup S; SearchArgs A;
     int rc = prepare_search(ix, text_begin, text_len, first_seq, n_seq, p, intervals, n_intervals, st, &S, &A);
     if (rc) return rc;
-    if (!ix->d_sa) { set_error("csv output needs an index built with sampling 1"); return GM_ERR_NEED_LOCATE; }
+    if (!ix->d_sa && !ix->d_saMark) { set_error("csv output needs an index with suffix array samples (sampling >= 1)"); return GM_ERR_NEED_LOCATE; }
     if (S.sel.len) { set_error("gm_locate does not take interleaved chunks"); return GM_ERR_BAD_ARG; }
     const uint64_t W = S.posEnd - S.posBase;
     L->pos_begin = S.posBase; L->n_positions = W;

@@ -39,7 +39,9 @@ struct SearchArgs {
     uint32_t* errorFlag;
     unsigned long long* counters;   // [0] node steps, [1] distinct rank lines (only with GM_COUNTERS)
     // ---- locate path (csv, --exclude-pseudo; /root/reference/src/algo.hpp:311-387) ----
-    const void* sa;                 // forward suffix array (sentinel-text positions, row_t each), sampling rate 1
+    const void* sa;                 // forward suffix array (sentinel-text positions, row_t each), sampling rate 1; nullptr when sampled
+    const uint2* saMark;            // sampled suffix array: per 32 rows {mark bits, samples before the word} ...
+    const uint32_t* saSamples;      // ... and the values of the marked rows
     const uint64_t* cumGlobal;      // sentinel-free cumulative sequence lengths of the WHOLE index, nSeqGlobal + 1
     uint32_t nSeqGlobal;
     const uint32_t* seqFile;        // fasta id per global sequence (mappingSeqIdFile, src/mappability.hpp:230-248)
@@ -326,6 +328,32 @@ template <int WPP> struct EnvBase {
     __device__ __forceinline__ row_t C(uint32_t c) const { return (row_t)A.C[c]; }
     __device__ __forceinline__ bool any(bool b) const { return __ballot(b) != 0ull; }
     __device__ __forceinline__ row_t sa(row_t row) const { return reinterpret_cast<const row_t*>(A.sa)[row]; }
+    // text position of a forward SA row for csv / --exclude-pseudo: one read with the full array; with a sampled one, LF steps
+    // (one rank block each: the symbol in front of the suffix and its rank) until a marked row (src/seqan_libdivsufsort.h:129-143)
+    __device__ __forceinline__ row_t locate(row_t row) const
+    {
+        if (A.sa) return sa(row);
+        constexpr uint32_t SPB = BlockGeom<WPP>::SPB, WPB = BlockGeom<WPP>::WPB, H = BlockGeom<WPP>::HDRW;
+        uint32_t r = (uint32_t)row, k = 0;
+        for (;;) {
+            const uint2 m = A.saMark[r >> 5];
+            const uint32_t bit = 1u << (r & 31u);
+            if (m.x & bit) return (row_t)(A.saSamples[m.y + (uint32_t)__popc(m.x & (bit - 1u))] + k);
+            const uint32_t* blk = A.blk[0] + (size_t)(r / SPB) * WPB;
+            const uint32_t off = r % SPB, w = off >> 5, t = off & 31u;
+            const uint32_t c = ((blk[H + w] >> t) & 1u) | (((blk[H + WPP + w] >> t) & 1u) << 1) | (((blk[H + 2 * WPP + w] >> t) & 1u) << 2);
+            // a sentinel in front of the suffix is never reached (sequence starts are sampled) and a walk is shorter than the
+            // largest sampling rate: anything else is a damaged index file, which must not hang the device
+            if (c >= NLET || k >= 64u) return (row_t)0;
+            row_t rk[NLET];
+            block_rank<WPP>(blk, off, rk);
+            uint32_t nx = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < NLET; ++i) nx = c == i ? (uint32_t)(A.C[i] + rk[i]) : nx;   // selects, not an indexed array (scratch)
+            r = nx;
+            ++k;
+        }
+    }
     struct Item { row_t p0; uint32_t w[7]; };
     __device__ __forceinline__ Item item(row_t row) const
     {
@@ -466,7 +494,7 @@ template <int WPP> struct FileSetEnv : EnvBase<WPP> {
     {
         uint32_t* bits = A.fileBits + (size_t)this->slice_pos(rt, kmer) * A.wordsPerKmer;
         for (row_t r = 0; r < w; ++r) {
-            const uint2 sp = locate_position(A.cumGlobal, A.nSeqGlobal, this->sa(flo + r));
+            const uint2 sp = locate_position(A.cumGlobal, A.nSeqGlobal, this->locate(flo + r));
             const uint32_t f = A.seqFile[sp.x];
             atomicOr(&bits[f >> 5], 1u << (f & 31u));
         }
@@ -504,7 +532,7 @@ template <int WPP> struct OccEmitEnv : EnvBase<WPP> {
         const size_t slot = (size_t)rt.strand * A.windowLen + (this->slice_pos(rt, kmer) - A.posBase);
         const uint64_t base = A.offs[slot] + atomicAdd(&A.cnt2[slot], (uint32_t)w);
         for (row_t r = 0; r < w; ++r) {
-            const uint2 sp = locate_position(A.cumGlobal, A.nSeqGlobal, this->sa(flo + r));
+            const uint2 sp = locate_position(A.cumGlobal, A.nSeqGlobal, this->locate(flo + r));
             A.emit[base + r] = (uint64_t)sp.x << 32 | sp.y;
         }
     }
@@ -970,6 +998,41 @@ template <typename TValue>
 __global__ __launch_bounds__(256) void run_values_kernel(const TValue* __restrict__ c, const uint32_t* __restrict__ starts, uint64_t nRuns, uint16_t* __restrict__ val)
 {
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nRuns; r += (uint64_t)gridDim.x * blockDim.x) val[r] = (uint16_t)c[starts[r]];
+}
+
+// ---- sampling of the suffix array (-S) ---------------------------------------------------------------------------------------
+// mark[row / 32] bit row % 32 = SA[row] lies at an in-sequence offset that is a multiple of `s` (never on a sentinel)
+__global__ __launch_bounds__(256) void sa_mark_kernel(const uint32_t* __restrict__ sa, const uint64_t* __restrict__ cum, uint32_t nSeq, uint64_t n, uint32_t s,
+                                                      uint2* __restrict__ mark)
+{
+    const uint64_t words = (n + 31) / 32;
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t bits = 0;
+        for (uint32_t t = 0; t < 32; ++t) {
+            const uint64_t row = w * 32 + t;
+            if (row >= n) break;
+            const uint2 sp = locate_position(cum, nSeq, sa[row]);
+            const uint64_t len = cum[sp.x + 1] - cum[sp.x];
+            if (sp.y < len && sp.y % s == 0u) bits |= 1u << t;
+        }
+        mark[w] = make_uint2(bits, (uint32_t)__popc(bits));   // .y: count, turned into "samples before this word" by a scan
+    }
+}
+__global__ __launch_bounds__(256) void sa_mark_counts_kernel(const uint2* __restrict__ mark, uint64_t words, uint32_t* __restrict__ cnt)
+{
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (uint64_t)gridDim.x * blockDim.x) cnt[w] = mark[w].y;
+}
+__global__ __launch_bounds__(256) void sa_mark_offsets_kernel(uint2* __restrict__ mark, uint64_t words, const uint32_t* __restrict__ before)
+{
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (uint64_t)gridDim.x * blockDim.x) mark[w].y = before[w];
+}
+__global__ __launch_bounds__(256) void sa_compact_kernel(const uint32_t* __restrict__ sa, const uint2* __restrict__ mark, uint64_t n, uint32_t* __restrict__ samples)
+{
+    for (uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; row < n; row += (uint64_t)gridDim.x * blockDim.x) {
+        const uint2 m = mark[row >> 5];
+        const uint32_t bit = 1u << (row & 31u);
+        if (m.x & bit) samples[m.y + (uint32_t)__popc(m.x & (bit - 1u))] = sa[row];
+    }
 }
 
 // zero the calling shard's chunks of a workspace (elements of `eb` bytes, positions [0, n) of the range)

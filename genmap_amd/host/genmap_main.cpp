@@ -76,7 +76,9 @@ int index_main(int argc, const char** argv)
     if (!isFile && !isDir) { std::cerr << "ERROR: You forgot to specify --fasta-file or --fasta-directory.\n"; return 1; }
     const std::string algo = a.get("algorithm", "divsufsort");
     if (algo != "divsufsort" && algo != "skew") { std::cerr << "genmap index: the value '" << algo << "' of option -A is not one of [divsufsort, skew]\n"; return 1; }
-    const int sampling = std::atoi(a.get("sampling", "10").c_str());
+    // the reference defaults to -S 10 to bound host memory; here the array lives in 288 GB of HBM and the full one (1) also lets
+    // the search settle narrow nodes by reading the text, so 1 is the default and 2..64 are honoured when asked for
+    const int sampling = std::atoi(a.get("sampling", "1").c_str());
     if (sampling < 1 || sampling > 64) { std::cerr << "genmap index: the value of -S must be in [1, 64]\n"; return 1; }
     const bool verbose = a.has("verbose");
     std::string fastaPath = isDir ? a.get("fasta-directory") : a.get("fasta-file");
@@ -120,29 +122,33 @@ int index_main(int argc, const char** argv)
     if (seqLen.size() <= 0xFFFFull && maxLen <= 0xFFFFFFFFull) { meta.seqNoBits = 16; meta.seqPosBits = 32; meta.bwtBits = total <= 0xFFFFFFFFull ? 32 : 64; }
     else if (seqLen.size() <= 0xFFFFFFFFull && maxLen <= 0xFFFFull) { meta.seqNoBits = 32; meta.seqPosBits = 16; meta.bwtBits = 64; }
     else { meta.seqNoBits = 64; meta.seqPosBits = 64; meta.bwtBits = 64; }
-    meta.sampling = 1;   // this build keeps the whole suffix array (4 B/row of 288 GB: locate is one read, no LF walk)
-    if (a.has("sampling") && sampling != 1)
-        std::cerr << "WARNING: -S " << sampling << " is not honoured: this build always stores the full suffix array (index.info says sampling_rate:1).\n";
+    meta.sampling = (uint32_t)sampling;
+    if (sampling > 1 && meta.bwtBits == 64) { rmdir(indexPath.c_str()); std::cerr << "ERROR: -S " << sampling << ": a sampled suffix array is supported for indexes of fewer than 2^32 - 1 rows; use -S 1.\n"; return 1; }
     if (verbose)
         std::cout << "Index will be constructed using " << (dna5 ? "dna5/rna5" : "dna4/rna4") << " alphabet.\n"
                   << "- The BWT is represented by " << meta.bwtBits << " bit values.\n"
-                  << "- The suffix array is kept unsampled (requested sampling rate " << sampling << ") as pairs of " << meta.seqNoBits << " and " << meta.seqPosBits << " bit values.\n";
+                  << "- The suffix array is sampled at rate " << sampling << " and kept as pairs of " << meta.seqNoBits << " and " << meta.seqPosBits << " bit values.\n";
     std::cout << "Suffix sorting runs on the GPU (prefix doubling, algorithm option '" << algo << "' is accepted for compatibility).\n" << std::flush;
 
     const double t0 = wall();
     gm_index* ix = nullptr;
     std::cout << "Create fwd Index ... Create bwd Index ... " << std::flush;
-    int rc = gm_index_build(text.data(), seqLen.data(), (uint32_t)seqLen.size(), 1, (uint32_t)std::atoi(a.get("block-bytes", "0").c_str()),
+    int rc = gm_index_build(text.data(), seqLen.data(), (uint32_t)seqLen.size(), (uint32_t)sampling, (uint32_t)std::atoi(a.get("block-bytes", "0").c_str()),
                             std::atoi(a.get("device", "0").c_str()), &ix);
     if (rc) { rmdir(indexPath.c_str()); return fail_gm("index construction failed", rc); }
     std::cout << "done!\n";
     gm_index_info info; gm_index_get_info(ix, &info);
-    std::vector<uint8_t> bf(info.n_rows), br(info.n_rows); std::vector<uint32_t> sa(info.n_rows);
+    std::vector<uint8_t> bf(info.n_rows), br(info.n_rows); gmh::SaFiles sa;
     rc = gm_index_export_bwt(ix, bf.data(), br.data());
-    if (!rc) rc = gm_index_export_sa(ix, sa.data());
+    if (!rc && sampling == 1) { sa.full.resize(info.n_rows * (info.row_bits / 32)); rc = gm_index_export_sa(ix, sa.full.data()); }
+    if (!rc && sampling > 1) {
+        uint64_t ns = 0;
+        rc = gm_index_export_sa_sampled(ix, nullptr, nullptr, &ns);
+        if (!rc) { sa.marks.resize((info.n_rows + 31) / 32); sa.samples.resize(ns); rc = gm_index_export_sa_sampled(ix, sa.marks.data(), sa.samples.data(), &ns); }
+    }
     gm_index_free(ix);
     if (rc) return fail_gm("index export failed", rc);
-    if (!gmh::write_index_dir(indexPath, meta, text, bf, br, sa.data(), err)) { std::cerr << "ERROR: " << err << "\n"; return 1; }
+    if (!gmh::write_index_dir(indexPath, meta, text, bf, br, sa, err)) { std::cerr << "ERROR: " << err << "\n"; return 1; }
     if (verbose) std::cout << "Index of " << info.n_rows << " rows built and written in " << (wall() - t0) << " seconds\n";
     std::cout << "Index created successfully.\n";
     return 0;
@@ -176,7 +182,7 @@ int map_main(int argc, const char** argv)
     if (infix == 0) { std::cerr << "ERROR: overlap cannot be larger than min(K - 1, K - E - 2) = " << std::min(K - 1u, K - E - 2u) << ".\n"; return 1; }
 
     std::string indexPath = a.get("index");
-    gmh::IndexMeta meta; std::vector<uint8_t> text, bf, br; std::vector<uint32_t> sa;
+    gmh::IndexMeta meta; std::vector<uint8_t> text, bf, br; gmh::SaFiles sa;
     const double tRead = wall();
     if (!gmh::read_index_dir(indexPath, meta, text, bf, br, sa, err)) { std::cout << err << (err.empty() || err.back() != '\n' ? "\n" : ""); return 1; }
     const double readSeconds = wall() - tRead;
@@ -259,8 +265,12 @@ int map_main(int argc, const char** argv)
         std::vector<std::thread> th;
         const uint32_t bb = (uint32_t)std::atoi(a.get("block-bytes", "0").c_str());
         for (size_t d = 0; d < devices.size(); ++d)
-            th.emplace_back([&, d] { rcs[d] = gm_index_import(bf.data(), br.data(), sa.empty() ? nullptr : sa.data(), text.data(), seqLen.data(), (uint32_t)seqLen.size(),
-                                                               sa.empty() ? 0 : 1, bb, devices[d], &replicas[d]); });
+            th.emplace_back([&, d] {
+                rcs[d] = !sa.marks.empty()
+                    ? gm_index_import_sampled(bf.data(), br.data(), sa.marks.data(), sa.samples.data(), sa.samples.size(), text.data(), seqLen.data(),
+                                              (uint32_t)seqLen.size(), meta.sampling, bb, devices[d], &replicas[d])
+                    : gm_index_import(bf.data(), br.data(), sa.full.empty() ? nullptr : sa.full.data(), text.data(), seqLen.data(), (uint32_t)seqLen.size(),
+                                      sa.full.empty() ? 0 : 1, bb, devices[d], &replicas[d]); });
         for (auto& t : th) t.join();
     }
     for (size_t d = 0; d < devices.size(); ++d) if (rcs[d]) { for (auto* r : replicas) gm_index_free(r); return fail_gm("cannot load the index onto the GPU", rcs[d]); }
@@ -269,7 +279,7 @@ int map_main(int argc, const char** argv)
     if (verbose)   // load, compute and write are reported separately
         std::cout << "- Index files read in " << (std::round(readSeconds * 100.0) / 100.0) << " seconds, loaded onto " << devices.size() << " GPU(s) in "
                   << (std::round((wall() - tLoad) * 100.0) / 100.0) << " seconds\n" << std::flush;
-    { std::vector<uint8_t>().swap(bf); std::vector<uint8_t>().swap(br); std::vector<uint32_t>().swap(sa); }
+    { std::vector<uint8_t>().swap(bf); std::vector<uint8_t>().swap(br); sa = gmh::SaFiles(); }
 
     const double start = wall();
     uint64_t textBegin = 0; uint32_t firstSeq = 0;

@@ -147,7 +147,7 @@ static bool read_packed4(const std::string& path, std::vector<uint8_t>& v, std::
 }
 
 bool write_index_dir(const std::string& dir, const IndexMeta& m, const std::vector<uint8_t>& text, const std::vector<uint8_t>& bf,
-                     const std::vector<uint8_t>& br, const uint32_t* sa, std::string& err)
+                     const std::vector<uint8_t>& br, const SaFiles& sa, std::string& err)
 {
     const std::string p = dir + (dir.empty() || dir.back() == '/' ? "" : "/") + "index";
     {
@@ -163,16 +163,19 @@ bool write_index_dir(const std::string& dir, const IndexMeta& m, const std::vect
         for (auto& r : m.ids) f << r.file << ';' << r.length << ';' << r.name << '\n';
     }
     if (!write_packed4(p + ".txt4", text, err) || !write_packed4(p + ".bwt4", bf, err) || !write_packed4(p + ".rev.bwt4", br, err)) return false;
-    if (sa) {
-        std::ofstream f(p + ".sa", std::ios::binary);
-        if (!f) { err = "cannot write " + p + ".sa"; return false; }
-        f.write((const char*)sa, (std::streamsize)(bf.size() * 4));
-    }
+    auto put = [&](const std::string& name, const std::vector<uint32_t>& v) {
+        std::ofstream f(name, std::ios::binary);
+        if (f) f.write((const char*)v.data(), (std::streamsize)(v.size() * 4));
+        if (!f) { err = "cannot write " + name; return false; }
+        return true;
+    };
+    if (!sa.full.empty() && !put(p + ".sa", sa.full)) return false;
+    if (!sa.marks.empty() && (!put(p + ".sa.marks", sa.marks) || !put(p + ".sa.samples", sa.samples))) return false;
     return true;
 }
 
 bool read_index_dir(const std::string& dir, IndexMeta& m, std::vector<uint8_t>& text, std::vector<uint8_t>& bf, std::vector<uint8_t>& br,
-                    std::vector<uint32_t>& sa, std::string& err)
+                    SaFiles& sa, std::string& err)
 {
     const std::string p = dir + (dir.empty() || dir.back() == '/' ? "" : "/") + "index";
     std::ifstream fi(p + ".info");
@@ -210,9 +213,25 @@ bool read_index_dir(const std::string& dir, IndexMeta& m, std::vector<uint8_t>& 
     }
     } catch (const std::exception&) { err = "ERROR: Malformed index.info / index.ids file (a number was expected).\n"; return false; }
     if (!read_packed4(p + ".txt4", text, err) || !read_packed4(p + ".bwt4", bf, err) || !read_packed4(p + ".rev.bwt4", br, err)) return false;
-    sa.clear();
-    std::ifstream fs(p + ".sa", std::ios::binary);
-    if (fs) { sa.resize(bf.size()); fs.read((char*)sa.data(), (std::streamsize)(sa.size() * 4)); if (!fs) { err = "truncated " + p + ".sa"; return false; } }
+    sa.full.clear(); sa.marks.clear(); sa.samples.clear();
+    auto get = [&](const std::string& name, std::vector<uint32_t>& v, uint64_t count, bool wholeFile) {   // false: absent or truncated (err set)
+        std::ifstream f(name, std::ios::binary);
+        if (!f) return false;
+        if (wholeFile) { f.seekg(0, std::ios::end); count = (uint64_t)f.tellg() / 4; f.seekg(0); }
+        v.resize(count);
+        f.read((char*)v.data(), (std::streamsize)(count * 4));
+        if (!f) { err = "truncated " + name; v.clear(); return false; }
+        return true;
+    };
+    if (m.sampling <= 1) {   // one entry per row: uint32, or uint64 for indexes of 2^32 - 1 rows and more
+        if (!get(p + ".sa", sa.full, 0, true)) { if (!err.empty()) return false; }
+        else if (sa.full.size() != bf.size() && sa.full.size() != 2 * bf.size()) { err = "truncated " + p + ".sa"; return false; }
+    }
+    else {
+        const bool a = get(p + ".sa.marks", sa.marks, (bf.size() + 31) / 32, false);
+        if (!a && !err.empty()) return false;
+        if (a && !get(p + ".sa.samples", sa.samples, 0, true)) { if (err.empty()) err = "cannot read " + p + ".sa.samples"; return false; }
+    }
     return true;
 }
 

@@ -33,11 +33,14 @@ struct IndexMeta {
 // The index directory written by `genmap index` of this build (layout documented in DESIGN.md):
 //   index.info  index.ids          text, same keys/rows as the reference's
 //   index.txt4  index.bwt4  index.rev.bwt4   4-bit packed codes (text without sentinels; BWTs with code 5 = sentinel)
-//   index.sa                       forward suffix array, uint32 little endian (present when sampling == 1)
+//   index.sa                       sampling_rate 1: the forward suffix array, uint32 little endian, one entry per row
+//   index.sa.marks index.sa.samples   sampling_rate s > 1: one bit per row (uint32 words, bit row % 32), and SA[row] of the
+//                                  marked rows in row order (rows whose in-sequence offset is a multiple of s)
+struct SaFiles { std::vector<uint32_t> full, marks, samples; };
 bool write_index_dir(const std::string& dir, const IndexMeta& meta, const std::vector<uint8_t>& text,
-                     const std::vector<uint8_t>& bwtFwd, const std::vector<uint8_t>& bwtRev, const uint32_t* saOrNull, std::string& err);
+                     const std::vector<uint8_t>& bwtFwd, const std::vector<uint8_t>& bwtRev, const SaFiles& sa, std::string& err);
 bool read_index_dir(const std::string& dir, IndexMeta& meta, std::vector<uint8_t>& text, std::vector<uint8_t>& bwtFwd,
-                    std::vector<uint8_t>& bwtRev, std::vector<uint32_t>& sa, std::string& err);
+                    std::vector<uint8_t>& bwtRev, SaFiles& sa, std::string& err);
 
 // ---- writers (src/output.hpp) -------------------------------------------------------------------------------
 struct SeqTable { std::vector<std::string> names; std::vector<uint64_t> lengths; };

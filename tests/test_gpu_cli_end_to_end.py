@@ -26,8 +26,12 @@ def _same_tree(a, b):
         assert filecmp.cmp(a / f, b / f, shallow=False), f
 
 
+@pytest.mark.parametrize("sampling", [None, 10, 3])
 @pytest.mark.parametrize("case", sorted(H.CASES))
-def test_cli_reproduces_reference_outputs(case, tmp_path):
+def test_cli_reproduces_reference_outputs(case, sampling, tmp_path):
+    """sampling None: the default index (full suffix array).  -S 10 (the reference's default, src/indexing.hpp:311-315) and -S 3:
+    the sampled array on disk and in HBM, locate by LF walk; run on the outputs that locate (csv, --exclude-pseudo) plus one
+    frequency format."""
     assert GENMAP.exists(), "genmap binary not built (python -c 'import __graft_entry__ as g; g.build()')"
     d = H.CASES_DIR / f"case_{case}"
     directory, fl = H.CASES[case]
@@ -37,14 +41,21 @@ def test_cli_reproduces_reference_outputs(case, tmp_path):
         src.mkdir()
         for f in d.glob("*.fa"):
             shutil.copy(f, src / f.name)
-        subprocess.check_call([str(GENMAP), "index", "-FD", str(src), "-I", str(idx), "-A", "skew"], stdout=subprocess.DEVNULL)
+    smp = [] if sampling is None else ["-S", str(sampling)]
+    if directory:
+        subprocess.check_call([str(GENMAP), "index", "-FD", str(src), "-I", str(idx), "-A", "skew"] + smp, stdout=subprocess.DEVNULL)
     else:
-        subprocess.check_call([str(GENMAP), "index", "-F", str(d / "genome.fa"), "-I", str(idx), "-A", "divsufsort"], stdout=subprocess.DEVNULL)
+        subprocess.check_call([str(GENMAP), "index", "-F", str(d / "genome.fa"), "-I", str(idx), "-A", "divsufsort"] + smp, stdout=subprocess.DEVNULL)
+    if sampling is not None:
+        assert f"sampling_rate:{sampling}\n" in (idx / "index.info").read_text()
+        assert (idx / "index.sa.samples").exists() and not (idx / "index.sa").exists()
     flags = ["-E", str(fl["E"]), "-K", str(fl["K"])] + (["-nc"] if fl.get("nc") else []) + (["-ep"] if fl.get("ep") else [])
     if (d / "subset.bed").exists():
         flags += ["-S", str(d / "subset.bed")]
     for sub, ff in FORMAT_FLAGS.items():
         if not (d / sub).is_dir():
+            continue
+        if sampling is not None and sub not in ("csv", "raw_freq16", "txt_map") and not fl.get("ep"):
             continue
         for xo in H.xo_variants(case):
             out = tmp_path / f"out_{sub}_{xo}"

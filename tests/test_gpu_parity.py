@@ -102,8 +102,8 @@ def test_gpu_csv_locations_match_reference_fixtures(case):
     d = H.CASES_DIR / f"case_{case}"
     gen, directory, fl, bed = H.load_case(case)
     rc = not fl.get("nc", False)
-    for bb in (0, WIDE):
-      ix = g.Index.build(gen.codes, gen.seq_len, sampling=1, block_bytes=bb)
+    for bb, smp in ((0, 1), (WIDE, 1), (0, 10), (64, 2)):   # full suffix array; sampled: locate walks the LF mapping
+      ix = g.Index.build(gen.codes, gen.seq_len, sampling=smp, block_bytes=bb)
       for xo in H.xo_variants(case):
         for name, first, nseq, tb, tl in gen.file_slices():
             iv = civ = None
@@ -119,14 +119,16 @@ def test_gpu_csv_locations_match_reference_fixtures(case):
       ix.close()
 
 
-def test_gpu_exclude_pseudo_and_locations_vs_oracle():
-    """BASELINE configs[4] shape (5 related genomes, K=24 E=1, -ep, csv) at test size."""
+@pytest.mark.parametrize("sampling", [1, 10, 64])
+def test_gpu_exclude_pseudo_and_locations_vs_oracle(sampling):
+    """BASELINE configs[4] shape (5 related genomes, K=24 E=1, -ep, csv) at test size; with the full and a sampled suffix array."""
     g = _gm()
     from genmap_amd import synth
     files = synth.bacteria5(0.004)
     gen = H.Genome(files)
     ora = H.OracleIndex(gen.codes, gen.seq_len, keep_sa=True)
-    ix = g.Index.build(gen.codes, gen.seq_len, sampling=1)
+    ix = g.Index.build(gen.codes, gen.seq_len, sampling=sampling)
+    assert ix.info()["sampling"] == sampling
     K, E = 24, 1
     for name, first, nseq, tb, tl in gen.file_slices():
         exp, _, locs = ora.mappability(K, E, first_seq=first, n_seq=nseq, text_begin=tb, text_len=tl, value_bits=16, directory=True,
@@ -136,6 +138,54 @@ def test_gpu_exclude_pseudo_and_locations_vs_oracle():
         ent = _csv_entries(gen, first, nseq, K, ix.locate(K, E, first_seq=first, n_seq=nseq))
         assert ent == locs, name
     ix.close()
+
+
+@pytest.mark.parametrize("s", [2, 3, 10, 64])
+def test_gpu_sampled_suffix_array_is_the_full_one_thinned(s):
+    """-S s (src/indexing.hpp:311-315): rows whose in-sequence offset is a multiple of s keep their value, the others find it by
+    LF steps.  The marks and samples are those of the full array; the sampled form moves through export / import unchanged;
+    frequencies, --exclude-pseudo and locations equal the full index's."""
+    g = _gm()
+    rng = np.random.default_rng(77 + s)
+    lens = [1, 2, s - 1, s, s + 1, 700, 63, 5000, 3]
+    lens = [x for x in lens if x > 0]
+    codes = _repeat_text(rng, sum(lens), dna5=True)
+    full = g.Index.build(codes, lens, sampling=1)
+    smp = g.Index.build(codes, lens, sampling=s)
+    sa = full.export_sa()
+    cum = np.concatenate([[0], np.cumsum(lens)])
+    starts = cum[:-1] + np.arange(len(lens))                    # sentinel-text position of each sequence's first symbol
+    seq = np.searchsorted(starts, sa, side="right") - 1
+    off = sa - starts[seq]
+    want = (off < np.asarray(lens)[seq]) & (off % s == 0)
+    mk, sm = smp.export_sa_sampled()
+    bits = ((mk[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).astype(bool).reshape(-1)[:len(sa)]
+    assert np.array_equal(bits, want)
+    assert np.array_equal(sm, sa[want])
+    with pytest.raises(g.GenmapError):
+        smp.export_sa()
+    bf, br = smp.export_bwt()
+    again = g.Index.from_sampled(bf, br, mk, sm, codes, lens, s)
+    viaimport = g.Index.from_bwt(bf, br, codes, lens, sa_fwd=sa, sampling=s)   # a full array handed over, sampled on the device
+    mk2, sm2 = viaimport.export_sa_sampled()
+    assert np.array_equal(mk2, mk) and np.array_equal(sm2, sm)
+    with pytest.raises(g.GenmapError):
+        g.Index.from_sampled(bf, br, mk, sm[:-1], codes, lens, s)   # marks and samples disagree
+    fid = np.array([0, 0, 1, 1, 1, 2, 2, 3, 3][:len(lens)], dtype=np.uint32)
+    for K, E in ((12, 0), (16, 1), (20, 2)):
+        ref = full.locate(K, E)
+        exp_ep = full.map(K, E, value_bits=16, exclude_pseudo=True, seq_file_id=fid)
+        for ix in (smp, again, viaimport):
+            assert np.array_equal(ix.map(K, E, value_bits=16), full.map(K, E, value_bits=16))
+            assert np.array_equal(ix.map(K, E, value_bits=16, exclude_pseudo=True, seq_file_id=fid), exp_ep)
+            got = ix.locate(K, E)
+            assert got[0] == ref[0] and all(np.array_equal(a, b) for a, b in zip(got[1:], ref[1:]))
+    with pytest.raises(g.GenmapError):
+        g.Index.build(codes, lens, sampling=65)
+    with pytest.raises(g.GenmapError):
+        g.Index.build(codes, lens, sampling=s, block_bytes=WIDE)
+    for ix in (full, smp, again, viaimport):
+        ix.close()
 
 
 @pytest.mark.parametrize("wide", [False, True])
