@@ -692,10 +692,10 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     uint32_t verifyT = 0;
     if (ix->d_sa && ix->d_textS) {   // narrow nodes are resolved against the text when the SA is resident
         int t = 1;
-        if (plan.stepSize >= 32) t = 4;   // long blocks (e.g. K=100): a narrow node still covers many k-mers (profiles/r01c)
         // long k-mers with errors: a two-row node has a long way to go by rank steps; with the 32-byte row records two reads
         // settle it (K=100 e=1: +8 % on 3.09 Gbp, +12 % on 249 Mbp; K=30: -20 %, profiles/r02/sweep_*_steal_verify.txt)
-        else if (p->K >= 64 && p->E >= 1 && ix->d_ctx && ix->tune.useCtx) t = 2;
+        if (p->K >= 64 && p->E >= 1 && ix->d_ctx && ix->tune.useCtx) t = 2;
+        else if (plan.stepSize >= 32) t = 4;   // long blocks: a narrow node still covers many k-mers (profiles/r01c)
         if (ix->tune.verifyT >= 0) t = ix->tune.verifyT;
         verifyT = (uint32_t)std::max(0, std::min(t, (int)VERIFY_TMAX));
     }
@@ -790,7 +790,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     if (ix->tune.fetchBatch > 0) A.fetchBatch = (uint32_t)std::min(ix->tune.fetchBatch, 64);
     // e = 0: a single row is almost always the k-mer's own location.  Beyond ~1 G rows a lone-row step is an HBM miss
     // like the verification reads it postpones, and no longer pays (3.09 Gbp e = 2: 90.7 vs 86.7 M k-mers/s without).
-    A.probation = (p->E == 0 || ix->nRows >= (1ull << 30)) ? 0u : 2u;
+    A.probation = p->E == 0 ? 0u : 2u;   // 3.09 Gbp: e=1 +8.5 %, e=2 +4 % over 0 (profiles/r02/sweep_grch38_retune.txt); K=100: no difference
     if (ix->tune.probation >= 0) A.probation = (uint32_t)ix->tune.probation;
     A.verifyCost = (uint32_t)std::max(0, ix->tune.verifyCost);
     A.chunkBlocks = chunked ? p->chunk_blocks : 0u; A.chunkStride = p->chunk_stride; A.chunkIndex = p->chunk_index;

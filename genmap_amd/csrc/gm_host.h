@@ -46,7 +46,16 @@ inline uint32_t tuned_infix_length(uint32_t K, uint32_t E)
     uint32_t n;
     switch (E) {
         case 0: n = K > 15 ? clampu(K - 15, 1, 31) : 1; break;
-        case 1: n = clampu(K / 6, 5, 16); break;
+        case 1:
+            // re-measured on the 3.09 Gbp index with cooperative reads and verification records (profiles/r02/sweep_grch38_steps.txt):
+            // the longest block whose first (exact) part still has >= 17 characters (infix >= 35), and whose window K + n - 1
+            // stays within 127 symbols (five 32-symbol LDS chunks) when that is in reach.  K=50 +9 %, 64 +13 %, 100 +11 %,
+            // 150 +27 %, 250 +48 % over n = clamp(K / 6, 5, 16); K <= 43 keeps that rule (K=30: n = 5 is the optimum).
+            if (K >= 128) n = 48;
+            else if (K >= 60) { n = clampu(K / 4, 16, 24); if (K + n - 1 > 127 && K <= 112) n = 128 - K; }
+            else if (K >= 44) n = std::min<uint32_t>(16, K - 34);
+            else n = clampu(K / 6, 5, 16);
+            break;
         case 2: n = clampu(K / 6, 7, 16); break;
         case 3: n = clampu(K / 4, 9, 16); break;
         default: n = clampu(K / 4, 11, 16); break;

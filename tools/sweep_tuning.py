@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Build one index, then time gm_map_device under several settings of the library's scheduling knobs (gm_index_set_tuning).
 Usage: sweep_tuning.py --workload grch38 --cfg 30,0,1.0 30,2,0.06 -- "" "skip_dup=1" "skip_dup=1,fetch_batch=16" ...
-A cfg is K,E,frac (frac = share of the k-mers: a contiguous range from the middle of the text).  INFIX=n is a pseudo-knob."""
+A cfg is K,E,frac (frac = share of the k-mers: a contiguous range from the middle of the text).  INFIX=n and STEP=n (k-mers per block, infix = K - n + 1) are pseudo-knobs."""
 import argparse, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -30,6 +30,7 @@ for cfg in a.cfg:
         for kv in filter(None, st.split(",")):
             k, v = kv.split("=")
             if k == "INFIX": infix = int(v)
+            elif k == "STEP": infix = K - int(v) + 1   # k-mers per block
             else: knobs[k] = int(v)
         ix.set_tuning(**knobs)
         step = K - (infix or g.tuned_infix_length(K, E)) + 1
@@ -37,11 +38,15 @@ for cfg in a.cfg:
         kb = ((nk - span) // 2) // step * step
         rng = None if frac >= 1.0 else (kb, kb + span)
         out.zero_()
-        for r in range(a.reps + 1):
-            ix.map_device(out.data_ptr(), K, E, infix=infix, value_bits=8, kmer_range=rng, stream=stream)
+        try:
+            for r in range(a.reps + 1):
+                ix.map_device(out.data_ptr(), K, E, infix=infix, value_bits=8, kmer_range=rng, stream=stream)
+        except g.GenmapError as ex:   # a setting that does not apply to this (K, E)
+            print(f"K={K} E={E} frac={frac:<5} {st:45s} skipped: {ex}", flush=True)
+            continue
         ms = ix.kernel_times(a.reps)
         chk = int(out[:n].to(torch.int64).sum().item())
         if base is None: base = chk
         best = min(ms)
-        print(f"K={K} E={E} frac={frac:<5} {st or '(default)':45s} {best:10.2f} ms  {(span if rng else nk)/best/1e3:10.4g} k-mers/s  checksum {'ok' if chk == base else 'DIFFERS'}", flush=True)
+        print(f"K={K} E={E} frac={frac:<5} {st or '(default)':45s} {best:10.2f} ms  {(span if rng else nk)/best*1e3:10.4g} k-mers/s  checksum {'ok' if chk == base else 'DIFFERS'}", flush=True)
 ix.close()
