@@ -703,14 +703,28 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     const uint32_t vqCap = verifyT ? 64u + 64u * verifyT : 1u;
     const uint32_t winChunks = (31u + p->K + plan.stepSize - 1u + 31u) / 32u;
     const uint32_t nu = ix->wide ? 2u : 1u;
-    uint32_t ldsDepth = (uint32_t)std::max(0, ix->tune.ldsStack) / nu;   // the same LDS for the stack tops of wide nodes
-    ldsDepth = std::min(ldsDepth, depth);
-    const size_t ldsBytes = (size_t)(4u * vqCap * nu + 4u * 64u * (ldsDepth * nu + winChunks)) * 16u + 4u * 128u * 4u;   // == search_lds_bytes
-    int perCU = 0;
-    switch (ix->wpp) { case 1: rc = occupancy_blocks<1>(&perCU, ldsBytes); break; case 2: rc = occupancy_blocks<2>(&perCU, ldsBytes); break; case 3: rc = occupancy_blocks<3>(&perCU, ldsBytes); break; default: rc = occupancy_blocks<9>(&perCU, ldsBytes); break; }
-    if (rc) return rc;
     const int wantPerCU = std::max(1, ix->tune.blocksPerCU);   // default 4 = 4 waves/SIMD, what the kernel's VGPR count allows
-    perCU = std::max(1, std::min(perCU, wantPerCU));
+    auto lds_bytes_for = [&](uint32_t d) { return (size_t)(4u * vqCap * nu + 4u * 64u * (d * nu + winChunks)) * 16u + 4u * 128u * 4u; };   // == search_lds_bytes
+    auto blocks_for = [&](uint32_t d, int* nb) {
+        switch (ix->wpp) { case 1: return occupancy_blocks<1>(nb, lds_bytes_for(d)); case 2: return occupancy_blocks<2>(nb, lds_bytes_for(d)); case 3: return occupancy_blocks<3>(nb, lds_bytes_for(d)); default: return occupancy_blocks<9>(nb, lds_bytes_for(d)); }
+    };
+    // stack levels kept in LDS: four when they fit beside the needle windows and the verification queue at full occupancy;
+    // long windows (K >= ~60) trade levels for resident blocks -- a fourth block per CU is worth more than the levels
+    // (3.09 Gbp e=1: K=100 676 -> 600 ms, K=150 819 -> 642 ms; at equal occupancy deeper is better; profiles/r02/sweep_grch38_ldsstack.txt)
+    uint32_t ldsDepth = 0; int perCU = 0;
+    if (ix->tune.ldsStack >= 0) {
+        ldsDepth = std::min((uint32_t)ix->tune.ldsStack / nu, depth);   // the same LDS for the stack tops of wide nodes
+        rc = blocks_for(ldsDepth, &perCU); if (rc) return rc;
+        perCU = std::max(1, std::min(perCU, wantPerCU));
+    } else {
+        for (uint32_t d = std::min(4u / nu, depth); d >= 1u; --d) {
+            int nb = 0;
+            rc = blocks_for(d, &nb); if (rc) return rc;
+            nb = std::min(nb, wantPerCU);
+            if (nb > perCU) { perCU = nb; ldsDepth = d; }
+        }
+        perCU = std::max(1, perCU);
+    }
     uint64_t blocks = (uint64_t)ix->numCU * perCU;
     const uint64_t useful = (S->numRoots + 255) / 256;
     if (blocks > useful) blocks = std::max<uint64_t>(useful, 1);

@@ -26,7 +26,7 @@ namespace gm {
 // knobs of the search kernel's scheduling; set with gm_index_set_tuning (tests, sweeps), never read from the environment.
 // -1 = "library default for this call" (depends on K, E and the index size, see prepare_search)
 struct Tuning {
-    int verifyT = -1, ldsStack = 4, blocksPerCU = 4, qtable = -1, satMinW = 256, fetchBatch = -1, probation = -1, verifyCost = 3;
+    int verifyT = -1, ldsStack = -1, blocksPerCU = 4, qtable = -1, satMinW = 256, fetchBatch = -1, probation = -1, verifyCost = 3;
     int noStore = 0, noSaturate = 0, skipDup = -1, coop = -1, useCtx = 1, steal = -1;
 };
 }  // namespace gm
