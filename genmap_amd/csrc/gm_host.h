@@ -85,7 +85,7 @@ enum PlanError { PLAN_OK = 0, PLAN_BAD_E = -2, PLAN_BAD_K = -6, PLAN_BAD_OVERLAP
 // intervals are merged (the reference skips already-filled positions, algo.hpp:236-242; the value of a
 // position does not depend on which block computes it).
 inline int make_map_plan(uint32_t K, uint32_t E, uint32_t infix, int revcompl, uint64_t textLen,
-                         const uint64_t* intervals, uint64_t nIntervals, MapPlan* out)
+                         const uint64_t* intervals, uint64_t nIntervals, MapPlan* out, int partBias = 0)
 {
     MapPlan& p = *out;
     if (E > MAX_ERRORS) return PLAN_BAD_E;
@@ -99,7 +99,17 @@ inline int make_map_plan(uint32_t K, uint32_t E, uint32_t infix, int revcompl, u
     p.table.assign((size_t)p.stepSize * 8, OssRecord{0, 0, 0, 0});
     for (uint32_t n = 1; n <= p.stepSize; ++n)
         for (uint32_t s = 0; s < p.nSearches; ++s)
-            if (!oss_make_record(E, s, K - n + 1, &p.table[(size_t)(n - 1) * 8 + s])) return PLAN_BAD_OVERLAP;
+        {
+            // partBias (e = 1, two blocks): characters moved from the second block to the first; the scheme is exact for any
+            // positive lengths (gm_oss.h), the reference splits evenly
+            uint32_t lens[2]; const uint32_t* lp = nullptr;
+            const uint32_t L = K - n + 1;
+            if (E == 1 && partBias != 0 && L >= 2) {
+                const int a = std::max(1, std::min((int)L - 1, (int)(L / 2 + (L & 1u)) + partBias));
+                lens[0] = (uint32_t)a; lens[1] = L - (uint32_t)a; lp = lens;
+            }
+            if (!oss_make_record(E, s, L, &p.table[(size_t)(n - 1) * 8 + s], lp)) return PLAN_BAD_OVERLAP;
+        }
     p.blocks.clear();
     if (nIntervals == 0) {
         p.useList = false;

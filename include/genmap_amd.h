@@ -247,7 +247,8 @@ int gm_map_kernel_times(const gm_index *idx, double *ms, uint32_t n, uint32_t *n
 int gm_index_sync(gm_index *idx);
 
 /* scheduling knobs of the search kernel, for sweeps and tests (results never depend on them).  Names: verify_t,
- * lds_stack, blocks_per_cu, qtable, sat_min_w, fetch_batch, probation, verify_cost, no_store, no_saturate;
+ * lds_stack, blocks_per_cu, qtable, sat_min_w, fetch_batch, probation, verify_cost, no_store, no_saturate, skip_dup, coop,
+ * use_ctx, steal, part_bias;
  * value -1 restores the library default where one exists.  Nothing is read from the environment. */
 int gm_index_set_tuning(gm_index *idx, const char *name, int64_t value);
 
