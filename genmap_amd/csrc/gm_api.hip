@@ -849,11 +849,18 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
         rc = grow(&ix->d_bits, &ix->bitsCap, (text_len + 1) * wordsPerKmer); if (rc) return rc;
         GM_HIP(hipStreamSynchronize(st));
     } else {
-        rc = grow(&ix->d_acc, &ix->accCap, 2 * (text_len + 4)); if (rc) return rc;
+        rc = grow(&ix->d_acc, &ix->accCap, 2 * (text_len + 4) + 16); if (rc) return rc;
     }
     // E = 0 with single-row verification: plain stores into one plane per strand instead of atomics
     const bool store = !ep && p->E == 0 && A.verifyT <= 1 && !ix->tune.noStore;
-    const uint64_t plane = text_len + 4;
+    const uint64_t plane = (text_len + 4 + 15) & ~15ull;   // both planes aligned alike: finalize2 reads 16 bytes per lane
+    // kernels over positions: blockIdx.y walks the shard's own chunk ranges (one range without chunks), blockIdx.x one range
+    auto range_grid = [](const ChunkSel& c, uint64_t n, uint32_t perThread) {
+        uint64_t nr = 1, span = n;
+        if (c.len) { const uint64_t chunks = (n + c.len - 1) / c.len; nr = chunks > c.index ? (chunks - c.index + c.stride - 1) / c.stride : 0; span = c.len; }
+        const uint64_t gx = std::max<uint64_t>(1, std::min<uint64_t>((span / perThread + 255) / 256, 1u << 16));
+        return dim3((unsigned)gx, (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nr, 65535)), 1);
+    };
 
     // a shard (kmer_begin/kmer_end) touches only its own positions [r0, r1) of the accumulators and of out
     const bool sharded = (p->flags & GM_MAP_FLAG_RANGE) || p->kmer_begin != 0 || p->kmer_end != 0 || S.sel.len != 0;
@@ -867,13 +874,13 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
         else if (store) {
             const size_t pb = p->value_bits == 8 ? 1 : 2;   // plane element: as wide as the result
             if (sel.len) {
-                hipLaunchKernelGGL(clear_chunks_kernel, dim3(grid_for(rn)), dim3(256), 0, st, (uint8_t*)ix->d_acc + r0 * pb, (uint32_t)pb, rn, sel);
-                hipLaunchKernelGGL(clear_chunks_kernel, dim3(grid_for(rn)), dim3(256), 0, st, (uint8_t*)ix->d_acc + (plane + r0) * pb, (uint32_t)pb, rn, sel);
+                hipLaunchKernelGGL(clear_chunks_kernel, range_grid(sel, rn, 16), dim3(256), 0, st, (uint8_t*)ix->d_acc + r0 * pb, (uint32_t)pb, rn, sel);
+                hipLaunchKernelGGL(clear_chunks_kernel, range_grid(sel, rn, 16), dim3(256), 0, st, (uint8_t*)ix->d_acc + (plane + r0) * pb, (uint32_t)pb, rn, sel);
             } else {
                 GM_HIP(hipMemsetAsync((uint8_t*)ix->d_acc + r0 * pb, 0, rn * pb, st));
                 GM_HIP(hipMemsetAsync((uint8_t*)ix->d_acc + (plane + r0) * pb, 0, rn * pb, st));
             }
-        } else if (sel.len) hipLaunchKernelGGL(clear_chunks_kernel, dim3(grid_for(rn)), dim3(256), 0, st, (uint8_t*)(ix->d_acc + r0), 4u, rn, sel);
+        } else if (sel.len) hipLaunchKernelGGL(clear_chunks_kernel, range_grid(sel, rn, 4), dim3(256), 0, st, (uint8_t*)(ix->d_acc + r0), 4u, rn, sel);
         else GM_HIP(hipMemsetAsync(ix->d_acc + r0, 0, rn * sizeof(uint32_t), st));
     }
     GM_HIP(hipMemsetAsync(ix->d_small, 0, SMALL_ZEROED, st));
@@ -886,22 +893,22 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
     GM_HIP(hipEventRecord(ix->evRing[slot][1], st));
     ix->evCount++;
     if (text_len > 0) {
-        const unsigned g4 = grid_for((rn + 3) / 4), g1 = grid_for(rn);
+        const dim3 g4 = range_grid(sel, rn, 4), g1 = range_grid(sel, rn, 1), g16 = range_grid(sel, rn, 16);
         const uint16_t* pf = (const uint16_t*)ix->d_acc + r0;
         const uint8_t* pf8 = (const uint8_t*)ix->d_acc + r0;
         if (p->value_bits == 8) {
             uint8_t* o = (uint8_t*)d_out + r0;
             if (rn == 0) {}
-            else if (ep) hipLaunchKernelGGL(finalize_fileset_kernel<uint8_t>, dim3(g1), dim3(256), 0, st, ix->d_bits + r0 * wordsPerKmer, wordsPerKmer, o, rn, sel);
-            else if (store) hipLaunchKernelGGL((finalize2_kernel<uint8_t, uint8_t>), dim3(g1), dim3(256), 0, st, pf8, pf8 + plane, o, rn, 255u, sel);
-            else hipLaunchKernelGGL(finalize_kernel<uint8_t>, dim3(g4), dim3(256), 0, st, ix->d_acc + r0, o, rn, 255u, sel);
+            else if (ep) hipLaunchKernelGGL(finalize_fileset_kernel<uint8_t>, g1, dim3(256), 0, st, ix->d_bits + r0 * wordsPerKmer, wordsPerKmer, o, rn, sel);
+            else if (store) hipLaunchKernelGGL((finalize2_kernel<uint8_t, uint8_t>), g16, dim3(256), 0, st, pf8, pf8 + plane, o, rn, 255u, sel);
+            else hipLaunchKernelGGL(finalize_kernel<uint8_t>, g4, dim3(256), 0, st, ix->d_acc + r0, o, rn, 255u, sel);
             rc = launch_reset_limits(ix, (uint8_t*)d_out, n_seq, p->K, st);
         } else {
             uint16_t* o = (uint16_t*)d_out + r0;
             if (rn == 0) {}
-            else if (ep) hipLaunchKernelGGL(finalize_fileset_kernel<uint16_t>, dim3(g1), dim3(256), 0, st, ix->d_bits + r0 * wordsPerKmer, wordsPerKmer, o, rn, sel);
-            else if (store) hipLaunchKernelGGL((finalize2_kernel<uint16_t, uint16_t>), dim3(g1), dim3(256), 0, st, pf, pf + plane, o, rn, 65535u, sel);
-            else hipLaunchKernelGGL(finalize_kernel<uint16_t>, dim3(g4), dim3(256), 0, st, ix->d_acc + r0, o, rn, 65535u, sel);
+            else if (ep) hipLaunchKernelGGL(finalize_fileset_kernel<uint16_t>, g1, dim3(256), 0, st, ix->d_bits + r0 * wordsPerKmer, wordsPerKmer, o, rn, sel);
+            else if (store) hipLaunchKernelGGL((finalize2_kernel<uint16_t, uint16_t>), g16, dim3(256), 0, st, pf, pf + plane, o, rn, 65535u, sel);
+            else hipLaunchKernelGGL(finalize_kernel<uint16_t>, g4, dim3(256), 0, st, ix->d_acc + r0, o, rn, 65535u, sel);
             rc = launch_reset_limits(ix, (uint16_t*)d_out, n_seq, p->K, st);
         }
         if (rc) return rc;

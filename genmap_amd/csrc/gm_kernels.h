@@ -80,7 +80,33 @@ struct SearchArgs {
 
 // which positions of a range belong to the calling shard (interleaved chunks of `len` positions); len == 0: all of them
 struct ChunkSel { uint32_t len, stride, index; };
-__device__ __forceinline__ bool chunk_mine(const ChunkSel& c, uint64_t j) { return c.len == 0u || (uint32_t)((j / c.len) % c.stride) == c.index; }
+// The calling shard's positions of [0, n) as ranges: range q = [b, e).  Kernels over positions walk blockIdx.y over these ranges
+// and blockIdx.x / threads inside one, so that a shard touches only its own chunks, without a division per position.
+__device__ __forceinline__ uint64_t own_ranges(const ChunkSel& c, uint64_t n)
+{
+    if (c.len == 0u) return n ? 1u : 0u;
+    const uint64_t chunks = (n + c.len - 1) / c.len;                       // chunks of [0, n), the last one possibly short
+    return chunks > c.index ? (chunks - c.index + c.stride - 1) / c.stride : 0u;
+}
+__device__ __forceinline__ void own_range(const ChunkSel& c, uint64_t n, uint64_t q, uint64_t& b, uint64_t& e)
+{
+    if (c.len == 0u) { b = 0; e = n; return; }
+    b = (q * c.stride + c.index) * (uint64_t)c.len;
+    e = b + c.len < n ? b + c.len : n;
+}
+// saturating sums of packed unsigned bytes / halfwords (a plane holds min(count, MAX) of one strand)
+__device__ __forceinline__ uint32_t sat_add_u8x4(uint32_t x, uint32_t y)
+{
+    const uint32_t sum = ((x & 0x7F7F7F7Fu) + (y & 0x7F7F7F7Fu)) ^ ((x ^ y) & 0x80808080u);
+    const uint32_t c = ((x & y) | ((x | y) & ~sum)) & 0x80808080u;        // carry out of each byte
+    return sum | ((c >> 7) * 0xFFu);
+}
+__device__ __forceinline__ uint32_t sat_add_u16x2(uint32_t x, uint32_t y)
+{
+    const uint32_t sum = ((x & 0x7FFF7FFFu) + (y & 0x7FFF7FFFu)) ^ ((x ^ y) & 0x80008000u);
+    const uint32_t c = ((x & y) | ((x | y) & ~sum)) & 0x80008000u;
+    return sum | ((c >> 15) * 0xFFFFu);
+}
 
 
 // sentinel-text position -> (seqNo, seqPos); sequence s starts at cum[s] + s
@@ -941,33 +967,60 @@ __global__ __launch_bounds__(256) void qmer_table_kernel(const uint32_t* __restr
     NodeIO<row_t>::store_qentry(out, idx, flo, rlo, w);
 }
 
-// store planes -> c[]
+// store planes -> c[]: 16 bytes per lane where the three arrays are aligned alike (the planes are; `out` is the caller's)
 template <typename TValue, typename TPlane>
 __global__ __launch_bounds__(256) void finalize2_kernel(const TPlane* __restrict__ accF, const TPlane* __restrict__ accR, TValue* __restrict__ out, uint64_t n, uint32_t maxVal, ChunkSel sel)
 {
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {   // (grid-stride: n may exceed 2^32)
-        if (!chunk_mine(sel, j)) continue;
-        const uint32_t v = (uint32_t)accF[j] + accR[j];   // each plane holds min(count, its own maximum)
-        out[j] = (TValue)(v < maxVal ? v : maxVal);
+    static_assert(sizeof(TValue) == sizeof(TPlane), "planes are as wide as the result");
+    constexpr uint32_t EPV = 16u / sizeof(TValue);
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t nr = own_ranges(sel, n);
+    const bool full = maxVal == (sizeof(TValue) == 1 ? 255u : 65535u);
+    for (uint64_t q = blockIdx.y; q < nr; q += gridDim.y) {
+        uint64_t b, e;
+        own_range(sel, n, q, b, e);
+        const uintptr_t ao = reinterpret_cast<uintptr_t>(out + b), af = reinterpret_cast<uintptr_t>(accF + b), ar = reinterpret_cast<uintptr_t>(accR + b);
+        uint64_t bb = b, be = b;   // [bb, be): whole 16-byte vectors
+        if (full && ((ao ^ af) & 15u) == 0u && ((ao ^ ar) & 15u) == 0u) {
+            bb = b + ((16u - (uint32_t)(ao & 15u)) & 15u) / sizeof(TValue);
+            if (bb > e) bb = e;
+            be = bb + (e - bb) / EPV * EPV;
+        }
+        for (uint64_t j = b + tid; j < bb; j += nth) { const uint32_t v = (uint32_t)accF[j] + accR[j]; out[j] = (TValue)(v < maxVal ? v : maxVal); }
+        for (uint64_t j = be + tid; j < e; j += nth) { const uint32_t v = (uint32_t)accF[j] + accR[j]; out[j] = (TValue)(v < maxVal ? v : maxVal); }
+        const uint4* F = reinterpret_cast<const uint4*>(accF + bb); const uint4* R = reinterpret_cast<const uint4*>(accR + bb);
+        uint4* O = reinterpret_cast<uint4*>(out + bb);
+        for (uint64_t v = tid; v < (be - bb) / EPV; v += nth) {
+            const uint4 x = F[v], y = R[v];
+            uint4 r;
+            if (sizeof(TValue) == 1) { r.x = sat_add_u8x4(x.x, y.x); r.y = sat_add_u8x4(x.y, y.y); r.z = sat_add_u8x4(x.z, y.z); r.w = sat_add_u8x4(x.w, y.w); }
+            else { r.x = sat_add_u16x2(x.x, y.x); r.y = sat_add_u16x2(x.y, y.y); r.z = sat_add_u16x2(x.z, y.z); r.w = sat_add_u16x2(x.w, y.w); }
+            O[v] = r;
+        }
     }
 }
 
 template <typename TValue>
 __global__ __launch_bounds__(256) void finalize_kernel(const uint32_t* __restrict__ acc, TValue* __restrict__ out, uint64_t n, uint32_t maxVal, ChunkSel sel)
 {
-    for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4ull; i < n; i += (uint64_t)gridDim.x * blockDim.x * 4ull) {
-    const bool aligned = ((reinterpret_cast<uintptr_t>(out + i)) & (sizeof(TValue) * 4 - 1)) == 0 && ((reinterpret_cast<uintptr_t>(acc + i)) & 15) == 0;
-    if (sel.len) {
-        for (uint64_t j = i; j < n && j < i + 4; ++j) if (chunk_mine(sel, j)) { const uint32_t v = acc[j]; out[j] = (TValue)(v < maxVal ? v : maxVal); }
-    } else if (i + 4 <= n && aligned) {
-        const uint4 v = *reinterpret_cast<const uint4*>(acc + i);
-        TValue r[4] = {(TValue)(v.x < maxVal ? v.x : maxVal), (TValue)(v.y < maxVal ? v.y : maxVal),
-                       (TValue)(v.z < maxVal ? v.z : maxVal), (TValue)(v.w < maxVal ? v.w : maxVal)};
-        if (sizeof(TValue) == 1) *reinterpret_cast<uint32_t*>(out + i) = *reinterpret_cast<uint32_t*>(r);
-        else *reinterpret_cast<uint2*>(out + i) = *reinterpret_cast<uint2*>(r);
-    } else {
-        for (uint64_t j = i; j < n && j < i + 4; ++j) { const uint32_t v = acc[j]; out[j] = (TValue)(v < maxVal ? v : maxVal); }
-    }
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t nr = own_ranges(sel, n);
+    for (uint64_t q = blockIdx.y; q < nr; q += gridDim.y) {
+        uint64_t b, e;
+        own_range(sel, n, q, b, e);
+        // whole groups of four positions where acc is 16-byte and out 4- (8-) byte aligned
+        uint64_t bb = b + ((16u - (uint32_t)(reinterpret_cast<uintptr_t>(acc + b) & 15u)) & 15u) / 4u, be;
+        if (bb > e) bb = e;
+        if ((reinterpret_cast<uintptr_t>(out + bb) & (sizeof(TValue) * 4 - 1)) != 0) { bb = b; be = b; } else be = bb + (e - bb) / 4 * 4;
+        for (uint64_t j = b + tid; j < bb; j += nth) { const uint32_t v = acc[j]; out[j] = (TValue)(v < maxVal ? v : maxVal); }
+        for (uint64_t j = be + tid; j < e; j += nth) { const uint32_t v = acc[j]; out[j] = (TValue)(v < maxVal ? v : maxVal); }
+        for (uint64_t g = tid; g < (be - bb) / 4; g += nth) {
+            const uint4 v = *reinterpret_cast<const uint4*>(acc + bb + g * 4);
+            TValue r[4] = {(TValue)(v.x < maxVal ? v.x : maxVal), (TValue)(v.y < maxVal ? v.y : maxVal),
+                           (TValue)(v.z < maxVal ? v.z : maxVal), (TValue)(v.w < maxVal ? v.w : maxVal)};
+            if (sizeof(TValue) == 1) *reinterpret_cast<uint32_t*>(out + bb + g * 4) = *reinterpret_cast<uint32_t*>(r);
+            else *reinterpret_cast<uint2*>(out + bb + g * 4) = *reinterpret_cast<uint2*>(r);
+        }
     }
 }
 
@@ -975,11 +1028,15 @@ __global__ __launch_bounds__(256) void finalize_kernel(const uint32_t* __restric
 template <typename TValue>
 __global__ __launch_bounds__(256) void finalize_fileset_kernel(const uint32_t* __restrict__ bits, uint32_t wordsPerKmer, TValue* __restrict__ out, uint64_t n, ChunkSel sel)
 {
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
-        if (!chunk_mine(sel, j)) continue;
-        uint32_t c = 0;
-        for (uint32_t w = 0; w < wordsPerKmer; ++w) c += (uint32_t)__popc(bits[j * wordsPerKmer + w]);
-        out[j] = (TValue)c;
+    const uint64_t nr = own_ranges(sel, n);
+    for (uint64_t q = blockIdx.y; q < nr; q += gridDim.y) {
+        uint64_t b, e;
+        own_range(sel, n, q, b, e);
+        for (uint64_t j = b + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < e; j += (uint64_t)gridDim.x * blockDim.x) {
+            uint32_t c = 0;
+            for (uint32_t w = 0; w < wordsPerKmer; ++w) c += (uint32_t)__popc(bits[j * wordsPerKmer + w]);
+            out[j] = (TValue)c;
+        }
     }
 }
 
@@ -1038,9 +1095,20 @@ __global__ __launch_bounds__(256) void sa_compact_kernel(const uint32_t* __restr
 // zero the calling shard's chunks of a workspace (elements of `eb` bytes, positions [0, n) of the range)
 __global__ __launch_bounds__(256) void clear_chunks_kernel(uint8_t* __restrict__ base, uint32_t eb, uint64_t n, ChunkSel sel)
 {
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
-        if (!chunk_mine(sel, j)) continue;
-        if (eb == 1) base[j] = 0; else if (eb == 2) reinterpret_cast<uint16_t*>(base)[j] = 0; else reinterpret_cast<uint32_t*>(base)[j] = 0;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t nr = own_ranges(sel, n);
+    for (uint64_t q = blockIdx.y; q < nr; q += gridDim.y) {
+        uint64_t b, e;
+        own_range(sel, n, q, b, e);
+        uint8_t* p = base + b * eb;                    // bytes [0, nb): head up to a 16-byte boundary, whole vectors, tail
+        const uint64_t nb = (e - b) * eb;
+        uint64_t h = (16u - (uint32_t)(reinterpret_cast<uintptr_t>(p) & 15u)) & 15u;
+        if (h > nb) h = nb;
+        const uint64_t nv = (nb - h) / 16;
+        for (uint64_t j = tid; j < h; j += nth) p[j] = 0;
+        for (uint64_t j = h + nv * 16 + tid; j < nb; j += nth) p[j] = 0;
+        uint4* v = reinterpret_cast<uint4*>(p + h);
+        for (uint64_t j = tid; j < nv; j += nth) v[j] = make_uint4(0, 0, 0, 0);
     }
 }
 
