@@ -347,9 +347,88 @@ bool save_wig(const void* c, uint64_t n, int width, const std::string& stem, con
     (void)n;
     return write_wig([&](auto fn) { for_each_run(c, width, seqs, fn); }, stem, seqs, mappability, err);
 }
+// ---- run lists from the GPU, formatted on all host cores ---------------------------------------------------------------
+// A wig / bedgraph / bed line depends only on its run (and, for wig's "variableStep" header, on the run before it in the same
+// sequence), so batches of runs are formatted by all host threads into per-thread buffers and written in order.  At 3.09 Gbp
+// the single-threaded writer spent 18.5 s of a 28 s `genmap map -bg` here (profiles/r02/cli_scale_grch38.txt).
+namespace {
+inline void append_u64(std::string& o, uint64_t v)
+{
+    char b[24]; int n = 0;
+    do { b[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) o.push_back(b[--n]);
+}
+enum class RunText { Wig, Bedgraph, Bed };
+
+bool write_runs_parallel(const RunsInput& runs, const SeqTable& seqs, RunText kind, bool mappability, BufferedFile& f)
+{
+    std::vector<std::string> valueText(65536);   // text of every value (operator<< of float == "%g", of integers == "%u")
+    {
+        std::vector<uint8_t> used(65536, 0);
+        for (uint64_t r = 0; r < runs.n; ++r) used[runs.value[r]] = 1;
+        for (uint32_t v = 0; v < 65536; ++v) if (used[v]) { char b[32]; int n = mappability ? fmt_float(b, inverse_of(v)) : snprintf(b, sizeof b, "%u", v); valueText[v].assign(b, (size_t)n); }
+    }
+    std::vector<uint64_t> cum(seqs.lengths.size() + 1, 0);
+    for (size_t s = 0; s < seqs.lengths.size(); ++s) cum[s + 1] = cum[s] + seqs.lengths[s];
+    auto seq_of = [&](uint64_t pos) {   // sequence holding slice position pos (empty trailing positions belong to the last one)
+        size_t s = (size_t)(std::upper_bound(cum.begin(), cum.end(), pos) - cum.begin());
+        s = s ? s - 1 : 0;
+        return std::min(s, seqs.lengths.size() - 1);
+    };
+    const unsigned T = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    const uint64_t BATCH = 16ull << 20;
+    std::vector<std::string> buf(T);
+    for (uint64_t b0 = 0; b0 < runs.n; b0 += BATCH) {
+        const uint64_t b1 = std::min(runs.n, b0 + BATCH), per = (b1 - b0 + T - 1) / T;
+        auto work = [&](unsigned t) {
+            std::string& o = buf[t]; o.clear();
+            const uint64_t r0 = std::min(b1, b0 + t * per), r1 = std::min(b1, r0 + per);
+            if (r0 >= r1) return;
+            o.reserve((size_t)(r1 - r0) * 40);
+            size_t s = seq_of(runs.start[r0]);
+            // wig: span of the previous non-zero run of the same sequence (src/output.hpp:88-90)
+            uint64_t lastSpan = 0;
+            if (kind == RunText::Wig && r0 > 0 && seq_of(runs.start[r0 - 1]) == s) lastSpan = runs.length[r0 - 1];
+            for (uint64_t r = r0; r < r1; ++r) {
+                const uint64_t st = runs.start[r];
+                while (s + 1 < seqs.lengths.size() && st >= cum[s + 1]) { ++s; lastSpan = 0; }
+                const uint64_t in = st - cum[s], len = runs.length[r];
+                const uint32_t v = runs.value[r];
+                if (v == 0) continue;
+                if (kind == RunText::Wig) {
+                    if (lastSpan != len) { o += "variableStep chrom="; o += seqs.names[s]; o += " span="; append_u64(o, len); o.push_back('\n'); }
+                    append_u64(o, in + 1); o.push_back(' '); o += valueText[v]; o.push_back('\n');
+                    lastSpan = len;
+                } else {
+                    o += seqs.names[s]; o.push_back('\t'); append_u64(o, in); o.push_back('\t'); append_u64(o, in + len); o.push_back('\t');
+                    if (kind == RunText::Bed) { o.push_back('-'); o.push_back('\t'); }
+                    o += valueText[v]; o.push_back('\n');
+                }
+            }
+        };
+        if (b1 - b0 < (1u << 16)) { for (unsigned t = 0; t < T; ++t) work(t); }   // small outputs: not worth the threads
+        else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < T; ++t) th.emplace_back(work, t);
+            for (auto& x : th) x.join();
+        }
+        for (unsigned t = 0; t < T; ++t) f.put(buf[t]);
+    }
+    return true;
+}
+}  // namespace
+
 bool save_wig_runs(const RunsInput& runs, const std::string& stem, const SeqTable& seqs, bool mappability, std::string& err)
 {
-    return write_wig([&](auto fn) { for_each_given_run(runs, seqs, fn); }, stem, seqs, mappability, err);
+    {
+        BufferedFile f(stem + ".wig");
+        if (!f.ok()) { err = "cannot write " + stem + ".wig"; return false; }
+        if (!seqs.lengths.empty()) write_runs_parallel(runs, seqs, RunText::Wig, mappability, f);
+    }
+    BufferedFile g(stem + ".chrom.sizes");   // src/output.hpp:129-133
+    if (!g.ok()) { err = "cannot write " + stem + ".chrom.sizes"; return false; }
+    for (size_t s = 0; s < seqs.lengths.size(); ++s) { g.put(seqs.names[s]); g.put('\t'); g.put_u64(seqs.lengths[s]); g.put('\n'); }
+    return true;
 }
 
 template <class Each>
@@ -373,7 +452,10 @@ bool save_bedgraph(const void* c, uint64_t n, int width, const std::string& stem
 }
 bool save_bedgraph_runs(const RunsInput& runs, const std::string& stem, const SeqTable& seqs, bool bedgraph, bool mappability, std::string& err)
 {
-    return write_bedgraph([&](auto fn) { for_each_given_run(runs, seqs, fn); }, stem, seqs, bedgraph, mappability, err);
+    BufferedFile f(stem + (bedgraph ? ".bedgraph" : ".bed"));
+    if (!f.ok()) { err = "cannot write " + stem; return false; }
+    if (!seqs.lengths.empty()) write_runs_parallel(runs, seqs, bedgraph ? RunText::Bedgraph : RunText::Bed, mappability, f);
+    return true;
 }
 
 bool save_csv(const std::string& stem, const CsvInput& in, const SeqTable& seqs, uint32_t K, bool revCompl,

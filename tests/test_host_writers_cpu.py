@@ -118,6 +118,39 @@ def test_run_length_writers_reproduce_reference_files(case, hostlib, tmp_path):
     assert checked >= 4
 
 
+def _runs_vectorised(c, lens):
+    c = np.asarray(c); n = len(c)
+    head = np.ones(n, bool); head[1:] = c[1:] != c[:-1]
+    head[np.cumsum(lens)[:-1]] = True
+    st = np.flatnonzero(head); ln = np.diff(np.append(st, n)); va = c[st]
+    keep = va != 0
+    z = np.zeros(1, np.uint64)
+    return (np.concatenate([st[keep].astype(np.uint64), z]), np.concatenate([ln[keep].astype(np.uint64), z]),
+            np.concatenate([va[keep].astype(np.uint16), z.astype(np.uint16)]), int(keep.sum()))
+
+
+@pytest.mark.parametrize("kind", [0, 2])   # mappability (1/v as %g), 16-bit frequencies
+def test_run_length_writers_on_all_cores_equal_the_serial_ones(kind, hostlib, tmp_path):
+    """run lists long enough for the threaded formatter (several threads, unequal shares, sequence boundaries inside a share,
+    a span repeated across a share boundary) against the dense single-threaded writers of the same vector"""
+    rng = np.random.default_rng(5 + kind)
+    lens = np.array([250_001, 7, 190_000, 1, 359_991], dtype=np.uint64)
+    n = int(lens.sum())
+    c = np.ascontiguousarray(np.repeat(rng.integers(0, 4, size=n), rng.integers(1, 4, size=n))[:n].astype(np.uint16))
+    assert len(c) == n
+    c[1000:3000] = 7; c[300_000:300_050] = 65535
+    names = ["chrA", "s 2", "chrB", "x", "tail"]
+    st, ln, va, nr = _runs_vectorised(c, [int(x) for x in lens])
+    assert nr > (1 << 17)
+    for bit, exts in ((4, [".wig", ".chrom.sizes"]), (8, [".bedgraph"]), (16, [".bed"])):
+        a, b = tmp_path / f"dense{bit}", tmp_path / f"runs{bit}"
+        a.mkdir(); b.mkdir()
+        assert hostlib.gmh_save_outputs(H._ptr(c), n, 2, str(a / "o").encode(), kind, bit, _names(names), H._ptr(lens), len(lens)) == 0
+        assert hostlib.gmh_save_outputs_runs(nr, H._ptr(st), H._ptr(ln), H._ptr(va), str(b / "o").encode(), kind, bit, _names(names), H._ptr(lens), len(lens)) == 0
+        for ext in exts:
+            assert filecmp.cmp(a / ("o" + ext), b / ("o" + ext), shallow=False), (kind, bit, ext)
+
+
 @pytest.mark.parametrize("case", sorted(H.CASES))
 def test_csv_writer_reproduces_reference_files(case, hostlib, tmp_path):
     """oracle location lists -> gm_locate's CSR layout -> C++ csv writer == golden csv"""
