@@ -262,11 +262,11 @@ bool save_raw(const void* c, uint64_t n, int width, const std::string& stem, Val
     const char* ext = kind == ValueKind::Mappability ? ".map" : kind == ValueKind::Freq8 ? ".freq8" : ".freq16";   // src/mappability.hpp:104-112
     BufferedFile f(stem + ext);
     if (!f.ok()) { err = "cannot write " + stem + ext; return false; }
-    if (kind == ValueKind::Mappability) {   // float32 of 1/v, 0 stays 0 (src/output.hpp:17-24)
-        std::vector<float> buf(1 << 16);
+    if (kind == ValueKind::Mappability) {   // float32 of 1/v, 0 stays 0 (src/output.hpp:17-24); converted on all host cores
+        std::vector<float> buf((size_t)std::min<uint64_t>(n, 64ull << 20));
         for (uint64_t i = 0; i < n; i += buf.size()) {
-            uint64_t m = std::min<uint64_t>(buf.size(), n - i);
-            for (uint64_t j = 0; j < m; ++j) buf[j] = inverse_of(val_at(c, width, i + j));
+            const uint64_t m = std::min<uint64_t>(buf.size(), n - i);
+            parallel_ranges(m, [&](uint64_t b, uint64_t e) { for (uint64_t j = b; j < e; ++j) buf[j] = inverse_of(val_at(c, width, i + j)); });
             f.put((const char*)buf.data(), m * sizeof(float));
         }
     } else {
@@ -279,13 +279,37 @@ bool save_txt(const void* c, uint64_t n, int width, const std::string& stem, con
 {
     BufferedFile f(stem + ".txt");
     if (!f.ok()) { err = "cannot write " + stem + ".txt"; return false; }
+    // text of every value that occurs (operator<< of a float == "%g"), then the positions of a sequence in batches formatted by
+    // all host cores: "v v v ... v\n" (src/output.hpp:43-69)
+    std::vector<std::string> valueText(width == 1 ? 256 : 65536);
+    {
+        std::vector<uint8_t> used(valueText.size(), 0);
+        parallel_ranges(n, [&](uint64_t b, uint64_t e) { for (uint64_t j = b; j < e; ++j) used[val_at(c, width, j)] = 1; });   // (racing writers store the same 1)
+        for (uint32_t v = 0; v < valueText.size(); ++v) if (used[v]) { char t[32]; int k = mappability ? fmt_float(t, inverse_of(v)) : snprintf(t, sizeof t, "%u", v); valueText[v].assign(t, (size_t)k); }
+    }
+    const unsigned T = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    std::vector<std::string> buf(T);
     uint64_t pos = 0;
-    for (size_t s = 0; s < seqs.lengths.size(); ++s) {   // src/output.hpp:43-69
+    for (size_t s = 0; s < seqs.lengths.size(); ++s) {
         f.put('>'); f.put(seqs.names[s]); f.put('\n');
-        for (uint64_t k = 0; k < seqs.lengths[s]; ++k, ++pos) {
-            if (k) f.put(' ');
-            f.put_value(val_at(c, width, pos), mappability);
+        const uint64_t len = seqs.lengths[s], BATCH = 64ull << 20;
+        for (uint64_t k0 = 0; k0 < len; k0 += BATCH) {
+            const uint64_t k1 = std::min(len, k0 + BATCH), per = (k1 - k0 + T - 1) / T;
+            auto work = [&](unsigned t) {
+                std::string& o = buf[t]; o.clear();
+                const uint64_t a0 = std::min(k1, k0 + t * per), a1 = std::min(k1, a0 + per);
+                o.reserve((size_t)(a1 - a0) * 4);
+                for (uint64_t k = a0; k < a1; ++k) { if (k) o.push_back(' '); o += valueText[val_at(c, width, pos + k)]; }
+            };
+            if (k1 - k0 < (1u << 16)) { for (unsigned t = 0; t < T; ++t) work(t); }
+            else {
+                std::vector<std::thread> th;
+                for (unsigned t = 0; t < T; ++t) th.emplace_back(work, t);
+                for (auto& x : th) x.join();
+            }
+            for (unsigned t = 0; t < T; ++t) f.put(buf[t]);
         }
+        pos += len;
         f.put('\n');
     }
     (void)n;

@@ -149,6 +149,19 @@ def test_run_length_writers_on_all_cores_equal_the_serial_ones(kind, hostlib, tm
         assert hostlib.gmh_save_outputs_runs(nr, H._ptr(st), H._ptr(ln), H._ptr(va), str(b / "o").encode(), kind, bit, _names(names), H._ptr(lens), len(lens)) == 0
         for ext in exts:
             assert filecmp.cmp(a / ("o" + ext), b / ("o" + ext), shallow=False), (kind, bit, ext)
+    # the dense txt / raw writers, also threaded: against a restatement in Python
+    t = tmp_path / "txt"; t.mkdir()
+    assert hostlib.gmh_save_outputs(H._ptr(c), n, 2, str(t / "o").encode(), kind, 3, _names(names), H._ptr(lens), len(lens)) == 0
+    inv = np.zeros(65536, np.float32); inv[1:] = np.float32(1) / np.arange(1, 65536, dtype=np.float32)
+    text = np.array([("%g" % inv[v]) if kind == 0 else str(v) for v in range(65536)], dtype=object)
+    exp, pos = [], 0
+    for nm, ln in zip(names, lens):
+        exp.append(">" + nm + "\n" + " ".join(text[c[pos:pos + int(ln)]]) + "\n"); pos += int(ln)
+    assert (t / "o.txt").read_text() == "".join(exp)
+    if kind == 0:
+        assert np.array_equal(np.fromfile(t / "o.map", dtype=np.float32), inv[c])
+    else:
+        assert np.array_equal(np.fromfile(t / "o.freq16", dtype=np.uint16), c)
 
 
 @pytest.mark.parametrize("case", sorted(H.CASES))
