@@ -294,6 +294,38 @@ def test_gpu_interleaved_chunk_shards_fill_one_vector():
     ix.close()
 
 
+def test_gpu_result_vector_at_any_alignment_and_width_with_chunks():
+    """clear / finalize move 16 bytes per lane where planes and result are aligned alike and fall back to single elements where
+    they are not: results at odd device offsets, 8- and 16-bit, plain e = 0 planes, e = 1 accumulators and --exclude-pseudo bit
+    sets, alone and as interleaved chunks (chunk lengths are no multiples of 16)"""
+    g = _gm()
+    import torch
+    from genmap_amd.distributed import ShardPlan
+    rng = np.random.default_rng(78)
+    lens = [100003, 19, 77777, 5, 60001]
+    codes = _repeat_text(rng, sum(lens), True)
+    n = sum(lens)
+    fid = np.array([0, 0, 1, 1, 2], dtype=np.uint32)
+    ix = g.Index.build(codes, lens, sampling=1)
+    st = torch.cuda.current_stream().cuda_stream
+    for K, E, bits, ep in ((30, 0, 8, False), (30, 0, 16, False), (21, 1, 8, False), (21, 1, 16, False), (24, 1, 16, True), (24, 0, 8, True)):
+        kw = dict(value_bits=bits, exclude_pseudo=ep, seq_file_id=fid if ep else None)
+        full = ix.map(K, E, **kw)
+        tdt = torch.uint8 if bits == 8 else torch.uint16
+        for off in (0, 1, 3, 8, 13):
+            for world in (1, 3):
+                plan = ShardPlan(n - K + 1, K - g.tuned_infix_length(K, E) + 1, world, chunks_per_rank=5)
+                dev = torch.zeros(plan.padded_len(n) + 64, dtype=tdt, device="cuda:0")
+                view = dev[off:]
+                for r in range(world):
+                    ix.map_device(view.data_ptr(), K, E, chunks=plan.chunk_arg(r) if world > 1 else None, stream=st, **kw)
+                torch.cuda.synchronize()
+                whole = dev.cpu().numpy() if bits == 8 else dev.view(torch.int16).cpu().numpy().view(np.uint16)
+                assert np.array_equal(whole[off:off + n], full), (K, E, bits, ep, off, world)
+                assert not whole[:off].any() and not whole[off + n:off + n + 32].any()   # nothing written outside the vector
+    ix.close()
+
+
 def test_gpu_many_short_sequences_and_extremes():
     """read-set-like input (thousands of short sequences, many shorter than K), K at the encoding limit, K == 1,
     texts shorter than K, 8-bit saturation on a low-complexity text"""
