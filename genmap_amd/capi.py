@@ -35,7 +35,7 @@ class IndexInfo(C.Structure):
 
 class MapStats(C.Structure):
     _fields_ = [("kmers", C.c_uint64), ("roots", C.c_uint64), ("node_steps", C.c_uint64), ("rank_lines", C.c_uint64),
-                ("detail", C.c_uint64 * 20), ("search_ms", C.c_double), ("total_ms", C.c_double)]
+                ("detail", C.c_uint64 * 40), ("search_ms", C.c_double), ("total_ms", C.c_double)]
 
 
 class Runs(C.Structure):
@@ -405,5 +405,7 @@ class Index:
         s = MapStats()
         _check(self._lib, self._lib.gm_last_map_stats(self._h, C.byref(s)))
         d = {k: getattr(s, k) for k, _ in MapStats._fields_}
-        d["detail"] = dict(zip(("steps_oss", "steps_ext", "ext_w1", "ext_w2_4", "oss_w1", "pushes", "verify_items", "verify_items_oss", "verify_chunks", "wave_iterations", "active_lane_sum", "verify_rounds", "cyc_fetch", "cyc_verify", "cyc_step", "cyc_pop", "cyc_share", "cyc_stage32", "cyc_stage1", "stolen"), list(s.detail)))
+        d["detail"] = dict(zip(("steps_oss", "steps_ext", "ext_w1", "ext_w2_4", "oss_w1", "pushes", "verify_items", "verify_items_oss", "verify_chunks", "wave_iterations", "active_lane_sum", "verify_rounds", "cyc_fetch", "cyc_verify", "cyc_step", "cyc_pop", "cyc_share", "cyc_stage32", "cyc_stage1", "stolen",
+                                "w_pop", "w_saturated", "w_share", "w_stage3", "w_stage2", "w_stage1", "w_defer", "w_split", "w_miss_round", "w_leaf", "w_leaf_flush",
+                                "w_v_block", "w_v_chunk", "w_v_event", "w_v_kmer", "w_push_hbm"), list(s.detail)))
         return d

@@ -29,9 +29,9 @@ void set_error(const char* fmt, ...)
 // dimension and wide indexes have more rows than that
 static inline unsigned grid_for(uint64_t n, unsigned bs = 256) { return (unsigned)std::min<uint64_t>((n + bs - 1) / bs, 1u << 22); }
 
-// d_small: work counter (8 B) | pad | statistics counters (17 x 8 B at +16), zeroed by every call  ||  +256: sticky error flag
+// d_small: work counter (8 B) | pad | statistics counters (42 x 8 B at +16), zeroed by every call  ||  +512: sticky error flag
 // (set by a device-side invariant check, surfaced and cleared by the next host-side check: gm_map, gm_index_sync, gm_last_map_stats)
-constexpr size_t SMALL_BYTES = 512, SMALL_ZEROED = 256, SMALL_ERR_OFF = 256;
+constexpr size_t SMALL_BYTES = 1024, SMALL_ZEROED = 512, SMALL_ERR_OFF = 512;   // [0,16) work counter, [16,512) statistics, 512: sticky error flag
 
 // ---- rank block construction -------------------------------------------------------------------------------
 // cnt[c * (nb + 1) + q] = letters c in block q; entry nb is zero so that the exclusive scan leaves the total there.
@@ -814,7 +814,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     // indexes (3.09 Gbp: e=1 +8 %, e=0 +1 %), small calls (tail of the kernel); it costs 30 % at e = 2, where stolen subtrees
     // are searched before the counters that would have pruned them saturate (profiles/r02/sweep_chr1_steal_*.txt)
     const bool stealDefault = (p->E <= 1 && p->K < 64 && ix->nRows >= (1ull << 30)) || S->numRoots < 64ull * 4ull * 1024ull;
-    A.steal = ix->tune.steal >= 0 ? (uint32_t)(ix->tune.steal != 0) : (stealDefault ? 1u : 0u);
+    A.steal = ix->tune.steal >= 0 ? (uint32_t)std::min(ix->tune.steal, 64) : (stealDefault ? 1u : 0u);   // value: idle lanes that trigger an exchange
     A.coop = ix->tune.coop >= 0 ? (uint32_t)(ix->tune.coop != 0) : (ix->wpp == 1 ? 1u : 0u);
     if (ix->wide) A.coop = 0u;
     *Aout = A;
@@ -1361,10 +1361,10 @@ int gm_last_map_stats(const gm_index* cix, gm_map_stats* out)
     { const uint32_t slot = (uint32_t)((ix->evCount - 1) % gm_index::EV_RING); GM_HIP(hipEventElapsedTime(&a, ix->evRing[slot][0], ix->evRing[slot][1])); }
     GM_HIP(hipEventElapsedTime(&b, ix->ev[0], ix->ev[3]));
     ix->stats.search_ms = a; ix->stats.total_ms = b;
-    unsigned long long cnt[22] = {0};
+    unsigned long long cnt[42] = {0};
     GM_HIP(hipMemcpy(cnt, reinterpret_cast<char*>(ix->d_small) + 16, sizeof(cnt), hipMemcpyDeviceToHost));
     ix->stats.node_steps = cnt[0]; ix->stats.rank_lines = cnt[1];
-    for (int i = 0; i < 20; ++i) ix->stats.detail[i] = cnt[2 + i];
+    for (int i = 0; i < 40; ++i) ix->stats.detail[i] = cnt[2 + i];
     int rc = check_device_error(ix);
     *out = ix->stats;
     return rc;

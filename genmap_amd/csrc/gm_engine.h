@@ -193,7 +193,7 @@ GM_HD void lane_children(NodeT<typename Env::row_t>& nd, bool& have, const RootT
         const R cx = tc == 0 ? cnt[0] : tc == 1 ? cnt[1] : tc == 2 ? cnt[2] : cnt[3];
         const R pnew = tc == 0 ? pn[0] : tc == 1 ? pn[1] : tc == 2 ? pn[2] : pn[3];
         const R onew = olo + (tc == 0 ? sm[0] : tc == 1 ? sm[1] : tc == 2 ? sm[2] : sm[3]);
-        if (ps.leaf) env.leaf(rt, ps.kmer, pl.right ? onew : pnew, cx);
+        if (ps.leaf) { env.note_wave(9); env.leaf(rt, ps.kmer, pl.right ? onew : pnew, cx); }
         else {
             keep.flo = pl.right ? onew : pnew;
             keep.rlo = pl.right ? pnew : onew;
@@ -211,6 +211,7 @@ GM_HD void lane_children(NodeT<typename Env::row_t>& nd, bool& have, const RootT
             const bool on = ((miss >> x) & 1u) != 0u;
             if (!env.any(on)) continue;
             if (on) {
+                env.note_wave(8);
                 const R pnew = pn[x], onew = olo + sm[x];
                 if (ps.leaf) env.leaf(rt, ps.kmer, pl.right ? onew : pnew, cnt[x]);
                 else {
@@ -224,7 +225,7 @@ GM_HD void lane_children(NodeT<typename Env::row_t>& nd, bool& have, const RootT
             }
         }
     }
-    if (ps.leaf) env.leaf_flush(rt, ps.kmer);
+    if (ps.leaf) { env.note_wave(10); env.leaf_flush(rt, ps.kmer); }
     nd = keep; have = haveKeep;
 }
 
@@ -274,13 +275,14 @@ GM_HD uint32_t scan_side(Env& env, const RootT<typename Env::row_t>& rt, const t
         const uint32_t q = down ? q0 - i : q0 + i;
         const uint64_t n8 = env.needle8(rt, q, down);
         const uint64_t t8 = env.text8(it, (int32_t)q - (int32_t)a0, down);
-        env.note_chunk();
+        env.note_chunk(); env.note_wave(12);
         uint64_t ev = bytes_nonzero(n8 ^ t8) | (0x8080808080808080ull & ~bytes_nonzero(n8 ^ 0x0404040404040404ull))   // mismatch, pattern N
                       | (0x8080808080808080ull & ~bytes_nonzero(t8 ^ 0x0505050505050505ull));                           // sentinel
         const uint32_t left = need - i;
         if (left < 8u) ev &= (1ull << (8u * left)) - 1ull;
         const uint64_t sent = 0x8080808080808080ull & ~bytes_nonzero(t8 ^ 0x0505050505050505ull);
         while (ev) {
+            env.note_wave(13);
             const uint32_t bit = ctz64(ev);
             ev &= ev - 1ull;
             const uint32_t j = bit >> 3;
@@ -307,6 +309,7 @@ GM_HD void verify_item(typename Env::row_t row, uint32_t meta, const RootT<typen
     if (mode == M_OSS) {
         const uint32_t nb = oss_nb(rt.rec);
         for (uint32_t bi = t; bi < nb; ++bi) {
+            env.note_wave(11);
             const uint32_t right = oss_right(rt.rec, bi), blen = oss_bl(rt.rec, bi), u = oss_u(rt.rec, bi), l = oss_l(rt.rec, bi);
             const uint32_t need = blen - (bx - a);
             uint32_t c = 0;
@@ -328,6 +331,7 @@ GM_HD void verify_item(typename Env::row_t row, uint32_t meta, const RootT<typen
     const uint32_t rlim = scan_side(env, rt, it, a0, bx, false, smax + K - bx, budget, rc, rp);
     const uint32_t llim = scan_side(env, rt, it, a0, a - 1u, true, a - smin, budget, lc, lp);
     for (uint32_t s = smin; s <= smax; ++s) {
+        env.note_wave(14);
         const uint32_t lenL = a - s, lenR = s + K - bx;
         if (lenL > llim || lenR > rlim) continue;
         uint32_t d = 0;

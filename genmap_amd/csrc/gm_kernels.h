@@ -74,7 +74,8 @@ struct SearchArgs {
     uint32_t startPacked[2];        // 8 bits per search: startPos of the regular block shape (n == stepSize)
     uint32_t skipDup;               // 1: the range-hi block is not loaded when it is the range-lo block (saves a translation per shared step)
     uint32_t coop;                  // 1: rank blocks are read by groups of lanes (rank2_coop); 32- and 64-byte blocks
-    uint32_t steal;                 // 1: lanes without work take the bottom of a neighbour's stack (work sharing inside the wavefront)
+    uint32_t steal;                 // > 0: lanes without work take the bottom of a neighbour's stack (work sharing inside the wavefront),
+                                    //      an exchange runs when at least this many lanes are idle
     uint32_t chunkBlocks, chunkStride, chunkIndex;   // != 0: this call owns the chunks c = chunkIndex (mod chunkStride) of chunkBlocks blocks each
 };
 
@@ -198,6 +199,9 @@ template <int WPP> struct EnvBase {
     uint32_t K;
 #ifdef GM_COUNTERS
     uint32_t steps = 0, lines = 0, stOss = 0, stExt = 0, stExtW1 = 0, stExtW4 = 0, stOssW1 = 0, pushes = 0, vItems = 0, vItemsOss = 0, vChunks = 0;
+    uint32_t whit[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // a wavefront passed here (counted by its first enabled lane): the dynamic cost of a region = passes x its instructions
+    __device__ __forceinline__ void note_wave(int i) { const unsigned long long m = __ballot(true); if (__lane_id() == (unsigned)(__ffsll((long long)m) - 1)) whit[i]++; }
     __device__ __forceinline__ void note_chunk() { vChunks++; }
     __device__ __forceinline__ void note_item(uint32_t mode) { vItems++; vItemsOss += (mode == M_OSS); }
     __device__ __forceinline__ void note_step(uint32_t mode, row_t w)
@@ -208,6 +212,7 @@ template <int WPP> struct EnvBase {
     __device__ __forceinline__ void note_step(uint32_t, row_t) {}
     __device__ __forceinline__ void note_chunk() {}
     __device__ __forceinline__ void note_item(uint32_t) {}
+    __device__ __forceinline__ void note_wave(int) {}
 #endif
     __device__ __forceinline__ EnvBase(const SearchArgs& a, uint4* s, uint32_t k) : A(a), stk(s), lstk(nullptr), lwin(nullptr), woff(0), sp(0), sbase(0), K(k) {}
     __device__ __forceinline__ Node pop()
@@ -343,6 +348,7 @@ template <int WPP> struct EnvBase {
         const uint32_t lv = sbase + sp;
         // wave-uniform fast path (scalar branch, no exec-mask juggling): nobody in the wavefront is past the LDS levels
         if (__ballot(lv >= A.ldsDepth) == 0ull) { IO::store(lstk + (size_t)lv * IO::NU * 64u, 64u, nd); ++sp; return; }
+        note_wave(15);
         if (lv < A.ldsDepth) { IO::store(lstk + (size_t)lv * IO::NU * 64u, 64u, nd); ++sp; }
         else if (lv < A.stackDepth) { IO::store(stk + (size_t)(lv - A.ldsDepth) * IO::NU * 64u, 64u, nd); ++sp; }
         else *A.errorFlag = 1u;   // never expected: depth = stack_bound(E, stepSize) (+ STEAL_LEVELS with work sharing)
@@ -643,8 +649,10 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
         for (int tries = 0; tries < 4 && !have && env.sp > 0; ++tries) {
 #endif
             nd = env.pop(); w1run = 0;
+            env.note_wave(0);
             uint32_t smin, smax;
             covered_kmers(nd.meta, rt.n, A.K, smin, smax);
+            if (nd.w >= A.satMinW) env.note_wave(1);
             have = !(nd.w >= A.satMinW && env.saturated(rt, smin, smax));   // pending work for k-mers that already reached MAX is dropped
         }
         GM_LAP2(tPop);
@@ -657,7 +665,8 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
             const bool idle = !have && env.sp == 0u && fs == 0u;
             const bool rich = have && env.sp >= 1u && env.sbase < STEAL_LEVELS;
             const unsigned long long im = __ballot(idle), vm = __ballot(rich);
-            if (im != 0ull && vm != 0ull) {
+            if ((uint32_t)__popcll(im) >= A.steal && vm != 0ull) {
+                env.note_wave(2);
                 const uint32_t np = min((uint32_t)__popcll(im), (uint32_t)__popcll(vm));
                 const uint32_t ri = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
                 const uint32_t rv = __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0u));
@@ -699,6 +708,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
         // ---- root fetch, pipelined over iterations so that the wavefront never waits for it ----
         // stage 3: the q-mer table entry has arrived -> the root becomes the lane's node (or turns out empty)
         if (fs == 2u) {
+            env.note_wave(3);
             fs = 0u;
             if (ftW != 0u) {
                 rt = frt; env.on_root();
@@ -708,6 +718,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
         }
         // stage 2: window chunks and record have arrived -> stage the window in LDS, look the first q characters up
         if (fs == 1u) {
+            env.note_wave(4);
             env.woff = fwoff;   // the window itself went from HBM straight into this lane's LDS slots (stage 1)
             frt.rec.x = frec.x; frt.rec.y = frec.y; frt.rec.z = frec.z; frt.rec.w = frec.w;
             if (fql == 0u) { rt = frt; env.on_root(); nd = root_node(rt, (row_t)A.nRows); have = true; fs = 0u; w1run = 0; }
@@ -756,6 +767,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                     poolBase = base;
                 }
             }
+            env.note_wave(5);
             const uint32_t avail = (uint32_t)(poolEnd - poolCur);
             const uint32_t want = (uint32_t)__popcll(m);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -831,6 +843,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                 const bool e = narrow && r < nd.w;
                 const unsigned long long m = __ballot(e);
                 if (m == 0ull) break;
+                env.note_wave(6);
                 if (e) {
                     const uint32_t slot = qsize + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                     IO::store_item(vq + (size_t)slot * NU, nd.flo + r, nd.meta, rt.win, rt.n | rt.strand << 8 | rt.search << 9);
@@ -872,6 +885,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
 #endif
         if (have) {
             if (meta_mode(nd.meta) == M_SPLIT) {
+                env.note_wave(7);
                 Node left; split_node(nd, left, A.K);
                 uint32_t smin, smax;
                 covered_kmers(left.meta, rt.n, A.K, smin, smax);
@@ -917,6 +931,8 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     atomicAdd(&A.counters[9], (unsigned long long)env.vItemsOss);
     atomicAdd(&A.counters[10], (unsigned long long)env.vChunks);
     atomicAdd(&A.counters[21], (unsigned long long)nSteals);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) if (env.whit[i]) atomicAdd(&A.counters[22 + i], (unsigned long long)env.whit[i]);
     if (lane == 0) {
         atomicAdd(&A.counters[11], (unsigned long long)wvIter);
         atomicAdd(&A.counters[12], (unsigned long long)wvActive);

@@ -227,12 +227,16 @@ typedef struct gm_map_stats {
     uint64_t roots;           /* (block, strand, search) work items */
     uint64_t node_steps;      /* bidirectional extensions evaluated (0 unless the library was built with GM_COUNTERS) */
     uint64_t rank_lines;      /* distinct rank blocks those steps read (same) */
-    uint64_t detail[20];      /* GM_COUNTERS only: steps in OSS phase, in extension phase, extension steps at range
+    uint64_t detail[40];      /* GM_COUNTERS only: steps in OSS phase, in extension phase, extension steps at range
                                  width 1, at width 2..4, OSS steps at width 1, nodes pushed to lane stacks,
                                  verification items, of which in OSS phase, 8-symbol comparison chunks,
                                  wavefront iterations, lanes holding a node summed over iterations, verification rounds,
                                  shader cycles (summed over wavefronts) in root fetch, verification, stepping;
-                                 [15..19]: cycles in pop, work sharing, fetch stages 3+2, fetch stage 1 (parts of "root fetch"), stolen nodes */
+                                 [15..19]: cycles in pop, work sharing, fetch stages 3+2, fetch stage 1 (parts of "root fetch"), stolen nodes;
+                                 [20..35]: how often a WAVEFRONT executed a code region (any lane enabled): pop, saturation
+                                 test, work-sharing exchange, fetch stage 3, 2, 1, deferral round, split, mismatch round,
+                                 leaf, leaf flush, verification: OSS block, 8-symbol chunk, mismatch event, k-mer loop
+                                 iteration; stack push past the LDS levels */
     double   search_ms;       /* HIP-event time of the search kernel alone */
     double   total_ms;        /* memset + search + finalize, HIP events on the call's stream */
 } gm_map_stats;

@@ -92,6 +92,7 @@ template <int WPP> struct EmuEnv {
     void note_step(uint32_t, uint32_t) {}
     bool any(bool b) const { return b; }
     void note_chunk() {}
+    void note_wave(int) {}
     void note_item(uint32_t) {}
     uint32_t leafSum = 0;
     void leaf(const Root&, uint32_t, uint32_t, uint32_t w) { leafSum += w; }
