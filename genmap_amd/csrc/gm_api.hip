@@ -810,11 +810,14 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     A.chunkBlocks = chunked ? p->chunk_blocks : 0u; A.chunkStride = p->chunk_stride; A.chunkIndex = p->chunk_index;
     A.skipDup = ix->tune.skipDup >= 0 ? (uint32_t)(ix->tune.skipDup != 0) : 1u;   // profiles/r02: +3..8 % on 3.09 Gbp, +1..5 % on 249 Mbp
     // groups of lanes read the rank blocks (rank2_coop): +4..12 % with 32-byte blocks on 249 Mbp and 3.09 Gbp (profiles/r02)
-    // work sharing inside the wavefront pays where lanes run dry often and pruning by saturation is rare: e <= 1 on large
-    // indexes (3.09 Gbp: e=1 +8 %, e=0 +1 %), small calls (tail of the kernel); it costs 30 % at e = 2, where stolen subtrees
-    // are searched before the counters that would have pruned them saturate (profiles/r02/sweep_chr1_steal_*.txt)
-    const bool stealDefault = (p->E <= 1 && p->K < 64 && ix->nRows >= (1ull << 30)) || S->numRoots < 64ull * 4ull * 1024ull;
-    A.steal = ix->tune.steal >= 0 ? (uint32_t)std::min(ix->tune.steal, 64) : (stealDefault ? 1u : 0u);   // value: idle lanes that trigger an exchange
+    // work sharing inside the wavefront (value = idle lanes that trigger an exchange): every idle lane at e <= 1 on large
+    // indexes (3.09 Gbp: e=1 +8 %, e=0 +1 %) and in small calls (tail of the kernel).  At e = 2 that costs 6..30 % -- stolen
+    // subtrees are searched before the counters that would have pruned them saturate -- but an exchange only when a quarter of
+    // the wavefront is idle gains 1.5 % (3.09 Gbp) to 5 % (249 Mbp) (profiles/r02/sweep_steal_e2.txt, sweep_chr1_steal_*.txt)
+    uint32_t stealDefault = 0u;
+    if ((p->E <= 1 && p->K < 64 && ix->nRows >= (1ull << 30)) || S->numRoots < 64ull * 4ull * 1024ull) stealDefault = 1u;
+    else if (p->E >= 2 && p->K < 64) stealDefault = 16u;
+    A.steal = ix->tune.steal >= 0 ? (uint32_t)std::min(ix->tune.steal, 64) : stealDefault;
     A.coop = ix->tune.coop >= 0 ? (uint32_t)(ix->tune.coop != 0) : (ix->wpp == 1 ? 1u : 0u);
     if (ix->wide) A.coop = 0u;
     *Aout = A;
