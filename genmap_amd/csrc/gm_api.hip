@@ -816,7 +816,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     // the wavefront is idle gains 1.5 % (3.09 Gbp) to 5 % (249 Mbp) (profiles/r02/sweep_steal_e2.txt, sweep_chr1_steal_*.txt)
     uint32_t stealDefault = 0u;
     if ((p->E <= 1 && p->K < 64 && ix->nRows >= (1ull << 30)) || S->numRoots < 64ull * 4ull * 1024ull) stealDefault = 1u;
-    else if (p->E >= 2 && p->K < 64) stealDefault = 16u;
+    else if (p->E >= 2) stealDefault = p->K < 64 ? 16u : 8u;   // K=100 e=2: 8 -> +5.7 %, 16 -> 0 (sweep_steal_longk.txt); e=1 at K >= 64: sharing loses 5..9 %
     A.steal = ix->tune.steal >= 0 ? (uint32_t)std::min(ix->tune.steal, 64) : stealDefault;
     A.coop = ix->tune.coop >= 0 ? (uint32_t)(ix->tune.coop != 0) : (ix->wpp == 1 ? 1u : 0u);
     if (ix->wide) A.coop = 0u;
