@@ -270,7 +270,7 @@ template <int WPP> struct EnvBase {
     // for; a butterfly of DPP exchanges then hands every owner the pieces of its own blocks.  Must be called with all 64
     // lanes enabled; lanes without a query pass lo = hi = 0.
     static __device__ __forceinline__ uint32_t opaque_zero() { uint32_t z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); return z; }
-    template <int CTRL> static __device__ __forceinline__ uint32_t dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false); }
+    template <int CTRL> static __device__ __forceinline__ uint32_t dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }   // every lane has a source inside its quad: bound_ctrl spares the zeroing of the destination
     template <int CTRL> static __device__ __forceinline__ uint4 dpp4(const uint4& v) { return make_uint4(dpp<CTRL>(v.x), dpp<CTRL>(v.y), dpp<CTRL>(v.z), dpp<CTRL>(v.w)); }
     static __device__ __forceinline__ uint4 sel4(bool c, const uint4& a, const uint4& b) { return make_uint4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w); }
     // exchange step of the transposition: lanes that differ in bit `bit` of their group index swap lo's upper with hi's lower register
