@@ -172,15 +172,17 @@ GM_HD void lane_children(NodeT<typename Env::row_t>& nd, bool& have, const RootT
 #pragma unroll
     for (int x = 0; x < (int)NLET; ++x) { cnt[x] = rh[x] - rl[x]; tot += cnt[x]; pn[x] = env.C((uint32_t)x) + rl[x]; }
     R run = nd.w - tot;   // sentinels in BWT[lo,hi) sort before every letter
-    uint32_t valid = 0;
+    uint32_t nonEmpty = 0;
 #pragma unroll
-    for (int x = 0; x < (int)NLET; ++x) {
-        sm[x] = run; run += cnt[x];
-        const uint32_t delta = ((uint32_t)x != tc || tc == SYM_N) ? 1u : 0u;       // find2:250, algo.hpp:111-112,148-149
-        const bool ok = cnt[x] != 0u && !(pl.exact && delta)                         // exact segment: only the needle letter
-                        && !(pl.minErr > 0u && pl.charsLeft + delta < pl.minErr + 1u);   // find2:254-258
-        valid |= (ok ? 1u : 0u) << x;
-    }
+    for (int x = 0; x < (int)NLET; ++x) { sm[x] = run; run += cnt[x]; nonEmpty |= (cnt[x] != 0u ? 1u : 0u) << x; }
+    // Which letters may be taken, as a mask (the same three conditions per letter would cost ~10 instructions each):
+    //   delta(x) = x != needle letter || needle letter is N                       find2:250, algo.hpp:111-112,148-149
+    //   exact segment: only delta == 0                                            find2:330, algo.hpp:117-125
+    //   lower bound of the block still reachable: charsLeft + delta >= minErr + 1   find2:254-258
+    const uint32_t matchBit = tc < SYM_N ? 1u << tc : 0u;
+    const bool okMatch = !(pl.minErr > 0u && pl.charsLeft < pl.minErr + 1u);
+    const bool okMiss = !pl.exact && !(pl.minErr > 0u && pl.charsLeft < pl.minErr);
+    const uint32_t valid = nonEmpty & ((okMatch ? matchBit : 0u) | (okMiss ? ((1u << NLET) - 1u) & ~matchBit : 0u));
 
     Node keep; keep.flo = keep.rlo = keep.w = keep.meta = 0;
     bool haveKeep = false;
