@@ -650,10 +650,13 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
 #endif
             nd = env.pop(); w1run = 0;
             env.note_wave(0);
-            uint32_t smin, smax;
-            covered_kmers(nd.meta, rt.n, A.K, smin, smax);
-            if (nd.w >= A.satMinW) env.note_wave(1);
-            have = !(nd.w >= A.satMinW && env.saturated(rt, smin, smax));   // pending work for k-mers that already reached MAX is dropped
+            have = true;
+            if (nd.w >= A.satMinW) {   // pending work for k-mers that already reached MAX is dropped
+                env.note_wave(1);
+                uint32_t smin, smax;
+                covered_kmers(nd.meta, rt.n, A.K, smin, smax);
+                have = !env.saturated(rt, smin, smax);
+            }
         }
         GM_LAP2(tPop);
         // ---- work sharing inside the wavefront: idle lanes take the bottom of the stack of lanes that have pending nodes ----
@@ -887,11 +890,15 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
             if (meta_mode(nd.meta) == M_SPLIT) {
                 env.note_wave(7);
                 Node left; split_node(nd, left, A.K);
-                uint32_t smin, smax;
-                covered_kmers(left.meta, rt.n, A.K, smin, smax);
-                const bool leftDone = nd.w >= A.satMinW && env.saturated(rt, smin, smax);
-                covered_kmers(nd.meta, rt.n, A.K, smin, smax);
-                if (nd.w >= A.satMinW && env.saturated(rt, smin, smax)) { if (leftDone) have = false; else nd = left; }
+                bool leftDone = false, rightDone = false;
+                if (nd.w >= A.satMinW) {   // (both halves have the parent's width)
+                    uint32_t smin, smax;
+                    covered_kmers(left.meta, rt.n, A.K, smin, smax);
+                    leftDone = env.saturated(rt, smin, smax);
+                    covered_kmers(nd.meta, rt.n, A.K, smin, smax);
+                    rightDone = env.saturated(rt, smin, smax);
+                }
+                if (rightDone) { if (leftDone) have = false; else nd = left; }
                 else if (!leftDone) env.push(left);
             }
             if constexpr (!COOP) if (have) {
