@@ -67,3 +67,18 @@ def test_tuned_infix_is_always_schedulable():
                 continue  # the call is rejected with GM_ERR_BAD_OVERLAP (infix shorter than the number of blocks)
             assert nb[E] <= t <= K, (K, E, t)
     assert g.tuned_infix_length(256, 0) == 0 and g.tuned_infix_length(30, 5) == 0
+
+
+def test_tuned_block_shape_at_one_error_follows_the_measured_rule():
+    """e = 1 (profiles/r02/sweep_grch38_steps*.txt): from K = 44 the first, exact OSS part keeps at least 17 characters
+    (infix >= 35); up to K = 112 the window K + n - 1 fits five 32-symbol LDS chunks; blocks never shrink as K grows past
+    the cliffs except where the window bound bites; BASELINE shapes are pinned"""
+    import genmap_amd as g
+    n = lambda K: K - g.tuned_infix_length(K, 1) + 1
+    assert (n(30), n(50), n(64), n(100), n(150), n(250)) == (5, 16, 16, 24, 48, 48)
+    assert g.tuned_infix_length(30, 0) == 16 and g.tuned_infix_length(30, 2) == 24 and g.tuned_infix_length(24, 1) == 20
+    for K in range(44, 256):
+        assert g.tuned_infix_length(K, 1) >= 35, K
+        if K <= 112:
+            assert K + n(K) - 1 <= 127, K
+        assert 5 <= n(K) <= 48
