@@ -137,7 +137,14 @@ def main():
     n = int(len(codes))
     log(f"workload {desc}: ready in {time.time() - t0:.1f} s")
     t0 = time.time()
-    ix = g.Index.build(codes, lens, sampling=args.sampling, block_bytes=args.block_bytes, device=local_rank)
+    if args.same_device and world > 1:   # rehearsal on one device: the builder's temporaries do not fit twice, build in turn
+        ix = None
+        for r in range(world):
+            if r == rank:
+                ix = g.Index.build(codes, lens, sampling=args.sampling, block_bytes=args.block_bytes, device=local_rank)
+            dist.barrier()
+    else:
+        ix = g.Index.build(codes, lens, sampling=args.sampling, block_bytes=args.block_bytes, device=local_rank)
     t_build = time.time() - t0
     info = ix.info()
     log(f"index built on the GPU in {t_build:.1f} s: {info['n_rows']} rows, {info['block_bytes']}-B blocks, {info['device_bytes'] / 2**30:.2f} GiB")

@@ -1,5 +1,12 @@
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "shard or chunk or baseline_settings or fixture or many_short or gtest_matrix or rehearsal or midsize or run_length" 2>&1 | tail -3
+#!/bin/bash
+# Two ranks sharing ONE device (gloo control plane) against one rank, same workload: what the multi-GPU data path costs beyond the
+# search itself (interleaved chunks, strided clear / finalize, IPC peer copies).  tools/rehearsal_2rank.sh [scale] [sampling]
+SC=${1:-0.25}; SA=${2:-1}
 export MASTER_ADDR=127.0.0.1
-echo "== N=1 scale 0.25"; timeout 600 python bench.py --workload grch38 --scale 0.25 --no-cpu-baseline --no-counters --no-host-rate --sub "" --steps 10 --warmup 2 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms'])"
-echo "== N=2 same device p2p"; timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --workload grch38 --scale 0.25 --same-device --backend gloo --steps 10 --warmup 2 --verify 2>&1 | grep -v Warning | tail -3 | cut -c1-900
-echo "== N=2 same device collective"; timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 2 --workload grch38 --scale 0.25 --same-device --backend gloo --comm collective --steps 10 --warmup 2 --verify 2>&1 | grep -v Warning | tail -2 | cut -c1-900
+echo "== N=1 scale $SC sampling $SA"; timeout 900 python bench.py --workload grch38 --scale $SC --sampling $SA --no-cpu-baseline --no-counters --no-host-rate --sub "" --steps 10 --warmup 2 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('k-mers/s %.4g  ms/step %.2f  kernel ms %.2f' % (d['value'], d['ms_per_step'], d['roofline']['kernel_ms']))"
+echo "== N=2 same device, peer copies"; timeout 1200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --workload grch38 --scale $SC --sampling $SA --same-device --backend gloo --steps 10 --warmup 2 --verify 2>&1 | grep -v Warning | grep "verify\|^{" | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); print('k-mers/s %.4g  ms/step %.2f  per-rank search ms %s  per-rank wait ms %s  imbalance %.3f  %s' % (d['value'], d['ms_per_step'], [round(x, 2) for x in d['per_rank_search_ms']], [round(x, 2) for x in d['per_rank_comm_wait_ms']], d['shard_imbalance'], d['comm']))
+    else: print(l.strip())"
