@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--comm", default="p2p", choices=["p2p", "collective"], help="N > 1: chunks pushed into the root's vector with peer DMA copies "
                     "overlapping the search kernel (falls back to the collective when IPC is not available), or one gather collective per step")
+    ap.add_argument("--watchdog", type=float, default=900.0, help="N > 1: seconds the measured part may take before the run gives up")
     ap.add_argument("--verify", action="store_true", help="N > 1: after the timed steps rank 0 recomputes the whole vector alone and compares it with the gathered one")
     ap.add_argument("--no-host-rate", action="store_true", help="skip value_host (its gm_map call launches the search kernel in four pieces: keeps a rocprofv3 kernel trace of the timed launches clean)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -254,7 +255,20 @@ def main():
             log("pinned host rate failed:", e)
         return pageable, pinned
 
+    if world > 1:
+        # a multi-rank run that stops making progress (a peer that died, a transfer that never completes) must not sit
+        # in a barrier until the launcher's own limit: say so and leave
+        import threading
+
+        def _watchdog():
+            print(f"[bench] rank {rank}: no result after {args.watchdog} s in the multi-rank run -- giving up", file=sys.stderr, flush=True)
+            os._exit(4)
+        wd = threading.Timer(args.watchdog, _watchdog)
+        wd.daemon = True
+        wd.start()
     head = measure(args.K, args.E, args.steps, args.warmup)
+    if world > 1:
+        wd.cancel()
     subs = []
     if world == 1 and args.sub:
         for item in args.sub.split(";"):
