@@ -252,7 +252,8 @@ int gm_index_sync(gm_index *idx);
 
 /* scheduling knobs of the search kernel, for sweeps and tests (results never depend on them).  Names: verify_t,
  * lds_stack, blocks_per_cu, qtable, sat_min_w, fetch_batch, probation, verify_cost, no_store, no_saturate, skip_dup, coop,
- * use_ctx, steal, part_bias;
+ * use_ctx, steal (0: no work sharing inside a wavefront, n > 0: an exchange when at least n lanes are idle), part_bias
+ * (e = 1: characters moved from the second OSS block to the first; every split gives the same result);
  * value -1 restores the library default where one exists.  Nothing is read from the environment. */
 int gm_index_set_tuning(gm_index *idx, const char *name, int64_t value);
 
