@@ -13,8 +13,12 @@ A "step" is one complete computeMappability pass (src/algo.hpp:405-483) over the
 clear of the accumulators, the search kernel, finalize/resetLimits, and -- for N > 1 -- the gather of the ranks' chunks of
 the frequency vector to rank 0.  Each rank holds a full index replica and computes interleaved chunks of whole k-mer
 blocks (strong scaling: the genome is fixed).  The headline line is K=30, e=0; the same JSON line carries sub-records
-for (30,1), (30,2) and (100,1) measured in the same run, each with its own roofline (numerator counted in-run by the
-instrumented twin library, denominator = HIP-event time of the search kernel over the timed steps) and CPU baseline.
+for (30,1), (30,2) and (100,1) -- config C3 and C4 of BASELINE.json -- measured in the same run AT EVERY N, each with its
+own roofline (numerator counted by the instrumented twin library after the timed part, shard by shard for N > 1;
+denominator = HIP-event time of the search kernel over the timed steps, the slowest rank's for N > 1) and CPU baseline.
+
+  python bench.py --workload bacteria5 [--gpus 2]      config C5: five FASTA files, K=24 e=1, --exclude-pseudo frequencies
+                                                       (+ csv location lists), contiguous shares per file and rank
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -35,6 +39,16 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 def log(*a):
     if int(os.environ.get("RANK", "0")) == 0:
         print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+_T0 = time.time()
+TRACE = False
+
+
+def mark(*a):
+    """stage marker of EVERY rank with a time stamp (--trace): where a multi-rank run stands when it stops making progress"""
+    if TRACE:
+        print(f"[bench r{os.environ.get('RANK', '0')} +{time.time() - _T0:7.1f}s]", *a, file=sys.stderr, flush=True)
 
 
 class CpuBaseline:
@@ -87,25 +101,36 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="grch38")
+    ap.add_argument("--workload", default="grch38", help="grch38 | chr1 | ecoli (one FASTA, frequency pass) | bacteria5 (config C5: five FASTA files, --exclude-pseudo, csv)")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--fasta", default=None, help="real FASTA file instead of the synthetic workload")
-    ap.add_argument("--K", type=int, default=30)
-    ap.add_argument("--E", type=int, default=0)
-    ap.add_argument("--sub", default="30,1:2;30,2:1;100,1:2", help="sub-records 'K,E:steps;...' measured after the headline (N=1 only); '' = none")
+    ap.add_argument("--K", type=int, default=0, help="default 30 (24 for bacteria5)")
+    ap.add_argument("--E", type=int, default=-1, help="default 0 (1 for bacteria5)")
+    ap.add_argument("--sub", default="30,1:2;30,2:1;100,1:2", help="sub-records 'K,E:steps;...' measured after the headline; '' = none")
     ap.add_argument("--block-bytes", type=int, default=0)
     ap.add_argument("--infix", type=int, default=0, help="common-infix length (SearchParams.overlap); 0 = library default")
-    ap.add_argument("--sampling", type=int, default=1, help="1: keep the suffix array resident (narrow nodes are verified against the text); 0: rank queries only")
+    ap.add_argument("--sampling", type=int, default=1, help="1: keep the suffix array resident (narrow nodes are verified against the text); 0: rank queries only; "
+                    "2..64: sampled suffix array (the reference's -S; bacteria5 only needs it for locate)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the single-GPU rehearsal of the N>1 path)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--comm", default="p2p", choices=["p2p", "collective"], help="N > 1: chunks pushed into the root's vector with peer DMA copies "
-                    "overlapping the search kernel (falls back to the collective when IPC is not available), or one gather collective per step")
-    ap.add_argument("--watchdog", type=float, default=900.0, help="N > 1: seconds the measured part may take before the run gives up")
+                    "overlapping the search kernel (falls back to the collective when IPC is not available or far slower than predicted), or one gather collective per step")
+    ap.add_argument("--watchdog", type=float, default=900.0, help="N > 1: seconds one measured record may take before the run gives up")
     ap.add_argument("--verify", action="store_true", help="N > 1: after the timed steps rank 0 recomputes the whole vector alone and compares it with the gathered one")
     ap.add_argument("--no-host-rate", action="store_true", help="skip value_host (its gm_map call launches the search kernel in four pieces: keeps a rocprofv3 kernel trace of the timed launches clean)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true")
+    ap.add_argument("--no-csv", action="store_true", help="bacteria5: skip the csv location lists (gm_locate), time the --exclude-pseudo frequencies only")
+    ap.add_argument("--trace", type=float, default=0.0, help="print stage markers from every rank and, after this many seconds, every thread's Python stack (diagnosis of a stalled multi-rank run)")
     args = ap.parse_args()
+    if args.trace > 0:
+        global TRACE
+        TRACE = True
+        import faulthandler
+        faulthandler.dump_traceback_later(args.trace, repeat=True, file=sys.stderr)
+    c5 = args.workload == "bacteria5" and not args.fasta
+    args.K = args.K or (24 if c5 else 30)
+    args.E = args.E if args.E >= 0 else (1 if c5 else 0)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -127,11 +152,19 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+    cdev = dev if args.backend == "nccl" else "cpu"   # where the small control tensors of the collectives live
 
     t0 = time.time()
+    files5 = fid = None
     if args.fasta:
         codes, lens = read_fasta(args.fasta)
         desc, data = f"{os.path.basename(args.fasta)} {len(codes)} bp in {len(lens)} sequences", "real FASTA"
+    elif c5:
+        files5 = synth.bacteria5(args.scale)
+        codes = np.concatenate([c for _, recs in files5 for _, c in recs])
+        lens = [len(c) for _, recs in files5 for _, c in recs]
+        fid = np.array([f for f, (_, recs) in enumerate(files5) for _ in recs], dtype=np.uint32)
+        desc, data = f"S5 five-bacteria-like {len(codes)} bp in {len(files5)} FASTA files / {len(lens)} sequences Dna5", "synthetic"
     else:
         codes, lens, desc = synth.workload(args.workload, args.scale)
         data = "synthetic"
@@ -143,6 +176,7 @@ def main():
         for r in range(world):
             if r == rank:
                 ix = g.Index.build(codes, lens, sampling=args.sampling, block_bytes=args.block_bytes, device=local_rank)
+                mark("index built")
             dist.barrier()
     else:
         ix = g.Index.build(codes, lens, sampling=args.sampling, block_bytes=args.block_bytes, device=local_rank)
@@ -150,7 +184,7 @@ def main():
     info = ix.info()
     log(f"index built on the GPU in {t_build:.1f} s: {info['n_rows']} rows, {info['block_bytes']}-B blocks, {info['device_bytes'] / 2**30:.2f} GiB")
 
-    from genmap_amd.distributed import PeerGather, ShardPlan, gather_chunks
+    from genmap_amd.distributed import PeerGather, ShardPlan, gather_chunks, gather_frequency, gather_locations, max_shard_len, shard_ranges
     stream = torch.cuda.current_stream().cuda_stream
     out = None
 
@@ -160,23 +194,61 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if world == 1:
+            return float(x)
+        t = torch.tensor([x], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def per_rank_of(values):
+        if world == 1:
+            return None
+        mine = torch.tensor(values, dtype=torch.float64, device=cdev)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        return [[float(v) for v in x.tolist()] for x in allv]
+
+    class Watchdog:
+        """a multi-rank run that stops making progress (a peer that died, a transfer that never completes) must not sit in a
+        barrier until the launcher's own limit: say so and leave"""
+
+        def __enter__(self):
+            self.t = None
+            if world > 1:
+                import threading
+
+                def _fire():
+                    print(f"[bench] rank {rank}: no result after {args.watchdog} s in the multi-rank run -- giving up", file=sys.stderr, flush=True)
+                    os._exit(4)
+                self.t = threading.Timer(args.watchdog, _fire)
+                self.t.daemon = True
+                self.t.start()
+            return self
+
+        def __exit__(self, *exc):
+            if self.t:
+                self.t.cancel()
+            return False
+
     def measure(K, E, steps, warmup):
         """W warm-up steps, then exactly `steps` timed steps between barrier + synchronize; returns the record."""
         nonlocal out
         infix = args.infix or g.tuned_infix_length(K, E)
         num_kmers = n - K + 1
         plan = ShardPlan(num_kmers, K - infix + 1, world)
-        if out is None:
+        if out is None or out.numel() < plan.padded_len(n):
             out = torch.zeros(plan.padded_len(n), dtype=torch.uint8, device=dev)        # -fs: 8-bit frequencies
-        comm = {"wait_s": 0.0, "mode": "none"}
+        comm = {"wait_s": 0.0, "mode": "none", "note": None}
         pg = None
+        mark(f"measure K={K} E={E}: plan {plan.nchunks} chunks of {plan.chunk_len} positions")
         if world > 1 and args.comm == "p2p":
-            pg = PeerGather(plan, n, 1, rank, local_rank, dist)
+            pg = PeerGather(plan, n, 1, rank, local_rank, dist, mark=mark)
+            mark(f"PeerGather ready: ok={pg.ok} launches={pg.launches}")
             if not pg.ok:
                 log("peer copies not available between these ranks: falling back to the gather collective")
+                comm["note"] = "peer copies not available (IPC open / probe failed): gather collective"
                 pg.close(); pg = None
-        if world > 1:
-            comm["mode"] = "peer DMA copies overlapping compute" if pg else "gather collective"
 
         def one_step():
             if pg is None:
@@ -196,25 +268,51 @@ def main():
             pg.finish()
             comm["wait_s"] += time.perf_counter() - t1
 
-        for _ in range(warmup):
+        if pg is not None:
+            # One untimed step first: if the peer copies take far longer than the search plus a transfer at a fifth of one xGMI
+            # link would (a fabric that routes through host memory, a driver that serialises the copies behind the persistent
+            # kernel), every rank switches to the gather collective and the line says so.
+            sync()
+            t1 = time.perf_counter()
             one_step()
+            sync()
+            wall = time.perf_counter() - t1
+            mine = float(np.sum(ix.kernel_times(pg.launches))) * 1e-3
+            predicted = mine + (pg.nbytes / world) / 10e9
+            slow = max_over_ranks(1.0 if wall > 10.0 * predicted + 0.05 else 0.0)
+            mark(f"p2p probe step: {wall * 1e3:.1f} ms, predicted {predicted * 1e3:.1f} ms")
+            if slow > 0:
+                comm["note"] = f"first p2p step took {wall * 1e3:.0f} ms against {predicted * 1e3:.0f} ms predicted: switched to the gather collective"
+                log(comm["note"])
+                pg.close(); pg = None
+        if world > 1:
+            comm["mode"] = "peer DMA copies overlapping compute" if pg else "gather collective"
+        comm["wait_s"] = 0.0
+        for i in range(warmup):
+            one_step()
+            mark(f"warm-up step {i} issued")
         sync()
+        mark("warm-up done")
+        warm_wait = comm["wait_s"]
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for i in range(steps):
             one_step()
+            mark(f"step {i} issued")
         sync()
+        mark("timed steps done")
         dt = time.perf_counter() - t0
         launches = pg.launches if pg else 1
-        kms = ix.kernel_times(steps * launches)   # HIP events around the search kernel of each timed launch, on the launch stream
+        kms = ix.kernel_times(min(steps * launches, 64 // launches * launches))   # HIP events around the search kernel of each timed launch, on the launch stream
         kms = [float(np.sum(kms[i * launches:(i + 1) * launches])) for i in range(len(kms) // launches)]
         if args.verify and world > 1:
             sync()
             if rank == 0:
-                got = torch.empty(n, dtype=torch.uint8, device=dev)
                 if pg:
-                    g.push_pieces(local_rank, got.data_ptr(), pg.local_ptr, 0, 0, n, 1, 0, None)
+                    got = torch.empty(pg.nbytes, dtype=torch.uint8, device=dev)
+                    pg.assemble(got.data_ptr())
+                    got = got[:n]
                 else:
-                    got.copy_(out[:n])
+                    got = out[:n]
                 ref = torch.zeros(n + 16, dtype=torch.uint8, device=dev)
                 ix.map_device(ref.data_ptr(), K, E, infix=args.infix, value_bits=8, stream=stream)
                 torch.cuda.synchronize()
@@ -222,18 +320,16 @@ def main():
                 log(f"verify K={K} E={E}: gathered vector {'==' if same else '!='} single-rank vector ({comm['mode']})")
                 if not same:
                     raise SystemExit("gathered result differs from the single-rank result")
+                del got, ref
             sync()
         if pg:
             pg.close()
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        if world > 1:
-            if args.backend != "nccl":
-                t = t.cpu()
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = max_over_ranks(dt)
+        my_ms = float(np.mean(kms))
+        pr = per_rank_of([my_ms, (comm["wait_s"] - warm_wait) / max(1, steps) * 1e3])
         return {"K": K, "E": E, "infix": infix, "num_kmers": num_kmers, "steps": steps, "warmup": warmup, "dt": dt,
-                "kernel_ms": float(np.mean(kms)), "kernel_ms_min": float(np.min(kms)), "my_compute_ms": float(np.mean(kms)), "plan": plan,
-                "comm_mode": comm["mode"], "my_comm_wait_ms": comm["wait_s"] / max(1, steps + warmup) * 1e3}
+                "kernel_ms": max(r[0] for r in pr) if pr else my_ms, "kernel_ms_min": float(np.min(kms)), "plan": plan,
+                "comm_mode": comm["mode"], "comm_note": comm["note"], "per_rank": pr}
 
     def host_rate(K, E):
         """PCIe-inclusive rates of the drop-in call gm_map (host result vector), never `value`: into ordinary (pageable) memory,
@@ -255,60 +351,118 @@ def main():
             log("pinned host rate failed:", e)
         return pageable, pinned
 
-    if world > 1:
-        # a multi-rank run that stops making progress (a peer that died, a transfer that never completes) must not sit
-        # in a barrier until the launcher's own limit: say so and leave
-        import threading
+    # ---- config C5: one pass = every FASTA file's --exclude-pseudo frequencies (+ csv location lists), contiguous shares ----
+    def measure_c5(K, E, steps, warmup):
+        slices, first = [], 0
+        for _, recs in files5:
+            tl = sum(len(c) for _, c in recs)
+            slices.append((first, len(recs), tl)); first += len(recs)
+        infix = args.infix or g.tuned_infix_length(K, E)
+        step_size = K - infix + 1
+        total_kmers = sum(tl - K + 1 for _, _, tl in slices)
+        bufs = []
+        for _, _, tl in slices:
+            rg = shard_ranges(tl - K + 1, step_size, world)
+            bufs.append((rg, torch.zeros(tl + max_shard_len(rg) + 16, dtype=torch.uint16, device=dev)))
+        t_csv = {"s": 0.0, "occ": 0}
 
-        def _watchdog():
-            print(f"[bench] rank {rank}: no result after {args.watchdog} s in the multi-rank run -- giving up", file=sys.stderr, flush=True)
-            os._exit(4)
-        wd = threading.Timer(args.watchdog, _watchdog)
-        wd.daemon = True
-        wd.start()
-    head = measure(args.K, args.E, args.steps, args.warmup)
-    if world > 1:
-        wd.cancel()
-    subs = []
-    if world == 1 and args.sub:
-        for item in args.sub.split(";"):
+        def one_step(csv):
+            for (fs, ns, tl), (rg, buf) in zip(slices, bufs):
+                ix.map_device(buf.data_ptr(), K, E, first_seq=fs, n_seq=ns, infix=args.infix, value_bits=16, exclude_pseudo=True, seq_file_id=fid,
+                              kmer_range=rg[rank] if world > 1 else None, stream=stream)
+                if world > 1:
+                    torch.cuda.current_stream().synchronize()
+                    gather_frequency(buf, rg, rank, world, dist, stage_on_host=(args.backend != "nccl"))
+            if csv:
+                t1 = time.perf_counter()
+                for (fs, ns, tl), (rg, buf) in zip(slices, bufs):
+                    loc = ix.locate(K, E, first_seq=fs, n_seq=ns, infix=args.infix, kmer_range=rg[rank] if world > 1 else None)
+                    merged = gather_locations(loc, rank, world, dist, device=dev if args.backend == "nccl" else None) if world > 1 else loc
+                    if rank == 0:
+                        t_csv["occ"] += len(merged[2]) + len(merged[4])
+                t_csv["s"] += time.perf_counter() - t1
+
+        for _ in range(warmup):
+            one_step(False)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_step(False)
+        sync()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        kms = ix.kernel_times(min(64, steps * len(slices)))
+        my_ms = float(np.sum(kms)) / max(1, len(kms) // len(slices))
+        pr = per_rank_of([my_ms, 0.0])
+        rec = {"K": K, "E": E, "infix": infix, "num_kmers": total_kmers, "steps": steps, "warmup": warmup, "dt": dt, "kernel_ms": max(r[0] for r in pr) if pr else my_ms,
+               "per_rank": pr, "csv": None}
+        if not args.no_csv:
+            sync()
+            t0 = time.perf_counter()
+            one_step(True)
+            sync()
+            dtc = max_over_ranks(time.perf_counter() - t0)
+            rec["csv"] = {"value": total_kmers / dtc, "unit": "k-mers/s", "ms_per_pass": dtc * 1e3, "locate_ms": max_over_ranks(t_csv["s"]) * 1e3, "occurrences": t_csv["occ"],
+                          "note": "one pass incl. gm_locate of every file: location lists sorted on the device and delivered to HOST memory (PCIe-inclusive), gathered to rank 0"}
+        return rec
+
+    if c5:
+        with Watchdog():
+            head = measure_c5(args.K, args.E, args.steps, args.warmup)
+        subs, value_host, value_host_pinned = [], None, None
+    else:
+        with Watchdog():
+            head = measure(args.K, args.E, args.steps, args.warmup)
+        subs = []
+        for item in filter(None, args.sub.split(";")):
             ke, st = item.split(":")
             K, E = map(int, ke.split(","))
-            subs.append(measure(K, E, int(st), 1 if E < 2 else 0))
+            with Watchdog():
+                subs.append(measure(K, E, int(st), 1 if E < 2 else 0))
             log(f"sub-record K={K} E={E}: {subs[-1]['dt'] / subs[-1]['steps'] * 1e3:.1f} ms/step")
-    value_host, value_host_pinned = host_rate(args.K, args.E) if (world == 1 and not args.no_host_rate) else (None, None)
+        value_host, value_host_pinned = host_rate(args.K, args.E) if (world == 1 and not args.no_host_rate) else (None, None)
 
-    # per-rank diagnosis for N > 1: compute ms per rank and shard imbalance (so that a scaling run is readable)
-    per_rank = None
+    # ---- the multi-rank part ends here: every rank but 0 releases its index and leaves; rank 0 counts and prints ----
+    bwt_host = sa_host = None
+    want_twin = not args.no_counters and g.lib_path(True).exists() and not c5
+    if rank == 0 and (not args.no_cpu_baseline or want_twin):
+        bwt_host = ix.export_bwt()
+        if want_twin and args.sampling == 1:
+            sa_host = ix.export_sa()
+    ix.close()
+    out = None
+    torch.cuda.empty_cache()
     if world > 1:
-        mine = torch.tensor([head["my_compute_ms"], head["my_comm_wait_ms"]], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        allms = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allms, mine)
-        per_rank = [[float(v) for v in x.tolist()] for x in allms]
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
 
     # ---- roofline numerators: count node steps / distinct rank lines with the instrumented twin (untimed) ----
-    # The timed index is released first: the twin needs the same HBM (verification records included) to run the same schedule.
+    # The timed indexes are released first: the twin needs the same HBM (verification records included) to run the same schedule.
+    # N > 1: the twin walks the ranks' shards one after the other with the shard arguments the ranks used.
     counted = {}
-    bwt_host = None
-    if rank == 0 and world == 1 and (not args.no_cpu_baseline or not args.no_counters):
-        bwt_host = ix.export_bwt()
-    if rank == 0 and world == 1 and not args.no_counters and g.lib_path(True).exists():
+    if want_twin:
         try:
             bf, br = bwt_host
-            sa_host = ix.export_sa() if args.sampling == 1 else None
-            ix.close()
-            out = None
-            torch.cuda.empty_cache()
             ixp = g.Index.from_bwt(bf, br, codes, lens, sa_fwd=sa_host, sampling=args.sampling,
                                    block_bytes=info["block_bytes"], device=local_rank, profiling=True)
-            del sa_host
+            sa_host = None
             if ixp.info()["verify_records"] != info["verify_records"]:
                 log("warning: the instrumented twin did not get the same verification records as the timed index")
-            tmp = torch.zeros(n + 16, dtype=torch.uint8, device=dev)
+            tmp = torch.zeros(max(r["plan"].padded_len(n) for r in [head] + subs), dtype=torch.uint8, device=dev)
             for rec in [head] + subs:
-                ixp.map_device(tmp.data_ptr(), rec["K"], rec["E"], infix=args.infix, value_bits=8, stream=stream)
-                sp = ixp.last_stats()
-                counted[(rec["K"], rec["E"])] = sp
+                tot = None
+                for r in range(world):
+                    ixp.map_device(tmp.data_ptr(), rec["K"], rec["E"], infix=args.infix, value_bits=8, chunks=rec["plan"].chunk_arg(r), stream=stream)
+                    sp = ixp.last_stats()
+                    if tot is None:
+                        tot = sp
+                    else:
+                        for k in ("rank_lines", "roots", "node_steps", "kmers"):
+                            tot[k] += sp[k]
+                        for k in tot["detail"]:
+                            tot["detail"][k] += sp["detail"][k]
+                counted[(rec["K"], rec["E"])] = tot
             ixp.close()
             del tmp
         except Exception as e:  # measurement aid only
@@ -326,65 +480,80 @@ def main():
         # per row and 8 needle + 8 text symbols per chunk
         ver = 32 * d["verify_items"] + 8 * d["verify_chunks"] if info["verify_records"] else 4 * d["verify_items"] + 16 * d["verify_chunks"]
         alg = bb * sp["rank_lines"] + 16 * sp["roots"] + n + n + ver
-        ach = alg / (rec["kernel_ms"] * 1e-3) / 1e9
+        # N > 1: per GPU -- a rank's share of the bytes over the slowest rank's kernel time, against one GPU's peak
+        ach = alg / world / (rec["kernel_ms"] * 1e-3) / 1e9
         return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": None,   # PMC FETCH_SIZE/WRITE_SIZE need rocprofv3 around the process: tools/profile_round.sh -> profiles/
-                "kernel": "search_kernel", "kernel_ms": rec["kernel_ms"], "algorithmic_bytes": alg, "rank_lines": sp["rank_lines"],
+                "per_gpu": True, "kernel": "search_kernel", "kernel_ms": rec["kernel_ms"], "algorithmic_bytes": alg, "rank_lines": sp["rank_lines"],
                 "roots": sp["roots"], "node_steps": sp["node_steps"], "node_steps_per_kmer": sp["node_steps"] / rec["num_kmers"],
                 "verify_items": d["verify_items"], "verify_chunks": d["verify_chunks"],
                 "lanes_with_node_per_iteration": d["active_lane_sum"] / max(1, d["wave_iterations"])}
 
-    if rank == 0:
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                cpu = CpuBaseline(codes, lens, bwt_host, os.cpu_count() or 1)
-            except Exception as e:
-                log("cpu baseline failed:", e)
+    cpu = None
+    if not args.no_cpu_baseline:
+        try:
+            cpu = CpuBaseline(codes, lens, bwt_host, os.cpu_count() or 1)
+        except Exception as e:
+            log("cpu baseline failed:", e)
 
-        def cpu_rec(rec):
-            if cpu is None:
-                return None
-            guess = {0: 100_000_000, 1: 10_000_000}.get(rec["E"], 1_000_000)
-            try:
-                return cpu.run(rec["K"], rec["E"], guess)
-            except Exception as e:
-                log("cpu baseline failed:", e)
-                return None
+    def cpu_rec(rec):
+        if cpu is None:
+            return None
+        guess = {0: 100_000_000, 1: 10_000_000}.get(rec["E"], 1_000_000)
+        try:
+            return cpu.run(rec["K"], rec["E"], guess)
+        except Exception as e:
+            log("cpu baseline failed:", e)
+            return None
 
-        def wl(rec):
-            return f"{desc}, K={rec['K']} E={rec['E']}, both strands, -fs (8-bit), common infix {rec['infix']}"
+    def wl(rec):
+        if c5:
+            return f"{desc}, K={rec['K']} E={rec['E']}, both strands, --exclude-pseudo, 16-bit, common infix {rec['infix']}, -S {args.sampling}"
+        return f"{desc}, K={rec['K']} E={rec['E']}, both strands, -fs (8-bit), common infix {rec['infix']}"
 
-        result = {
-            "metric": "k-mers/sec (whole node) for (k,e)-mappability on 3.1 Gbp index", "value": head["num_kmers"] * head["steps"] / head["dt"], "unit": "k-mers/s",
-            "n_gpus": world, "steps": head["steps"], "warmup": head["warmup"], "ms_per_step": head["dt"] / head["steps"] * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32 ranks / u8 counts", "data": data,
-            "config": {"workload": wl(head), "K": head["K"], "E": head["E"], "text_len": n, "block_bytes": info["block_bytes"],
-                       "parallelism": head["plan"].describe(), "index_build_s": round(t_build, 2), "index_device_gib": round(info["device_bytes"] / 2**30, 2)},
-            "value_host": value_host,   # gm_map with the result vector delivered to host memory (PCIe-inclusive); never `value`
-            "value_host_pinned": value_host_pinned,   # the same into a page-locked vector
-            "roofline": roofline(head),
-        }
-        if per_rank is not None:
-            result["per_rank_search_ms"] = [r[0] for r in per_rank]         # search kernel per step, per rank
-            result["per_rank_comm_wait_ms"] = [r[1] for r in per_rank]      # host time per step spent waiting for the gather / the copies
-            result["shard_imbalance"] = max(r[0] for r in per_rank) / max(1e-9, float(np.mean([r[0] for r in per_rank])))
-            result["comm"] = head["comm_mode"]
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_rec(head)
-        if subs:
-            result["sub"] = []
-            for rec in subs:
-                r = {"workload": wl(rec), "K": rec["K"], "E": rec["E"], "value": rec["num_kmers"] * rec["steps"] / rec["dt"], "unit": "k-mers/s",
-                     "steps": rec["steps"], "warmup": rec["warmup"], "ms_per_step": rec["dt"] / rec["steps"] * 1e3, "roofline": roofline(rec)}
-                if not args.no_cpu_baseline:
-                    r["cpu_baseline"] = cpu_rec(rec)
-                result["sub"].append(r)
-        print(json.dumps(result), flush=True)
-    ix.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    def rank_fields(r, rec):
+        pr = rec.get("per_rank")
+        if pr:
+            r["per_rank_search_ms"] = [x[0] for x in pr]          # search kernel per step, per rank
+            r["per_rank_comm_wait_ms"] = [x[1] for x in pr]       # host time per step spent waiting for the gather / the copies
+            r["shard_imbalance"] = max(x[0] for x in pr) / max(1e-9, float(np.mean([x[0] for x in pr])))
+            r["comm"] = rec.get("comm_mode")
+            if rec.get("comm_note"):
+                r["comm_note"] = rec["comm_note"]
+
+    if c5:
+        parallelism = "one GPU" if world == 1 else f"contiguous shares of whole k-mer blocks per FASTA file and rank, index replicated, one gather of the 16-bit shares to rank 0 ({world} ranks)"
+    else:
+        parallelism = head["plan"].describe()
+    result = {
+        "metric": "k-mers/sec (whole node) for (k,e)-mappability on 3.1 Gbp index" if not c5 else "k-mers/sec (whole node) for (k,e)-mappability, config C5 (multi-genome index, --exclude-pseudo)",
+        "value": head["num_kmers"] * head["steps"] / head["dt"], "unit": "k-mers/s",
+        "n_gpus": world, "steps": head["steps"], "warmup": head["warmup"], "ms_per_step": head["dt"] / head["steps"] * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32 ranks / u8 counts" if not c5 else "u32 ranks / u16 counts", "data": data,
+        "config": {"workload": wl(head), "K": head["K"], "E": head["E"], "text_len": n, "block_bytes": info["block_bytes"],
+                   "parallelism": parallelism, "index_build_s": round(t_build, 2), "index_device_gib": round(info["device_bytes"] / 2**30, 2)},
+        "value_host": value_host,   # gm_map with the result vector delivered to host memory (PCIe-inclusive); never `value`
+        "value_host_pinned": value_host_pinned,   # the same into a page-locked vector
+    }
+    if c5:
+        result["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "kernel": "search_kernel (FileSetEnv)",
+                              "kernel_ms": head["kernel_ms"], "note": "locate-bound pass; the byte roofline is reported for the frequency workloads"}
+        result["csv"] = head["csv"]
+    else:
+        result["roofline"] = roofline(head)
+    rank_fields(result, head)
+    if not args.no_cpu_baseline and not c5:
+        result["cpu_baseline"] = cpu_rec(head)
+    if subs:
+        result["sub"] = []
+        for rec in subs:
+            r = {"workload": wl(rec), "K": rec["K"], "E": rec["E"], "value": rec["num_kmers"] * rec["steps"] / rec["dt"], "unit": "k-mers/s",
+                 "steps": rec["steps"], "warmup": rec["warmup"], "ms_per_step": rec["dt"] / rec["steps"] * 1e3, "roofline": roofline(rec)}
+            rank_fields(r, rec)
+            if not args.no_cpu_baseline:
+                r["cpu_baseline"] = cpu_rec(rec)
+            result["sub"].append(r)
+    print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

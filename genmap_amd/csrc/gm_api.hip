@@ -261,12 +261,11 @@ static int index_common_setup(gm_index* ix, const uint8_t* codes, const uint64_t
 static int sample_sa(gm_index* ix, const uint32_t* d_saFull)
 {
     const uint64_t n = ix->nRows, words = (n + 31) / 32;
-    GM_HIP(hipMalloc(&ix->d_saMark, words * sizeof(uint2)));
+    GM_HIP(hipMalloc(&ix->d_saMark, words * sizeof(uint2)));   // (owned by the index: gm_index_free releases it on every path)
     hipLaunchKernelGGL(sa_mark_kernel, dim3(grid_for(words)), dim3(256), 0, 0, d_saFull, ix->d_cum, ix->nSeq, n, ix->sampling, ix->d_saMark);
-    GM_HIP(hipGetLastError());
     uint32_t *d_cnt = nullptr, *d_before = nullptr; void* d_tmp = nullptr; size_t tmpBytes = 0;
-    int rc = GM_OK;
-    if (hipMalloc(&d_cnt, words * 4) != hipSuccess || hipMalloc(&d_before, words * 4) != hipSuccess) rc = GM_ERR_OOM;
+    int rc = hipGetLastError() == hipSuccess ? GM_OK : GM_ERR_HIP;
+    if (!rc && (hipMalloc(&d_cnt, words * 4) != hipSuccess || hipMalloc(&d_before, words * 4) != hipSuccess)) rc = GM_ERR_OOM;
     if (!rc) {
         hipLaunchKernelGGL(sa_mark_counts_kernel, dim3(grid_for(words)), dim3(256), 0, 0, ix->d_saMark, words, d_cnt);
         if (rocprim::exclusive_scan(nullptr, tmpBytes, d_cnt, d_before, 0u, words, rocprim::plus<uint32_t>()) != hipSuccess) rc = GM_ERR_HIP;
@@ -487,7 +486,8 @@ int gm_index_get_info(const gm_index* ix, gm_index_info* info)
     info->block_bytes = ix->wpp == 1 ? 32 : (ix->wpp == 3 || ix->wpp == 2) ? 64 : 128;
     info->row_bits = ix->wide ? 64 : 32;
     info->device_bytes = 2 * ix->blkBytes + ix->textLen + (ix->nSeq + 1) * 8ull + (ix->d_sa ? ix->nRows * (ix->wide ? 9ull : 5ull) : 0ull) + (ix->d_ctx ? ix->nRows * 32ull : 0ull) + ix->qtableBytes
-                       + (ix->d_saMark ? (ix->nRows + 31) / 32 * 8ull + ix->nSamples * 4ull : 0ull);
+                       + (ix->d_saMark ? (ix->nRows + 31) / 32 * 8ull + ix->nSamples * 4ull : 0ull)
+                       + ix->shardOutCap;   // the result buffer gm_map / gm_map_shard keep between calls
     if (!ix->d_sa && !ix->d_saMark) info->sampling = 0;
     info->device = ix->device;
     info->verify_records = ix->d_ctx ? 1u : 0u;
@@ -832,8 +832,10 @@ static int launch_reset_limits(gm_index* ix, TValue* d_out, uint32_t n_seq, uint
     return GM_OK;
 }
 
+// wrote (optional): the slice positions [wrote[0], wrote[1]) this call has written into d_out (everything else is untouched,
+// except for the zeros of resetLimits at the sequence ends)
 static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t first_seq, uint32_t n_seq, const gm_map_params* p,
-                    const uint64_t* intervals, uint64_t n_intervals, const uint32_t* seq_file_id, void* d_out, hipStream_t st)
+                    const uint64_t* intervals, uint64_t n_intervals, const uint32_t* seq_file_id, void* d_out, hipStream_t st, uint64_t* wrote = nullptr)
 {
     if (!d_out) { set_error("null output"); return GM_ERR_BAD_ARG; }
     SearchSetup S; SearchArgs A;
@@ -870,7 +872,8 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
     const uint64_t r0 = sharded ? std::min<uint64_t>(S.posBase, text_len) : 0;
     const uint64_t r1 = sharded ? std::min<uint64_t>(std::max<uint64_t>(S.posEnd, r0), text_len) : text_len;
     const uint64_t rn = r1 - r0;
-    GM_HIP(hipEventRecord(ix->ev[0], st));
+    if (wrote) { wrote[0] = r0; wrote[1] = r1; }
+    if (ix->pieceIndex == 0) GM_HIP(hipEventRecord(ix->ev[0], st));
     const ChunkSel sel = S.sel;   // positions are relative to r0 == posBase (a multiple of the block length)
     if (rn > 0) {
         if (ep) GM_HIP(hipMemsetAsync(ix->d_bits + r0 * wordsPerKmer, 0, rn * wordsPerKmer * sizeof(uint32_t), st));
@@ -886,7 +889,7 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
         } else if (sel.len) hipLaunchKernelGGL(clear_chunks_kernel, range_grid(sel, rn, 4), dim3(256), 0, st, (uint8_t*)(ix->d_acc + r0), 4u, rn, sel);
         else GM_HIP(hipMemsetAsync(ix->d_acc + r0, 0, rn * sizeof(uint32_t), st));
     }
-    GM_HIP(hipMemsetAsync(ix->d_small, 0, SMALL_ZEROED, st));
+    GM_HIP(hipMemsetAsync(ix->d_small, 0, ix->pieceIndex == 0 ? SMALL_ZEROED : 16, st));   // later pieces of one call keep adding to the statistics
     A.acc = ix->d_acc; A.accPlane = plane; A.fileBits = ix->d_bits;
     A.maxVal = ix->tune.noSaturate ? 0xFFFFFFFFu : (p->value_bits == 8 ? 255u : 65535u); A.wordsPerKmer = wordsPerKmer; A.seqFile = ix->d_seqFile;
 
@@ -920,8 +923,8 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
     GM_HIP(hipEventRecord(ix->evDone, st));
     ix->doneValid = true;
     ix->evValid = true;
-    ix->stats = gm_map_stats{};
-    ix->stats.kmers = S.kmers; ix->stats.roots = S.numRoots;
+    if (ix->pieceIndex == 0) { ix->stats = gm_map_stats{}; ix->statPieces = 0; }
+    ix->stats.kmers += S.kmers; ix->stats.roots += S.numRoots; ix->statPieces += 1;
     return GM_OK;
 }
 
@@ -1172,6 +1175,7 @@ int gm_map_shard(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t 
         const uint32_t S = (n_intervals == 0 && e > b && e - b >= (1ull << 26)) ? 4u : 1u;
         const bool pinned = S > 1 && host_memory_is_pinned(h_out);
         uint64_t pbs[4] = {0, 0, 0, 0}, pes[4] = {0, 0, 0, 0};
+        ix->pieceIndex = 0;
         for (uint32_t s2 = 0; s2 < S; ++s2) {   // every launch is queued before the first piece is collected
             gm_map_params q = *p;
             uint64_t pb = b, pe = e;
@@ -1180,11 +1184,19 @@ int gm_map_shard(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t 
                 q.flags |= GM_MAP_FLAG_RANGE; q.kmer_begin = pb; q.kmer_end = std::min<uint64_t>(pe, ke);
                 if (pe <= pb) continue;
             }
+            uint64_t wrote[2] = {0, 0};
+            int rc = map_impl(ix, text_begin, text_len, first_seq, n_seq, &q, intervals, n_intervals, seq_file_id, d_out, ix->stCompute, wrote);
+            ix->pieceIndex += 1;
+            if (rc) { ix->pieceIndex = 0; return rc; }
+            // A selection's blocks begin at interval starts, not at multiples of the block length: the share delivers exactly the
+            // positions its blocks span (what map_impl wrote; d_out is not cleared elsewhere), never the step-rounded window --
+            // a block belongs to the share that holds its first k-mer, so the shares' spans are disjoint.  Unselected positions
+            // outside every span are zero by definition and stay the caller's.
+            if (n_intervals > 0) { pb = wrote[0]; pe = wrote[1]; }
             pbs[s2] = pb; pes[s2] = pe;
-            int rc = map_impl(ix, text_begin, text_len, first_seq, n_seq, &q, intervals, n_intervals, seq_file_id, d_out, ix->stCompute);
-            if (rc) return rc;
             GM_HIP(hipEventRecord(ix->evShard[s2], ix->stCompute));
         }
+        ix->pieceIndex = 0;
         for (uint32_t s2 = 0; s2 < S; ++s2) {
             if (pes[s2] <= pbs[s2]) continue;
             GM_HIP(hipStreamWaitEvent(ix->stCopy, ix->evShard[s2], 0));
@@ -1202,6 +1214,7 @@ int gm_map_shard(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t 
     const uint64_t span = ke > base ? ke - base : 0;
     const uint64_t rows = (span + rowLen - 1) / rowLen;                        // one chunk of every shard per row
     const uint32_t S = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(rows, 1), 4);   // launches: copy of launch s overlaps compute of s + 1
+    ix->pieceIndex = 0;
     for (uint32_t s = 0; s < S; ++s) {
         const uint64_t r0 = rows * s / S, r1 = rows * (s + 1) / S;
         if (r1 <= r0) continue;
@@ -1209,7 +1222,8 @@ int gm_map_shard(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t 
         q.flags |= GM_MAP_FLAG_RANGE;
         q.kmer_begin = base + r0 * rowLen; q.kmer_end = std::min<uint64_t>(base + r1 * rowLen, ke);   // rows start at multiples of the row length: chunk numbers keep their residue
         int rc = map_impl(ix, text_begin, text_len, first_seq, n_seq, &q, nullptr, 0, seq_file_id, d_out, ix->stCompute);
-        if (rc) return rc;
+        ix->pieceIndex += 1;
+        if (rc) { ix->pieceIndex = 0; return rc; }
         GM_HIP(hipEventRecord(ix->evShard[s], ix->stCompute));
         GM_HIP(hipStreamWaitEvent(ix->stCopy, ix->evShard[s], 0));
         // own chunks of rows [r0, r1): a strided copy; the last row may hold a short (or no) chunk of this shard
@@ -1222,9 +1236,10 @@ int gm_map_shard(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t 
         if (full > 0) GM_HIP(hipMemcpy2DAsync(h_out + first * eb, rowLen * eb, d_out + first * eb, rowLen * eb, chunkLen * eb, full, hipMemcpyDeviceToHost, ix->stCopy));
         if (lastLen > 0) GM_HIP(hipMemcpyAsync(h_out + lastBegin * eb, d_out + lastBegin * eb, lastLen * eb, hipMemcpyDeviceToHost, ix->stCopy));
     }
+    ix->pieceIndex = 0;
     // the tail past the last k-mer (K - 1 zeros) belongs to the chunk that holds position numKmers - 1 when that chunk is short;
     // otherwise it lies in later chunk slots nobody owns: the shard owning the LAST chunk delivers it
-    if (ke >= numKmers && numKmers > 0) {
+    if (ke >= numKmers && numKmers > 0 && base < numKmers) {   // (a range that starts in the last partial block holds no whole block: nothing to deliver)
         const uint64_t lastChunk = (numKmers - 1 - base) / chunkLen;
         if (lastChunk % p->chunk_stride == p->chunk_index) {
             const uint64_t from = base + (lastChunk + 1) * chunkLen;
@@ -1319,12 +1334,24 @@ void gm_runs_free(gm_runs* R)
 int gm_index_set_tuning(gm_index* ix, const char* name, int64_t value)
 {
     if (!ix || !name) return GM_ERR_BAD_ARG;
-    struct { const char* n; int* f; } tab[] = {
-        {"verify_t", &ix->tune.verifyT}, {"lds_stack", &ix->tune.ldsStack}, {"blocks_per_cu", &ix->tune.blocksPerCU}, {"qtable", &ix->tune.qtable},
-        {"sat_min_w", &ix->tune.satMinW}, {"fetch_batch", &ix->tune.fetchBatch}, {"probation", &ix->tune.probation}, {"verify_cost", &ix->tune.verifyCost},
-        {"no_store", &ix->tune.noStore}, {"no_saturate", &ix->tune.noSaturate}, {"skip_dup", &ix->tune.skipDup}, {"coop", &ix->tune.coop}, {"use_ctx", &ix->tune.useCtx}, {"steal", &ix->tune.steal}, {"part_bias", &ix->tune.partBias},
+    const Tuning dflt;   // -1 restores these (for part_bias, which may be negative, -1 is a value: 0 is its default)
+    struct { const char* n; int* f; int d; int64_t lo, hi; } tab[] = {
+        {"verify_t", &ix->tune.verifyT, dflt.verifyT, 0, (int64_t)VERIFY_TMAX}, {"lds_stack", &ix->tune.ldsStack, dflt.ldsStack, 0, 64},
+        {"blocks_per_cu", &ix->tune.blocksPerCU, dflt.blocksPerCU, 1, 8}, {"qtable", &ix->tune.qtable, dflt.qtable, 0, 15},
+        {"sat_min_w", &ix->tune.satMinW, dflt.satMinW, 1, 0x7FFFFFFF}, {"fetch_batch", &ix->tune.fetchBatch, dflt.fetchBatch, 1, 64},
+        {"probation", &ix->tune.probation, dflt.probation, 0, 255}, {"verify_cost", &ix->tune.verifyCost, dflt.verifyCost, 0, 1 << 20},
+        {"no_store", &ix->tune.noStore, dflt.noStore, 0, 1}, {"no_saturate", &ix->tune.noSaturate, dflt.noSaturate, 0, 1},
+        {"skip_dup", &ix->tune.skipDup, dflt.skipDup, 0, 1}, {"coop", &ix->tune.coop, dflt.coop, 0, 1}, {"use_ctx", &ix->tune.useCtx, dflt.useCtx, 0, 1},
+        {"steal", &ix->tune.steal, dflt.steal, 0, 64}, {"part_bias", &ix->tune.partBias, dflt.partBias, -255, 255},
+        {"child_tables", &ix->tune.childTables, dflt.childTables, 0, 1},
     };
-    for (auto& t : tab) if (!strcmp(t.n, name)) { *t.f = (int)value; return GM_OK; }
+    for (auto& t : tab) if (!strcmp(t.n, name)) {
+        const bool isBias = t.f == &ix->tune.partBias;
+        if (value == -1 && !isBias) { *t.f = t.d; return GM_OK; }
+        if (value < t.lo || value > t.hi) { set_error("tuning knob '%s': value %lld outside [%lld, %lld]", name, (long long)value, (long long)t.lo, (long long)t.hi); return GM_ERR_BAD_ARG; }
+        *t.f = (int)value;
+        return GM_OK;
+    }
     set_error("unknown tuning knob '%s'", name);
     return GM_ERR_BAD_ARG;
 }
@@ -1361,7 +1388,12 @@ int gm_last_map_stats(const gm_index* cix, gm_map_stats* out)
     GM_HIP(hipSetDevice(ix->device));
     GM_HIP(hipEventSynchronize(ix->ev[3]));
     float a = 0, b = 0;
-    { const uint32_t slot = (uint32_t)((ix->evCount - 1) % gm_index::EV_RING); GM_HIP(hipEventElapsedTime(&a, ix->evRing[slot][0], ix->evRing[slot][1])); }
+    for (uint32_t k = 0; k < std::min<uint32_t>(std::max<uint32_t>(ix->statPieces, 1u), gm_index::EV_RING); ++k) {   // a call delivered in pieces: the sum of its launches
+        float t = 0;
+        const uint32_t slot = (uint32_t)((ix->evCount - 1 - k) % gm_index::EV_RING);
+        GM_HIP(hipEventElapsedTime(&t, ix->evRing[slot][0], ix->evRing[slot][1]));
+        a += t;
+    }
     GM_HIP(hipEventElapsedTime(&b, ix->ev[0], ix->ev[3]));
     ix->stats.search_ms = a; ix->stats.total_ms = b;
     unsigned long long cnt[42] = {0};

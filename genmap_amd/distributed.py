@@ -65,44 +65,123 @@ class ShardPlan:
                 f"index replicated, one gather of the 8-bit chunks to rank 0")
 
 
+class PiecePlan:
+    """How the gathered vector is cut into separately allocated PIECES of whole chunk rows (a row = one chunk slot of every rank),
+    and which strided copies carry a rank's chunks of a row-aligned k-mer range into them.  Pure arithmetic (CPU-testable)."""
+
+    def __init__(self, plan: ShardPlan, text_len: int, item_bytes: int, piece_bytes: int):
+        self.plan, self.item = plan, item_bytes
+        self.nbytes = plan.padded_len(text_len) * item_bytes
+        self.row_bytes = plan.chunk_len * plan.world * item_bytes
+        nrows = max(1, plan.rows // plan.world)
+        self.rows_per_piece = max(1, piece_bytes // max(1, self.row_bytes))
+        self.piece_off = [r * self.row_bytes for r in range(0, nrows, self.rows_per_piece)]
+        # the last piece runs to the end of the padded vector (the K - 1 zeros behind the last k-mer may lie past the last row)
+        self.piece_len = [(self.piece_off[i + 1] if i + 1 < len(self.piece_off) else self.nbytes) - o for i, o in enumerate(self.piece_off)]
+
+    def locate(self, byte_off: int):
+        """(piece number, offset inside it) of a byte offset of the vector"""
+        q = min(byte_off // (self.rows_per_piece * self.row_bytes), len(self.piece_off) - 1)
+        return q, byte_off - self.piece_off[q]
+
+    def copies(self, rank: int, sub_range):
+        """[(piece, first byte inside the piece, first byte of the vector, pitch, bytes per chunk, chunks)]: the chunks of `rank`
+        inside sub_range, as runs of rows that lie in one piece"""
+        plan, item = self.plan, self.item
+        row_len = plan.chunk_len * plan.world
+        r0, r1 = sub_range[0] // row_len, -(-sub_range[1] // row_len)
+        rows = [c for c in range(r0, r1) if c * plan.world + rank < plan.nchunks]
+        out, k = [], 0
+        while k < len(rows):
+            q = rows[k] // self.rows_per_piece
+            e = k
+            while e < len(rows) and rows[e] // self.rows_per_piece == q:
+                e += 1
+            first = (rows[k] * plan.world + rank) * plan.chunk_len * item
+            out.append((q, first - self.piece_off[q], first, row_len * item, plan.chunk_len * item, e - k))
+            k = e
+        return out
+
+
 class PeerGather:
-    """The root's result vector shared through a HIP IPC handle; every other rank pushes its finished chunks into it with
+    """The root's result vector shared through HIP IPC handles; every rank pushes its finished chunks into it with
     device-to-device copies (xGMI, DMA engines) on a copy stream of its own while its search kernel works on the next chunks.
 
       pg = PeerGather(plan, text_len, item_bytes, rank, local_device, dist)      # collective; pg.ok False -> use gather_chunks
       for sub in plan.sub_ranges(pg.launches):                                    # every step
           ix.map_device(pg.local_ptr, ..., kmer_range=sub, chunks=plan.chunk_arg(rank), stream=compute)
-          pg.push(sub, compute_stream_event)                                      # rank != root: async copies of the chunks just computed
+          pg.push(sub, compute_stream_event)                                      # async copies of the chunks just computed
       pg.finish()                                                                 # wait for this rank's copies
+      (root, after a barrier) pg.assemble(dst_ptr)                                # the gathered vector as one contiguous array
 
-    The root computes straight into the shared vector.  Setup ends with a pattern exchange: if any rank's test chunk does not
-    arrive, every rank falls back to the RCCL gather (ok == False on all ranks)."""
+    The shared vector is NOT one allocation: opening an IPC handle of a 3.09 GB allocation never returned on MI355X / ROCm 7.2
+    (profiles/r03/rehearsal_2rank_3p09gbp_diag.txt; 0.77 GB works), so the root allocates PIECES of whole chunk rows, at most
+    `piece_bytes` each, and exports one handle per piece.  Every rank -- the root too -- computes into a contiguous vector of
+    its own (local_ptr) and copies its chunks into the pieces.  An open that does not return within `ipc_timeout` seconds, or a
+    probe pattern that does not arrive, makes every rank fall back to the RCCL gather (ok == False on all ranks)."""
 
-    def __init__(self, plan: ShardPlan, text_len: int, item_bytes: int, rank: int, device: int, dist, launches: int = 4):
+    PIECE_BYTES = 512 << 20
+
+    def __init__(self, plan: ShardPlan, text_len: int, item_bytes: int, rank: int, device: int, dist, launches: int = 4, mark=None,
+                 piece_bytes: int = 0, ipc_timeout: float = 60.0):
+        import threading
         import torch
         from . import capi
+        mark = mark or (lambda *a: None)
         self.plan, self.rank, self.device, self.item, self.dist = plan, rank, device, item_bytes, dist
         self.launches = max(1, min(launches, plan.rows // plan.world if plan.world else 1))
         self.nbytes = plan.padded_len(text_len) * item_bytes
         self.ok = False
-        self.local_ptr = capi.device_alloc(device, self.nbytes)      # rank 0: the shared result; others: their own staging vector
-        self.remote_ptr = None
+        self.local_ptr = capi.device_alloc(device, self.nbytes)      # this rank's own contiguous vector: what its kernel writes
         self.copy_stream = torch.cuda.Stream(device=device)
-        handle = [capi.ipc_export(device, self.local_ptr) if rank == 0 else None]
+        self.pieces = PiecePlan(plan, text_len, item_bytes, piece_bytes or self.PIECE_BYTES)
+        self.piece_off, self.piece_len = self.pieces.piece_off, self.pieces.piece_len
+        self.piece_ptr: List[int] = []
+        self._opened: List[int] = []
+        mark(f"PeerGather: {self.nbytes} bytes in {len(self.piece_off)} pieces of at most {max(self.piece_len)} bytes")
         good = 1
+        handles = [None]
         try:
-            dist.broadcast_object_list(handle, src=0)
+            if rank == 0:
+                self.piece_ptr = [capi.device_alloc(device, n) for n in self.piece_len]
+                handles = [[capi.ipc_export(device, q) for q in self.piece_ptr]]
+            dist.broadcast_object_list(handles, src=0)
+            mark("PeerGather: handles exchanged")
             if rank != 0:
-                self.remote_ptr = capi.ipc_open(device, handle[0])
-        except Exception:
+                box = {}
+
+                def _open():
+                    try:
+                        box["ptrs"] = [capi.ipc_open(device, h) for h in handles[0]]
+                    except Exception as e:   # noqa: BLE001 -- any failure means "no peer copies here"
+                        box["err"] = e
+                th = threading.Thread(target=_open, daemon=True)
+                th.start()
+                th.join(ipc_timeout)
+                if th.is_alive() or "ptrs" not in box:
+                    mark(f"PeerGather: IPC open {'did not return in %.0f s' % ipc_timeout if th.is_alive() else 'failed: %s' % box.get('err')}")
+                    good = 0
+                else:
+                    self.piece_ptr = self._opened = box["ptrs"]
+                    mark("PeerGather: IPC handles opened")
+        except Exception as e:   # noqa: BLE001
+            mark(f"PeerGather: IPC setup failed: {e}")
             good = 0
-        # pattern exchange: rank r writes r + 1 into the first bytes of its first chunk
-        if good and rank != 0 and plan.nchunks > rank:
+        # pattern exchange: rank r writes r + 1 into the first bytes of its first chunk and of its last one
+        probes = []
+        if good and plan.nchunks > rank:
+            mine = list(range(rank, plan.nchunks, plan.world))
+            probes = sorted({mine[0], mine[-1]})
+        if good and rank != 0 and probes:
             t = torch.full((min(64, plan.chunk_len * item_bytes),), rank + 1, dtype=torch.uint8, device=f"cuda:{device}")
             try:
-                capi.push_pieces(device, self.remote_ptr + rank * plan.chunk_len * item_bytes, t.data_ptr(), 0, 0, t.numel(), 1, 0, self.copy_stream.cuda_stream)
+                for c in probes:
+                    q, off = self._locate(c * plan.chunk_len * item_bytes)
+                    capi.push_pieces(device, self.piece_ptr[q] + off, t.data_ptr(), 0, 0, t.numel(), 1, 0, self.copy_stream.cuda_stream)
                 self.copy_stream.synchronize()
-            except Exception:
+                mark("PeerGather: probe patterns pushed")
+            except Exception as e:   # noqa: BLE001
+                mark(f"PeerGather: probe push failed: {e}")
                 good = 0
         flag = torch.tensor([good], dtype=torch.int32)
         cpu_ok = dist.get_backend() != "nccl"
@@ -113,39 +192,54 @@ class PeerGather:
             for r in range(1, plan.world):
                 if plan.nchunks <= r:
                     continue
-                probe = torch.empty(1, dtype=torch.uint8, device=f"cuda:{device}")
-                capi.push_pieces(device, probe.data_ptr(), self.local_ptr + r * plan.chunk_len * item_bytes, 0, 0, 1, 1, 0, None)
-                torch.cuda.synchronize()
-                if int(probe.item()) != r + 1:
-                    flag[0] = 0
+                mine = list(range(r, plan.nchunks, plan.world))
+                for c in sorted({mine[0], mine[-1]}):
+                    q, off = self._locate(c * plan.chunk_len * item_bytes)
+                    probe = torch.empty(1, dtype=torch.uint8, device=f"cuda:{device}")
+                    capi.push_pieces(device, probe.data_ptr(), self.piece_ptr[q] + off, 0, 0, 1, 1, 0, None)
+                    torch.cuda.synchronize()
+                    if int(probe.item()) != r + 1:
+                        flag[0] = 0
+                    capi.push_pieces(device, self.piece_ptr[q] + off, self.local_ptr, 0, 0, min(64, plan.chunk_len * item_bytes), 1, 0, None)   # zeros again
+            torch.cuda.synchronize()
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         self.ok = int(flag.item()) == 1
+        mark(f"PeerGather: probes checked, ok={self.ok}")
+
+    def _locate(self, byte_off: int):
+        return self.pieces.locate(byte_off)
 
     def push(self, sub_range, after_event):
-        """rank != root: copy this rank's chunks inside sub_range (row-aligned k-mer range) to the root, after `after_event`"""
-        if self.rank == 0:
-            return
+        """copy this rank's chunks inside sub_range (row-aligned k-mer range) into the root's pieces, after `after_event`"""
         from . import capi
-        plan, item = self.plan, self.item
-        row_len = plan.chunk_len * plan.world
-        r0, r1 = sub_range[0] // row_len, -(-sub_range[1] // row_len)
-        rows = [c for c in range(r0, r1) if c * plan.world + self.rank < plan.nchunks]
-        if not rows:
+        todo = self.pieces.copies(self.rank, sub_range)
+        if not todo:
             return
         self.copy_stream.wait_event(after_event)
-        first = (rows[0] * plan.world + self.rank) * plan.chunk_len * item
-        capi.push_pieces(self.device, self.remote_ptr, self.local_ptr, first, row_len * item, plan.chunk_len * item, len(rows), 0, self.copy_stream.cuda_stream)
+        for q, in_piece, in_vector, pitch, nbytes, count in todo:   # dst and src advance by the same offsets
+            capi.push_pieces(self.device, self.piece_ptr[q], self.local_ptr + (in_vector - in_piece), in_piece, pitch, nbytes, count, 0,
+                             self.copy_stream.cuda_stream)
 
     def finish(self):
         self.copy_stream.synchronize()
 
+    def assemble(self, dst_ptr: int, stream=None):
+        """root: the pieces as ONE contiguous vector of nbytes at dst_ptr (device-to-device, after every rank has finished)"""
+        from . import capi
+        assert self.rank == 0
+        for q, off in enumerate(self.piece_off):
+            capi.push_pieces(self.device, dst_ptr + off, self.piece_ptr[q], 0, 0, self.piece_len[q], 1, 0, stream)
+
     def close(self):
         from . import capi
         try:
-            if self.remote_ptr:
-                capi.ipc_close(self.device, self.remote_ptr)
+            for q in self._opened:
+                capi.ipc_close(self.device, q)
         finally:
             self.dist.barrier()
+            if self.rank == 0:
+                for q in self.piece_ptr:
+                    capi.device_free(self.device, q)
             capi.device_free(self.device, self.local_ptr)
 
 

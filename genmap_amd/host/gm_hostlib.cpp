@@ -411,8 +411,12 @@ bool write_runs_parallel(const RunsInput& runs, const SeqTable& seqs, RunText ki
             o.reserve((size_t)(r1 - r0) * 40);
             size_t s = seq_of(runs.start[r0]);
             // wig: span of the previous non-zero run of the same sequence (src/output.hpp:88-90)
+            // (a run list may hold zero runs, which the serial writer skips without touching last_occ: walk back to the nearest
+            // non-zero run of this sequence)
             uint64_t lastSpan = 0;
-            if (kind == RunText::Wig && r0 > 0 && seq_of(runs.start[r0 - 1]) == s) lastSpan = runs.length[r0 - 1];
+            if (kind == RunText::Wig)
+                for (uint64_t q = r0; q > 0 && runs.start[q - 1] >= cum[s]; --q)
+                    if (runs.value[q - 1] != 0) { lastSpan = runs.length[q - 1]; break; }
             for (uint64_t r = r0; r < r1; ++r) {
                 const uint64_t st = runs.start[r];
                 while (s + 1 < seqs.lengths.size() && st >= cum[s + 1]) { ++s; lastSpan = 0; }
@@ -499,31 +503,49 @@ bool save_csv(const std::string& stem, const CsvInput& in, const SeqTable& seqs,
     std::vector<uint64_t> cum(seqs.lengths.size() + 1, 0);
     for (size_t s = 0; s < seqs.lengths.size(); ++s) cum[s + 1] = cum[s] + seqs.lengths[s];
 
-    auto put_lists = [&](const uint64_t* list, uint64_t b, uint64_t e) {   // :246-265 / :267-284
+    // A row depends on its position alone, so shares of the window are formatted by all host cores into per-thread buffers and
+    // written in order (the single-threaded writer spent 25 of the 27.7 s of config C5 here, profiles/r02/cli_c5.txt).
+    auto put_lists = [&](std::string& o, const uint64_t* list, uint64_t b, uint64_t e) {   // :246-265 / :267-284
         uint64_t i = b, prevSeqs = 0;
         for (size_t fi = 0; fi < lastSeqOfFile.size(); ++fi) {
-            f.put(';');
+            o.push_back(';');
             bool first = true;
             while (i < e && (list[i] >> 32) <= lastSeqOfFile[fi]) {
-                if (!first) f.put('|');
-                f.put_u64((list[i] >> 32) - prevSeqs); f.put(','); f.put_u64(list[i] & 0xFFFFFFFFull);
+                if (!first) o.push_back('|');
+                append_u64(o, (list[i] >> 32) - prevSeqs); o.push_back(','); append_u64(o, list[i] & 0xFFFFFFFFull);
                 first = false; ++i;
             }
             prevSeqs = lastSeqOfFile[fi] + 1;
         }
     };
-    size_t s = 0;
-    for (uint64_t jj = 0; jj < in.nPositions; ++jj) {
-        const uint64_t pb = in.plusOff[jj], pe = in.plusOff[jj + 1], mb = in.minusOff[jj], me = in.minusOff[jj + 1];
-        if (pb == pe && mb == me) continue;                    // "is there at least a hit" (src/algo.hpp:378)
-        const uint64_t j = in.posBegin + jj;
-        while (s + 1 < seqs.lengths.size() && cum[s + 1] <= j) ++s;   // myPosLocalize (src/common.hpp:21-28)
-        const uint64_t off = j - cum[s];
-        if ((int64_t)off > (int64_t)seqs.lengths[s] - (int64_t)K) continue;   // k-mer spans two sequences (src/algo.hpp:381)
-        f.put_u64(s); f.put(','); f.put_u64(off);
-        put_lists(in.plus, pb, pe);
-        if (revCompl) put_lists(in.minus, mb, me);
-        f.put('\n');
+    auto format_range = [&](std::string& o, uint64_t j0, uint64_t j1) {
+        if (j0 >= j1) return;
+        size_t s = (size_t)(std::upper_bound(cum.begin(), cum.end(), in.posBegin + j0) - cum.begin());
+        s = std::min(s ? s - 1 : 0, seqs.lengths.size() - 1);
+        for (uint64_t jj = j0; jj < j1; ++jj) {
+            const uint64_t pb = in.plusOff[jj], pe = in.plusOff[jj + 1], mb = in.minusOff[jj], me = in.minusOff[jj + 1];
+            if (pb == pe && mb == me) continue;                    // "is there at least a hit" (src/algo.hpp:378)
+            const uint64_t j = in.posBegin + jj;
+            while (s + 1 < seqs.lengths.size() && cum[s + 1] <= j) ++s;   // myPosLocalize (src/common.hpp:21-28)
+            const uint64_t off = j - cum[s];
+            if ((int64_t)off > (int64_t)seqs.lengths[s] - (int64_t)K) continue;   // k-mer spans two sequences (src/algo.hpp:381)
+            append_u64(o, s); o.push_back(','); append_u64(o, off);
+            put_lists(o, in.plus, pb, pe);
+            if (revCompl) put_lists(o, in.minus, mb, me);
+            o.push_back('\n');
+        }
+    };
+    const unsigned T = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    const uint64_t BATCH = 1ull << 21;   // positions per round: bounds the buffered text (a row is ~100 bytes on config C5)
+    std::vector<std::string> buf(T);
+    for (uint64_t b0 = 0; b0 < in.nPositions; b0 += BATCH) {
+        const uint64_t b1 = std::min(in.nPositions, b0 + BATCH), per = (b1 - b0 + T - 1) / T;
+        auto work = [&](unsigned t) { buf[t].clear(); format_range(buf[t], std::min(b1, b0 + t * per), std::min(b1, b0 + (t + 1) * per)); };
+        if (T == 1 || b1 - b0 < (1u << 14)) { buf[0].clear(); format_range(buf[0], b0, b1); f.put(buf[0]); continue; }
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; ++t) th.emplace_back(work, t);
+        for (auto& x : th) x.join();
+        for (unsigned t = 0; t < T; ++t) f.put(buf[t]);
     }
     return true;
 }

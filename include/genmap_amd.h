@@ -250,11 +250,14 @@ int gm_map_kernel_times(const gm_index *idx, double *ms, uint32_t n, uint32_t *n
 /* wait until every call issued on this index has finished; GM_ERR_INTERNAL if one of them tripped a device-side check */
 int gm_index_sync(gm_index *idx);
 
-/* scheduling knobs of the search kernel, for sweeps and tests (results never depend on them).  Names: verify_t,
- * lds_stack, blocks_per_cu, qtable, sat_min_w, fetch_batch, probation, verify_cost, no_store, no_saturate, skip_dup, coop,
- * use_ctx, steal (0: no work sharing inside a wavefront, n > 0: an exchange when at least n lanes are idle), part_bias
- * (e = 1: characters moved from the second OSS block to the first; every split gives the same result);
- * value -1 restores the library default where one exists.  Nothing is read from the environment. */
+/* scheduling knobs of the search kernel, for sweeps and tests.  Names: verify_t, lds_stack, blocks_per_cu, qtable,
+ * sat_min_w, fetch_batch, probation, verify_cost, skip_dup, coop, use_ctx, child_tables, steal (0: no work sharing inside a
+ * wavefront, n > 0: an exchange when at least n lanes are idle), part_bias (e = 1: characters moved from the second OSS block
+ * to the first; every split gives the same result; may be negative, default 0).  Results never depend on these.
+ * Two TEST-ONLY knobs do change the output: no_saturate = 1 counts without the min(total, MAX) clamp and stores the low bits,
+ * no_store = 1 only switches e = 0 from plain stores to the atomic accumulators (same result).
+ * value -1 restores the library default of any knob except part_bias; values outside a knob's range are GM_ERR_BAD_ARG.
+ * Nothing is read from the environment. */
 int gm_index_set_tuning(gm_index *idx, const char *name, int64_t value);
 
 /* reference default of SearchParams.overlap (common-infix length) for (K,E,-xo): src/mappability.hpp:519-543.

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from genmap_amd.distributed import ShardPlan, gather_chunks, gather_frequency, max_shard_len, shard_ranges
+from genmap_amd.distributed import PiecePlan, ShardPlan, gather_chunks, gather_frequency, max_shard_len, shard_ranges
 
 
 def test_shard_ranges_cover_and_align():
@@ -44,6 +44,41 @@ def test_shard_plan_partitions_every_position_once():
             for r in range(world):
                 assert len(plan.positions_of(r)) >= 50
         assert plan.chunk_arg(0) is None if world == 1 else plan.chunk_arg(1) == (plan.chunk_blocks, 1, world)
+
+
+def test_piece_plan_carries_every_chunk_into_separately_allocated_pieces():
+    """PeerGather's arithmetic without a GPU: the root's vector is several allocations of whole chunk rows (an IPC handle of one
+    3 GB allocation could not be opened); every rank's strided copies of every launch, replayed on numpy arrays, must leave the
+    pieces equal to the unsharded vector -- for piece sizes from one row to everything, 8- and 16-bit items, ragged last chunks"""
+    for nk, step, world, cpr, K in ((100_003, 7, 2, 5, 24), (99_991, 15, 3, 4, 30), (5_000, 1, 8, 3, 4), (64, 7, 4, 2, 3), (30_000, 5, 1, 6, 30)):
+        plan = ShardPlan(nk, step, world, chunks_per_rank=cpr)
+        n = nk + K - 1
+        for item in (1, 2):
+            truth = ((np.arange(n * item, dtype=np.int64) * 131 + 7) % 251).astype(np.uint8)
+            truth[nk * item:] = 0                                          # the zeros of resetLimits behind the last k-mer
+            for piece_bytes in (1, 3 * plan.chunk_len * world * item, 1 << 40):
+                pp = PiecePlan(plan, n, item, piece_bytes)
+                assert pp.piece_off[0] == 0 and sum(pp.piece_len) == pp.nbytes == plan.padded_len(n) * item
+                assert all(o % pp.row_bytes == 0 for o in pp.piece_off)
+                if piece_bytes == 1:
+                    assert len(pp.piece_off) == max(1, plan.rows // world)
+                pieces = [np.zeros(m, np.uint8) for m in pp.piece_len]      # gm_device_alloc zeroes
+                for rank in range(world):
+                    local = np.zeros(pp.nbytes, np.uint8)
+                    for b, e in plan.positions_of(rank):                    # what the rank's kernel writes: its own chunks ...
+                        local[b * item:e * item] = truth[b * item:e * item]
+                    # (... and the zeros at the end of every sequence, which leave `local` as it is)
+                    for sub in plan.sub_ranges(3):
+                        for q, in_piece, in_vector, pitch, nbytes, count in pp.copies(rank, sub):
+                            assert 0 <= in_piece and in_vector - in_piece == pp.piece_off[q]
+                            for i in range(count):
+                                assert in_piece + i * pitch + nbytes <= pp.piece_len[q], "a chunk must not straddle pieces"
+                                pieces[q][in_piece + i * pitch:in_piece + i * pitch + nbytes] = local[in_vector + i * pitch:in_vector + i * pitch + nbytes]
+                got = np.concatenate(pieces)[:n * item]
+                assert np.array_equal(got, truth), (nk, step, world, item, piece_bytes)
+                for off in (0, pp.nbytes - 1, pp.nbytes // 2):
+                    q, o = pp.locate(off)
+                    assert pp.piece_off[q] + o == off and 0 <= o < pp.piece_len[q]
 
 
 def _chunk_worker(rank, world, port, nk, step, q):

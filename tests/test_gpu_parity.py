@@ -294,6 +294,41 @@ def test_gpu_interleaved_chunk_shards_fill_one_vector():
     ix.close()
 
 
+def test_gpu_range_shares_of_a_selection_fill_one_vector():
+    """`genmap map -D a,b -S sel.bed`: every device takes a k-mer range of the selection (gm_map_shard with kmer_begin/kmer_end
+    AND intervals).  A selection's blocks start at interval begins, not at multiples of the block length, so a share delivers
+    exactly the span of its own blocks: the shares written into one 0xEE-filled vector must reproduce the selected positions of
+    the unsharded call and leave every other byte alone -- twice, so that stale bytes of the library's kept buffer would show."""
+    g = _gm()
+    rng = np.random.default_rng(78)
+    lens = [200000, 33, 150000]
+    codes = _repeat_text(rng, sum(lens), True)
+    n = sum(lens)
+    ix = g.Index.build(codes, lens, sampling=1)
+    for K, E, bits in ((30, 1, 8), (24, 0, 16), (100, 1, 8)):
+        nk = n - K + 1
+        step = K - g.tuned_infix_length(K, E) + 1
+        # intervals that start and end off the block grid, one straddling each cut, one touching the end of the text, overlaps
+        cuts = [0, nk // 3 + 1, nk // 3 + 1, 2 * nk // 3 - 5, nk]
+        iv = [(7, 7 + 3 * step + 2), (cuts[1] - 2 * step - 1, cuts[1] + 5 * step + 3), (cuts[1] + step, cuts[1] + 2 * step),
+              (cuts[3] - 1, cuts[3] + 1), (cuts[3] + 11 * step, cuts[3] + 11 * step + 1), (n - 3 * K, n)]
+        full = ix.map(K, E, value_bits=bits, intervals=iv)
+        sel = np.zeros(n, bool)
+        for a, b in iv:
+            sel[a:min(b, nk)] = True
+        hosts = []
+        for fill in ((0xEE, 0x11) if bits == 8 else (0xEEEE, 0x1111)):   # two fills: a byte both runs agree on was delivered
+            host = np.full(n, fill, dtype=full.dtype)
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                ix.map_shard(host, K, E, value_bits=bits, kmer_range=(a, b), intervals=iv)
+            hosts.append(host)
+            ix.map(K, E, value_bits=bits)   # an unrelated call in between leaves other bytes in the library's kept buffer
+        touched = hosts[0] == hosts[1]
+        assert touched[sel].all(), (K, E, bits)
+        assert np.array_equal(np.where(touched, hosts[0], 0), full), (K, E, bits)
+    ix.close()
+
+
 def test_gpu_result_vector_at_any_alignment_and_width_with_chunks():
     """clear / finalize move 16 bytes per lane where planes and result are aligned alike and fall back to single elements where
     they are not: results at odd device offsets, 8- and 16-bit, plain e = 0 planes, e = 1 accumulators and --exclude-pseudo bit

@@ -164,6 +164,30 @@ def test_run_length_writers_on_all_cores_equal_the_serial_ones(kind, hostlib, tm
         assert np.array_equal(np.fromfile(t / "o.freq16", dtype=np.uint16), c)
 
 
+def test_wig_run_writer_with_zero_runs_at_share_boundaries(hostlib, tmp_path):
+    """A run list may hold zero runs (selections leave them inside a sequence).  The serial writer skips them without touching
+    last_occ (src/output.hpp:88-113); the threaded one has to seed every share from the nearest NON-ZERO run before it.
+    Pattern: (1 x1)(0 x2)(2 x2)(0 x1)...: every zero run is as long as the run after it and the non-zero run before it is not,
+    so a share that starts behind a zero run and seeds from it would drop a `variableStep` header."""
+    reps = 1 << 16
+    c = np.ascontiguousarray(np.tile(np.array([1, 0, 0, 2, 2, 0], np.uint16), reps))
+    n = len(c)
+    lens = np.array([n // 2 + 3, n - n // 2 - 3], dtype=np.uint64)   # a sequence boundary inside a run
+    head = np.ones(n, bool); head[1:] = c[1:] != c[:-1]; head[int(lens[0])] = True
+    st = np.flatnonzero(head); ln = np.diff(np.append(st, n)); va = c[st]
+    assert len(st) >= (1 << 18) and (va == 0).sum() >= (1 << 17)
+    z = np.zeros(1, np.uint64)
+    st, ln, va = np.concatenate([st.astype(np.uint64), z]), np.concatenate([ln.astype(np.uint64), z]), np.concatenate([va.astype(np.uint16), z.astype(np.uint16)])
+    names = ["one", "two"]
+    for kind in (0, 2):
+        a, b = tmp_path / f"dense{kind}", tmp_path / f"runs{kind}"
+        a.mkdir(); b.mkdir()
+        assert hostlib.gmh_save_outputs(H._ptr(c), n, 2, str(a / "o").encode(), kind, 4 | 8 | 16, _names(names), H._ptr(lens), 2) == 0
+        assert hostlib.gmh_save_outputs_runs(len(st) - 1, H._ptr(st), H._ptr(ln), H._ptr(va), str(b / "o").encode(), kind, 4 | 8 | 16, _names(names), H._ptr(lens), 2) == 0
+        for ext in (".wig", ".bedgraph", ".bed"):
+            assert filecmp.cmp(a / ("o" + ext), b / ("o" + ext), shallow=False), (kind, ext)
+
+
 @pytest.mark.parametrize("case", sorted(H.CASES))
 def test_csv_writer_reproduces_reference_files(case, hostlib, tmp_path):
     """oracle location lists -> gm_locate's CSR layout -> C++ csv writer == golden csv"""
@@ -199,6 +223,60 @@ def test_csv_writer_reproduces_reference_files(case, hostlib, tmp_path):
                                   _names(file_names), H._ptr(spf), len(file_names), 0)
         assert rc == 0, hostlib.gmh_last_error()
         assert (tmp_path / (stem.name + ".csv")).read_bytes() == (d / "csv" / (stem.name + ".csv")).read_bytes(), (case, name)
+
+
+def test_csv_writer_on_all_cores_equals_a_restatement(hostlib, tmp_path):
+    """windows long enough for the threaded formatter (shares that start inside a sequence, positions without hits, k-mers that
+    would span two sequences, windows appended one after the other) against a restatement of src/output.hpp:189-288"""
+    rng = np.random.default_rng(11)
+    lens = np.array([30_011, 17, 25_000, 9, 14_963], dtype=np.uint64)
+    seqs_per_file = np.array([2, 1, 2], dtype=np.uint64)
+    file_names = ["a.fa", "b.fasta", "c.fa"]
+    seq_names = ["s0", "s one", "s2", "t", "u"]
+    K, n = 21, int(lens.sum())
+    cum = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    last_of_file = np.cumsum(seqs_per_file) - 1
+
+    def lists(count):
+        out = []
+        for c in count:
+            sq = np.sort(rng.integers(0, len(lens), size=c))
+            out.append([(int(a), int(rng.integers(0, 1 << 20))) for a in sq])
+        return out
+    cnt_p = rng.integers(0, 4, size=n) * (rng.random(n) < 0.7); cnt_m = rng.integers(0, 3, size=n) * (rng.random(n) < 0.5)
+    plus, minus = lists(cnt_p), lists(cnt_m)
+
+    def expect(j0, j1, header):
+        rows = []
+        if header:
+            rows.append('"k-mer"' + "".join(f';"+ strand {f}"' for f in file_names) + "".join(f';"- strand {f}"' for f in file_names) + "\n")
+        for j in range(j0, j1):
+            if not plus[j] and not minus[j]:
+                continue
+            s = int(np.searchsorted(cum, j, side="right") - 1)
+            off = j - cum[s]
+            if off > int(lens[s]) - K:
+                continue
+            row = f"{s},{off}"
+            for lst in (plus[j], minus[j]):
+                prev = 0
+                for fi, last in enumerate(last_of_file):
+                    row += ";" + "|".join(f"{a - prev},{b}" for a, b in lst if prev <= a <= last)
+                    prev = int(last) + 1
+            rows.append(row + "\n")
+        return "".join(rows)
+
+    stem = tmp_path / "x.genmap"
+    exp = ""
+    for w, (j0, j1) in enumerate(((0, 40_000), (40_000, 40_003), (40_003, n))):
+        po = np.zeros(j1 - j0 + 1, np.uint64); mo = np.zeros(j1 - j0 + 1, np.uint64)
+        po[1:] = np.cumsum([len(plus[j]) for j in range(j0, j1)]); mo[1:] = np.cumsum([len(minus[j]) for j in range(j0, j1)])
+        pl = np.asarray([(a << 32) | b for j in range(j0, j1) for a, b in plus[j]] + [0], dtype=np.uint64)
+        mi = np.asarray([(a << 32) | b for j in range(j0, j1) for a, b in minus[j]] + [0], dtype=np.uint64)
+        assert hostlib.gmh_save_csv(str(stem).encode(), j0, j1 - j0, H._ptr(po), H._ptr(mo), H._ptr(pl), H._ptr(mi), _names(seq_names), H._ptr(lens), len(lens), K, 1,
+                                    _names(file_names), H._ptr(seqs_per_file), len(file_names), int(w > 0)) == 0, hostlib.gmh_last_error()
+        exp += expect(j0, j1, w == 0)
+    assert (tmp_path / "x.genmap.csv").read_text() == exp
 
 
 def test_fasta_reader_matches_fixture_parsing(hostlib):

@@ -31,7 +31,7 @@ for K, E in ((30, 0), (30, 1), (100, 1)):
         print(f"K={K} E={E}: chunks gathered with the collective == unsharded: {same}")
         ok &= same
     # (b) peer copies into the root's vector, launch by launch
-    pg = PeerGather(plan, n, 1, rank, 0, dist, launches=3)
+    pg = PeerGather(plan, n, 1, rank, 0, dist, launches=3, piece_bytes=3 * plan.chunk_len * world)   # several pieces even at this size
     if not pg.ok:
         print("PeerGather: IPC not available here"); ok = False
     else:
@@ -41,9 +41,10 @@ for K, E in ((30, 0), (30, 1), (100, 1)):
             pg.push(sub, ev)
         torch.cuda.synchronize(); pg.finish(); dist.barrier()
         if rank == 0:
-            got = torch.empty(n, dtype=torch.uint8, device="cuda:0")
-            g.push_pieces(0, got.data_ptr(), pg.local_ptr, 0, 0, n, 1, 0, None)
+            got = torch.empty(pg.nbytes, dtype=torch.uint8, device="cuda:0")
+            pg.assemble(got.data_ptr())
             torch.cuda.synchronize()
+            got = got[:n]
             same = np.array_equal(got.cpu().numpy(), full)
             print(f"K={K} E={E}: chunks pushed over IPC peer copies == unsharded: {same}")
             ok &= same
