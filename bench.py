@@ -269,9 +269,10 @@ def main():
             comm["wait_s"] += time.perf_counter() - t1
 
         if pg is not None:
-            # One untimed step first: if the peer copies take far longer than the search plus a transfer at a fifth of one xGMI
+            # Two untimed steps first (a cold one, then a timed probe): if the peer copies take far longer than the search plus a transfer at a fifth of one xGMI
             # link would (a fabric that routes through host memory, a driver that serialises the copies behind the persistent
             # kernel), every rank switches to the gather collective and the line says so.
+            one_step()   # cold: builds the q-mer tables and the workspaces of this (K, E)
             sync()
             t1 = time.perf_counter()
             one_step()

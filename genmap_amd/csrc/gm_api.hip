@@ -631,7 +631,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     const uint32_t infix = p->infix > 0 ? (uint32_t)p->infix : (p->overlap >= 0 ? default_infix_length(p->K, p->E, p->overlap) : tuned_infix_length(p->K, p->E));
     if (infix == 0) return GM_ERR_BAD_OVERLAP;
     MapPlan& plan = S->plan;
-    int rc = make_map_plan(p->K, p->E, infix, p->revcompl, text_len, intervals, n_intervals, &plan, ix->tune.partBias);
+    int rc = make_map_plan(p->K, p->E, infix, p->revcompl, text_len, intervals, n_intervals, &plan, ix->tune.partBias, (uint32_t)std::max(0, ix->tune.ossWeights));
     if (rc) return rc;   // PlanError values coincide with gm_status
 
     // shard [kmer_begin, kmer_end): blocks whose first k-mer lies inside
@@ -736,7 +736,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         // host-device synchronisation
         uint64_t h = 1469598103934665603ull;
         auto mix = [&h](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
-        mix(p->K); mix(p->E); mix(plan.infix); mix((uint64_t)(int64_t)ix->tune.partBias); mix(text_begin); mix(text_len); mix(first_seq); mix(n_seq); mix(n_intervals);
+        mix(p->K); mix(p->E); mix(plan.infix); mix((uint64_t)(int64_t)ix->tune.partBias); mix((uint64_t)(int64_t)ix->tune.ossWeights); mix(text_begin); mix(text_len); mix(first_seq); mix(n_seq); mix(n_intervals);
         for (uint64_t k = 0; k < 2 * n_intervals; ++k) mix(intervals[k]);
         if (!ix->sigValid || ix->sig != h) {
             GM_HIP(hipMemcpyAsync(ix->d_table, plan.table.data(), plan.table.size() * sizeof(OssRecord), hipMemcpyHostToDevice, st));
@@ -1343,7 +1343,7 @@ int gm_index_set_tuning(gm_index* ix, const char* name, int64_t value)
         {"no_store", &ix->tune.noStore, dflt.noStore, 0, 1}, {"no_saturate", &ix->tune.noSaturate, dflt.noSaturate, 0, 1},
         {"skip_dup", &ix->tune.skipDup, dflt.skipDup, 0, 1}, {"coop", &ix->tune.coop, dflt.coop, 0, 1}, {"use_ctx", &ix->tune.useCtx, dflt.useCtx, 0, 1},
         {"steal", &ix->tune.steal, dflt.steal, 0, 64}, {"part_bias", &ix->tune.partBias, dflt.partBias, -255, 255},
-        {"child_tables", &ix->tune.childTables, dflt.childTables, 0, 1},
+        {"child_tables", &ix->tune.childTables, dflt.childTables, 0, 1}, {"oss_weights", &ix->tune.ossWeights, dflt.ossWeights, 0, 0xFFFFFF},
     };
     for (auto& t : tab) if (!strcmp(t.n, name)) {
         const bool isBias = t.f == &ix->tune.partBias;

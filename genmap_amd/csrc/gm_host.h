@@ -85,7 +85,7 @@ enum PlanError { PLAN_OK = 0, PLAN_BAD_E = -2, PLAN_BAD_K = -6, PLAN_BAD_OVERLAP
 // intervals are merged (the reference skips already-filled positions, algo.hpp:236-242; the value of a
 // position does not depend on which block computes it).
 inline int make_map_plan(uint32_t K, uint32_t E, uint32_t infix, int revcompl, uint64_t textLen,
-                         const uint64_t* intervals, uint64_t nIntervals, MapPlan* out, int partBias = 0)
+                         const uint64_t* intervals, uint64_t nIntervals, MapPlan* out, int partBias = 0, uint32_t ossWeights = 0)
 {
     MapPlan& p = *out;
     if (E > MAX_ERRORS) return PLAN_BAD_E;
@@ -102,11 +102,22 @@ inline int make_map_plan(uint32_t K, uint32_t E, uint32_t infix, int revcompl, u
         {
             // partBias (e = 1, two blocks): characters moved from the second block to the first; the scheme is exact for any
             // positive lengths (gm_oss.h), the reference splits evenly
-            uint32_t lens[2]; const uint32_t* lp = nullptr;
+            uint32_t lens[OSS_MAXB]; const uint32_t* lp = nullptr;
             const uint32_t L = K - n + 1;
             if (E == 1 && partBias != 0 && L >= 2) {
                 const int a = std::max(1, std::min((int)L - 1, (int)(L / 2 + (L & 1u)) + partBias));
                 lens[0] = (uint32_t)a; lens[1] = L - (uint32_t)a; lp = lens;
+            }
+            // ossWeights (any E >= 1): block i (left to right) gets a share of the infix proportional to nibble i of the
+            // value -- e.g. 0x7755 at e = 2 makes the two right blocks, with which searches 2 and 3 start, longer
+            const uint32_t nb = oss_scheme(E).s[0].nb;
+            if (E >= 1 && ossWeights != 0 && L >= nb) {
+                uint32_t W = 0, sum = 0;
+                for (uint32_t i = 0; i < nb; ++i) W += std::max(1u, (ossWeights >> (4u * i)) & 15u);
+                for (uint32_t i = 0; i < nb; ++i) { lens[i] = std::max(1u, L * std::max(1u, (ossWeights >> (4u * i)) & 15u) / W); sum += lens[i]; }
+                for (uint32_t i = 0; sum < L; i = (i + 1) % nb) { lens[i]++; sum++; }           // remainder: left to right
+                for (uint32_t i = nb; sum > L; ) { i = i ? i - 1 : nb - 1; if (lens[i] > 1) { lens[i]--; sum--; } }   // (minimum lengths pushed it over)
+                lp = lens;
             }
             if (!oss_make_record(E, s, L, &p.table[(size_t)(n - 1) * 8 + s], lp)) return PLAN_BAD_OVERLAP;
         }

@@ -253,7 +253,8 @@ int gm_index_sync(gm_index *idx);
 /* scheduling knobs of the search kernel, for sweeps and tests.  Names: verify_t, lds_stack, blocks_per_cu, qtable,
  * sat_min_w, fetch_batch, probation, verify_cost, skip_dup, coop, use_ctx, child_tables, steal (0: no work sharing inside a
  * wavefront, n > 0: an exchange when at least n lanes are idle), part_bias (e = 1: characters moved from the second OSS block
- * to the first; every split gives the same result; may be negative, default 0).  Results never depend on these.
+ * to the first; every split gives the same result; may be negative, default 0), oss_weights (e >= 1: nibble i = relative length of
+ * OSS block i, left to right; 0 = the reference's equal split).  Results never depend on these.
  * Two TEST-ONLY knobs do change the output: no_saturate = 1 counts without the min(total, MAX) clamp and stores the low bits,
  * no_store = 1 only switches e = 0 from plain stores to the atomic accumulators (same result).
  * value -1 restores the library default of any knob except part_bias; values outside a knob's range are GM_ERR_BAD_ARG.

@@ -909,3 +909,23 @@ def test_gpu_multi_rank_rehearsal_on_one_device(world):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                         "--master-port", str(29600 + world), os.path.join(root, "tools", "multi_check.py")], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0 and "MULTI_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_gpu_bench_two_ranks_on_one_device_at_0p77_gbp():
+    """bench.py --gpus 2 itself, both ranks on cuda:0, on a quarter of the metric's text (0.77 Gbp): peer copies into the root's
+    pieces (several IPC handles, the configuration an 8-GPU run has), --verify of every gathered vector against the single-rank
+    one, and the JSON line an N = 2 run prints: C4's (K=100, e=1) as a sub-record with its own roofline"""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29611",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "grch38", "--scale", "0.25", "--sampling", "0", "--same-device", "--backend", "gloo",
+           "--comm", "p2p", "--watchdog", "400", "--steps", "2", "--warmup", "1", "--verify", "--sub", "100,1:1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    for K, E in ((30, 0), (100, 1)):
+        assert f"verify K={K} E={E}: gathered vector == single-rank vector (peer DMA copies overlapping compute)" in r.stderr, r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["comm"] == "peer DMA copies overlapping compute" and len(line["per_rank_search_ms"]) == 2
+    sub = [s for s in line["sub"] if (s["K"], s["E"]) == (100, 1)]
+    assert sub and sub[0]["roofline"]["frac"] and sub[0]["roofline"]["rank_lines"] > 0 and line["roofline"]["frac"]
