@@ -173,8 +173,13 @@ GM_HD void lane_children(NodeT<typename Env::row_t>& nd, bool& have, const RootT
     for (int x = 0; x < (int)NLET; ++x) { cnt[x] = rh[x] - rl[x]; tot += cnt[x]; pn[x] = env.C((uint32_t)x) + rl[x]; }
     R run = nd.w - tot;   // sentinels in BWT[lo,hi) sort before every letter
     uint32_t nonEmpty = 0;
+    // Env::NLESS: the text letter N is never followed (neither here nor by the verification below): this pass then finds exactly
+    // the occurrences whose text window holds no N, and the occurrences with N in the text are added by a second pass that
+    // searches the N-holding text windows themselves (gm_api.hip: correction pass; Hamming distance is symmetric).  N is the
+    // largest letter, so the range arithmetic of the other children does not change.
+    constexpr int NX = Env::NLESS ? (int)SYM_N : (int)NLET;
 #pragma unroll
-    for (int x = 0; x < (int)NLET; ++x) { sm[x] = run; run += cnt[x]; nonEmpty |= (cnt[x] != 0u ? 1u : 0u) << x; }
+    for (int x = 0; x < (int)NLET; ++x) { sm[x] = run; run += cnt[x]; if (x < NX) nonEmpty |= (cnt[x] != 0u ? 1u : 0u) << x; }
     // Which letters may be taken, as a mask (the same three conditions per letter would cost ~10 instructions each):
     //   delta(x) = x != needle letter || needle letter is N                       find2:250, algo.hpp:111-112,148-149
     //   exact segment: only delta == 0                                            find2:330, algo.hpp:117-125
@@ -182,7 +187,7 @@ GM_HD void lane_children(NodeT<typename Env::row_t>& nd, bool& have, const RootT
     const uint32_t matchBit = tc < SYM_N ? 1u << tc : 0u;
     const bool okMatch = !(pl.minErr > 0u && pl.charsLeft < pl.minErr + 1u);
     const bool okMiss = !pl.exact && !(pl.minErr > 0u && pl.charsLeft < pl.minErr);
-    const uint32_t valid = nonEmpty & ((okMatch ? matchBit : 0u) | (okMiss ? ((1u << NLET) - 1u) & ~matchBit : 0u));
+    const uint32_t valid = nonEmpty & ((okMatch ? matchBit : 0u) | (okMiss ? ((1u << NX) - 1u) & ~matchBit : 0u));
 
     Node keep; keep.flo = keep.rlo = keep.w = keep.meta = 0;
     bool haveKeep = false;
@@ -209,7 +214,7 @@ GM_HD void lane_children(NodeT<typename Env::row_t>& nd, bool& have, const RootT
     const uint32_t miss = Env::EXACT_ONLY ? 0u : (hasMatch ? valid & ~(1u << tc) : valid);   // pattern N: every child is a mismatch (find2:250)
     if (!Env::EXACT_ONLY && env.any(miss != 0u)) {
 #pragma unroll
-        for (int x = 0; x < (int)NLET; ++x) {
+        for (int x = 0; x < NX; ++x) {
             const bool on = ((miss >> x) & 1u) != 0u;
             if (!env.any(on)) continue;
             if (on) {
@@ -282,7 +287,10 @@ GM_HD uint32_t scan_side(Env& env, const RootT<typename Env::row_t>& rt, const t
                       | (0x8080808080808080ull & ~bytes_nonzero(t8 ^ 0x0505050505050505ull));                           // sentinel
         const uint32_t left = need - i;
         if (left < 8u) ev &= (1ull << (8u * left)) - 1ull;
-        const uint64_t sent = 0x8080808080808080ull & ~bytes_nonzero(t8 ^ 0x0505050505050505ull);
+        uint64_t sent = 0x8080808080808080ull & ~bytes_nonzero(t8 ^ 0x0505050505050505ull);
+        if (Env::NLESS) {   // a text N ends the occurrence like a sentinel (those occurrences belong to the correction pass)
+            sent |= 0x8080808080808080ull & ~bytes_nonzero(t8 ^ 0x0404040404040404ull);   // (always an event of `ev` too)
+        }
         while (ev) {
             env.note_wave(13);
             const uint32_t bit = ctz64(ev);

@@ -146,4 +146,45 @@ inline int make_map_plan(uint32_t K, uint32_t E, uint32_t infix, int revcompl, u
     return PLAN_OK;
 }
 
+// ---- correction pass of N-less searches (gm_engine.h: Env::NLESS) ----------------------------------------------------------------
+// Starts t of the text windows [t, t + K) that overlap a run of N by 1..E letters (or hold a whole run of at most E letters) and
+// lie inside one sequence: exactly the windows that can be an occurrence with N in the text (a window holding more than E letters
+// of one run cannot; windows also touching other runs are kept -- they cost a search, not correctness).  No window without N is
+// ever listed.  runs: [begin, end) of maximal N runs of the concatenated text, sorted; cum: sequence limits.  out: [begin, end) pairs.
+inline void n_window_intervals(const std::vector<std::pair<uint64_t, uint64_t>>& runs, const std::vector<uint64_t>& cum, uint32_t K, uint32_t E,
+                               std::vector<uint64_t>& out)
+{
+    out.clear();
+    if (E == 0 || K == 0) return;
+    std::vector<std::pair<int64_t, int64_t>> iv;   // inclusive
+    for (auto& r : runs) {
+        const int64_t s = (int64_t)r.first, e = (int64_t)r.second, k = K, x = E;
+        iv.emplace_back(s - k + 1, s - k + x);                 // the window's tail overlaps the head of the run
+        iv.emplace_back(e - x, e - 1);                         // the window's head overlaps the tail of the run
+        if (e - s <= x) iv.emplace_back(s - k + 1, e - 1);     // the whole run inside the window
+    }
+    std::sort(iv.begin(), iv.end());
+    size_t sq = 0;
+    int64_t curB = 0, curE = -1;
+    auto emit = [&](int64_t b, int64_t e2) {   // clip [b, e2] to whole windows of single sequences
+        while (b <= e2) {
+            while (sq + 1 < cum.size() && (int64_t)cum[sq + 1] <= b) ++sq;
+            if (sq + 1 >= cum.size()) return;
+            const int64_t lastStart = (int64_t)cum[sq + 1] - (int64_t)K;   // last window start inside sequence sq
+            const int64_t hi = std::min(e2, lastStart);
+            if (hi >= b) { out.push_back((uint64_t)b); out.push_back((uint64_t)hi + 1); }
+            b = std::max(b, (int64_t)cum[sq + 1]);
+            if (hi == e2) return;
+        }
+    };
+    for (auto& v : iv) {
+        int64_t b = std::max<int64_t>(v.first, 0), e2 = v.second;
+        if (e2 < b) continue;
+        if (curE >= curB && b <= curE + 1) { curE = std::max(curE, e2); continue; }
+        if (curE >= curB) emit(curB, curE);
+        curB = b; curE = e2;
+    }
+    if (curE >= curB) emit(curB, curE);
+}
+
 }  // namespace gm

@@ -8,6 +8,7 @@
 // its current root in four VGPRs.
 #pragma once
 #include "gm_common.h"
+#include <vector>
 
 namespace gm {
 
@@ -89,6 +90,56 @@ inline bool oss_make_record(uint32_t E, uint32_t s, uint32_t infixLen, OssRecord
         r.z |= right << (18u + i);
     }
     *out = r;
+    return true;
+}
+
+// ---- jump patterns: the top of the search tree as direct table lookups ------------------------------------------------------
+// The first J characters of a search (in search order) are a contiguous substring of the needle window.  Every path of
+// _optimalSearchSchemeChildrenGM / ...ExactGM (find2_index_approx.hpp:223-369) through these J characters is "the needle
+// substring with some characters substituted", and which substitution sets are allowed depends only on the scheme's cumulative
+// bounds l/u -- not on the index.  So instead of walking the top of the tree node by node (at e = 2 on a 3 Gbp text that is
+// ~70 % of all steps: every string of <= 14 characters exists), the lane enumerates the PATTERNS of its search and reads the
+// SA ranges of the substituted J-mers from the table of all J-mers (one 16-byte read each); the tree walk starts at depth J.
+// Only substitutions by A,C,G,T are enumerated (the table holds no N): kernels that jump run with Env::NLESS (gm_engine.h).
+//
+// descriptor (u32): bits 0..2 number of substitutions (<= 4); substitution k at bits 3 + 6k: offset of the character inside the
+// J-mer in needle order (4 bits), rotation r in 1..3 (2 bits): the substituted letter is (needle letter + r) & 3.
+struct JumpSearch {
+    uint32_t J = 0;        // characters covered (0: no jump for this search)
+    uint32_t regionA = 0;  // window coordinate of the J-mer's first character, minus (n - 1)   [the infix starts at n - 1]
+    uint32_t meta0 = 0;    // (a - (n-1)) | (bx - (n-1)) << 9 | t << 18 of the node at depth J (errs and mode are added by the lane)
+    std::vector<uint32_t> pat;
+};
+
+// (host) Patterns of search s for an infix of length L split by rec; J characters.  Returns false if more than maxPatterns exist.
+inline bool oss_jump_patterns(uint32_t E, const OssRecord& rec, uint32_t L, uint32_t J, size_t maxPatterns, JumpSearch* out)
+{
+    out->J = 0; out->pat.clear();
+    if (J == 0 || J >= L || J > 15u) return false;
+    // the exact path through the first J characters: position, block and "block ends here" of every character
+    uint32_t a = oss_start(rec), bx = a, t = 0;    // coordinates relative to the infix start
+    uint32_t pos[16], blk[16]; bool endsBlock[16];
+    for (uint32_t i = 0; i < J; ++i) {
+        const bool right = oss_right(rec, t) != 0;
+        pos[i] = right ? bx : a - 1u;
+        blk[i] = t;
+        if (right) ++bx; else --a;
+        endsBlock[i] = (bx - a == oss_bl(rec, t));
+        if (endsBlock[i]) ++t;
+    }
+    out->regionA = a; out->meta0 = a | bx << 9 | t << 18; out->J = J;
+    // depth-first over the characters: match, or substitute while the block's upper bound allows; lower bound at block ends
+    struct Frame { uint32_t i, errs, desc; };
+    std::vector<Frame> st; st.push_back({0, 0, 0});
+    while (!st.empty()) {
+        const Frame f = st.back(); st.pop_back();
+        if (f.i == J) { out->pat.push_back(f.desc | f.errs); if (out->pat.size() > maxPatterns) { out->J = 0; out->pat.clear(); return false; } continue; }
+        const uint32_t b = blk[f.i], u = oss_u(rec, b), l = oss_l(rec, b);
+        // pushed in reverse so that patterns come out in the order of the tree walk (match first)
+        if (f.errs + 1u <= u && f.errs < 4u && !(endsBlock[f.i] && f.errs + 1u < l))
+            for (uint32_t r = 3; r >= 1; --r) st.push_back({f.i + 1u, f.errs + 1u, f.desc | ((pos[f.i] - a) | r << 4) << (3u + 6u * f.errs)});
+        if (!(endsBlock[f.i] && f.errs < l)) st.push_back({f.i + 1u, f.errs, f.desc});
+    }
     return true;
 }
 

@@ -36,9 +36,28 @@ template <int WPP> struct HostIndex {
     }
 };
 
-template <int WPP> struct EmuEnv {
+template <int WPP, bool NL = false> struct EmuEnv {
     typedef uint32_t row_t;
     static constexpr bool EXACT_ONLY = false;
+    static constexpr bool NLESS = NL;
+    // correction pass (scatter): a located occurrence adds one to ITS OWN slice position (the needle is a text window with N)
+    bool scatter = false;
+    const uint64_t* cumAll = nullptr; uint32_t nSeqAll = 0; uint64_t sliceBegin = 0, sliceLen = 0;
+    void scatter_at(uint32_t sentPos)
+    {
+        uint32_t lo = 0, hi = nSeqAll;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cumAll[mid] + mid <= sentPos) lo = mid; else hi = mid; }
+        const uint64_t g = (uint64_t)sentPos - lo;             // sentinel-free position
+        if (g < sliceBegin || g - sliceBegin >= sliceLen) return;
+        const uint64_t q = g - sliceBegin;
+        if (selBlocks) {   // a selection: only the positions the main pass computes (blocks sorted by position)
+            size_t a = 0, b = selBlocks->size();
+            while (b - a > 1) { const size_t m = (a + b) >> 1; if (MapPlan::block_pos((*selBlocks)[m]) <= q) a = m; else b = m; }
+            if (selBlocks->empty() || MapPlan::block_pos((*selBlocks)[a]) > q || q >= MapPlan::block_pos((*selBlocks)[a]) + MapPlan::block_n((*selBlocks)[a])) return;
+        }
+        uint32_t& v = (*acc)[q]; if (v != 0xFFFFFFFFu) ++v;
+    }
+    const std::vector<std::pair<uint32_t, uint32_t>>* selBlocks = nullptr;
     const uint32_t* saArr = nullptr;
     const std::vector<uint8_t>* textSent = nullptr;
     uint64_t verified = 0;
@@ -67,7 +86,7 @@ template <int WPP> struct EmuEnv {
         }
         return v;
     }
-    void leaf_at(const Root& rt, uint32_t kmer, uint32_t) { leafSum += 1; leaf_flush(rt, kmer); }
+    void leaf_at(const Root& rt, uint32_t kmer, uint32_t textPos) { if (scatter) { scatter_at(textPos); return; } leafSum += 1; leaf_flush(rt, kmer); }
     const HostIndex<WPP>* ix;
     const uint8_t* text;
     uint32_t K;
@@ -95,7 +114,7 @@ template <int WPP> struct EmuEnv {
     void note_wave(int) {}
     void note_item(uint32_t) {}
     uint32_t leafSum = 0;
-    void leaf(const Root&, uint32_t, uint32_t, uint32_t w) { leafSum += w; }
+    void leaf(const Root&, uint32_t, uint32_t flo, uint32_t w) { if (scatter) { for (uint32_t r = 0; r < w; ++r) scatter_at(saArr[flo + r]); return; } leafSum += w; }
     void leaf_flush(const Root& rt, uint32_t kmer)
     {
         uint32_t count = leafSum; leafSum = 0;
@@ -108,30 +127,52 @@ template <int WPP> struct EmuEnv {
     uint32_t C(uint32_t c) const { return ix->C[c]; }
 };
 
+// SA range of an ACGT string (most significant symbol first in idx) by right extensions from the root: what the device reads from
+// its table of all J-mers (gm_kernels.h: qmer_table_kernel)
 template <int WPP>
-static int run(const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nseqTotal, const uint8_t* text, uint64_t textLen,
-               const uint64_t* seqCum, uint32_t nseqLocal, uint32_t K, uint32_t E, uint32_t infix, int revcompl, int valueBits,
-               const uint64_t* intervals, uint64_t nIntervals, void* out, uint64_t* stats, const uint32_t* sa, uint32_t verifyT,
-               const uint8_t* allCodes, const uint64_t* allCum)
+static void table_entry(const HostIndex<WPP>& ix, uint32_t idx, uint32_t J, uint32_t& flo, uint32_t& rlo, uint32_t& w)
 {
-    MapPlan plan;
-    int rc = make_map_plan(K, E, infix, revcompl, textLen, intervals, nIntervals, &plan);
-    if (rc) return rc;
-    HostIndex<WPP> ix; ix.build(bf, br, rows, nseqTotal);
-    std::vector<uint32_t> acc(textLen ? textLen : 1, 0);
-    EmuEnv<WPP> env; env.ix = &ix; env.text = text; env.K = K; env.acc = &acc;
-    std::vector<uint8_t> textS;
-    if (sa && verifyT) {   // sentinel text: sequence s occupies [cum[s] + s, cum[s+1] + s), sentinel after it
-        textS.resize(rows);
-        for (uint32_t q = 0; q < nseqTotal; ++q) {
-            for (uint64_t i = allCum[q]; i < allCum[q + 1]; ++i) textS[i + q] = allCodes[i];
-            textS[allCum[q + 1] + q] = (uint8_t)SYM_SENT;
-        }
-        env.saArr = sa; env.textSent = &textS;
+    constexpr uint32_t SPB = BlockGeom<WPP>::SPB, WPB = BlockGeom<WPP>::WPB;
+    flo = 0; rlo = 0; w = (uint32_t)ix.n;
+    for (uint32_t i = 0; i < J && w; ++i) {
+        const uint32_t c = (idx >> (2u * (J - 1u - i))) & 3u;
+        uint32_t rl[NLET], rh[NLET];
+        block_rank<WPP>(ix.blk[1].data() + (size_t)(rlo / SPB) * WPB, rlo % SPB, rl);
+        block_rank<WPP>(ix.blk[1].data() + (size_t)((rlo + w) / SPB) * WPB, (rlo + w) % SPB, rh);
+        uint32_t tot = 0, below = 0;
+        for (uint32_t x = 0; x < NLET; ++x) { const uint32_t cx = rh[x] - rl[x]; tot += cx; if (x < c) below += cx; }
+        flo += (w - tot) + below; rlo = ix.C[c] + rl[c]; w = rh[c] - rl[c];
     }
-    uint32_t bound = stack_bound(E, plan.stepSize);
+}
+
+// all roots of a plan through one environment; jumpCap > 0: regular blocks whose jump region holds no N start from the patterns
+template <int WPP, class Env>
+static void search_plan(const MapPlan& plan, const HostIndex<WPP>& ix, Env& env, uint32_t K, uint32_t E, uint64_t rows, uint32_t verifyT, uint32_t jumpCap, uint64_t* nPatterns)
+{
+    std::vector<JumpSearch> jumps(plan.nSearches);
+    const uint32_t L = K - plan.stepSize + 1;
+    if (jumpCap && E >= 1) {
+        for (uint32_t J = std::min(jumpCap, L - 1u); J >= 1; --J) {   // one J for every search: the largest whose pattern lists stay small
+            bool ok = true;
+            for (uint32_t s = 0; s < plan.nSearches && ok; ++s) ok = oss_jump_patterns(E, plan.table[(size_t)(plan.stepSize - 1) * 8 + s], L, J, 4096, &jumps[s]);
+            if (ok) break;
+            for (auto& j : jumps) j = JumpSearch();
+        }
+    }
     uint64_t roots = plan.numRoots();
     uint32_t rpb = plan.nSearches * plan.nStrands;
+    auto walk = [&](Node nd, const Root& rt) {
+        bool have = true;
+        for (;;) {
+            if (!have) { if (env.stack.empty()) break; nd = env.stack.back(); env.stack.pop_back(); have = true; }
+            if (env.saArr && verifyT && nd.w <= verifyT) {   // the device defers these to a wave-wide verification round
+                for (uint32_t r2 = 0; r2 < nd.w; ++r2) verify_item(nd.flo + r2, nd.meta, rt, K, E, env);
+                env.verified += nd.w; have = false; continue;
+            }
+            if (meta_mode(nd.meta) == M_SPLIT) { Node left; split_node(nd, left, K); env.push(left); }
+            lane_step(nd, have, rt, K, E, env);
+        }
+    };
     for (uint64_t id = 0; id < roots; ++id) {
         uint64_t b = id / rpb; uint32_t r = (uint32_t)(id % rpb);
         Root rt;
@@ -140,16 +181,81 @@ static int run(const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nse
         rt.strand = r / plan.nSearches;
         rt.search = r % plan.nSearches;
         rt.rec = plan.table[(size_t)(rt.n - 1) * 8 + rt.search];
-        Node nd = root_node(rt, (uint32_t)rows);
-        bool have = true;
-        for (;;) {
-            if (!have) { if (env.stack.empty()) break; nd = env.stack.back(); env.stack.pop_back(); have = true; }
-            if (env.saArr && nd.w <= verifyT) {   // the device defers these to a wave-wide verification round
-                for (uint32_t r2 = 0; r2 < nd.w; ++r2) verify_item(nd.flo + r2, nd.meta, rt, K, E, env);
-                env.verified += nd.w; have = false; continue;
+        const JumpSearch& js = jumps[rt.search];
+        bool jumped = false;
+        if (js.J && rt.n == plan.stepSize) {
+            const uint32_t a0 = rt.n - 1u + js.regionA;
+            uint32_t base2 = 0; bool bad = false;
+            for (uint32_t i = 0; i < js.J; ++i) { const uint32_t c = env.text_char(rt, a0 + i); if (c >= SYM_N) bad = true; base2 = base2 << 2 | (c & 3u); }
+            if (!bad) {
+                jumped = true;
+                for (uint32_t d : js.pat) {
+                    uint32_t idx = base2;
+                    const uint32_t nsub = d & 7u;
+                    for (uint32_t k = 0; k < nsub; ++k) {
+                        const uint32_t f = (d >> (3u + 6u * k)) & 63u, off = f & 15u, rot = f >> 4;
+                        const uint32_t sh = 2u * (js.J - 1u - off), old = (idx >> sh) & 3u;
+                        idx ^= (old ^ ((old + rot) & 3u)) << sh;
+                    }
+                    Node nd;
+                    table_entry<WPP>(ix, idx, js.J, nd.flo, nd.rlo, nd.w);
+                    if (nPatterns) ++*nPatterns;
+                    if (!nd.w) continue;
+                    const uint32_t off = rt.n - 1u;
+                    nd.meta = meta_pack((js.meta0 & 0x1FFu) + off, ((js.meta0 >> 9) & 0x1FFu) + off, js.meta0 >> 18, nsub, M_OSS);
+                    walk(nd, rt);
+                }
             }
-            if (meta_mode(nd.meta) == M_SPLIT) { Node left; split_node(nd, left, K); env.push(left); }
-            lane_step(nd, have, rt, K, E, env);
+        }
+        if (!jumped) walk(root_node(rt, (uint32_t)rows), rt);
+    }
+}
+
+template <int WPP, bool NL>
+static int run(const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nseqTotal, const uint8_t* text, uint64_t textLen,
+               const uint64_t* seqCum, uint32_t nseqLocal, uint32_t K, uint32_t E, uint32_t infix, int revcompl, int valueBits,
+               const uint64_t* intervals, uint64_t nIntervals, void* out, uint64_t* stats, const uint32_t* sa, uint32_t verifyT,
+               const uint8_t* allCodes, const uint64_t* allCum, uint32_t jumpCap)
+{
+    MapPlan plan;
+    int rc = make_map_plan(K, E, infix, revcompl, textLen, intervals, nIntervals, &plan);
+    if (rc) return rc;
+    HostIndex<WPP> ix; ix.build(bf, br, rows, nseqTotal);
+    std::vector<uint32_t> acc(textLen ? textLen : 1, 0);
+    EmuEnv<WPP, NL> env; env.ix = &ix; env.text = text; env.K = K; env.acc = &acc;
+    std::vector<uint8_t> textS;
+    if (sa && (verifyT || NL)) {   // sentinel text: sequence s occupies [cum[s] + s, cum[s+1] + s), sentinel after it
+        textS.resize(rows);
+        for (uint32_t q = 0; q < nseqTotal; ++q) {
+            for (uint64_t i = allCum[q]; i < allCum[q + 1]; ++i) textS[i + q] = allCodes[i];
+            textS[allCum[q + 1] + q] = (uint8_t)SYM_SENT;
+        }
+        env.saArr = sa; env.textSent = &textS;
+    }
+    uint32_t bound = stack_bound(E, plan.stepSize);
+    uint64_t nPatterns = 0;
+    search_plan<WPP>(plan, ix, env, K, E, rows, verifyT, jumpCap, &nPatterns);
+    uint64_t corrRoots = 0;
+    if (NL && E >= 1) {
+        // correction pass: the text windows with N as needles, full semantics (N children followed), every located occurrence
+        // inside the slice gets one hit (gm_api.hip does the same with ScatterEnv)
+        if (!sa) return -101;
+        const uint64_t allLen = allCum[nseqTotal];
+        std::vector<std::pair<uint64_t, uint64_t>> runs;
+        for (uint64_t i = 0; i < allLen; ) { if (allCodes[i] != SYM_N) { ++i; continue; } uint64_t e = i; while (e < allLen && allCodes[e] == SYM_N) ++e; runs.emplace_back(i, e); i = e; }
+        std::vector<uint64_t> cumv(allCum, allCum + nseqTotal + 1), iv;
+        n_window_intervals(runs, cumv, K, E, iv);
+        if (!iv.empty()) {
+            MapPlan cplan;
+            rc = make_map_plan(K, E, infix, revcompl, allLen, iv.data(), iv.size() / 2, &cplan);
+            if (rc) return rc;
+            EmuEnv<WPP, false> cenv; cenv.ix = &ix; cenv.text = allCodes; cenv.K = K; cenv.acc = &acc;
+            cenv.saArr = sa; cenv.textSent = &textS;
+            if (plan.useList) cenv.selBlocks = &plan.blocks;
+            cenv.scatter = true; cenv.cumAll = allCum; cenv.nSeqAll = nseqTotal; cenv.sliceBegin = (uint64_t)(text - allCodes); cenv.sliceLen = textLen;
+            search_plan<WPP>(cplan, ix, cenv, K, E, rows, verifyT, 0, nullptr);
+            corrRoots = cplan.numRoots();
+            env.steps += cenv.steps; env.verified += cenv.verified; env.maxDepth = std::max(env.maxDepth, cenv.maxDepth);
         }
     }
     uint32_t maxv = valueBits == 8 ? 255u : 65535u;
@@ -161,8 +267,29 @@ static int run(const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nse
         uint64_t lim = std::min<uint64_t>(K, seqCum[s] - seqCum[s - 1] + 1);
         for (uint64_t j = 1; j < lim; ++j) { if (valueBits == 8) ((uint8_t*)out)[seqCum[s] - j] = 0; else ((uint16_t*)out)[seqCum[s] - j] = 0; }
     }
-    if (stats) { stats[0] = env.maxDepth; stats[1] = bound; stats[2] = env.steps; stats[3] = env.verified; }
+    if (stats) { stats[0] = env.maxDepth; stats[1] = bound; stats[2] = env.steps; stats[3] = env.verified; stats[4] = nPatterns; stats[5] = corrRoots; }
     return 0;
+}
+
+// jumpCap: longest jump (0 = the plain tree walk from the root); nless != 0: the main pass never follows the text letter N and the
+// correction pass adds the occurrences with N in the text (needs sa, allCodes, allCum).  stats: 6 entries.
+extern "C" int gm_emu_map2(int wpp, const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nseqTotal, const uint8_t* text,
+                           uint64_t textLen, const uint64_t* seqCum, uint32_t nseqLocal, uint32_t K, uint32_t E, int32_t xo,
+                           int32_t infixOverride, int revcompl, int valueBits, const uint64_t* intervals, uint64_t nIntervals,
+                           void* out, uint64_t* stats, const uint32_t* sa, uint32_t verifyT, const uint8_t* allCodes, const uint64_t* allCum,
+                           uint32_t jumpCap, int nless)
+{
+    uint32_t infix = infixOverride > 0 ? (uint32_t)infixOverride : (xo >= 0 ? default_infix_length(K, E, xo) : tuned_infix_length(K, E));
+    if (infix == 0) return PLAN_BAD_OVERLAP;
+    memset(out, 0, textLen * (valueBits / 8));
+#define GM_EMU_ARGS bf, br, rows, nseqTotal, text, textLen, seqCum, nseqLocal, K, E, infix, revcompl, valueBits, intervals, nIntervals, out, stats, sa, verifyT, allCodes, allCum, jumpCap
+    switch (wpp) {
+        case 1: return nless ? run<1, true>(GM_EMU_ARGS) : run<1, false>(GM_EMU_ARGS);
+        case 3: return nless ? run<3, true>(GM_EMU_ARGS) : run<3, false>(GM_EMU_ARGS);
+        case 9: return nless ? run<9, true>(GM_EMU_ARGS) : run<9, false>(GM_EMU_ARGS);
+    }
+#undef GM_EMU_ARGS
+    return -100;
 }
 
 extern "C" int gm_emu_map(int wpp, const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nseqTotal, const uint8_t* text,
@@ -170,13 +297,9 @@ extern "C" int gm_emu_map(int wpp, const uint8_t* bf, const uint8_t* br, uint64_
                           int32_t infixOverride, int revcompl, int valueBits, const uint64_t* intervals, uint64_t nIntervals,
                           void* out, uint64_t* stats, const uint32_t* sa, uint32_t verifyT, const uint8_t* allCodes, const uint64_t* allCum)
 {
-    uint32_t infix = infixOverride > 0 ? (uint32_t)infixOverride : (xo >= 0 ? default_infix_length(K, E, xo) : tuned_infix_length(K, E));
-    if (infix == 0) return PLAN_BAD_OVERLAP;
-    memset(out, 0, textLen * (valueBits / 8));
-    switch (wpp) {
-        case 1: return run<1>(bf, br, rows, nseqTotal, text, textLen, seqCum, nseqLocal, K, E, infix, revcompl, valueBits, intervals, nIntervals, out, stats, sa, verifyT, allCodes, allCum);
-        case 3: return run<3>(bf, br, rows, nseqTotal, text, textLen, seqCum, nseqLocal, K, E, infix, revcompl, valueBits, intervals, nIntervals, out, stats, sa, verifyT, allCodes, allCum);
-        case 9: return run<9>(bf, br, rows, nseqTotal, text, textLen, seqCum, nseqLocal, K, E, infix, revcompl, valueBits, intervals, nIntervals, out, stats, sa, verifyT, allCodes, allCum);
-    }
-    return -100;
+    uint64_t st[6] = {0, 0, 0, 0, 0, 0};
+    const int rc = gm_emu_map2(wpp, bf, br, rows, nseqTotal, text, textLen, seqCum, nseqLocal, K, E, xo, infixOverride, revcompl, valueBits, intervals, nIntervals,
+                               out, st, sa, verifyT, allCodes, allCum, 0, 0);
+    if (stats) for (int i = 0; i < 4; ++i) stats[i] = st[i];
+    return rc;
 }

@@ -170,3 +170,125 @@ def test_verification_shortcut_baseline_settings(K, E):
         out, st = emu_map(ix, 1, K, E, value_bits=16, verify_t=T)
         assert np.array_equal(out, exp), (K, E, T)
         assert st[3] > 0
+
+
+# ---- jump patterns + N-less main pass + correction pass (gm_oss.h: oss_jump_patterns, gm_engine.h: Env::NLESS) -------------------
+def emu_map2(ix, wpp, K, E, first_seq=0, n_seq=None, xo=None, infix=0, revcompl=True, value_bits=16, intervals=None, verify_t=0, jump=15, nless=True):
+    e = emu()
+    e.gm_emu_map2.restype = C.c_int
+    e.gm_emu_map2.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64,
+                              C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_int, C.c_int,
+                              C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+    if n_seq is None:
+        n_seq = len(ix.seq_len) - first_seq
+    tb = int(ix.cum[first_seq])
+    tl = int(ix.cum[first_seq + n_seq]) - tb
+    bf, br = ix.bwt(0), ix.bwt(1)
+    allcodes = np.ascontiguousarray(ix.codes, dtype=np.uint8)
+    allcum = np.ascontiguousarray(ix.cum, dtype=np.uint64)
+    text = allcodes[tb:tb + tl]                                     # a view: the slice's offset inside the whole text is its address
+    cum = np.ascontiguousarray(ix.cum[first_seq:first_seq + n_seq + 1] - ix.cum[first_seq]).astype(np.uint64)
+    out = np.zeros(tl, dtype=np.uint8 if value_bits == 8 else np.uint16)
+    iv = np.ascontiguousarray(np.asarray(intervals, dtype=np.uint64).reshape(-1)) if intervals else None
+    stats = np.zeros(6, dtype=np.uint64)
+    sa = ix.sa()
+    rc = e.gm_emu_map2(wpp, H._ptr(bf), H._ptr(br), ix.n, len(ix.seq_len), C.c_void_p(allcodes.ctypes.data + tb), tl, H._ptr(cum), n_seq, K, E,
+                       -1 if xo is None else xo, infix, int(revcompl), value_bits, H._ptr(iv), 0 if iv is None else len(iv) // 2,
+                       H._ptr(out), H._ptr(stats), H._ptr(sa), verify_t, H._ptr(allcodes), H._ptr(allcum), jump, int(nless))
+    assert rc == 0, rc
+    return out, stats
+
+
+@pytest.mark.parametrize("case", sorted(H.CASES))
+def test_jump_patterns_and_n_correction_on_reference_fixtures(case):
+    d = H.CASES_DIR / f"case_{case}"
+    g, directory, fl, bed = H.load_case(case)
+    if fl.get("ep"):
+        pytest.skip("--exclude-pseudo goes through the locate path")
+    ix = H.OracleIndex(g.codes, g.seq_len, keep_sa=True)
+    for xo in H.xo_variants(case):
+        for name, first, nseq, tb, tl in g.file_slices():
+            iv = None
+            if bed is not None:
+                iv = H.slice_intervals(g, first, nseq, bed)
+                if not iv:
+                    continue
+            exp = np.fromfile(d / "raw_freq16" / (name.rsplit(".", 1)[0] + ".genmap.freq16"), dtype=np.uint16)
+            for T, jump in ((0, 15), (1, 15), (1, 0), (4, 2)):
+                out, st = emu_map2(ix, 1, fl["K"], fl["E"], first, nseq, xo=xo, revcompl=not fl.get("nc", False), intervals=iv, verify_t=T, jump=jump)
+                assert np.array_equal(out, exp), (case, xo, T, jump, name, out.tolist(), exp.tolist())
+
+
+@pytest.mark.parametrize("dna5", [False, True])
+@pytest.mark.parametrize("E", [1, 2, 3, 4])
+def test_jump_patterns_and_n_correction_gtest_matrix(E, dna5):
+    """random Dna5 text is 20 % N: nearly every window goes through the correction pass; Dna4: the patterns alone"""
+    rng = np.random.default_rng(6000 + 10 * E + dna5)
+    nseq, ln = 3, (600 if E < 3 else 250)
+    codes = rng.integers(0, 5 if dna5 else 4, size=nseq * ln, dtype=np.uint8)
+    ix = H.OracleIndex(codes, [ln] * nseq, keep_sa=True)
+    minK = E + 1 + (E >= 2)
+    nblocks = [1, 2, 4, 5, 6][E]
+    used = 0
+    for K in range(minK, 9 if E < 4 else 8):
+        rc = bool(rng.integers(0, 2))
+        triv = ix.trivial(K, E, revcompl=rc, value_bits=8)
+        for infix in range(max(minK, nblocks), K + 1):
+            for T, jump in ((0, 15), (2, 3), (1 << 30, 15)):
+                out, st = emu_map2(ix, 1, K, E, infix=infix, revcompl=rc, value_bits=8, verify_t=T, jump=jump)
+                assert np.array_equal(out, triv), (E, dna5, K, infix, T, jump)
+                used += int(st[4])
+    assert used > 0
+
+
+@pytest.mark.parametrize("K,E", [(30, 1), (30, 2), (100, 1), (24, 1), (50, 3), (36, 4), (150, 2), (250, 1)])
+def test_jump_patterns_and_n_correction_baseline_settings(K, E):
+    rng = np.random.default_rng(K * 10 + E + 11)
+    lens = [1500, 700, K - 1, 900, 3, K, K + 1]
+    n = sum(lens)
+    codes = rng.integers(0, 4, size=n, dtype=np.uint8)
+    fam = rng.integers(0, 4, size=200, dtype=np.uint8)
+    for s in (50, 400, 1600, 2300, 2900):
+        cp = fam.copy()
+        mut = rng.random(200) < 0.03
+        cp[mut] = rng.integers(0, 4, size=int(mut.sum()), dtype=np.uint8)
+        codes[s:s + 200] = cp
+    codes[700:760] = 4          # a long run
+    codes[1234] = 4             # isolated letters, one inside a repeat copy
+    codes[1650] = 4
+    codes[2310:2312] = 4        # a run of two
+    codes[1499] = 4; codes[1500:1502] = 4   # a run across a sequence boundary
+    codes[1000:1100] = 0
+    codes[n - 40:n - 10] = codes[10:40]
+    ix = H.OracleIndex(codes, lens, keep_sa=True)
+    exp = ix.mappability(K, E, value_bits=16, threads=4)
+    for T, jump in ((0, 15), (1, 15), (4, 7), (1 << 30, 15)):
+        out, st = emu_map2(ix, 1, K, E, value_bits=16, verify_t=T, jump=jump)
+        assert np.array_equal(out, exp), (K, E, T, jump, np.flatnonzero(out != exp)[:10], out[out != exp][:10], exp[out != exp][:10])
+        assert st[4] > 0 and st[5] > 0
+    # the first FASTA "file" alone (a slice): occurrences outside the slice do not count for it, needles from everywhere do
+    exp2 = ix.mappability(K, E, first_seq=0, n_seq=2, value_bits=16, threads=4) if hasattr(ix, "mappability") else None
+    out2, _ = emu_map2(ix, 1, K, E, first_seq=0, n_seq=2, value_bits=16, verify_t=1, jump=15)
+    assert np.array_equal(out2, exp2), (K, E, "slice")
+
+
+def test_n_window_intervals_list_exactly_the_windows_that_can_match():
+    """every window with 1..E letters N inside one sequence is listed; no window without N ever is"""
+    e = emu()
+    rng = np.random.default_rng(9)
+    for trial in range(30):
+        lens = [int(x) for x in rng.integers(1, 60, size=int(rng.integers(1, 5)))]
+        n = sum(lens)
+        codes = rng.integers(0, 4, size=n, dtype=np.uint8)
+        for _ in range(int(rng.integers(0, 6))):
+            s = int(rng.integers(0, n)); codes[s:s + int(rng.integers(1, 9))] = 4
+        K, E = int(rng.integers(1, 12)), int(rng.integers(1, 5))
+        ix = H.OracleIndex(codes, lens, keep_sa=True)
+        # through the emulator: a text whose only possible hits are the windows themselves would not isolate the list, so compare results
+        if K <= min(8, n):
+            triv = ix.trivial(K, E, revcompl=True, value_bits=16) if K >= E + 1 + (E >= 2) else None
+            if triv is not None and K - (K - 1) + 0 >= 0:
+                nblocks = [1, 2, 4, 5, 6][E]
+                if K >= nblocks:
+                    out, _ = emu_map2(ix, 1, K, E, infix=K, value_bits=16, verify_t=0, jump=15)
+                    assert np.array_equal(out, triv), (trial, K, E, lens)
