@@ -480,14 +480,15 @@ def main():
         # + verification: one 32-byte record per row and 8 needle symbols per chunk -- or, without the records, the SA entry
         # per row and 8 needle + 8 text symbols per chunk
         ver = 32 * d["verify_items"] + 8 * d["verify_chunks"] if info["verify_records"] else 4 * d["verify_items"] + 16 * d["verify_chunks"]
-        alg = bb * sp["rank_lines"] + 16 * sp["roots"] + n + n + ver
+        # (a root that jumps reads one 16-byte table entry per pattern instead of the single q-mer entry: counted as jump_lookups)
+        alg = bb * sp["rank_lines"] + 16 * (d.get("jump_lookups", 0) or sp["roots"]) + n + n + ver
         # N > 1: per GPU -- a rank's share of the bytes over the slowest rank's kernel time, against one GPU's peak
         ach = alg / world / (rec["kernel_ms"] * 1e-3) / 1e9
         return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": None,   # PMC FETCH_SIZE/WRITE_SIZE need rocprofv3 around the process: tools/profile_round.sh -> profiles/
                 "per_gpu": True, "kernel": "search_kernel", "kernel_ms": rec["kernel_ms"], "algorithmic_bytes": alg, "rank_lines": sp["rank_lines"],
                 "roots": sp["roots"], "node_steps": sp["node_steps"], "node_steps_per_kmer": sp["node_steps"] / rec["num_kmers"],
-                "verify_items": d["verify_items"], "verify_chunks": d["verify_chunks"],
+                "verify_items": d["verify_items"], "verify_chunks": d["verify_chunks"], "jump_lookups": d.get("jump_lookups", 0),
                 "lanes_with_node_per_iteration": d["active_lane_sum"] / max(1, d["wave_iterations"])}
 
     cpu = None

@@ -86,7 +86,7 @@ def load_library(profiling=False):
     lib.gm_index_build.restype = C.c_int
     lib.gm_index_build.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)]
     lib.gm_index_import.restype = C.c_int
-    lib.gm_index_import.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)]
+    lib.gm_index_import.argtypes = [vp, vp, vp, C.c_uint32, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)]
     lib.gm_index_export_bwt.restype = C.c_int
     lib.gm_index_export_bwt.argtypes = [vp, vp, vp]
     lib.gm_index_import_sampled.restype = C.c_int
@@ -94,7 +94,7 @@ def load_library(profiling=False):
     lib.gm_index_export_sa_sampled.restype = C.c_int
     lib.gm_index_export_sa_sampled.argtypes = [vp, vp, vp, C.POINTER(C.c_uint64)]
     lib.gm_index_export_sa.restype = C.c_int
-    lib.gm_index_export_sa.argtypes = [vp, vp]
+    lib.gm_index_export_sa.argtypes = [vp, vp, C.c_uint32]
     lib.gm_index_get_info.restype = C.c_int
     lib.gm_index_get_info.argtypes = [vp, C.POINTER(IndexInfo)]
     lib.gm_index_free.argtypes = [vp]
@@ -243,7 +243,7 @@ class Index:
         wide = bool(block_bytes & WIDE_ROWS) or len(bf) >= 0xFFFFFFFF
         sa = None if sa_fwd is None else np.ascontiguousarray(sa_fwd, dtype=np.uint64 if wide else np.uint32)
         h = C.c_void_p()
-        _check(lib, lib.gm_index_import(_ptr(bf), _ptr(br), _ptr(sa), _ptr(codes), _ptr(sl), len(sl), sampling, block_bytes, device, C.byref(h)))
+        _check(lib, lib.gm_index_import(_ptr(bf), _ptr(br), _ptr(sa), 0 if sa is None else sa.itemsize, _ptr(codes), _ptr(sl), len(sl), sampling, block_bytes, device, C.byref(h)))
         return cls(h, lib, codes, sl)
 
     @classmethod
@@ -287,7 +287,7 @@ class Index:
     def export_sa(self):
         i = self.info()
         sa = np.empty(i["n_rows"], np.uint64 if i["row_bits"] == 64 else np.uint32)
-        _check(self._lib, self._lib.gm_index_export_sa(self._h, _ptr(sa)))
+        _check(self._lib, self._lib.gm_index_export_sa(self._h, _ptr(sa), sa.itemsize))
         return sa
 
     def export_sa_sampled(self):
@@ -407,5 +407,5 @@ class Index:
         d = {k: getattr(s, k) for k, _ in MapStats._fields_}
         d["detail"] = dict(zip(("steps_oss", "steps_ext", "ext_w1", "ext_w2_4", "oss_w1", "pushes", "verify_items", "verify_items_oss", "verify_chunks", "wave_iterations", "active_lane_sum", "verify_rounds", "cyc_fetch", "cyc_verify", "cyc_step", "cyc_pop", "cyc_share", "cyc_stage32", "cyc_stage1", "stolen",
                                 "w_pop", "w_saturated", "w_share", "w_stage3", "w_stage2", "w_stage1", "w_defer", "w_split", "w_miss_round", "w_leaf", "w_leaf_flush",
-                                "w_v_block", "w_v_chunk", "w_v_event", "w_v_kmer", "w_push_hbm"), list(s.detail)))
+                                "w_v_block", "w_v_chunk", "w_v_event", "w_v_kmer", "w_push_hbm", "jump_lookups"), list(s.detail)))
         return d

@@ -335,7 +335,7 @@ void gm_index_free(gm_index* ix)
     for (int i = 0; i < 4; ++i) if (ix->ev[i]) hipEventDestroy(ix->ev[i]);
     for (uint32_t i = 0; i < gm_index::EV_RING; ++i) for (int j = 0; j < 2; ++j) if (ix->evRing[i][j]) hipEventDestroy(ix->evRing[i][j]);
     if (ix->evDone) hipEventDestroy(ix->evDone);
-    hipFree(ix->d_shardOut);
+    hipFree(ix->d_shardOut); hipFree(ix->d_patterns); hipFree(ix->d_jinfo); hipFree(ix->d_cblocks);
     if (ix->h_stage) hipHostFree(ix->h_stage);
     for (auto& e : ix->evStage) if (e) hipEventDestroy(e);
     if (ix->stCompute) hipStreamDestroy(ix->stCompute);
@@ -374,7 +374,7 @@ int gm_index_build(const uint8_t* codes, const uint64_t* seq_len, uint32_t n_seq
     return GM_OK;
 }
 
-int gm_index_import(const uint8_t* bwt_fwd, const uint8_t* bwt_rev, const uint32_t* sa_fwd, const uint8_t* codes, const uint64_t* seq_len,
+int gm_index_import(const uint8_t* bwt_fwd, const uint8_t* bwt_rev, const void* sa_fwd, uint32_t sa_entry_bytes, const uint8_t* codes, const uint64_t* seq_len,
                     uint32_t n_seq, uint32_t sampling, uint32_t block_bytes, int device, gm_index** out)
 {
     if (!bwt_fwd || !bwt_rev || !codes || !seq_len || !n_seq || !out) { set_error("null argument"); return GM_ERR_BAD_ARG; }
@@ -390,8 +390,11 @@ int gm_index_import(const uint8_t* bwt_fwd, const uint8_t* bwt_rev, const uint32
         rc = pack_dispatch(ix, d, d_bwt);
     }
     hipFree(d_bwt);
+    if (!rc && sa_fwd && sa_entry_bytes != (ix->wide ? 8u : 4u)) {
+        set_error("sa_fwd entries of %u bytes, but this index has %s rows", sa_entry_bytes, ix->wide ? "64-bit" : "32-bit"); rc = GM_ERR_BAD_ARG;
+    }
     if (!rc && sa_fwd && sampling == 1) {
-        const size_t rb = ix->wide ? 8 : 4;   // sa_fwd is an array of uint64_t for wide indexes
+        const size_t rb = ix->wide ? 8 : 4;
         if (hipMalloc(&ix->d_sa, ix->nRows * rb) != hipSuccess) rc = GM_ERR_OOM;
         else if (hipMemcpy(ix->d_sa, sa_fwd, ix->nRows * rb, hipMemcpyHostToDevice) != hipSuccess) rc = GM_ERR_HIP;
         if (!rc) rc = make_sentinel_text(ix);
@@ -414,7 +417,7 @@ int gm_index_import_sampled(const uint8_t* bwt_fwd, const uint8_t* bwt_rev, cons
 {
     if (!mark_words || !samples || sampling < 2) { set_error("gm_index_import_sampled: marks, samples and a sampling rate of 2..64"); return GM_ERR_BAD_ARG; }
     gm_index* ix = nullptr;
-    int rc = gm_index_import(bwt_fwd, bwt_rev, nullptr, codes, seq_len, n_seq, sampling, block_bytes, device, &ix);
+    int rc = gm_index_import(bwt_fwd, bwt_rev, nullptr, 0, codes, seq_len, n_seq, sampling, block_bytes, device, &ix);
     if (rc) return rc;
     const uint64_t words = (ix->nRows + 31) / 32;
     // "samples before this word" is recomputed here; a file whose marks and sample count disagree is rejected
@@ -469,9 +472,10 @@ int gm_index_export_bwt(const gm_index* ix, uint8_t* bwt_fwd, uint8_t* bwt_rev)
     return GM_OK;
 }
 
-int gm_index_export_sa(const gm_index* ix, uint32_t* sa)
+int gm_index_export_sa(const gm_index* ix, void* sa, uint32_t sa_entry_bytes)
 {
     if (!ix || !sa) return GM_ERR_BAD_ARG;
+    if (sa_entry_bytes != (ix->wide ? 8u : 4u)) { set_error("sa entries of %u bytes, but this index has %s rows", sa_entry_bytes, ix->wide ? "64-bit" : "32-bit"); return GM_ERR_BAD_ARG; }
     if (!ix->d_sa) { set_error("index holds no full suffix array (sampling %u)", ix->d_saMark ? ix->sampling : 0u); return GM_ERR_NEED_LOCATE; }
     GM_HIP(hipSetDevice(ix->device));
     GM_HIP(hipMemcpy(sa, ix->d_sa, ix->nRows * (ix->wide ? 8 : 4), hipMemcpyDeviceToHost));
@@ -509,10 +513,10 @@ template <typename T> static int grow(T** p, uint64_t* cap, uint64_t need)
     return GM_OK;
 }
 
-enum LeafMode { LEAF_COUNT = 0, LEAF_FILESET = 1, LEAF_OCC_COUNT = 2, LEAF_OCC_EMIT = 3, LEAF_STORE = 4, LEAF_STORE8 = 5 };
+enum LeafMode { LEAF_COUNT = 0, LEAF_FILESET = 1, LEAF_OCC_COUNT = 2, LEAF_OCC_EMIT = 3, LEAF_STORE = 4, LEAF_STORE8 = 5, LEAF_COUNT_JUMP = 6, LEAF_SCATTER = 7 };
 
 // nu = 16-byte units per stored node / queue entry: 1, or 2 with 64-bit rows (gm_kernels.h: NodeIO)
-static inline size_t search_lds_bytes(const SearchArgs& A, uint32_t nu) { return (size_t)(4u * A.vqCap * nu + 4u * 64u * (A.ldsDepth * nu + A.winChunks)) * 16u + 4u * 128u * 4u; }
+static inline size_t search_lds_bytes(const SearchArgs& A, uint32_t nu) { return (size_t)(4u * A.vqCap * nu + 4u * 64u * (A.ldsDepth * nu + A.winChunks)) * 16u + 4u * 128u * 4u + (A.lqCap ? 4u * (A.lqCap * 16u + 80u * 4u) : 0u); }
 
 template <int WPP, class EnvT>
 static int launch_one(const SearchArgs& A, unsigned blocks, hipStream_t st)
@@ -540,6 +544,8 @@ static int launch_mode(int mode, const SearchArgs& A, unsigned blocks, hipStream
 {
     switch (mode) {
         case LEAF_COUNT: return launch_one<WPP, CountEnv<WPP>>(A, blocks, st);
+        case LEAF_COUNT_JUMP: return launch_one<WPP, CountEnv<WPP, true>>(A, blocks, st);
+        case LEAF_SCATTER: return launch_one<WPP, ScatterEnv<WPP>>(A, blocks, st);
         case LEAF_FILESET: return launch_one<WPP, FileSetEnv<WPP>>(A, blocks, st);
         case LEAF_OCC_COUNT: return launch_one<WPP, OccCountEnv<WPP>>(A, blocks, st);
         case LEAF_STORE: return launch_one<WPP, StoreEnv<WPP, uint16_t>>(A, blocks, st);
@@ -604,17 +610,80 @@ static int get_qtable(gm_index* ix, uint32_t* qio, const uint4** out)
     return GM_OK;
 }
 
+// maximal runs of the letter N in the whole text (needed once per index, by the correction pass of N-less calls)
+__global__ __launch_bounds__(256) void n_run_bounds_kernel(const uint8_t* __restrict__ text, uint64_t n, uint64_t* __restrict__ starts, uint64_t* __restrict__ ends,
+                                                            unsigned long long* __restrict__ counts, uint64_t cap)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        if (text[i] != SYM_N) continue;
+        if (i == 0 || text[i - 1] != SYM_N) { const unsigned long long k = atomicAdd(&counts[0], 1ull); if (k < cap) starts[k] = i; }
+        if (i + 1 == n || text[i + 1] != SYM_N) { const unsigned long long k = atomicAdd(&counts[1], 1ull); if (k < cap) ends[k] = i + 1; }
+    }
+}
+static int ensure_n_runs(gm_index* ix)
+{
+    if (ix->nRunsValid) return GM_OK;
+    ix->nRuns.clear();
+    if (ix->alphabet == 5) {
+        unsigned long long* d_cnt = nullptr; uint64_t *d_s = nullptr, *d_e = nullptr;
+        int rc = GM_OK;
+        unsigned long long cnt[2] = {0, 0};
+        if (hipMalloc(&d_cnt, 16) != hipSuccess) return GM_ERR_OOM;
+        for (int pass = 0; pass < 2 && !rc; ++pass) {
+            const uint64_t cap = pass ? cnt[0] : 0;
+            if (pass) { if (cap == 0) break; if (hipMalloc(&d_s, cap * 8) != hipSuccess || hipMalloc(&d_e, cap * 8) != hipSuccess) { rc = GM_ERR_OOM; break; } }
+            if (hipMemset(d_cnt, 0, 16) != hipSuccess) { rc = GM_ERR_HIP; break; }
+            hipLaunchKernelGGL(n_run_bounds_kernel, dim3(grid_for(ix->textLen)), dim3(256), 0, 0, ix->d_text, ix->textLen, d_s, d_e, d_cnt, cap);
+            if (hipGetLastError() != hipSuccess || hipMemcpy(cnt, d_cnt, 16, hipMemcpyDeviceToHost) != hipSuccess) rc = GM_ERR_HIP;
+        }
+        if (!rc && cnt[0]) {
+            std::vector<uint64_t> hs(cnt[0]), he(cnt[0]);
+            if (cnt[0] != cnt[1] || hipMemcpy(hs.data(), d_s, cnt[0] * 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(he.data(), d_e, cnt[0] * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = GM_ERR_HIP;
+            else {
+                std::sort(hs.begin(), hs.end()); std::sort(he.begin(), he.end());
+                for (size_t i = 0; i < hs.size(); ++i) ix->nRuns.emplace_back(hs[i], he[i]);
+            }
+        }
+        hipFree(d_cnt); hipFree(d_s); hipFree(d_e);
+        if (rc) { set_error("cannot list the runs of N of the text"); return rc; }
+    }
+    ix->nRunsValid = true;
+    return GM_OK;
+}
+// block list of the correction pass: the text windows with 1..E letters N of a run (gm_host.h: n_window_intervals), cached per (K, E, infix)
+static int ensure_correction_blocks(gm_index* ix, uint32_t K, uint32_t E, uint32_t infix)
+{
+    if (ix->corrValid && ix->corrK == K && ix->corrE == E && ix->corrInfix == infix) return GM_OK;
+    int rc = ensure_n_runs(ix); if (rc) return rc;
+    ix->corrValid = false; ix->nCBlocks = 0;
+    std::vector<uint64_t> iv;
+    n_window_intervals(ix->nRuns, ix->cum, K, E, iv);
+    if (!iv.empty()) {
+        MapPlan cp;
+        rc = make_map_plan(K, E, infix, 1, ix->textLen, iv.data(), iv.size() / 2, &cp);
+        if (rc) return rc;
+        if (!cp.blocks.empty()) {
+            rc = grow(&ix->d_cblocks, &ix->cblocksCap, (uint64_t)cp.blocks.size()); if (rc) return rc;
+            GM_HIP(hipMemcpy(ix->d_cblocks, cp.blocks.data(), cp.blocks.size() * sizeof(uint2), hipMemcpyHostToDevice));
+            ix->nCBlocks = cp.blocks.size();
+        }
+    }
+    ix->corrK = K; ix->corrE = E; ix->corrInfix = infix; ix->corrValid = true;
+    return GM_OK;
+}
+
 struct SearchSetup {
     MapPlan plan;
     ChunkSel sel{0, 0, 0};   // interleaved chunks: which positions of [posBase, posEnd) this call owns
     uint64_t blockBegin = 0, blockEnd = 0, numRoots = 0, kmers = 0;
     unsigned blocks = 1;
     uint64_t posBase = 0, posEnd = 0;   // slice positions covered by the selected blocks: [posBase, posEnd)
+    bool jump = false;                  // the call runs the N-less kernel (with jump patterns where they apply) + the correction pass
 };
 
 // validation, planning, workspace, uploads; fills every SearchArgs field that does not depend on the leaf policy
 static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t first_seq, uint32_t n_seq, const gm_map_params* p,
-                          const uint64_t* intervals, uint64_t n_intervals, hipStream_t st, SearchSetup* S, SearchArgs* Aout)
+                          const uint64_t* intervals, uint64_t n_intervals, hipStream_t st, SearchSetup* S, SearchArgs* Aout, bool wantJump = false, uint32_t lqCap = 0)
 {
     if (!ix || !p) { set_error("null argument"); return GM_ERR_BAD_ARG; }
     if (p->value_bits != 8 && p->value_bits != 16) return GM_ERR_BAD_VALUE_BITS;
@@ -704,7 +773,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     const uint32_t winChunks = (31u + p->K + plan.stepSize - 1u + 31u) / 32u;
     const uint32_t nu = ix->wide ? 2u : 1u;
     const int wantPerCU = std::max(1, ix->tune.blocksPerCU);   // default 4 = 4 waves/SIMD, what the kernel's VGPR count allows
-    auto lds_bytes_for = [&](uint32_t d) { return (size_t)(4u * vqCap * nu + 4u * 64u * (d * nu + winChunks)) * 16u + 4u * 128u * 4u; };   // == search_lds_bytes
+    auto lds_bytes_for = [&](uint32_t d) { return (size_t)(4u * vqCap * nu + 4u * 64u * (d * nu + winChunks)) * 16u + 4u * 128u * 4u + (lqCap ? 4u * (lqCap * 16u + 80u * 4u) : 0u); };   // == search_lds_bytes
     auto blocks_for = [&](uint32_t d, int* nb) {
         switch (ix->wpp) { case 1: return occupancy_blocks<1>(nb, lds_bytes_for(d)); case 2: return occupancy_blocks<2>(nb, lds_bytes_for(d)); case 3: return occupancy_blocks<3>(nb, lds_bytes_for(d)); default: return occupancy_blocks<9>(nb, lds_bytes_for(d)); }
     };
@@ -731,17 +800,57 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     S->blocks = (unsigned)blocks;
     rc = grow(&ix->d_stack, &ix->stackCap, blocks * 256ull * std::max<uint32_t>(depth - ldsDepth, 1u) * nu); if (rc) return rc;
 
+    // ---- jump patterns (frequency calls with errors on an index that can locate): one J for every search ----
+    std::vector<uint32_t> patHost; std::vector<uint4> jinfoHost; uint32_t jumpJ = 0, jumpAPacked[2] = {0, 0};
+    const uint4* jtab = nullptr;
+    S->jump = wantJump && p->E >= 1 && (ix->d_sa || ix->d_saMark) && ix->tune.jump != 0 && !ix->wide;
+    if (S->jump) {
+        const uint32_t L = plan.infix;
+        uint32_t J = 1;   // longest tabulated string: as for the q-mer tables below
+        while (J < 15 && (1ull << (2 * J)) < 4ull * ix->nRows) ++J;
+        if (ix->tune.jump > 0) J = std::min<uint32_t>(J, (uint32_t)ix->tune.jump);
+        if (ix->tune.qtable >= 0) J = std::min<uint32_t>(J, (uint32_t)ix->tune.qtable);
+        J = L >= 2 ? std::min(J, L - 1u) : 0u;
+        if (J) { rc = get_qtable(ix, &J, &jtab); if (rc) return rc; }   // (shorter when the device is short of memory)
+        std::vector<JumpSearch> js(plan.nSearches);
+        for (; J >= 1; --J) {
+            bool ok = true; size_t total = 0;
+            for (uint32_t s2 = 0; s2 < plan.nSearches && ok; ++s2) {
+                ok = oss_jump_patterns(p->E, plan.table[(size_t)(plan.stepSize - 1) * 8 + s2], L, J, 4096, &js[s2]) && !js[s2].pat.empty();
+                total += js[s2].pat.size();
+            }
+            if (ok && total < 65000) break;
+        }
+        if (J >= 1) { uint32_t J2 = J; rc = get_qtable(ix, &J2, &jtab); if (rc) return rc; if (J2 != J) J = 0; }
+        if (J >= 1) {
+            jumpJ = J;
+            jinfoHost.assign(8, make_uint4(0, 0, 0, 0));
+            for (uint32_t s2 = 0; s2 < plan.nSearches; ++s2) {
+                jinfoHost[s2] = make_uint4((uint32_t)patHost.size() | (uint32_t)js[s2].pat.size() << 16, js[s2].meta0, js[s2].pat[0], 0u);
+                jumpAPacked[s2 >> 2] |= js[s2].regionA << (8u * (s2 & 3u));
+                patHost.insert(patHost.end(), js[s2].pat.begin(), js[s2].pat.end());
+            }
+            const void *p0 = ix->d_patterns, *j0 = ix->d_jinfo;
+            rc = grow(&ix->d_patterns, &ix->patternsCap, (uint64_t)patHost.size()); if (rc) return rc;
+            rc = grow(&ix->d_jinfo, &ix->jinfoCap, 8); if (rc) return rc;
+            if (p0 != ix->d_patterns || j0 != ix->d_jinfo) ix->sigValid = false;   // reallocated: contents are gone
+        }
+    }
     {   // the call's small device-side tables (OSS records, block list, local sequence limits) are uploaded only when the
         // call differs from the previous one on this index: a loop over shards or repeated passes launches without any
         // host-device synchronisation
         uint64_t h = 1469598103934665603ull;
         auto mix = [&h](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
-        mix(p->K); mix(p->E); mix(plan.infix); mix((uint64_t)(int64_t)ix->tune.partBias); mix((uint64_t)(int64_t)ix->tune.ossWeights); mix(text_begin); mix(text_len); mix(first_seq); mix(n_seq); mix(n_intervals);
+        mix(p->K); mix(p->E); mix(plan.infix); mix((uint64_t)(int64_t)ix->tune.partBias); mix((uint64_t)(int64_t)ix->tune.ossWeights); mix(jumpJ); mix(patHost.size()); mix(text_begin); mix(text_len); mix(first_seq); mix(n_seq); mix(n_intervals);
         for (uint64_t k = 0; k < 2 * n_intervals; ++k) mix(intervals[k]);
         if (!ix->sigValid || ix->sig != h) {
             GM_HIP(hipMemcpyAsync(ix->d_table, plan.table.data(), plan.table.size() * sizeof(OssRecord), hipMemcpyHostToDevice, st));
             if (plan.useList && !plan.blocks.empty())
                 GM_HIP(hipMemcpyAsync(ix->d_blocks, plan.blocks.data(), plan.blocks.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
+            if (jumpJ) {
+                GM_HIP(hipMemcpyAsync(ix->d_patterns, patHost.data(), patHost.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+                GM_HIP(hipMemcpyAsync(ix->d_jinfo, jinfoHost.data(), 8 * sizeof(uint4), hipMemcpyHostToDevice, st));
+            }
             std::vector<uint64_t> cumLocal((size_t)n_seq + 1);
             for (uint32_t s = 0; s <= n_seq; ++s) cumLocal[s] = ix->cum[first_seq + s] - text_begin;
             GM_HIP(hipMemcpyAsync(ix->d_cumLocal, cumLocal.data(), cumLocal.size() * 8, hipMemcpyHostToDevice, st));
@@ -787,7 +896,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
             A.qlenPacked |= q << (4u * s);
         }
     }
-    A.text4 = ix->d_text4; A.textBegin = text_begin; A.vqCap = vqCap; A.ldsDepth = ldsDepth; A.winChunks = winChunks;
+    A.text4 = ix->d_text4; A.textBegin = text_begin; A.vqCap = vqCap; A.ldsDepth = ldsDepth; A.winChunks = winChunks; A.lqCap = lqCap;
     A.workCounter = reinterpret_cast<unsigned long long*>(ix->d_small);
     A.errorFlag = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ix->d_small) + SMALL_ERR_OFF);
     A.counters = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ix->d_small) + 16);
@@ -820,6 +929,9 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     A.steal = ix->tune.steal >= 0 ? (uint32_t)std::min(ix->tune.steal, 64) : stealDefault;
     A.coop = ix->tune.coop >= 0 ? (uint32_t)(ix->tune.coop != 0) : (ix->wpp == 1 ? 1u : 0u);
     if (ix->wide) A.coop = 0u;
+    A.jumpJ = jumpJ; A.jumpAPacked[0] = jumpAPacked[0]; A.jumpAPacked[1] = jumpAPacked[1];
+    A.patterns = ix->d_patterns; A.jinfo = ix->d_jinfo; A.jtab = jtab;
+    A.sliceBegin = text_begin; A.sliceLen = text_len; A.ownBegin = 0; A.ownEnd = text_len; A.ownChunkLen = 0; A.selBlocks = nullptr; A.nSelBlocks = 0;
     *Aout = A;
     return GM_OK;
 }
@@ -839,9 +951,10 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
 {
     if (!d_out) { set_error("null output"); return GM_ERR_BAD_ARG; }
     SearchSetup S; SearchArgs A;
-    int rc = prepare_search(ix, text_begin, text_len, first_seq, n_seq, p, intervals, n_intervals, st, &S, &A);
+    int rc = prepare_search(ix, text_begin, text_len, first_seq, n_seq, p, intervals, n_intervals, st, &S, &A, /*wantJump=*/p->exclude_pseudo == 0, /*leaf queue*/p->exclude_pseudo ? 128u : 0u);
     if (rc) return rc;
     const bool ep = p->exclude_pseudo != 0;
+    if (S.jump) { rc = ensure_correction_blocks(ix, p->K, p->E, S.plan.infix); if (rc) return rc; }
     uint32_t wordsPerKmer = 0;
     if (ep) {
         if (!ix->d_sa && !ix->d_saMark) { set_error("--exclude-pseudo needs an index with suffix array samples (sampling >= 1)"); return GM_ERR_NEED_LOCATE; }
@@ -895,7 +1008,22 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
 
     const uint32_t slot = (uint32_t)(ix->evCount % gm_index::EV_RING);
     GM_HIP(hipEventRecord(ix->evRing[slot][0], st));
-    if (S.numRoots > 0) { rc = launch_search(ix, ep ? LEAF_FILESET : store ? (p->value_bits == 8 ? LEAF_STORE8 : LEAF_STORE) : LEAF_COUNT, A, S.blocks, st); if (rc) return rc; }
+    if (S.numRoots > 0) { rc = launch_search(ix, ep ? LEAF_FILESET : store ? (p->value_bits == 8 ? LEAF_STORE8 : LEAF_STORE) : S.jump ? LEAF_COUNT_JUMP : LEAF_COUNT, A, S.blocks, st); if (rc) return rc; }
+    if (S.jump && ix->nCBlocks > 0 && rn > 0 && !(S.plan.useList && S.plan.blocks.empty())) {
+        // correction pass: the text windows that hold N, from the whole index, searched with the full rules; every occurrence
+        // inside this call's positions adds one at its own position (ScatterEnv)
+        SearchArgs C = A;
+        C.text = ix->d_text; C.textBegin = 0; C.numKmers = ix->textLen >= p->K ? ix->textLen - p->K + 1 : 0;
+        C.blockList = ix->d_cblocks; C.blockBegin = 0; C.numRoots = ix->nCBlocks * C.rootsPerBlock; C.chunkBlocks = 0;
+        C.ownBegin = r0; C.ownEnd = r1; C.ownChunkLen = sel.len;
+        C.selBlocks = S.plan.useList ? ix->d_blocks : nullptr; C.nSelBlocks = (uint32_t)S.plan.blocks.size();
+        C.steal = C.numRoots < 64ull * 4ull * 1024ull ? 1u : C.steal;
+        C.lqCap = 128u;   // leaves are located by the whole wavefront (gm_kernels.h: LeafQueueEnv)
+        GM_HIP(hipMemsetAsync(ix->d_small, 0, 16, st));   // the work counter; statistics keep adding up
+        const uint64_t useful = (C.numRoots + 255) / 256;
+        const unsigned cb = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ix->numCU * std::max(1, std::min(ix->tune.blocksPerCU, 4)), useful));
+        rc = launch_search(ix, LEAF_SCATTER, C, std::min(cb, std::max(1u, S.blocks)), st); if (rc) return rc;
+    }
     GM_HIP(hipEventRecord(ix->evRing[slot][1], st));
     ix->evCount++;
     if (text_len > 0) {
@@ -934,7 +1062,7 @@ static int locate_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uin
 {
     hipStream_t st = nullptr;
     SearchSetup S; SearchArgs A;
-    int rc = prepare_search(ix, text_begin, text_len, first_seq, n_seq, p, intervals, n_intervals, st, &S, &A);
+    int rc = prepare_search(ix, text_begin, text_len, first_seq, n_seq, p, intervals, n_intervals, st, &S, &A, false, 128u);
     if (rc) return rc;
     if (!ix->d_sa && !ix->d_saMark) { set_error("csv output needs an index with suffix array samples (sampling >= 1)"); return GM_ERR_NEED_LOCATE; }
     if (S.sel.len) { set_error("gm_locate does not take interleaved chunks"); return GM_ERR_BAD_ARG; }
@@ -1344,6 +1472,7 @@ int gm_index_set_tuning(gm_index* ix, const char* name, int64_t value)
         {"skip_dup", &ix->tune.skipDup, dflt.skipDup, 0, 1}, {"coop", &ix->tune.coop, dflt.coop, 0, 1}, {"use_ctx", &ix->tune.useCtx, dflt.useCtx, 0, 1},
         {"steal", &ix->tune.steal, dflt.steal, 0, 64}, {"part_bias", &ix->tune.partBias, dflt.partBias, -255, 255},
         {"child_tables", &ix->tune.childTables, dflt.childTables, 0, 1}, {"oss_weights", &ix->tune.ossWeights, dflt.ossWeights, 0, 0xFFFFFF},
+        {"jump", &ix->tune.jump, dflt.jump, 0, 15},
     };
     for (auto& t : tab) if (!strcmp(t.n, name)) {
         const bool isBias = t.f == &ix->tune.partBias;

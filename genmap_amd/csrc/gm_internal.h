@@ -27,7 +27,7 @@ namespace gm {
 // -1 = "library default for this call" (depends on K, E and the index size, see prepare_search)
 struct Tuning {
     int verifyT = -1, ldsStack = -1, blocksPerCU = 4, qtable = -1, satMinW = 256, fetchBatch = -1, probation = -1, verifyCost = 3;
-    int noStore = 0, noSaturate = 0, skipDup = -1, coop = -1, useCtx = 1, steal = -1, partBias = 0, childTables = -1, ossWeights = 0;
+    int noStore = 0, noSaturate = 0, skipDup = -1, coop = -1, useCtx = 1, steal = -1, partBias = 0, childTables = -1, ossWeights = 0, jump = -1;
 };
 }  // namespace gm
 
@@ -85,6 +85,13 @@ struct gm_index {
     hipEvent_t evStage[4] = {};
     gm::Tuning tune;
     gm_map_stats stats{};
+    // ---- jump patterns and the correction pass of N-less frequency calls (gm_oss.h, gm_engine.h: Env::NLESS) ----
+    uint32_t* d_patterns = nullptr; uint64_t patternsCap = 0;
+    uint4* d_jinfo = nullptr; uint64_t jinfoCap = 0;
+    bool nRunsValid = false;
+    std::vector<std::pair<uint64_t, uint64_t>> nRuns;     // maximal runs of N of the whole text, sorted
+    uint2* d_cblocks = nullptr; uint64_t cblocksCap = 0;   // block list of the text windows that hold N, for (corrK, corrE, corrInfix)
+    uint64_t nCBlocks = 0; uint32_t corrK = 0, corrE = 0, corrInfix = 0; bool corrValid = false;
     uint32_t pieceIndex = 0;   // gm_map_shard delivers a call in several launches: launch number inside the call (statistics accumulate)
     uint32_t statPieces = 0;   // launches the statistics of the last call cover
     int buildRounds[2] = {0, 0};

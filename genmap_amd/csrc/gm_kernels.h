@@ -66,6 +66,7 @@ struct SearchArgs {
     uint32_t vqCap;                 // queue entries per wavefront
     uint32_t ldsDepth;              // stack entries per lane kept in LDS (deeper ones spill to `stack`)
     uint32_t winChunks;             // 16-byte chunks per lane for the needle window
+    uint32_t lqCap;                 // leaf queue entries per wavefront (locating leaf policies: FileSetEnv, OccEmitEnv; 0 elsewhere)
     // ---- q-mer range tables: the first (always exact) OSS block of a root starts from a lookup instead of q steps ----
     const uint4* qtabA;             // {fwd lo, rev lo, width, 0} of every ACGT string of length q (two tables at most per call)
     const uint4* qtabB;
@@ -77,6 +78,18 @@ struct SearchArgs {
     uint32_t steal;                 // > 0: lanes without work take the bottom of a neighbour's stack (work sharing inside the wavefront),
                                     //      an exchange runs when at least this many lanes are idle
     uint32_t chunkBlocks, chunkStride, chunkIndex;   // != 0: this call owns the chunks c = chunkIndex (mod chunkStride) of chunkBlocks blocks each
+    // ---- jump patterns (gm_oss.h): kernels compiled with Env::JUMPS start every regular root at depth jumpJ ----
+    const uint32_t* patterns;       // descriptors of every search, back to back
+    const uint4* jinfo;             // per search {first pattern | patterns << 16, meta at depth J relative to n - 1, first descriptor, 0}
+    const uint4* jtab;              // table of all J-mers
+    uint32_t jumpJ;                 // 0: no jumps in this call (every root starts at the tree's root)
+    uint32_t jumpAPacked[2];        // 8 bits per search: window coordinate of the J-mer's first character, minus (n - 1)
+    // ---- correction pass (ScatterEnv): occurrences are added at THEIR OWN position if the main pass computes that position ----
+    uint64_t sliceBegin, sliceLen;  // the slice of the main pass inside the whole text
+    uint64_t ownBegin, ownEnd;      // slice positions the call owns (a shard's range), and of those the chunks chunkIndex (mod chunkStride)
+    uint32_t ownChunkLen;           // positions per chunk (0: no chunks)
+    const uint2* selBlocks;         // a selection's blocks, sorted by position (nullptr: every position is computed)
+    uint32_t nSelBlocks;
 };
 
 // which positions of a range belong to the calling shard (interleaved chunks of `len` positions); len == 0: all of them
@@ -185,6 +198,9 @@ constexpr uint32_t VERIFY_TMAX = 4;    // widest range resolved by verification
 
 template <int WPP> struct EnvBase {
     static constexpr bool EXACT_ONLY = false;   // StoreEnv: the kernel only ever runs with E = 0
+    static constexpr bool NLESS = false;        // the text letter N is never followed (gm_engine.h); a correction pass adds those occurrences
+    static constexpr bool JUMPS = false;        // regular roots start from the jump patterns of their search (gm_oss.h)
+    static constexpr bool LEAFQ = false;        // leaves are queued per wavefront and located 64 rows at a time (LeafQueueEnv)
     typedef typename BlockGeom<WPP>::row_t row_t;
     typedef NodeT<row_t> Node;
     typedef RootT<row_t> Root;
@@ -198,7 +214,7 @@ template <int WPP> struct EnvBase {
     uint32_t sbase;      // raised when a neighbour takes the bottom entry (work sharing), back to 0 when the stack runs empty
     uint32_t K;
 #ifdef GM_COUNTERS
-    uint32_t steps = 0, lines = 0, stOss = 0, stExt = 0, stExtW1 = 0, stExtW4 = 0, stOssW1 = 0, pushes = 0, vItems = 0, vItemsOss = 0, vChunks = 0;
+    uint32_t steps = 0, lines = 0, stOss = 0, stExt = 0, stExtW1 = 0, stExtW4 = 0, stOssW1 = 0, pushes = 0, vItems = 0, vItemsOss = 0, vChunks = 0, jumps = 0;
     uint32_t whit[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // a wavefront passed here (counted by its first enabled lane): the dynamic cost of a region = passes x its instructions
     __device__ __forceinline__ void note_wave(int i) { const unsigned long long m = __ballot(true); if (__lane_id() == (unsigned)(__ffsll((long long)m) - 1)) whit[i]++; }
@@ -353,6 +369,7 @@ template <int WPP> struct EnvBase {
         else if (lv < A.stackDepth) { IO::store(stk + (size_t)(lv - A.ldsDepth) * IO::NU * 64u, 64u, nd); ++sp; }
         else *A.errorFlag = 1u;   // never expected: depth = stack_bound(E, stepSize) (+ STEAL_LEVELS with work sharing)
     }
+    __device__ __forceinline__ void drain(bool) {}
     __device__ __forceinline__ void on_root() {}
     __device__ __forceinline__ uint32_t root_hits() const { return 0u; }     // travels with stolen work (CountEnv: gate of the saturation check)
     __device__ __forceinline__ void set_root_hits(uint32_t) {}
@@ -456,10 +473,11 @@ template <int WPP> struct EnvBase {
 };
 
 // leaf policy 1: frequency only -- hits[a-ab] = min(countOccurrences(it) + hits[a-ab], max) (algo.hpp:48,191)
-template <int WPP> struct CountEnv : EnvBase<WPP> {
+template <int WPP, bool JUMP = false> struct CountEnv : EnvBase<WPP> {
     using EnvBase<WPP>::A;
     typedef typename EnvBase<WPP>::row_t row_t;
     typedef typename EnvBase<WPP>::Root Root;
+    static constexpr bool NLESS = JUMP, JUMPS = JUMP;   // the tables of the jump hold A,C,G,T strings only
     uint32_t leafSum = 0;
     uint32_t rootHits = 0;   // hits this lane has added for its current root (gates the saturation check)
     __device__ __forceinline__ CountEnv(const SearchArgs& a, uint4* s, uint32_t k) : EnvBase<WPP>(a, s, k) {}
@@ -516,19 +534,93 @@ template <int WPP, typename TPlane> struct StoreEnv : EnvBase<WPP> {
     }
 };
 
+// Leaves of the locating policies (getOccurrences of every matching range, algo.hpp:328-345) are not walked by the lane that
+// found them -- a repeat leaf of 500 rows would hold the other 63 lanes for 500 dependent reads -- but queued per wavefront in LDS
+// as {first row, rows, target}; when enough have gathered, the whole wavefront expands the queue row by row: a prefix sum over the
+// entries' widths, every lane finds the entry its row belongs to and locates that one row (consecutive rows of a leaf are
+// consecutive suffix-array entries: coalesced reads), then Derived::row_action(target, index inside the leaf, seqNo, seqPos).
+constexpr uint32_t LQ_DRAIN = 48;         // entries that trigger a drain (the queue holds SearchArgs::lqCap)
+constexpr uint32_t LQ_PIECE = 1u << 24;   // a leaf wider than this is queued in pieces: 64 entries' rows fit 32 bits
+template <int WPP, class Derived> struct LeafQueueEnv : EnvBase<WPP> {
+    using EnvBase<WPP>::A;
+    typedef typename EnvBase<WPP>::row_t row_t;
+    static constexpr bool LEAFQ = true;
+    uint4* lq = nullptr;          // LDS: entries {row lo, rows, target lo, target hi (56 bits) | row bits 32..39 << 24}
+    uint32_t* lqCtl = nullptr;    // LDS: [0] entries pushed, [1..64] scratch of the expansion (exclusive prefix sums)
+    __device__ __forceinline__ LeafQueueEnv(const SearchArgs& a, uint4* s, uint32_t k) : EnvBase<WPP>(a, s, k) {}
+    // called by one lane (any control flow): returns false when the queue is full -- the caller then walks the leaf itself
+    __device__ __forceinline__ bool enqueue(row_t flo, uint32_t w, uint64_t target)
+    {
+        const uint32_t slot = atomicAdd(&lqCtl[0], 1u);
+        if (slot >= A.lqCap) return false;
+        lq[slot] = make_uint4((uint32_t)flo, w, (uint32_t)target, (uint32_t)(target >> 32) | (uint32_t)((uint64_t)flo >> 32) << 24);
+        return true;
+    }
+    // called by the whole wavefront at a uniform point of the loop
+    __device__ __forceinline__ void drain(bool finishing)
+    {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t pushed = __hip_atomic_load(&lqCtl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)pushed);
+        if (cnt == 0u || (!finishing && cnt < LQ_DRAIN)) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t n = cnt < A.lqCap ? cnt : A.lqCap;
+        for (uint32_t base = 0; base < n; base += 64u) {
+            uint4 mine = make_uint4(0, 0, 0, 0);
+            if (base + lane < n) mine = lq[base + lane];
+            uint32_t incl = mine.y;   // inclusive prefix sum of the widths over the lanes
+#pragma unroll
+            for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)incl, (int)d); if (lane >= d) incl += up; }
+            const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+            lqCtl[1 + lane] = incl - mine.y;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (uint32_t g0 = 0; g0 < total; g0 += 64u) {
+                const uint32_t g = g0 + lane;
+                if (g < total) {
+                    uint32_t i = 0;   // the last entry whose first row is <= g (entries without rows share their successor's start)
+#pragma unroll
+                    for (uint32_t step = 32u; step >= 1u; step >>= 1) if (lqCtl[1 + (i | step)] <= g) i |= step;
+                    const uint4 e = lq[base + i];
+                    const uint32_t r = g - lqCtl[1 + i];
+                    const row_t row = (row_t)(((uint64_t)(e.w >> 24) << 32 | e.x) + r);
+                    const uint2 sp = locate_position(A.cumGlobal, A.nSeqGlobal, this->locate(row));
+                    static_cast<Derived*>(this)->row_action((uint64_t)(e.w & 0xFFFFFFu) << 32 | e.z, r, sp);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0u) lqCtl[0] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+};
+
 // leaf policy 2: --exclude-pseudo -- the set of fasta files that contain the k-mer (algo.hpp:351-364)
-template <int WPP> struct FileSetEnv : EnvBase<WPP> {
+template <int WPP> struct FileSetEnv : LeafQueueEnv<WPP, FileSetEnv<WPP>> {
     using EnvBase<WPP>::A;
     typedef typename EnvBase<WPP>::row_t row_t;
     typedef typename EnvBase<WPP>::Root Root;
-    __device__ __forceinline__ FileSetEnv(const SearchArgs& a, uint4* s, uint32_t k) : EnvBase<WPP>(a, s, k) {}
+    __device__ __forceinline__ FileSetEnv(const SearchArgs& a, uint4* s, uint32_t k) : LeafQueueEnv<WPP, FileSetEnv<WPP>>(a, s, k) {}
+    // target = the k-mer's slice position
+    __device__ __forceinline__ void row_action(uint64_t pos, uint32_t, uint2 sp)
+    {
+        const uint32_t f = A.seqFile[sp.x];
+        uint32_t* word = &A.fileBits[(size_t)pos * A.wordsPerKmer + (f >> 5)];
+        if (!((__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (f & 31u)) & 1u)) atomicOr(word, 1u << (f & 31u));   // mostly set already
+    }
     __device__ __forceinline__ void leaf(const Root& rt, uint32_t kmer, row_t flo, row_t w)
     {
-        uint32_t* bits = A.fileBits + (size_t)this->slice_pos(rt, kmer) * A.wordsPerKmer;
-        for (row_t r = 0; r < w; ++r) {
-            const uint2 sp = locate_position(A.cumGlobal, A.nSeqGlobal, this->locate(flo + r));
-            const uint32_t f = A.seqFile[sp.x];
-            atomicOr(&bits[f >> 5], 1u << (f & 31u));
+        const uint64_t pos = this->slice_pos(rt, kmer);
+        while (w > 0) {
+            const uint32_t piece = w < (row_t)LQ_PIECE ? (uint32_t)w : LQ_PIECE;
+            if (!this->enqueue(flo, piece, pos))   // queue full: this lane walks the piece itself
+                for (uint32_t r = 0; r < piece; ++r) row_action(pos, r, locate_position(A.cumGlobal, A.nSeqGlobal, this->locate(flo + r)));
+            flo += piece; w -= piece;
         }
     }
     __device__ __forceinline__ void leaf_flush(const Root&, uint32_t) {}
@@ -554,18 +646,22 @@ template <int WPP> struct OccCountEnv : EnvBase<WPP> {
 };
 
 // leaf policy 4: csv pass 2 -- getOccurrences(iterator) of every leaf (algo.hpp:328-345), unsorted
-template <int WPP> struct OccEmitEnv : EnvBase<WPP> {
+template <int WPP> struct OccEmitEnv : LeafQueueEnv<WPP, OccEmitEnv<WPP>> {
     using EnvBase<WPP>::A;
     typedef typename EnvBase<WPP>::row_t row_t;
     typedef typename EnvBase<WPP>::Root Root;
-    __device__ __forceinline__ OccEmitEnv(const SearchArgs& a, uint4* s, uint32_t k) : EnvBase<WPP>(a, s, k) {}
+    __device__ __forceinline__ OccEmitEnv(const SearchArgs& a, uint4* s, uint32_t k) : LeafQueueEnv<WPP, OccEmitEnv<WPP>>(a, s, k) {}
+    // target = the leaf's first slot of the emit array
+    __device__ __forceinline__ void row_action(uint64_t base, uint32_t r, uint2 sp) { A.emit[base + r] = (uint64_t)sp.x << 32 | sp.y; }
     __device__ __forceinline__ void leaf(const Root& rt, uint32_t kmer, row_t flo, row_t w)
     {
         const size_t slot = (size_t)rt.strand * A.windowLen + (this->slice_pos(rt, kmer) - A.posBase);
-        const uint64_t base = A.offs[slot] + atomicAdd(&A.cnt2[slot], (uint32_t)w);
-        for (row_t r = 0; r < w; ++r) {
-            const uint2 sp = locate_position(A.cumGlobal, A.nSeqGlobal, this->locate(flo + r));
-            A.emit[base + r] = (uint64_t)sp.x << 32 | sp.y;
+        uint64_t base = A.offs[slot] + atomicAdd(&A.cnt2[slot], (uint32_t)w);
+        while (w > 0) {
+            const uint32_t piece = w < (row_t)LQ_PIECE ? (uint32_t)w : LQ_PIECE;
+            if (!this->enqueue(flo, piece, base))
+                for (uint32_t r = 0; r < piece; ++r) row_action(base, r, locate_position(A.cumGlobal, A.nSeqGlobal, this->locate(flo + r)));
+            flo += piece; w -= piece; base += piece;
         }
     }
     __device__ __forceinline__ void leaf_flush(const Root&, uint32_t) {}
@@ -575,6 +671,63 @@ template <int WPP> struct OccEmitEnv : EnvBase<WPP> {
         const uint2 sp = locate_position(A.cumGlobal, A.nSeqGlobal, textPos);
         A.emit[A.offs[slot] + atomicAdd(&A.cnt2[slot], 1u)] = (uint64_t)sp.x << 32 | sp.y;
     }
+};
+
+// leaf policy 5: the correction pass of an N-less frequency call.  The needles are the text windows that hold N (of the WHOLE
+// index); an occurrence found at text position p means: the k-mer AT p matches that window, i.e. p's own frequency misses this
+// hit (Hamming distance is symmetric, and N never equals anything on either side: algo.hpp:111-112, find2:250).  So every
+// located occurrence inside the slice adds one to its own position -- if the main pass computes that position at all.
+// Leaves go through the wavefront's leaf queue (a needle inside a poly-A run matches millions of rows).  All rows of a leaf hold
+// the SAME k-mer, hence the same frequency: when the main pass alone has already brought one of them to MAX, the result of every
+// one of them is MAX whatever is added, and the leaf is dropped.
+template <int WPP> struct ScatterEnv : LeafQueueEnv<WPP, ScatterEnv<WPP>> {
+    using EnvBase<WPP>::A;
+    typedef typename EnvBase<WPP>::row_t row_t;
+    typedef typename EnvBase<WPP>::Root Root;
+    __device__ __forceinline__ ScatterEnv(const SearchArgs& a, uint4* s, uint32_t k) : LeafQueueEnv<WPP, ScatterEnv<WPP>>(a, s, k) {}
+    // slice position of (seqNo, seqPos) if this call computes it, else ~0
+    __device__ __forceinline__ uint64_t own_position(uint2 sp) const
+    {
+        const uint64_t g = A.cumGlobal[sp.x] + sp.y;
+        if (g < A.sliceBegin || g - A.sliceBegin >= A.sliceLen) return ~0ull;
+        const uint64_t q = g - A.sliceBegin;
+        if (q < A.ownBegin || q >= A.ownEnd) return ~0ull;
+        if (A.ownChunkLen && ((q - A.ownBegin) / A.ownChunkLen) % A.chunkStride != A.chunkIndex) return ~0ull;
+        if (A.selBlocks) {
+            uint32_t lo = 0, hi = A.nSelBlocks;
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; const uint2 e = A.selBlocks[mid]; if (((uint64_t)(e.y >> 8) << 32 | e.x) <= q) lo = mid; else hi = mid; }
+            const uint2 e = A.selBlocks[lo];
+            const uint64_t b = (uint64_t)(e.y >> 8) << 32 | e.x;
+            if (q < b || q >= b + (e.y & 0xFFu)) return ~0ull;
+        }
+        return q;
+    }
+    __device__ __forceinline__ void row_action(uint64_t, uint32_t, uint2 sp)
+    {
+        const uint64_t q = own_position(sp);
+        if (q == ~0ull) return;
+        uint32_t* p = &A.acc[q];
+        if (atomicAdd(p, 1u) == 0xFFFFFFFFu) atomicOr(p, 0x80000000u);
+    }
+    __device__ __forceinline__ void leaf(const Root&, uint32_t, row_t flo, row_t w)
+    {
+        if (w >= 16u) {   // wide: is the k-mer of these rows at MAX already?  (the first few rows that this call computes decide)
+            for (uint32_t r = 0; r < 8u && r < w; ++r) {
+                const uint64_t q = own_position(locate_position(A.cumGlobal, A.nSeqGlobal, this->locate(flo + r)));
+                if (q == ~0ull) continue;
+                if (__hip_atomic_load(&A.acc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= A.maxVal) return;
+                break;
+            }
+        }
+        while (w > 0) {
+            const uint32_t piece = w < (row_t)LQ_PIECE ? (uint32_t)w : LQ_PIECE;
+            if (!this->enqueue(flo, piece, 0ull))
+                for (uint32_t r = 0; r < piece; ++r) row_action(0ull, r, locate_position(A.cumGlobal, A.nSeqGlobal, this->locate(flo + r)));
+            flo += piece; w -= piece;
+        }
+    }
+    __device__ __forceinline__ void leaf_flush(const Root&, uint32_t) {}
+    __device__ __forceinline__ void leaf_at(const Root&, uint32_t, row_t textPos) { row_action(0ull, 0u, locate_position(A.cumGlobal, A.nSeqGlobal, textPos)); }
 };
 
 #ifdef GM_WAVES
@@ -609,6 +762,13 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     // that lane's needle window (wlane) and the owner may not stage a new window while users[owner] != 0
     uint32_t* const users = reinterpret_cast<uint32_t*>(smem + 4u * A.vqCap * NU + 4u * 64u * (A.ldsDepth * NU + A.winChunks)) + wv * 128u;   // [64] users | [64] pairing
     uint32_t* const pairing = users + 64;
+    if constexpr (EnvT::LEAFQ) {   // leaf queue behind everything else: [4 x lqCap entries] [4 x 80 control words]
+        uint4* const lqBase = smem + 4u * A.vqCap * NU + 4u * 64u * (A.ldsDepth * NU + A.winChunks) + (4u * 128u * 4u) / 16u;
+        env.lq = lqBase + wv * A.lqCap;
+        env.lqCtl = reinterpret_cast<uint32_t*>(lqBase + 4u * A.lqCap) + wv * 80u;
+        if (lane == 0u) env.lqCtl[0] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    }
     uint4* const lstkW = smem + 4u * A.vqCap * NU + wv * (A.ldsDepth * NU * 64u);
     uint4* const stkW = A.stack + (gl & ~(size_t)63) * A.spillDepth * NU;
     uint32_t wlane = lane;
@@ -629,6 +789,11 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     row_t ftFlo = 0, ftRlo = 0, ftW = 0;
     unsigned long long fx0 = 0, fx1 = 0;
     const uint4* fsrc = A.text4;
+    // jump patterns of the lane's current root (Env::JUMPS): 2-bit packed J-mer of the needle, cursor | end << 16 into A.patterns,
+    // the next pattern's descriptor (prefetched), meta of the node at depth J (with the errors of the pattern whose table entry
+    // is in flight; bit 30 marks the first pattern of a root: the root context is installed with it)
+    uint32_t jb = 0, jpp = 0, jd = 0, jm = 0;   // jm: errs field = errors of the pattern in flight, bit 30 = first pattern of its root
+    uint4 fji = make_uint4(0, 0, 0, 0);
     unsigned long long poolCur = 0, poolEnd = 0, poolBase = 0, poolBlock = 0;   // wave-uniform
     uint32_t poolRem = 0;
     bool globalDone = false;                        // wave-uniform
@@ -710,7 +875,36 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
         GM_LAP2(tShare);
         // ---- root fetch, pipelined over iterations so that the wavefront never waits for it ----
         // stage 3: the q-mer table entry has arrived -> the root becomes the lane's node (or turns out empty)
-        if (fs == 2u) {
+        if constexpr (EnvT::JUMPS) {
+            // the table entry of the current pattern has arrived, and the lane has finished the subtree of the one before
+            if (fs == 2u && !have && env.sp == 0u) {
+                env.note_wave(3);
+                const bool first = (jm >> 30) != 0u;
+                if (first) { rt = frt; env.on_root(); jm &= 0x3FFFFFFFu; }
+                // every k-mer of the block at MAX: nothing a further pattern finds can change the result
+                const bool sat = !first && env.root_hits() >= A.maxVal && env.saturated(rt, 0u, rt.n - 1u);
+                if (ftW != 0u && !sat) {
+                    nd.flo = ftFlo; nd.rlo = ftRlo; nd.w = ftW; nd.meta = jm;
+                    have = true; w1run = 0;
+                }
+                const uint32_t jp = jpp & 0xFFFFu, jpe = jpp >> 16;
+                if (!sat && jp < jpe) {   // the next pattern: substituted J-mer -> table read; the descriptor after it is prefetched
+                    uint32_t idx = jb;
+#pragma unroll 1
+                    for (uint32_t k = 0; k < (jd & 7u); ++k) {
+                        const uint32_t f = (jd >> (3u + 6u * k)) & 63u, sh = 2u * (A.jumpJ - 1u - (f & 15u)), old = (idx >> sh) & 3u;
+                        idx ^= (old ^ ((old + (f >> 4)) & 3u)) << sh;
+                    }
+                    IO::load_qentry(A.jtab, idx, ftFlo, ftRlo, ftW);
+                    jm = (jm & ~(7u << META_ERRS_SHIFT)) | (jd & 7u) << META_ERRS_SHIFT;
+                    jpp += 1u;
+                    if (jp + 1u < jpe) jd = A.patterns[jp + 1u];
+#ifdef GM_COUNTERS
+                    env.jumps++;
+#endif
+                } else fs = 0u;
+            }
+        } else if (fs == 2u) {
             env.note_wave(3);
             fs = 0u;
             if (ftW != 0u) {
@@ -744,8 +938,31 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                 uint32_t r = __builtin_bitreverse32(lo2);
                 r = ((r & 0xAAAAAAAAu) >> 1) | ((r & 0x55555555u) << 1);
                 const uint32_t idx = frt.strand ? (~lo2 & m2) : (fql ? r >> (32u - 2u * fql) : 0u);
+                if constexpr (EnvT::JUMPS) {
+                    // N inside the J-mer (it may lie in a block that allows errors): this root walks the tree from its root
+                    if (bad) { rt = frt; env.on_root(); nd = root_node(rt, (row_t)A.nRows); have = true; fs = 0u; w1run = 0; }
+                    else {
+                        jb = idx;
+                        // fji = {first pattern | patterns << 16, meta at depth J relative to n - 1, first descriptor}
+                        jm = meta_pack((fji.y & 0x1FFu) + frt.n - 1u, ((fji.y >> 9) & 0x1FFu) + frt.n - 1u, fji.y >> 18, fji.z & 7u, 1u);   // "mode" bit 30: first pattern
+                        uint32_t x = idx;   // the first pattern's descriptor travels with the search's record
+#pragma unroll 1
+                        for (uint32_t k = 0; k < (fji.z & 7u); ++k) {
+                            const uint32_t f = (fji.z >> (3u + 6u * k)) & 63u, sh = 2u * (A.jumpJ - 1u - (f & 15u)), old = (x >> sh) & 3u;
+                            x ^= (old ^ ((old + (f >> 4)) & 3u)) << sh;
+                        }
+                        IO::load_qentry(A.jtab, x, ftFlo, ftRlo, ftW);
+                        jpp = ((fji.x & 0xFFFFu) + 1u) | ((fji.x & 0xFFFFu) + (fji.x >> 16)) << 16;
+                        if ((fji.x >> 16) > 1u) jd = A.patterns[(fji.x & 0xFFFFu) + 1u];
+                        fs = 2u;
+#ifdef GM_COUNTERS
+                        env.jumps++;
+#endif
+                    }
+                } else {
                 if (bad) fs = 0u;   // a pattern N never matches in an exact block (find2:330): this root finds nothing
                 else { IO::load_qentry(((A.qselMask >> frt.search) & 1u) ? A.qtabB : A.qtabA, idx, ftFlo, ftRlo, ftW); fs = 2u; }
+                }
             }
         }
         GM_LAP2(tSt32);
@@ -795,9 +1012,17 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                     frt.search = r - frt.strand * A.nSearches;
                     const uint4* recp = A.table + ((size_t)(frt.n - 1u) * 8u + frt.search);
                     uint32_t startPos;
+                    if constexpr (EnvT::JUMPS) {
+                        // regular blocks jump over the first jumpJ characters of their search; odd shapes (end of the text or of an
+                        // interval) walk the tree from its root
+                        fql = (frt.n == A.stepSize) ? A.jumpJ : 0u;
+                        startPos = (A.jumpAPacked[frt.search >> 2] >> (8u * (frt.search & 3u))) & 0xFFu;
+                        fji = A.jinfo[frt.search];   // (every search has patterns when jumpJ != 0: the host picks one J for all)
+                    } else {
                     fql = (A.qlenPacked >> (4u * frt.search)) & 15u;
                     if (frt.n == A.stepSize) startPos = (A.startPacked[frt.search >> 2] >> (8u * (frt.search & 3u))) & 0xFFu;
                     else { const uint4 q = *recp; startPos = (q.y >> 16) & 0xFFu; }   // odd block shape (end of text / interval): rare
+                    }
                     fa0 = frt.n - 1u + startPos;
                     const uint32_t W = A.K + frt.n - 1u;
                     const uint64_t g = A.textBegin + frt.win;
@@ -878,8 +1103,9 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
             }
         }
         GM_LAP(tVerify);
+        env.drain(false);   // locating policies: queued leaves, once enough have gathered
         if (__ballot(have) == 0ull && qsize == 0u) {
-            if (__ballot(!exhausted || fs != 0u || env.sp != 0u) == 0ull) break;   // nothing in flight, nothing queued or stacked, nothing left to draw
+            if (__ballot(!exhausted || fs != 0u || env.sp != 0u) == 0ull) { env.drain(true); break; }   // nothing in flight, nothing queued or stacked, nothing left to draw
             continue;
         }
 
@@ -938,6 +1164,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     atomicAdd(&A.counters[9], (unsigned long long)env.vItemsOss);
     atomicAdd(&A.counters[10], (unsigned long long)env.vChunks);
     atomicAdd(&A.counters[21], (unsigned long long)nSteals);
+    atomicAdd(&A.counters[38], (unsigned long long)env.jumps);   // detail[36]: table reads of jump patterns
 #pragma unroll
     for (int i = 0; i < 16; ++i) if (env.whit[i]) atomicAdd(&A.counters[22 + i], (unsigned long long)env.whit[i]);
     if (lane == 0) {

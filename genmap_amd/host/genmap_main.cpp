@@ -140,7 +140,7 @@ int index_main(int argc, const char** argv)
     gm_index_info info; gm_index_get_info(ix, &info);
     std::vector<uint8_t> bf(info.n_rows), br(info.n_rows); gmh::SaFiles sa;
     rc = gm_index_export_bwt(ix, bf.data(), br.data());
-    if (!rc && sampling == 1) { sa.full.resize(info.n_rows * (info.row_bits / 32)); rc = gm_index_export_sa(ix, sa.full.data()); }
+    if (!rc && sampling == 1) { sa.full.resize(info.n_rows * (info.row_bits / 32)); rc = gm_index_export_sa(ix, sa.full.data(), info.row_bits / 8); }
     if (!rc && sampling > 1) {
         uint64_t ns = 0;
         rc = gm_index_export_sa_sampled(ix, nullptr, nullptr, &ns);
@@ -269,7 +269,7 @@ int map_main(int argc, const char** argv)
                 rcs[d] = !sa.marks.empty()
                     ? gm_index_import_sampled(bf.data(), br.data(), sa.marks.data(), sa.samples.data(), sa.samples.size(), text.data(), seqLen.data(),
                                               (uint32_t)seqLen.size(), meta.sampling, bb, devices[d], &replicas[d])
-                    : gm_index_import(bf.data(), br.data(), sa.full.empty() ? nullptr : sa.full.data(), text.data(), seqLen.data(), (uint32_t)seqLen.size(),
+                    : gm_index_import(bf.data(), br.data(), sa.full.empty() ? nullptr : sa.full.data(), sa.full.size() == 2 * bf.size() ? 8u : 4u, text.data(), seqLen.data(), (uint32_t)seqLen.size(),
                                       sa.full.empty() ? 0 : 1, bb, devices[d], &replicas[d]); });
         for (auto& t : th) t.join();
     }
@@ -315,10 +315,14 @@ int map_main(int argc, const char** argv)
             auto computed = [&]() { if (verbose && !computeReported) { computeReported = true; std::cout << "- " << fileNames[fi] << ": computed in " << (std::round((wall() - tCompute) * 1000.0) / 1000.0) << " seconds\n"; } };
             auto report = [&](const char* what) { if (verbose) std::cout << "- " << what << " written in " << (std::round((wall() - t) * 100.0) / 100.0) << " seconds\n"; };
             const uint64_t* ivp = intervals.empty() ? nullptr : intervals.data();
-            if (!raw && !txt && !csv && replicas.size() == 1) {
+            bool runsOnly = !raw && !txt && !csv && replicas.size() == 1;
+            gm_runs* R = nullptr;
+            if (runsOnly) {
                 // only run-length formats requested: the GPU hands back the runs, the frequency vector never crosses PCIe
-                gm_runs* R = nullptr;
                 rc = gm_map_runs(ix, textBegin, textLen, firstSeq, nSeq, &p, ivp, intervals.size() / 2, seqFile.data(), &R);
+                if (rc == GM_ERR_TOO_LONG) { runsOnly = false; rc = 0; }   // a fasta file of 2^32 - 1 positions or more: the dense vector and the host-side scan
+            }
+            if (runsOnly) {
                 if (rc) { for (auto* r : replicas) gm_index_free(r); return fail_gm("computeMappability failed", rc); }
                 computed();
                 gmh::RunsInput ri; ri.n = R->n_runs; ri.start = R->start; ri.length = R->length; ri.value = R->value;

@@ -75,8 +75,10 @@ int gm_index_build(const uint8_t *codes, const uint64_t *seq_len, uint32_t n_seq
                    uint32_t sampling, uint32_t block_bytes, int device, gm_index **out);
 
 /* Adopt BWTs that already exist on the host (an index file read from disk, or another builder):
- * uploads them and packs the rank blocks on the GPU.  sa_fwd may be NULL (no locate). */
-int gm_index_import(const uint8_t *bwt_fwd, const uint8_t *bwt_rev, const uint32_t *sa_fwd,
+ * uploads them and packs the rank blocks on the GPU.  sa_fwd may be NULL (no locate); otherwise it holds one entry per row,
+ * sa_entry_bytes wide: 4 (uint32_t) for indexes of fewer than 2^32 - 1 rows, 8 (uint64_t) for wider ones and for indexes
+ * forced wide with GM_BLOCK_WIDE_ROWS.  A width that does not match the index is GM_ERR_BAD_ARG (it used to be a silent cast). */
+int gm_index_import(const uint8_t *bwt_fwd, const uint8_t *bwt_rev, const void *sa_fwd, uint32_t sa_entry_bytes,
                     const uint8_t *codes, const uint64_t *seq_len, uint32_t n_seq,
                     uint32_t sampling, uint32_t block_bytes, int device, gm_index **out);
 
@@ -97,7 +99,7 @@ int gm_index_export_sa_sampled(const gm_index *idx, uint32_t *mark_words, uint32
 int gm_index_export_bwt(const gm_index *idx, uint8_t *bwt_fwd, uint8_t *bwt_rev);
 
 /* Copy the forward suffix array (n_rows x uint32, sentinel-text positions; uint64 for wide indexes) back to the host; needs sampling 1. */
-int gm_index_export_sa(const gm_index *idx, uint32_t *sa_fwd);
+int gm_index_export_sa(const gm_index *idx, void *sa_fwd, uint32_t sa_entry_bytes);   /* entries as wide as gm_index_info.row_bits says */
 
 int gm_index_get_info(const gm_index *idx, gm_index_info *info);
 void gm_index_free(gm_index *idx);

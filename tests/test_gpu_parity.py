@@ -207,7 +207,8 @@ def test_gpu_gtest_matrix(E, dna5, wide):
             triv = ora.trivial(K, E, revcompl=rc, value_bits=8)
             for infix in range(max(minK, nblocks), K + 1):
                 for T in (0, 1, 4):   # verification of narrow nodes off / width 1 / width <= 4
-                    ix.set_tuning(verify_t=T, steal=T & 1, coop=(T + 1) & 1)
+                    # T = 4 also turns the jump patterns / N-less pass off: the plain tree walk from the root with N children
+                    ix.set_tuning(verify_t=T, steal=T & 1, coop=(T + 1) & 1, jump=(0 if T == 4 else (-1 if T == 0 else 3)))
                     out = ix.map(K, E, infix=infix, revcompl=rc, value_bits=8)
                     assert np.array_equal(out, triv), (E, dna5, K, infix, T, wide)
     finally:
@@ -228,10 +229,11 @@ def test_gpu_baseline_settings_small(K, E):
             for T in (0, 1, 4):
                 # rank blocks read by one lane / by groups of lanes; verification from the 32-byte row records / from SA + text;
                 # idle lanes steal from their neighbours' stacks or not
-                for coop, ctx, steal in (((1, 1, 0), (0, 0, 0), (1, 0, 1), (0, 1, 1)) if bb in (32, 64) else ((0, 1, 0), (0, 0, 1))):
-                    ix.set_tuning(verify_t=T, coop=coop, use_ctx=ctx, steal=steal)
+                # ... jump patterns + N-less pass + correction pass (default), short jumps, or the plain tree walk with N children
+                for coop, ctx, steal, jump in (((1, 1, 0, -1), (0, 0, 0, 0), (1, 0, 1, 7), (0, 1, 1, -1)) if bb in (32, 64) else ((0, 1, 0, -1), (0, 0, 1, 0))):
+                    ix.set_tuning(verify_t=T, coop=coop, use_ctx=ctx, steal=steal, jump=jump)
                     out = ix.map(K, E, value_bits=bits)
-                    assert np.array_equal(out, exp), (K, E, bits, bb, T, coop, ctx, steal)
+                    assert np.array_equal(out, exp), (K, E, bits, bb, T, coop, ctx, steal, jump)
         ix.close()
 
 
@@ -792,7 +794,7 @@ def test_gpu_full_size_grch38_e0_everywhere_e1_e2_k100_on_intervals():
     bf, br = ix.export_bwt()
     ora = H.OracleIndex(codes, lens, keep_sa=False, bwt=(bf, br))
     del bf, br
-    iv = _interval_set(lens, 100)
+    iv = _interval_set(lens, 100, n_per=50000)   # ~400 k positions: seconds for the oracle on the GPU box's host cores
     sel = np.zeros(n, bool)
     for a, b in iv:
         sel[a:b] = True
@@ -929,3 +931,14 @@ def test_gpu_bench_two_ranks_on_one_device_at_0p77_gbp():
     assert line["n_gpus"] == 2 and line["comm"] == "peer DMA copies overlapping compute" and len(line["per_rank_search_ms"]) == 2
     sub = [s for s in line["sub"] if (s["K"], s["E"]) == (100, 1)]
     assert sub and sub[0]["roofline"]["frac"] and sub[0]["roofline"]["rank_lines"] > 0 and line["roofline"]["frac"]
+
+
+def test_gpu_index_of_more_than_2_to_32_rows():
+    """tools/wide_rows_smoke.py: an index of 4.32 G rows (64-bit rows for real, not forced): two copies of a 2.16 Gbp genome, so
+    every frequency must be exactly twice (up to MAX) what the 32-bit path of this library -- pinned by the rest of the suite --
+    computes on one copy: K=30 e=0 (8- and 16-bit) and e=1 on intervals at the N-block edges, a sequence boundary, the copy
+    boundary and the end of the text, and the doubling property on the whole e=0 vector"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "wide_rows_smoke.py")], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0 and "WIDE_ROWS_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
