@@ -516,7 +516,7 @@ template <typename T> static int grow(T** p, uint64_t* cap, uint64_t need)
 enum LeafMode { LEAF_COUNT = 0, LEAF_FILESET = 1, LEAF_OCC_COUNT = 2, LEAF_OCC_EMIT = 3, LEAF_STORE = 4, LEAF_STORE8 = 5, LEAF_COUNT_JUMP = 6, LEAF_SCATTER = 7 };
 
 // nu = 16-byte units per stored node / queue entry: 1, or 2 with 64-bit rows (gm_kernels.h: NodeIO)
-static inline size_t search_lds_bytes(const SearchArgs& A, uint32_t nu) { return (size_t)(4u * A.vqCap * nu + 4u * 64u * (A.ldsDepth * nu + A.winChunks)) * 16u + 4u * 128u * 4u + (A.lqCap ? 4u * (A.lqCap * 16u + 80u * 4u) : 0u); }
+static inline size_t search_lds_bytes(const SearchArgs& A, uint32_t nu) { return (size_t)(4u * A.vqCap * nu + 4u * 64u * (A.ldsDepth * nu + A.winChunks)) * 16u + 4u * 128u * 4u + 128u + (A.lqCap ? 4u * (A.lqCap * 16u + 80u * 4u) : 0u); }
 
 template <int WPP, class EnvT>
 static int launch_one(const SearchArgs& A, unsigned blocks, hipStream_t st)
@@ -672,6 +672,16 @@ static int ensure_correction_blocks(gm_index* ix, uint32_t K, uint32_t E, uint32
     return GM_OK;
 }
 
+// relative lengths of the OSS blocks (gm_host.h: make_map_plan).  The scheme is exact for any positive lengths; the reference
+// splits evenly.  e = 2: searches 2 and 3 start with ONE exact block (the third / the fourth): blocks of 5,5,7,7 instead of 6,6,6,6
+// characters make their free-branching part two levels shorter at the price of a shorter exact start of search 1 --
+// 3.09 Gbp, K = 30: +17 % without and +20 % with jump patterns (profiles/r03/sweep_oss_weights_e2*.txt).
+static uint32_t oss_weights_for(const gm_index* ix, uint32_t E)
+{
+    if (ix->tune.ossWeights >= 0) return (uint32_t)ix->tune.ossWeights;
+    return E == 2 ? 0x7755u : 0u;
+}
+
 struct SearchSetup {
     MapPlan plan;
     ChunkSel sel{0, 0, 0};   // interleaved chunks: which positions of [posBase, posEnd) this call owns
@@ -700,7 +710,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     const uint32_t infix = p->infix > 0 ? (uint32_t)p->infix : (p->overlap >= 0 ? default_infix_length(p->K, p->E, p->overlap) : tuned_infix_length(p->K, p->E));
     if (infix == 0) return GM_ERR_BAD_OVERLAP;
     MapPlan& plan = S->plan;
-    int rc = make_map_plan(p->K, p->E, infix, p->revcompl, text_len, intervals, n_intervals, &plan, ix->tune.partBias, (uint32_t)std::max(0, ix->tune.ossWeights));
+    int rc = make_map_plan(p->K, p->E, infix, p->revcompl, text_len, intervals, n_intervals, &plan, ix->tune.partBias, oss_weights_for(ix, p->E));
     if (rc) return rc;   // PlanError values coincide with gm_status
 
     // shard [kmer_begin, kmer_end): blocks whose first k-mer lies inside
@@ -773,7 +783,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     const uint32_t winChunks = (31u + p->K + plan.stepSize - 1u + 31u) / 32u;
     const uint32_t nu = ix->wide ? 2u : 1u;
     const int wantPerCU = std::max(1, ix->tune.blocksPerCU);   // default 4 = 4 waves/SIMD, what the kernel's VGPR count allows
-    auto lds_bytes_for = [&](uint32_t d) { return (size_t)(4u * vqCap * nu + 4u * 64u * (d * nu + winChunks)) * 16u + 4u * 128u * 4u + (lqCap ? 4u * (lqCap * 16u + 80u * 4u) : 0u); };   // == search_lds_bytes
+    auto lds_bytes_for = [&](uint32_t d) { return (size_t)(4u * vqCap * nu + 4u * 64u * (d * nu + winChunks)) * 16u + 4u * 128u * 4u + 128u + (lqCap ? 4u * (lqCap * 16u + 80u * 4u) : 0u); };   // == search_lds_bytes
     auto blocks_for = [&](uint32_t d, int* nb) {
         switch (ix->wpp) { case 1: return occupancy_blocks<1>(nb, lds_bytes_for(d)); case 2: return occupancy_blocks<2>(nb, lds_bytes_for(d)); case 3: return occupancy_blocks<3>(nb, lds_bytes_for(d)); default: return occupancy_blocks<9>(nb, lds_bytes_for(d)); }
     };
@@ -1020,10 +1030,13 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
         C.steal = C.numRoots < 64ull * 4ull * 1024ull ? 1u : C.steal;
         C.lqCap = 128u;   // leaves are located by the whole wavefront (gm_kernels.h: LeafQueueEnv)
         GM_HIP(hipMemsetAsync(ix->d_small, 0, 16, st));   // the work counter; statistics keep adding up
+        GM_HIP(hipEventRecord(ix->ev[1], st));
         const uint64_t useful = (C.numRoots + 255) / 256;
         const unsigned cb = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ix->numCU * std::max(1, std::min(ix->tune.blocksPerCU, 4)), useful));
         rc = launch_search(ix, LEAF_SCATTER, C, std::min(cb, std::max(1u, S.blocks)), st); if (rc) return rc;
-    }
+        GM_HIP(hipEventRecord(ix->ev[2], st));
+        ix->corrTimed = true;
+    } else ix->corrTimed = false;
     GM_HIP(hipEventRecord(ix->evRing[slot][1], st));
     ix->evCount++;
     if (text_len > 0) {
@@ -1471,7 +1484,7 @@ int gm_index_set_tuning(gm_index* ix, const char* name, int64_t value)
         {"no_store", &ix->tune.noStore, dflt.noStore, 0, 1}, {"no_saturate", &ix->tune.noSaturate, dflt.noSaturate, 0, 1},
         {"skip_dup", &ix->tune.skipDup, dflt.skipDup, 0, 1}, {"coop", &ix->tune.coop, dflt.coop, 0, 1}, {"use_ctx", &ix->tune.useCtx, dflt.useCtx, 0, 1},
         {"steal", &ix->tune.steal, dflt.steal, 0, 64}, {"part_bias", &ix->tune.partBias, dflt.partBias, -255, 255},
-        {"child_tables", &ix->tune.childTables, dflt.childTables, 0, 1}, {"oss_weights", &ix->tune.ossWeights, dflt.ossWeights, 0, 0xFFFFFF},
+        {"child_tables", &ix->tune.childTables, dflt.childTables, 0, 1}, {"oss_weights", &ix->tune.ossWeights, dflt.ossWeights, 0, 0xFFFFFF},   // (-1: 5,5,7,7 at e = 2, the even split elsewhere)
         {"jump", &ix->tune.jump, dflt.jump, 0, 15},
     };
     for (auto& t : tab) if (!strcmp(t.n, name)) {
@@ -1529,6 +1542,7 @@ int gm_last_map_stats(const gm_index* cix, gm_map_stats* out)
     GM_HIP(hipMemcpy(cnt, reinterpret_cast<char*>(ix->d_small) + 16, sizeof(cnt), hipMemcpyDeviceToHost));
     ix->stats.node_steps = cnt[0]; ix->stats.rank_lines = cnt[1];
     for (int i = 0; i < 40; ++i) ix->stats.detail[i] = cnt[2 + i];
+    if (ix->corrTimed) { float c = 0; GM_HIP(hipEventElapsedTime(&c, ix->ev[1], ix->ev[2])); ix->stats.detail[37] = (uint64_t)(c * 1000.0f); }   // correction pass, microseconds
     int rc = check_device_error(ix);
     *out = ix->stats;
     return rc;

@@ -27,7 +27,7 @@ namespace gm {
 // -1 = "library default for this call" (depends on K, E and the index size, see prepare_search)
 struct Tuning {
     int verifyT = -1, ldsStack = -1, blocksPerCU = 4, qtable = -1, satMinW = 256, fetchBatch = -1, probation = -1, verifyCost = 3;
-    int noStore = 0, noSaturate = 0, skipDup = -1, coop = -1, useCtx = 1, steal = -1, partBias = 0, childTables = -1, ossWeights = 0, jump = -1;
+    int noStore = 0, noSaturate = 0, skipDup = -1, coop = -1, useCtx = 1, steal = -1, partBias = 0, childTables = -1, ossWeights = -1, jump = -1;
 };
 }  // namespace gm
 
@@ -92,6 +92,7 @@ struct gm_index {
     std::vector<std::pair<uint64_t, uint64_t>> nRuns;     // maximal runs of N of the whole text, sorted
     uint2* d_cblocks = nullptr; uint64_t cblocksCap = 0;   // block list of the text windows that hold N, for (corrK, corrE, corrInfix)
     uint64_t nCBlocks = 0; uint32_t corrK = 0, corrE = 0, corrInfix = 0; bool corrValid = false;
+    bool corrTimed = false;    // ev[1], ev[2] bracket the correction pass of the last call
     uint32_t pieceIndex = 0;   // gm_map_shard delivers a call in several launches: launch number inside the call (statistics accumulate)
     uint32_t statPieces = 0;   // launches the statistics of the last call cover
     int buildRounds[2] = {0, 0};

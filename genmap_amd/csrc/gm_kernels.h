@@ -711,6 +711,20 @@ template <int WPP> struct ScatterEnv : LeafQueueEnv<WPP, ScatterEnv<WPP>> {
     }
     __device__ __forceinline__ void leaf(const Root&, uint32_t, row_t flo, row_t w)
     {
+        if (w >= (row_t)A.maxVal) {
+            // The k-mer X of these rows occurs w times.  If X holds no N, the main pass has counted at least its w exact occurrences
+            // for every one of the rows: they are at MAX whether this call owns them or not -- nothing to add.  (An X with N is
+            // counted by this pass alone and has to be walked.)
+            const uint2 sp = locate_position(A.cumGlobal, A.nSeqGlobal, this->locate(flo));
+            const uint8_t* x = A.text + (A.cumGlobal[sp.x] + sp.y);   // A.text: the whole text in this pass
+            bool hasN = false;
+            for (uint32_t i = 0; i < this->K; i += 8u) {
+                uint64_t m = 0x8080808080808080ull & ~bytes_nonzero(EnvBase<WPP>::load8_up(x + i) ^ 0x0404040404040404ull);
+                if (this->K - i < 8u) m &= (1ull << (8u * (this->K - i))) - 1ull;
+                hasN |= m != 0ull;
+            }
+            if (!hasN) return;
+        }
         if (w >= 16u) {   // wide: is the k-mer of these rows at MAX already?  (the first few rows that this call computes decide)
             for (uint32_t r = 0; r < 8u && r < w; ++r) {
                 const uint64_t q = own_position(locate_position(A.cumGlobal, A.nSeqGlobal, this->locate(flo + r)));
@@ -762,8 +776,14 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     // that lane's needle window (wlane) and the owner may not stage a new window while users[owner] != 0
     uint32_t* const users = reinterpret_cast<uint32_t*>(smem + 4u * A.vqCap * NU + 4u * 64u * (A.ldsDepth * NU + A.winChunks)) + wv * 128u;   // [64] users | [64] pairing
     uint32_t* const pairing = users + 64;
+    // the searches' jump records (Env::JUMPS), 8 x 16 bytes per block behind the work-sharing bookkeeping
+    uint4* const jl = smem + 4u * A.vqCap * NU + 4u * 64u * (A.ldsDepth * NU + A.winChunks) + (4u * 128u * 4u) / 16u;
+    if constexpr (EnvT::JUMPS) {
+        if (threadIdx.x < 8u) jl[threadIdx.x] = A.jumpJ ? A.jinfo[threadIdx.x] : make_uint4(0, 0, 0, 0);
+        __syncthreads();
+    }
     if constexpr (EnvT::LEAFQ) {   // leaf queue behind everything else: [4 x lqCap entries] [4 x 80 control words]
-        uint4* const lqBase = smem + 4u * A.vqCap * NU + 4u * 64u * (A.ldsDepth * NU + A.winChunks) + (4u * 128u * 4u) / 16u;
+        uint4* const lqBase = jl + 8;
         env.lq = lqBase + wv * A.lqCap;
         env.lqCtl = reinterpret_cast<uint32_t*>(lqBase + 4u * A.lqCap) + wv * 80u;
         if (lane == 0u) env.lqCtl[0] = 0u;
@@ -783,17 +803,14 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     bool have = false, exhausted = false;
     uint32_t w1run = 0;                             // consecutive steps this lane has taken on a single-row node
     // root fetch pipeline of this lane: 0 idle, 1 window/record loads in flight, 2 q-mer table lookup in flight
-    uint32_t fs = 0, fa0 = 0, fql = 0, fwoff = 0, fnch = 0, fshift = 0;
+    uint32_t fs = 0, fa0 = 0, fql = 0, fnch = 0;
     Root frt; frt.win = 0; frt.n = 1; frt.strand = 0; frt.search = 0; frt.rec = OssRecord{0, 0, 0, 0};
-    uint4 frec = make_uint4(0, 0, 0, 0);
     row_t ftFlo = 0, ftRlo = 0, ftW = 0;
-    unsigned long long fx0 = 0, fx1 = 0;
     const uint4* fsrc = A.text4;
     // jump patterns of the lane's current root (Env::JUMPS): 2-bit packed J-mer of the needle, cursor | end << 16 into A.patterns,
     // the next pattern's descriptor (prefetched), meta of the node at depth J (with the errors of the pattern whose table entry
     // is in flight; bit 30 marks the first pattern of a root: the root context is installed with it)
     uint32_t jb = 0, jpp = 0, jd = 0, jm = 0;   // jm: errs field = errors of the pattern in flight, bit 30 = first pattern of its root
-    uint4 fji = make_uint4(0, 0, 0, 0);
     unsigned long long poolCur = 0, poolEnd = 0, poolBase = 0, poolBlock = 0;   // wave-uniform
     uint32_t poolRem = 0;
     bool globalDone = false;                        // wave-uniform
@@ -916,12 +933,19 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
         // stage 2: window chunks and record have arrived -> stage the window in LDS, look the first q characters up
         if (fs == 1u) {
             env.note_wave(4);
-            env.woff = fwoff;   // the window itself went from HBM straight into this lane's LDS slots (stage 1)
-            frt.rec.x = frec.x; frt.rec.y = frec.y; frt.rec.z = frec.z; frt.rec.w = frec.w;
             if (fql == 0u) { rt = frt; env.on_root(); nd = root_node(rt, (row_t)A.nRows); have = true; fs = 0u; w1run = 0; }
             else {
-                // 16 symbols starting at the lowest text position of the q-mer, 4 bits each
-                const unsigned long long v = fshift ? (fx0 >> fshift) | (fx1 << (64u - fshift)) : fx0;
+                // 16 symbols starting at the lowest text position of the q-mer, 4 bits each: from the window this lane staged in
+                // LDS in stage 1 (the asynchronous global -> LDS loads are awaited explicitly: nothing else orders them)
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+                const uint32_t ni = env.woff + (frt.strand ? (A.K + frt.n - 1u) - fa0 - fql : fa0);
+                const uint8_t* wc = reinterpret_cast<const uint8_t*>(wbase + lane) + (ni >> 5) * 1024u;   // chunk stride: 64 lanes x 16 bytes
+                const uint4 c0 = *reinterpret_cast<const uint4*>(wc);
+                const uint2 c1 = *reinterpret_cast<const uint2*>(wc + 1024u);
+                const uint32_t bo = (ni & 31u) * 4u, b2 = bo & 63u;
+                const unsigned long long w0 = (unsigned long long)c0.y << 32 | c0.x, w1 = (unsigned long long)c0.w << 32 | c0.z, w2 = (unsigned long long)c1.y << 32 | c1.x;
+                const unsigned long long vl = bo < 64u ? w0 : w1, vh = bo < 64u ? w1 : w2;
+                const unsigned long long v = b2 ? (vl >> b2) | (vh << (64u - b2)) : vl;
                 // the table index without a loop over the symbols: nibbles -> 2-bit symbols (symbol i at bits 2i); a code above 3
                 // (N) anywhere in the q-mer makes the root empty
                 const unsigned long long qmask = fql >= 16u ? ~0ull : ((1ull << (4u * fql)) - 1ull);
@@ -943,7 +967,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                     if (bad) { rt = frt; env.on_root(); nd = root_node(rt, (row_t)A.nRows); have = true; fs = 0u; w1run = 0; }
                     else {
                         jb = idx;
-                        // fji = {first pattern | patterns << 16, meta at depth J relative to n - 1, first descriptor}
+                        const uint4 fji = jl[frt.search];   // {first pattern | patterns << 16, meta at depth J relative to n - 1, first descriptor}
                         jm = meta_pack((fji.y & 0x1FFu) + frt.n - 1u, ((fji.y >> 9) & 0x1FFu) + frt.n - 1u, fji.y >> 18, fji.z & 7u, 1u);   // "mode" bit 30: first pattern
                         uint32_t x = idx;   // the first pattern's descriptor travels with the search's record
 #pragma unroll 1
@@ -1017,7 +1041,6 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                         // interval) walk the tree from its root
                         fql = (frt.n == A.stepSize) ? A.jumpJ : 0u;
                         startPos = (A.jumpAPacked[frt.search >> 2] >> (8u * (frt.search & 3u))) & 0xFFu;
-                        fji = A.jinfo[frt.search];   // (every search has patterns when jumpJ != 0: the host picks one J for all)
                     } else {
                     fql = (A.qlenPacked >> (4u * frt.search)) & 15u;
                     if (frt.n == A.stepSize) startPos = (A.startPacked[frt.search >> 2] >> (8u * (frt.search & 3u))) & 0xFFu;
@@ -1026,10 +1049,10 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                     fa0 = frt.n - 1u + startPos;
                     const uint32_t W = A.K + frt.n - 1u;
                     const uint64_t g = A.textBegin + frt.win;
-                    fwoff = (uint32_t)(g & 31u);
+                    env.woff = (uint32_t)(g & 31u);   // (an idle lane: nothing reads its window offset before the new root's node exists)
                     fsrc = A.text4 + (g >> 5);
-                    fnch = (fwoff + W + 31u) >> 5;
-                    frec = *recp;
+                    fnch = (env.woff + W + 31u) >> 5;
+                    { const uint4 q = *recp; frt.rec.x = q.x; frt.rec.y = q.y; frt.rec.z = q.z; frt.rec.w = q.w; }
                     // the window goes from HBM straight into this lane's LDS slots (global_load_lds_dwordx4: chunk c of
                     // lane l lands at wbase + c * 1 KiB + l * 16 B -- exactly the [chunk][lane] layout text_char reads);
                     // the text has 20 chunks of padding behind it
@@ -1038,10 +1061,6 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                     if (fnch > 2u) __builtin_amdgcn_global_load_lds(fsrc + 2, wbase + 128, 16, 0, 0);
                     for (uint32_t c = 3u; c < A.winChunks; ++c)   // long windows (K > ~45): remaining chunks
                         if (c < fnch) __builtin_amdgcn_global_load_lds(fsrc + c, wbase + c * 64u, 16, 0, 0);
-                    const uint64_t p = g + (frt.strand ? (uint64_t)(W - fa0 - fql) : (uint64_t)fa0);   // lowest text position of the q-mer
-                    const unsigned long long* t64 = reinterpret_cast<const unsigned long long*>(A.text4) + (p >> 4);
-                    fshift = (uint32_t)(p & 15u) * 4u;
-                    fx0 = t64[0]; fx1 = t64[1];
                     fs = 1u;
                 } else if (globalDone && avail == 0u) {
                     exhausted = true;

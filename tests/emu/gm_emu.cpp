@@ -12,6 +12,9 @@
 
 using namespace gm;
 
+static uint32_t g_ossWeights = 0;   // relative OSS block lengths for the plans below (gm_host.h: make_map_plan), 0 = even split
+extern "C" void gm_emu_set_oss_weights(uint32_t w) { g_ossWeights = w; }
+
 template <int WPP> struct HostIndex {
     std::vector<uint32_t> blk[2];
     uint32_t C[NLET + 1];
@@ -218,7 +221,7 @@ static int run(const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nse
                const uint8_t* allCodes, const uint64_t* allCum, uint32_t jumpCap)
 {
     MapPlan plan;
-    int rc = make_map_plan(K, E, infix, revcompl, textLen, intervals, nIntervals, &plan);
+    int rc = make_map_plan(K, E, infix, revcompl, textLen, intervals, nIntervals, &plan, 0, g_ossWeights);
     if (rc) return rc;
     HostIndex<WPP> ix; ix.build(bf, br, rows, nseqTotal);
     std::vector<uint32_t> acc(textLen ? textLen : 1, 0);
@@ -247,7 +250,7 @@ static int run(const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nse
         n_window_intervals(runs, cumv, K, E, iv);
         if (!iv.empty()) {
             MapPlan cplan;
-            rc = make_map_plan(K, E, infix, revcompl, allLen, iv.data(), iv.size() / 2, &cplan);
+            rc = make_map_plan(K, E, infix, revcompl, allLen, iv.data(), iv.size() / 2, &cplan, 0, g_ossWeights);
             if (rc) return rc;
             EmuEnv<WPP, false> cenv; cenv.ix = &ix; cenv.text = allCodes; cenv.K = K; cenv.acc = &acc;
             cenv.saArr = sa; cenv.textSent = &textS;

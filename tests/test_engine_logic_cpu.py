@@ -292,3 +292,23 @@ def test_n_window_intervals_list_exactly_the_windows_that_can_match():
                 if K >= nblocks:
                     out, _ = emu_map2(ix, 1, K, E, infix=K, value_bits=16, verify_t=0, jump=15)
                     assert np.array_equal(out, triv), (trial, K, E, lens)
+
+
+@pytest.mark.parametrize("E,weights", [(1, 0x31), (2, 0x7755), (2, 0x1F31), (3, 0x12345), (4, 0x654321)])
+def test_uneven_oss_block_lengths_give_the_same_counts(E, weights):
+    """the scheme covers every error distribution exactly once for ANY positive block lengths (l/u bound errors per block, not
+    per position): the library's e = 2 default (blocks of 5,5,7,7 for an infix of 24) and lopsided splits, with and without jumps"""
+    rng = np.random.default_rng(8000 + E)
+    lens = [700, 31, 500]
+    codes = rng.integers(0, 4, size=sum(lens), dtype=np.uint8)
+    codes[100:160] = codes[900:960]; codes[300] = 4; codes[650:653] = 4
+    ix = H.OracleIndex(codes, lens, keep_sa=True)
+    K = 30 if E <= 2 else 36
+    exp = ix.mappability(K, E, value_bits=16, threads=4)
+    emu().gm_emu_set_oss_weights(weights)
+    try:
+        for T, jump, nless in ((0, 0, False), (1, 15, True), (4, 6, True)):
+            out, _ = emu_map2(ix, 1, K, E, value_bits=16, verify_t=T, jump=jump, nless=nless)
+            assert np.array_equal(out, exp), (E, hex(weights), T, jump)
+    finally:
+        emu().gm_emu_set_oss_weights(0)

@@ -9,7 +9,7 @@ import torch
 import genmap_amd as g
 from genmap_amd import synth
 
-DEFAULTS = dict(verify_t=-1, lds_stack=-1, blocks_per_cu=4, qtable=-1, sat_min_w=256, fetch_batch=-1, probation=-1, verify_cost=3, no_store=0, no_saturate=0, skip_dup=-1, coop=-1, use_ctx=1, steal=-1, part_bias=0, oss_weights=0, child_tables=-1, jump=-1)
+DEFAULTS = dict(verify_t=-1, lds_stack=-1, blocks_per_cu=4, qtable=-1, sat_min_w=256, fetch_batch=-1, probation=-1, verify_cost=3, no_store=0, no_saturate=0, skip_dup=-1, coop=-1, use_ctx=1, steal=-1, part_bias=0, oss_weights=-1, child_tables=-1, jump=-1)
 ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="chr1"); ap.add_argument("--scale", type=float, default=1.0)
 ap.add_argument("--cfg", nargs="+", default=["30,2,1.0"])
@@ -48,5 +48,6 @@ for cfg in a.cfg:
         chk = int(out[:n].to(torch.int64).sum().item())
         if base is None: base = chk
         best = min(ms)
-        print(f"K={K} E={E} frac={frac:<5} {st or '(default)':45s} {best:10.2f} ms  {(span if rng else nk)/best*1e3:10.4g} k-mers/s  checksum {'ok' if chk == base else 'DIFFERS'}", flush=True)
+        corr = ix.last_stats()["detail"].get("correction_us", 0) / 1e3
+        print(f"K={K} E={E} frac={frac:<5} {st or '(default)':45s} {best:10.2f} ms (correction pass {corr:8.2f})  {(span if rng else nk)/best*1e3:10.4g} k-mers/s  checksum {'ok' if chk == base else 'DIFFERS'}", flush=True)
 ix.close()
