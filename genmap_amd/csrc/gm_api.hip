@@ -673,13 +673,13 @@ static int ensure_correction_blocks(gm_index* ix, uint32_t K, uint32_t E, uint32
 }
 
 // relative lengths of the OSS blocks (gm_host.h: make_map_plan).  The scheme is exact for any positive lengths; the reference
-// splits evenly.  e = 2: searches 2 and 3 start with ONE exact block (the third / the fourth): blocks of 5,5,7,7 instead of 6,6,6,6
-// characters make their free-branching part two levels shorter at the price of a shorter exact start of search 1 --
-// 3.09 Gbp, K = 30: +17 % without and +20 % with jump patterns (profiles/r03/sweep_oss_weights_e2*.txt).
+// splits evenly.  e = 2: searches 2 and 3 start with ONE exact block (the third / the fourth): blocks in the proportion 5,4,7,8
+// instead of 6,6,6,6 make their free-branching part shorter at the price of a shorter exact start of search 1 --
+// 3.09 Gbp, K = 30: 5,5,7,7 +17 % without and +20 % with jump patterns, 5,4,7,8 another +8 % (profiles/r03/sweep_oss_weights_e2*.txt, sweep_shapes.txt).
 static uint32_t oss_weights_for(const gm_index* ix, uint32_t E)
 {
     if (ix->tune.ossWeights >= 0) return (uint32_t)ix->tune.ossWeights;
-    return E == 2 ? 0x7755u : 0u;
+    return E == 2 ? 0x8745u : 0u;
 }
 
 struct SearchSetup {
@@ -1484,7 +1484,7 @@ int gm_index_set_tuning(gm_index* ix, const char* name, int64_t value)
         {"no_store", &ix->tune.noStore, dflt.noStore, 0, 1}, {"no_saturate", &ix->tune.noSaturate, dflt.noSaturate, 0, 1},
         {"skip_dup", &ix->tune.skipDup, dflt.skipDup, 0, 1}, {"coop", &ix->tune.coop, dflt.coop, 0, 1}, {"use_ctx", &ix->tune.useCtx, dflt.useCtx, 0, 1},
         {"steal", &ix->tune.steal, dflt.steal, 0, 64}, {"part_bias", &ix->tune.partBias, dflt.partBias, -255, 255},
-        {"child_tables", &ix->tune.childTables, dflt.childTables, 0, 1}, {"oss_weights", &ix->tune.ossWeights, dflt.ossWeights, 0, 0xFFFFFF},   // (-1: 5,5,7,7 at e = 2, the even split elsewhere)
+        {"child_tables", &ix->tune.childTables, dflt.childTables, 0, 1}, {"oss_weights", &ix->tune.ossWeights, dflt.ossWeights, 0, 0xFFFFFF},   // (-1: 5,4,7,8 at e = 2, the even split elsewhere)
         {"jump", &ix->tune.jump, dflt.jump, 0, 15},
     };
     for (auto& t : tab) if (!strcmp(t.n, name)) {

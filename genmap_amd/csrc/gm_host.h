@@ -54,9 +54,11 @@ inline uint32_t tuned_infix_length(uint32_t K, uint32_t E)
             if (K >= 128) n = 48;
             else if (K >= 60) { n = clampu(K / 4, 16, 24); if (K + n - 1 > 127 && K <= 112) n = 128 - K; }
             else if (K >= 44) n = std::min<uint32_t>(16, K - 34);
-            else n = clampu(K / 6, 5, 16);
+            // K <= 43, re-measured in round 3 with jump patterns (profiles/r03/sweep_shapes.txt): the jump makes the top of the
+            // tree cheap, so longer blocks pay: K=30 n=8 +10 % over n=5 (flat up to 12), K=24 n=8 +13 %
+            else n = clampu(K / 3, 5, 8);
             break;
-        case 2: n = clampu(K / 6, 7, 16); break;
+        case 2: n = clampu(K / 6, 6, 16); break;   // K=30: n=6 +4 % over 7 with jump patterns and blocks of 5,4,7,8 (r03)
         case 3: n = clampu(K / 4, 9, 16); break;
         default: n = clampu(K / 4, 11, 16); break;
     }

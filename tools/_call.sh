@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
-(timeout 1500 python tools/sweep_tuning.py --workload grch38 --reps 1 --cfg 30,2,0.03 -- "oss_weights=30549" "oss_weights=30564" "oss_weights=34389" "oss_weights=34629" "oss_weights=30294" "oss_weights=26709" "oss_weights=30549,STEP=5" "oss_weights=30549,STEP=6" "oss_weights=30549,STEP=8" "oss_weights=30549,STEP=9" "oss_weights=30549,STEP=10" 2>&1 | grep -v amdgpu.ids) > gpurun_out/c10_sweep_e2.txt
-(timeout 900 python tools/sweep_tuning.py --workload grch38 --reps 1 --cfg 30,1,0.2 -- "" "STEP=4" "STEP=6" "STEP=7" "STEP=8" "oss_weights=101" "oss_weights=118" "oss_weights=103" 2>&1 | grep -v amdgpu.ids | grep -v "index in") >> gpurun_out/c10_sweep_e2.txt
+(timeout 1700 python -m pytest tests -m gpu -x -q --timeout 900 --durations=15 2>&1 | tail -40) > gpurun_out/c12_pytest_full.txt
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/c12_smoke.txt 2>&1
+(timeout 900 python bench.py 2> gpurun_out/c12_bench.err > gpurun_out/c12_bench.json)
