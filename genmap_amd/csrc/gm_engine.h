@@ -340,6 +340,10 @@ GM_HD void verify_item(typename Env::row_t row, uint32_t meta, const RootT<typen
     uint32_t rc = 0, lc = 0;
     const uint32_t rlim = scan_side(env, rt, it, a0, bx, false, smax + K - bx, budget, rc, rp);
     const uint32_t llim = scan_side(env, rt, it, a0, a - 1u, true, a - smin, budget, lc, lp);
+    // only the k-mers the two scans reach: a - s <= llim and s + K - bx <= rlim (a chance hit reaches none: no loop at all)
+    if (bx + rlim < K) return;
+    if (a > llim && a - llim > smin) smin = a - llim;
+    if (bx + rlim - K < smax) smax = bx + rlim - K;
     for (uint32_t s = smin; s <= smax; ++s) {
         env.note_wave(14);
         const uint32_t lenL = a - s, lenR = s + K - bx;

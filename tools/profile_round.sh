@@ -1,11 +1,13 @@
 #!/bin/bash
-# The measurement set that goes into profiles/<round>/ (run on the GPU box):  tools/profile_round.sh r02
-#   1. the default bench line (3.09 Gbp, K=30 e=0 + sub-records)          -> bench_default.json
-#   2. rocprofv3 --kernel-trace --stats of the same command (headline only) -> kernel_stats_short.csv
-#   3. PMC traffic of the same launch, separate passes                      -> pmc_FETCH_SIZE.txt, pmc_WRITE_SIZE.txt
-#   4. SQ counters + device-side step statistics of the search kernel       -> pmc_sq_<workload>.txt, step_stats_<workload>.txt
-R=${1:-r02}; O=gpurun_out/$R; mkdir -p $O
+# The measurement set that goes into profiles/<round>/ (run on the GPU box):  tools/profile_round.sh r03
+#   1. the default bench line (3.09 Gbp, K=30 e=0 + sub-records)                          -> bench_default.json
+#   2. rocprofv3 --kernel-trace --stats of the same command (headline launch only)        -> kernel_stats_short.csv
+#   3. the four configurations (30,0) (30,1) (30,2) (100,1) in ONE process under rocprofv3: kernel durations per configuration,
+#      and PMC traffic FETCH_SIZE / WRITE_SIZE in separate passes                            -> kernel_by_config.txt, pmc_by_config.txt
+#   4. SQ counters + device-side step statistics of the search kernels                     -> pmc_sq_grch38.txt, step_stats_grch38.txt
+R=${1:-r03}; O=gpurun_out/$R; mkdir -p $O
 export TMPDIR=/tmp
+CFGS="30,0,1.0 30,1,1.0 30,2,1.0 100,1,1.0"
 echo "== bench default"; timeout 1700 python bench.py > $O/bench_default.json 2> $O/bench_default.log; tail -c 1500 $O/bench_default.json; echo
 echo "== rocprofv3 kernel stats (headline launch only)"
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o p --output-format csv -- python bench.py --no-cpu-baseline --no-counters --no-host-rate --sub "" > $O/prof.log 2>&1
@@ -22,33 +24,64 @@ for f in glob.glob(f'{O}/prof/**/*kernel_stats.csv', recursive=True):
     print(open(f'{O}/kernel_stats_short.csv').read()[:2500])
 PY
 rm -rf $O/prof
-echo "== PMC traffic (FETCH_SIZE, WRITE_SIZE in separate passes)"
-for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $C --kernel-trace -d $O/pmc_$C -o p --output-format csv -- python bench.py --no-cpu-baseline --no-counters --no-host-rate --sub "" --steps 2 --warmup 1 > $O/pmc_$C.log 2>&1
-  python - $C $O <<'PY'
+echo "== the four configurations in one process: kernel durations (rocprofv3 --kernel-trace)"
+# sweep_tuning.py runs reps + 1 = 3 calls per configuration in the order of --cfg; a call with errors on this Dna5 text is a
+# search_kernel (CountEnv) dispatch followed by the small correction dispatch (ScatterEnv)
+timeout 1500 rocprofv3 --kernel-trace -d $O/kt -o p --output-format csv -- python tools/sweep_tuning.py --workload grch38 --reps 2 --cfg $CFGS -- "" > $O/kt.log 2>&1
+python - $O "$CFGS" <<'PY'
 import csv, glob, sys
-c, O = sys.argv[1], sys.argv[2]; vals = []
+O, cfgs = sys.argv[1], sys.argv[2].split()
+rows = []
+for f in glob.glob(f'{O}/kt/**/*kernel_trace.csv', recursive=True):
+    rows += [r for r in csv.DictReader(open(f)) if 'search_kernel' in r['Kernel_Name']]
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+main = [r for r in rows if 'ScatterEnv' not in r['Kernel_Name']]
+corr = [r for r in rows if 'ScatterEnv' in r['Kernel_Name']]
+with open(f'{O}/kernel_by_config.txt', 'w') as out:
+    out.write('# rocprofv3 --kernel-trace of tools/sweep_tuning.py --reps 2 (3 calls per configuration, the first one untimed warm-up); ms per dispatch\n')
+    for k, c in enumerate(cfgs):
+        d = main[3 * k:3 * k + 3]
+        ms = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in d]
+        name = d[0]['Kernel_Name'] if d else '?'
+        out.write(f'cfg {c}: {name[:70]}  dispatches ms {[round(x, 3) for x in ms]}  mean of the timed two {sum(ms[1:]) / max(1, len(ms) - 1):.3f}\n')
+    cms = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in corr]
+    out.write(f'correction pass (ScatterEnv) dispatches: {len(cms)}, ms {[round(x, 3) for x in cms]}\n')
+print(open(f'{O}/kernel_by_config.txt').read())
+PY
+rm -rf $O/kt
+echo "== PMC traffic per configuration (FETCH_SIZE, WRITE_SIZE in separate passes)"
+: > $O/pmc_by_config.txt
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 1500 rocprofv3 --pmc $C --kernel-trace -d $O/pmc_$C -o p --output-format csv -- python tools/sweep_tuning.py --workload grch38 --reps 1 --cfg $CFGS -- "" > $O/pmc_$C.log 2>&1
+  python - $C $O "$CFGS" <<'PY'
+import csv, glob, sys, collections
+c, O, cfgs = sys.argv[1], sys.argv[2], sys.argv[3].split()
+acc = collections.OrderedDict()
 for f in glob.glob(f'{O}/pmc_{c}/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'search_kernel' in r['Kernel_Name'] and r['Counter_Name'] == c: vals.append(float(r['Counter_Value']))
-print(c, 'per search_kernel dispatch (KB):', vals)
-open(f'{O}/pmc_{c}.txt', 'w').write(f'{c} per search_kernel dispatch (KB): {vals}\n')
+        if 'search_kernel' in r['Kernel_Name'] and 'ScatterEnv' not in r['Kernel_Name'] and r['Counter_Name'] == c:
+            acc[int(r['Dispatch_Id'])] = acc.get(int(r['Dispatch_Id']), 0.0) + float(r['Counter_Value'])
+vals = [acc[d] for d in sorted(acc)]
+with open(f'{O}/pmc_by_config.txt', 'a') as out:
+    for k, cf in enumerate(cfgs):   # 2 dispatches per configuration: the second one
+        v = vals[2 * k + 1] if 2 * k + 1 < len(vals) else float('nan')
+        out.write(f'{c} cfg {cf}: {v:.6g} KB per search_kernel dispatch = {v * 1024 / 1e9:.3f} GB (64 B per request)\n')
+print(open(f'{O}/pmc_by_config.txt').read())
 PY
   rm -rf $O/pmc_$C
 done
 echo "== SQ counters of the search kernel (one group per pass) and device-side step statistics"
-for WL in grch38 chr1; do
-  FR="30,0,1.0 30,1,0.2 100,1,1.0 30,2,0.06"; [ $WL = chr1 ] && FR="30,0,1.0 30,1,1.0 100,1,1.0 30,2,0.5"
-  : > $O/pmc_sq_$WL.txt
-  for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_THREAD_CYCLES_VALU SQ_INSTS_BRANCH SQ_WAVES GRBM_GUI_ACTIVE"; do
-    timeout 900 rocprofv3 --pmc $G --kernel-trace -d $O/pmc_sq -o p --output-format csv -- python tools/sweep_tuning.py --workload $WL --reps 1 --cfg $FR -- "" > $O/pmc_sq.log 2>&1
-    python - $O $WL <<'PY'
+WL=grch38; FR="30,0,1.0 30,1,0.2 100,1,1.0 30,2,0.06"
+: > $O/pmc_sq_$WL.txt
+for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_THREAD_CYCLES_VALU SQ_INSTS_BRANCH SQ_WAVES GRBM_GUI_ACTIVE"; do
+  timeout 900 rocprofv3 --pmc $G --kernel-trace -d $O/pmc_sq -o p --output-format csv -- python tools/sweep_tuning.py --workload $WL --reps 1 --cfg $FR -- "" > $O/pmc_sq.log 2>&1
+  python - $O $WL <<'PY'
 import csv, glob, sys, collections
 O, WL = sys.argv[1], sys.argv[2]
 acc = collections.OrderedDict()
 for f in glob.glob(f'{O}/pmc_sq/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'search_kernel' not in r['Kernel_Name']: continue
+        if 'search_kernel' not in r['Kernel_Name'] or 'ScatterEnv' in r['Kernel_Name']: continue
         acc.setdefault((int(r['Dispatch_Id']), r['Counter_Name']), 0.0)
         acc[(int(r['Dispatch_Id']), r['Counter_Name'])] += float(r['Counter_Value'])
 disp = sorted({d for d, _ in acc})
@@ -59,8 +92,8 @@ with open(f'{O}/pmc_sq_{WL}.txt', 'a') as out:
             for (dd, c), v in acc.items():
                 if dd == d: out.write(f'cfg#{k // 2} {c} {v:.6g}\n')
 PY
-    rm -rf $O/pmc_sq
-  done
-  timeout 900 python tools/stats_run.py --workload $WL --cfg 30,0 30,1 100,1 $([ $WL = chr1 ] && echo 30,2) > $O/step_stats_$WL.txt 2>&1
+  rm -rf $O/pmc_sq
 done
+timeout 900 python tools/stats_run.py --workload $WL --cfg 30,0 30,1 100,1 > $O/step_stats_$WL.txt 2>&1
+timeout 900 python tools/stats_run.py --workload $WL --frac 0.1 --cfg 30,2 >> $O/step_stats_$WL.txt 2>&1
 ls -la $O
