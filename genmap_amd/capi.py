@@ -90,9 +90,9 @@ def load_library(profiling=False):
     lib.gm_index_export_bwt.restype = C.c_int
     lib.gm_index_export_bwt.argtypes = [vp, vp, vp]
     lib.gm_index_import_sampled.restype = C.c_int
-    lib.gm_index_import_sampled.argtypes = [vp, vp, vp, vp, C.c_uint64, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)]
+    lib.gm_index_import_sampled.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_uint64, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)]
     lib.gm_index_export_sa_sampled.restype = C.c_int
-    lib.gm_index_export_sa_sampled.argtypes = [vp, vp, vp, C.POINTER(C.c_uint64)]
+    lib.gm_index_export_sa_sampled.argtypes = [vp, vp, vp, C.c_uint32, C.POINTER(C.c_uint64)]
     lib.gm_index_export_sa.restype = C.c_int
     lib.gm_index_export_sa.argtypes = [vp, vp, C.c_uint32]
     lib.gm_index_get_info.restype = C.c_int
@@ -253,13 +253,14 @@ class Index:
         bf = np.ascontiguousarray(bwt_fwd, dtype=np.uint8)
         br = np.ascontiguousarray(bwt_rev, dtype=np.uint8)
         mk = np.ascontiguousarray(mark_words, dtype=np.uint32)
-        sm = np.ascontiguousarray(samples, dtype=np.uint32)
+        wide = bool(block_bytes & WIDE_ROWS) or len(bf) >= 0xFFFFFFFF
+        sm = np.ascontiguousarray(samples, dtype=np.uint64 if wide else np.uint32)
         codes = np.ascontiguousarray(codes, dtype=np.uint8)
         sl = np.ascontiguousarray(seq_len, dtype=np.uint64)
         if len(mk) != (len(bf) + 31) // 32:
             raise ValueError("mark_words: one bit per row")
         h = C.c_void_p()
-        _check(lib, lib.gm_index_import_sampled(_ptr(bf), _ptr(br), _ptr(mk), _ptr(sm), len(sm), _ptr(codes), _ptr(sl), len(sl), sampling, block_bytes, device, C.byref(h)))
+        _check(lib, lib.gm_index_import_sampled(_ptr(bf), _ptr(br), _ptr(mk), _ptr(sm), sm.itemsize, len(sm), _ptr(codes), _ptr(sl), len(sl), sampling, block_bytes, device, C.byref(h)))
         return cls(h, lib, codes, sl)
 
     def close(self):
@@ -293,10 +294,11 @@ class Index:
     def export_sa_sampled(self):
         """(mark_words, samples): one bit per row, and SA[row] of the marked rows in row order"""
         n = C.c_uint64(0)
-        _check(self._lib, self._lib.gm_index_export_sa_sampled(self._h, None, None, C.byref(n)))
-        mk = np.empty((self.info()["n_rows"] + 31) // 32, np.uint32)
-        sm = np.empty(n.value, np.uint32)
-        _check(self._lib, self._lib.gm_index_export_sa_sampled(self._h, _ptr(mk), _ptr(sm), C.byref(n)))
+        i = self.info()
+        _check(self._lib, self._lib.gm_index_export_sa_sampled(self._h, None, None, 0, C.byref(n)))
+        mk = np.empty((i["n_rows"] + 31) // 32, np.uint32)
+        sm = np.empty(n.value, np.uint64 if i["row_bits"] == 64 else np.uint32)
+        _check(self._lib, self._lib.gm_index_export_sa_sampled(self._h, _ptr(mk), _ptr(sm), sm.itemsize, C.byref(n)))
         return mk, sm
 
     def _params(self, K, E, overlap, infix, revcompl, value_bits, exclude_pseudo, kmer_range, chunks=None):

@@ -232,7 +232,6 @@ static int index_common_setup(gm_index* ix, const uint8_t* codes, const uint64_t
     // 2^32 - 1 rows or more: 64-bit rows, ranges and text positions (the reference's 64-bit BWT variants, src/indexing.hpp:158-169)
     ix->wide = forceWide || ix->nRows >= 0xFFFFFFFFull;
     if (ix->wide) ix->wpp = WPP_WIDE;
-    if (ix->wide && sampling > 1) { set_error("a sampled suffix array is kept for 32-bit rows only; use sampling 1 (or 0) for this index"); return GM_ERR_BAD_ARG; }
     if (ix->nRows >= (1ull << 40)) { set_error("index of %llu rows is beyond this build (2^40 rows)", (unsigned long long)ix->nRows); return GM_ERR_TOO_LONG; }
     hipDeviceProp_t prop;
     GM_HIP(hipGetDeviceProperties(&prop, device));
@@ -258,11 +257,12 @@ static int index_common_setup(gm_index* ix, const uint8_t* codes, const uint64_t
 }
 
 // the sampled form of a full forward suffix array (device): marks + "samples before this word" per 32 rows, and the kept values
-static int sample_sa(gm_index* ix, const uint32_t* d_saFull)
+static int sample_sa(gm_index* ix, const void* d_saFull)   // entries as wide as the index's rows
 {
     const uint64_t n = ix->nRows, words = (n + 31) / 32;
     GM_HIP(hipMalloc(&ix->d_saMark, words * sizeof(uint2)));   // (owned by the index: gm_index_free releases it on every path)
-    hipLaunchKernelGGL(sa_mark_kernel, dim3(grid_for(words)), dim3(256), 0, 0, d_saFull, ix->d_cum, ix->nSeq, n, ix->sampling, ix->d_saMark);
+    if (ix->wide) hipLaunchKernelGGL(sa_mark_kernel<uint64_t>, dim3(grid_for(words)), dim3(256), 0, 0, (const uint64_t*)d_saFull, ix->d_cum, ix->nSeq, n, ix->sampling, ix->d_saMark);
+    else hipLaunchKernelGGL(sa_mark_kernel<uint32_t>, dim3(grid_for(words)), dim3(256), 0, 0, (const uint32_t*)d_saFull, ix->d_cum, ix->nSeq, n, ix->sampling, ix->d_saMark);
     uint32_t *d_cnt = nullptr, *d_before = nullptr; void* d_tmp = nullptr; size_t tmpBytes = 0;
     int rc = hipGetLastError() == hipSuccess ? GM_OK : GM_ERR_HIP;
     if (!rc && (hipMalloc(&d_cnt, words * 4) != hipSuccess || hipMalloc(&d_before, words * 4) != hipSuccess)) rc = GM_ERR_OOM;
@@ -280,8 +280,10 @@ static int sample_sa(gm_index* ix, const uint32_t* d_saFull)
     hipFree(d_cnt); hipFree(d_before); hipFree(d_tmp);
     if (rc) return rc;
     ix->nSamples = (uint64_t)last[0] + last[1];
-    GM_HIP(hipMalloc(&ix->d_saSamples, std::max<uint64_t>(ix->nSamples, 1) * 4));
-    hipLaunchKernelGGL(sa_compact_kernel, dim3(grid_for(n)), dim3(256), 0, 0, d_saFull, ix->d_saMark, n, ix->d_saSamples);
+    if (ix->nSamples >= (1ull << 32)) { set_error("more than 2^32 suffix array samples: use a larger sampling rate"); return GM_ERR_TOO_LONG; }   // (the mark words count them in 32 bits)
+    GM_HIP(hipMalloc(&ix->d_saSamples, std::max<uint64_t>(ix->nSamples, 1) * (ix->wide ? 8 : 4)));
+    if (ix->wide) hipLaunchKernelGGL(sa_compact_kernel<uint64_t>, dim3(grid_for(n)), dim3(256), 0, 0, (const uint64_t*)d_saFull, ix->d_saMark, n, (uint64_t*)ix->d_saSamples);
+    else hipLaunchKernelGGL(sa_compact_kernel<uint32_t>, dim3(grid_for(n)), dim3(256), 0, 0, (const uint32_t*)d_saFull, ix->d_saMark, n, (uint32_t*)ix->d_saSamples);
     GM_HIP(hipGetLastError());
     GM_HIP(hipDeviceSynchronize());
     return GM_OK;
@@ -364,7 +366,7 @@ int gm_index_build(const uint8_t* codes, const uint64_t* seq_len, uint32_t n_seq
             ix->d_sa = d_sa; d_sa = nullptr;
             if (hipMalloc(&d_sa, ix->nRows * rb) != hipSuccess) rc = GM_ERR_OOM;
         }
-        if (!rc && d == 0 && sampling > 1) rc = sample_sa(ix, (const uint32_t*)d_sa);   // -S: keep 1/s of it, locate walks the LF mapping
+        if (!rc && d == 0 && sampling > 1) rc = sample_sa(ix, d_sa);   // -S: keep 1/s of it, locate walks the LF mapping
     }
     hipFree(d_sa); hipFree(d_bwt);
     if (!rc && ix->d_sa) rc = make_sentinel_text(ix);
@@ -401,9 +403,10 @@ int gm_index_import(const uint8_t* bwt_fwd, const uint8_t* bwt_rev, const void* 
         if (!rc) rc = make_ctx(ix);
     }
     if (!rc && sa_fwd && sampling > 1) {   // the caller holds the full array: sample it on the device
-        uint32_t* d_full = nullptr;
-        if (hipMalloc(&d_full, ix->nRows * 4) != hipSuccess) rc = GM_ERR_OOM;
-        else if (hipMemcpy(d_full, sa_fwd, ix->nRows * 4, hipMemcpyHostToDevice) != hipSuccess) rc = GM_ERR_HIP;
+        void* d_full = nullptr;
+        const size_t rb = ix->wide ? 8 : 4;
+        if (hipMalloc(&d_full, ix->nRows * rb) != hipSuccess) rc = GM_ERR_OOM;
+        else if (hipMemcpy(d_full, sa_fwd, ix->nRows * rb, hipMemcpyHostToDevice) != hipSuccess) rc = GM_ERR_HIP;
         if (!rc) rc = sample_sa(ix, d_full);
         hipFree(d_full);
     }
@@ -412,13 +415,14 @@ int gm_index_import(const uint8_t* bwt_fwd, const uint8_t* bwt_rev, const void* 
     return GM_OK;
 }
 
-int gm_index_import_sampled(const uint8_t* bwt_fwd, const uint8_t* bwt_rev, const uint32_t* mark_words, const uint32_t* samples, uint64_t n_samples,
+int gm_index_import_sampled(const uint8_t* bwt_fwd, const uint8_t* bwt_rev, const uint32_t* mark_words, const void* samples, uint32_t sa_entry_bytes, uint64_t n_samples,
                             const uint8_t* codes, const uint64_t* seq_len, uint32_t n_seq, uint32_t sampling, uint32_t block_bytes, int device, gm_index** out)
 {
     if (!mark_words || !samples || sampling < 2) { set_error("gm_index_import_sampled: marks, samples and a sampling rate of 2..64"); return GM_ERR_BAD_ARG; }
     gm_index* ix = nullptr;
     int rc = gm_index_import(bwt_fwd, bwt_rev, nullptr, 0, codes, seq_len, n_seq, sampling, block_bytes, device, &ix);
     if (rc) return rc;
+    if (sa_entry_bytes != (ix->wide ? 8u : 4u)) { set_error("samples of %u bytes, but this index has %s rows", sa_entry_bytes, ix->wide ? "64-bit" : "32-bit"); gm_index_free(ix); return GM_ERR_BAD_ARG; }
     const uint64_t words = (ix->nRows + 31) / 32;
     // "samples before this word" is recomputed here; a file whose marks and sample count disagree is rejected
     std::vector<uint2> mk(words);
@@ -428,28 +432,29 @@ int gm_index_import_sampled(const uint8_t* bwt_fwd, const uint8_t* bwt_rev, cons
         set_error("sampled suffix array: %llu marks for %llu samples", (unsigned long long)run, (unsigned long long)n_samples);
         gm_index_free(ix); return GM_ERR_BAD_ARG;
     }
-    if (hipMalloc(&ix->d_saMark, words * sizeof(uint2)) != hipSuccess || hipMalloc(&ix->d_saSamples, std::max<uint64_t>(n_samples, 1) * 4) != hipSuccess) rc = GM_ERR_OOM;
+    if (hipMalloc(&ix->d_saMark, words * sizeof(uint2)) != hipSuccess || hipMalloc(&ix->d_saSamples, std::max<uint64_t>(n_samples, 1) * sa_entry_bytes) != hipSuccess) rc = GM_ERR_OOM;
     if (!rc && (hipMemcpy(ix->d_saMark, mk.data(), words * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess ||
-                hipMemcpy(ix->d_saSamples, samples, n_samples * 4, hipMemcpyHostToDevice) != hipSuccess)) rc = GM_ERR_HIP;
+                hipMemcpy(ix->d_saSamples, samples, n_samples * sa_entry_bytes, hipMemcpyHostToDevice) != hipSuccess)) rc = GM_ERR_HIP;
     if (rc) { gm_index_free(ix); return rc; }
     ix->nSamples = n_samples;
     *out = ix;
     return GM_OK;
 }
 
-int gm_index_export_sa_sampled(const gm_index* ix, uint32_t* mark_words, uint32_t* samples, uint64_t* n_samples)
+int gm_index_export_sa_sampled(const gm_index* ix, uint32_t* mark_words, void* samples, uint32_t sa_entry_bytes, uint64_t* n_samples)
 {
     if (!ix || !n_samples) return GM_ERR_BAD_ARG;
     if (!ix->d_saMark) { set_error("index holds no sampled suffix array (sampling %u)", ix->sampling); return GM_ERR_NEED_LOCATE; }
     *n_samples = ix->nSamples;
     if (!samples && !mark_words) return GM_OK;
     if (!samples || !mark_words) return GM_ERR_BAD_ARG;
+    if (sa_entry_bytes != (ix->wide ? 8u : 4u)) { set_error("samples of %u bytes, but this index has %s rows", sa_entry_bytes, ix->wide ? "64-bit" : "32-bit"); return GM_ERR_BAD_ARG; }
     GM_HIP(hipSetDevice(ix->device));
     const uint64_t words = (ix->nRows + 31) / 32;
     std::vector<uint2> mk(words);
     GM_HIP(hipMemcpy(mk.data(), ix->d_saMark, words * sizeof(uint2), hipMemcpyDeviceToHost));
     for (uint64_t w = 0; w < words; ++w) mark_words[w] = mk[w].x;
-    GM_HIP(hipMemcpy(samples, ix->d_saSamples, ix->nSamples * 4, hipMemcpyDeviceToHost));
+    GM_HIP(hipMemcpy(samples, ix->d_saSamples, ix->nSamples * sa_entry_bytes, hipMemcpyDeviceToHost));
     return GM_OK;
 }
 
@@ -490,7 +495,7 @@ int gm_index_get_info(const gm_index* ix, gm_index_info* info)
     info->block_bytes = ix->wpp == 1 ? 32 : (ix->wpp == 3 || ix->wpp == 2) ? 64 : 128;
     info->row_bits = ix->wide ? 64 : 32;
     info->device_bytes = 2 * ix->blkBytes + ix->textLen + (ix->nSeq + 1) * 8ull + (ix->d_sa ? ix->nRows * (ix->wide ? 9ull : 5ull) : 0ull) + (ix->d_ctx ? ix->nRows * 32ull : 0ull) + ix->qtableBytes
-                       + (ix->d_saMark ? (ix->nRows + 31) / 32 * 8ull + ix->nSamples * 4ull : 0ull)
+                       + (ix->d_saMark ? (ix->nRows + 31) / 32 * 8ull + ix->nSamples * (ix->wide ? 8ull : 4ull) : 0ull)
                        + ix->shardOutCap;   // the result buffer gm_map / gm_map_shard keep between calls
     if (!ix->d_sa && !ix->d_saMark) info->sampling = 0;
     info->device = ix->device;

@@ -47,7 +47,7 @@ struct gm_index {
     uint64_t* d_cum = nullptr;
     void* d_sa = nullptr;             // forward suffix array, uint32_t or (wide) uint64_t per row (kept when sampling == 1): locate = one HBM read
     uint2* d_saMark = nullptr;        // sampling > 1: per 32 rows {mark bits, samples before this word}
-    uint32_t* d_saSamples = nullptr;  //               SA values of the marked rows, in row order
+    void* d_saSamples = nullptr;      //               SA values of the marked rows, in row order (uint32_t, or uint64_t with 64-bit rows)
     uint64_t nSamples = 0;
     uint8_t* d_textS = nullptr;       // sentinel text (verification of narrow nodes), present with d_sa
     uint4* d_ctx = nullptr;           // verification records {SA[row], 56 symbols around it}, 32 B per row, when HBM allows (gm_kernels.h: CTX_*)

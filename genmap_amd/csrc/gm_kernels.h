@@ -41,7 +41,7 @@ struct SearchArgs {
     // ---- locate path (csv, --exclude-pseudo; /root/reference/src/algo.hpp:311-387) ----
     const void* sa;                 // forward suffix array (sentinel-text positions, row_t each), sampling rate 1; nullptr when sampled
     const uint2* saMark;            // sampled suffix array: per 32 rows {mark bits, samples before the word} ...
-    const uint32_t* saSamples;      // ... and the values of the marked rows
+    const void* saSamples;          // ... and the values of the marked rows (row_t each)
     const uint64_t* cumGlobal;      // sentinel-free cumulative sequence lengths of the WHOLE index, nSeqGlobal + 1
     uint32_t nSeqGlobal;
     const uint32_t* seqFile;        // fasta id per global sequence (mappingSeqIdFile, src/mappability.hpp:230-248)
@@ -383,22 +383,22 @@ template <int WPP> struct EnvBase {
     {
         if (A.sa) return sa(row);
         constexpr uint32_t SPB = BlockGeom<WPP>::SPB, WPB = BlockGeom<WPP>::WPB, H = BlockGeom<WPP>::HDRW;
-        uint32_t r = (uint32_t)row, k = 0;
+        row_t r = row; uint32_t k = 0;
         for (;;) {
-            const uint2 m = A.saMark[r >> 5];
-            const uint32_t bit = 1u << (r & 31u);
-            if (m.x & bit) return (row_t)(A.saSamples[m.y + (uint32_t)__popc(m.x & (bit - 1u))] + k);
+            const uint2 m = A.saMark[(size_t)(r >> 5)];
+            const uint32_t bit = 1u << ((uint32_t)r & 31u);
+            if (m.x & bit) return (row_t)(reinterpret_cast<const row_t*>(A.saSamples)[m.y + (uint32_t)__popc(m.x & (bit - 1u))] + k);
             const uint32_t* blk = A.blk[0] + (size_t)(r / SPB) * WPB;
-            const uint32_t off = r % SPB, w = off >> 5, t = off & 31u;
+            const uint32_t off = (uint32_t)(r % SPB), w = off >> 5, t = off & 31u;
             const uint32_t c = ((blk[H + w] >> t) & 1u) | (((blk[H + WPP + w] >> t) & 1u) << 1) | (((blk[H + 2 * WPP + w] >> t) & 1u) << 2);
             // a sentinel in front of the suffix is never reached (sequence starts are sampled) and a walk is shorter than the
             // largest sampling rate: anything else is a damaged index file, which must not hang the device
             if (c >= NLET || k >= 64u) return (row_t)0;
             row_t rk[NLET];
             block_rank<WPP>(blk, off, rk);
-            uint32_t nx = 0;
+            row_t nx = 0;
 #pragma unroll
-            for (uint32_t i = 0; i < NLET; ++i) nx = c == i ? (uint32_t)(A.C[i] + rk[i]) : nx;   // selects, not an indexed array (scratch)
+            for (uint32_t i = 0; i < NLET; ++i) nx = c == i ? (row_t)(A.C[i] + rk[i]) : nx;   // selects, not an indexed array (scratch)
             r = nx;
             ++k;
         }
@@ -1328,7 +1328,8 @@ __global__ __launch_bounds__(256) void run_values_kernel(const TValue* __restric
 
 // ---- sampling of the suffix array (-S) ---------------------------------------------------------------------------------------
 // mark[row / 32] bit row % 32 = SA[row] lies at an in-sequence offset that is a multiple of `s` (never on a sentinel)
-__global__ __launch_bounds__(256) void sa_mark_kernel(const uint32_t* __restrict__ sa, const uint64_t* __restrict__ cum, uint32_t nSeq, uint64_t n, uint32_t s,
+template <typename R>
+__global__ __launch_bounds__(256) void sa_mark_kernel(const R* __restrict__ sa, const uint64_t* __restrict__ cum, uint32_t nSeq, uint64_t n, uint32_t s,
                                                       uint2* __restrict__ mark)
 {
     const uint64_t words = (n + 31) / 32;
@@ -1352,7 +1353,8 @@ __global__ __launch_bounds__(256) void sa_mark_offsets_kernel(uint2* __restrict_
 {
     for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (uint64_t)gridDim.x * blockDim.x) mark[w].y = before[w];
 }
-__global__ __launch_bounds__(256) void sa_compact_kernel(const uint32_t* __restrict__ sa, const uint2* __restrict__ mark, uint64_t n, uint32_t* __restrict__ samples)
+template <typename R>
+__global__ __launch_bounds__(256) void sa_compact_kernel(const R* __restrict__ sa, const uint2* __restrict__ mark, uint64_t n, R* __restrict__ samples)
 {
     for (uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; row < n; row += (uint64_t)gridDim.x * blockDim.x) {
         const uint2 m = mark[row >> 5];

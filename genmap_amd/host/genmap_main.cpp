@@ -123,7 +123,6 @@ int index_main(int argc, const char** argv)
     else if (seqLen.size() <= 0xFFFFFFFFull && maxLen <= 0xFFFFull) { meta.seqNoBits = 32; meta.seqPosBits = 16; meta.bwtBits = 64; }
     else { meta.seqNoBits = 64; meta.seqPosBits = 64; meta.bwtBits = 64; }
     meta.sampling = (uint32_t)sampling;
-    if (sampling > 1 && meta.bwtBits == 64) { rmdir(indexPath.c_str()); std::cerr << "ERROR: -S " << sampling << ": a sampled suffix array is supported for indexes of fewer than 2^32 - 1 rows; use -S 1.\n"; return 1; }
     if (verbose)
         std::cout << "Index will be constructed using " << (dna5 ? "dna5/rna5" : "dna4/rna4") << " alphabet.\n"
                   << "- The BWT is represented by " << meta.bwtBits << " bit values.\n"
@@ -143,8 +142,8 @@ int index_main(int argc, const char** argv)
     if (!rc && sampling == 1) { sa.full.resize(info.n_rows * (info.row_bits / 32)); rc = gm_index_export_sa(ix, sa.full.data(), info.row_bits / 8); }
     if (!rc && sampling > 1) {
         uint64_t ns = 0;
-        rc = gm_index_export_sa_sampled(ix, nullptr, nullptr, &ns);
-        if (!rc) { sa.marks.resize((info.n_rows + 31) / 32); sa.samples.resize(ns); rc = gm_index_export_sa_sampled(ix, sa.marks.data(), sa.samples.data(), &ns); }
+        rc = gm_index_export_sa_sampled(ix, nullptr, nullptr, 0, &ns);
+        if (!rc) { sa.marks.resize((info.n_rows + 31) / 32); sa.samples.resize(ns * (info.row_bits / 32)); rc = gm_index_export_sa_sampled(ix, sa.marks.data(), sa.samples.data(), info.row_bits / 8, &ns); }   // (64-bit rows: two words per sample)
     }
     gm_index_free(ix);
     if (rc) return fail_gm("index export failed", rc);
@@ -264,10 +263,11 @@ int map_main(int argc, const char** argv)
     {
         std::vector<std::thread> th;
         const uint32_t bb = (uint32_t)std::atoi(a.get("block-bytes", "0").c_str());
+        const bool wideRows = (bb & GM_BLOCK_WIDE_ROWS) != 0 || bf.size() >= 0xFFFFFFFFull;   // 64-bit rows: two words per suffix array entry
         for (size_t d = 0; d < devices.size(); ++d)
             th.emplace_back([&, d] {
                 rcs[d] = !sa.marks.empty()
-                    ? gm_index_import_sampled(bf.data(), br.data(), sa.marks.data(), sa.samples.data(), sa.samples.size(), text.data(), seqLen.data(),
+                    ? gm_index_import_sampled(bf.data(), br.data(), sa.marks.data(), sa.samples.data(), wideRows ? 8u : 4u, sa.samples.size() / (wideRows ? 2 : 1), text.data(), seqLen.data(),
                                               (uint32_t)seqLen.size(), meta.sampling, bb, devices[d], &replicas[d])
                     : gm_index_import(bf.data(), br.data(), sa.full.empty() ? nullptr : sa.full.data(), sa.full.size() == 2 * bf.size() ? 8u : 4u, text.data(), seqLen.data(), (uint32_t)seqLen.size(),
                                       sa.full.empty() ? 0 : 1, bb, devices[d], &replicas[d]); });

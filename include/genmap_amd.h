@@ -86,14 +86,15 @@ int gm_index_import(const uint8_t *bwt_fwd, const uint8_t *bwt_rev, const void *
  * src/seqan_libdivsufsort.h:129-143): SA[row] is kept where its in-sequence offset is a multiple of s (sequence starts always
  * are); mark_words holds one bit per row (bit r % 32 of word r / 32), samples the kept values in row order.  locate walks the
  * LF mapping until it meets a marked row (at most s - 1 rank-block reads).  With sampling > 1 narrow search nodes are not
- * verified against the text (that needs one read per row, not a walk) and 64-bit rows are not supported.
+ * verified against the text (that needs one read per row, not a walk).  Works for 32- and 64-bit rows alike (the reference's
+ * default -S 10 on every index it accepts); samples are sa_entry_bytes wide (4, or 8 with 64-bit rows), fewer than 2^32 of them.
  * gm_index_build / gm_index_import take sampling > 1 directly (the full array is built or uploaded, sampled on the device and
  * released); these two entries move the sampled form itself, e.g. to and from an index directory. */
-int gm_index_import_sampled(const uint8_t *bwt_fwd, const uint8_t *bwt_rev, const uint32_t *mark_words, const uint32_t *samples,
+int gm_index_import_sampled(const uint8_t *bwt_fwd, const uint8_t *bwt_rev, const uint32_t *mark_words, const void *samples, uint32_t sa_entry_bytes,
                             uint64_t n_samples, const uint8_t *codes, const uint64_t *seq_len, uint32_t n_seq,
                             uint32_t sampling, uint32_t block_bytes, int device, gm_index **out);
 /* samples == NULL: only *n_samples is set.  mark_words: ceil(n_rows / 32) words. */
-int gm_index_export_sa_sampled(const gm_index *idx, uint32_t *mark_words, uint32_t *samples, uint64_t *n_samples);
+int gm_index_export_sa_sampled(const gm_index *idx, uint32_t *mark_words, void *samples, uint32_t sa_entry_bytes, uint64_t *n_samples);
 
 /* Copy the BWTs (codes 0..5, n_rows bytes each) back to the host: index files, parity tests. */
 int gm_index_export_bwt(const gm_index *idx, uint8_t *bwt_fwd, uint8_t *bwt_rev);

@@ -105,3 +105,28 @@ def test_cli_multi_device_shards(case, tmp_path):
         out = tmp_path / f"out_{sub}"; out.mkdir()
         subprocess.check_call([str(GENMAP), "map", "-I", str(idx), "-O", str(out), "-D", "0,0,0"] + flags + FORMAT_FLAGS[sub], stdout=subprocess.DEVNULL)
         _same_tree(out, d / sub)
+
+
+@pytest.mark.parametrize("case", ["1f", "3b"])
+def test_cli_sampled_suffix_array_with_64_bit_rows(case, tmp_path):
+    """the reference's default -S 10 on an index with 64-bit rows (forced here with --block-bytes 65600 = 64 | GM_BLOCK_WIDE_ROWS,
+    what 2^32 - 1 rows or more get by themselves): index.sa.samples holds 8-byte entries; csv and a frequency format"""
+    d = H.CASES_DIR / f"case_{case}"
+    directory, fl = H.CASES[case]
+    idx = tmp_path / "index"
+    wide = ["--block-bytes", "65600"]
+    if directory:
+        src = tmp_path / "fastas"; src.mkdir()
+        for f in d.glob("*.fa"):
+            shutil.copy(f, src / f.name)
+        subprocess.check_call([str(GENMAP), "index", "-FD", str(src), "-I", str(idx), "-S", "10"] + wide, stdout=subprocess.DEVNULL)
+    else:
+        subprocess.check_call([str(GENMAP), "index", "-F", str(d / "genome.fa"), "-I", str(idx), "-S", "10"] + wide, stdout=subprocess.DEVNULL)
+    assert (idx / "index.sa.samples").exists() and (idx / "index.sa.samples").stat().st_size % 8 == 0
+    flags = ["-E", str(fl["E"]), "-K", str(fl["K"])] + (["-nc"] if fl.get("nc") else []) + (["-ep"] if fl.get("ep") else [])
+    for sub in ("csv", "raw_freq16"):
+        if not (d / sub).is_dir():
+            continue
+        out = tmp_path / f"out_{sub}"; out.mkdir()
+        subprocess.check_call([str(GENMAP), "map", "-I", str(idx), "-O", str(out)] + flags + FORMAT_FLAGS[sub] + wide, stdout=subprocess.DEVNULL)
+        _same_tree(out, d / sub)

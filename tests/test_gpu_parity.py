@@ -102,7 +102,7 @@ def test_gpu_csv_locations_match_reference_fixtures(case):
     d = H.CASES_DIR / f"case_{case}"
     gen, directory, fl, bed = H.load_case(case)
     rc = not fl.get("nc", False)
-    for bb, smp in ((0, 1), (WIDE, 1), (0, 10), (64, 2)):   # full suffix array; sampled: locate walks the LF mapping
+    for bb, smp in ((0, 1), (WIDE, 1), (0, 10), (64, 2), (WIDE, 10)):   # full suffix array; sampled: locate walks the LF mapping (64-bit rows too)
       ix = g.Index.build(gen.codes, gen.seq_len, sampling=smp, block_bytes=bb)
       for xo in H.xo_variants(case):
         for name, first, nseq, tb, tl in gen.file_slices():
@@ -140,8 +140,9 @@ def test_gpu_exclude_pseudo_and_locations_vs_oracle(sampling):
     ix.close()
 
 
+@pytest.mark.parametrize("wide", [0, WIDE])
 @pytest.mark.parametrize("s", [2, 3, 10, 64])
-def test_gpu_sampled_suffix_array_is_the_full_one_thinned(s):
+def test_gpu_sampled_suffix_array_is_the_full_one_thinned(s, wide):
     """-S s (src/indexing.hpp:311-315): rows whose in-sequence offset is a multiple of s keep their value, the others find it by
     LF steps.  The marks and samples are those of the full array; the sampled form moves through export / import unchanged;
     frequencies, --exclude-pseudo and locations equal the full index's."""
@@ -150,9 +151,10 @@ def test_gpu_sampled_suffix_array_is_the_full_one_thinned(s):
     lens = [1, 2, s - 1, s, s + 1, 700, 63, 5000, 3]
     lens = [x for x in lens if x > 0]
     codes = _repeat_text(rng, sum(lens), dna5=True)
-    full = g.Index.build(codes, lens, sampling=1)
-    smp = g.Index.build(codes, lens, sampling=s)
+    full = g.Index.build(codes, lens, sampling=1, block_bytes=wide)     # wide: 64-bit rows (the reference's -S 10 on a >= 2^32-row index)
+    smp = g.Index.build(codes, lens, sampling=s, block_bytes=wide)
     sa = full.export_sa()
+    assert sa.dtype == (np.uint64 if wide else np.uint32)
     cum = np.concatenate([[0], np.cumsum(lens)])
     starts = cum[:-1] + np.arange(len(lens))                    # sentinel-text position of each sequence's first symbol
     seq = np.searchsorted(starts, sa, side="right") - 1
@@ -165,12 +167,12 @@ def test_gpu_sampled_suffix_array_is_the_full_one_thinned(s):
     with pytest.raises(g.GenmapError):
         smp.export_sa()
     bf, br = smp.export_bwt()
-    again = g.Index.from_sampled(bf, br, mk, sm, codes, lens, s)
-    viaimport = g.Index.from_bwt(bf, br, codes, lens, sa_fwd=sa, sampling=s)   # a full array handed over, sampled on the device
+    again = g.Index.from_sampled(bf, br, mk, sm, codes, lens, s, block_bytes=wide)
+    viaimport = g.Index.from_bwt(bf, br, codes, lens, sa_fwd=sa, sampling=s, block_bytes=wide)   # a full array handed over, sampled on the device
     mk2, sm2 = viaimport.export_sa_sampled()
     assert np.array_equal(mk2, mk) and np.array_equal(sm2, sm)
     with pytest.raises(g.GenmapError):
-        g.Index.from_sampled(bf, br, mk, sm[:-1], codes, lens, s)   # marks and samples disagree
+        g.Index.from_sampled(bf, br, mk, sm[:-1], codes, lens, s, block_bytes=wide)   # marks and samples disagree
     fid = np.array([0, 0, 1, 1, 1, 2, 2, 3, 3][:len(lens)], dtype=np.uint32)
     for K, E in ((12, 0), (16, 1), (20, 2)):
         ref = full.locate(K, E)
