@@ -184,8 +184,6 @@ def test_gpu_sampled_suffix_array_is_the_full_one_thinned(s, wide):
             assert got[0] == ref[0] and all(np.array_equal(a, b) for a, b in zip(got[1:], ref[1:]))
     with pytest.raises(g.GenmapError):
         g.Index.build(codes, lens, sampling=65)
-    with pytest.raises(g.GenmapError):
-        g.Index.build(codes, lens, sampling=s, block_bytes=WIDE)
     for ix in (full, smp, again, viaimport):
         ix.close()
 
