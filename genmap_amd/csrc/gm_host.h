@@ -161,9 +161,9 @@ inline void n_window_intervals(const std::vector<std::pair<uint64_t, uint64_t>>&
     std::vector<std::pair<int64_t, int64_t>> iv;   // inclusive
     for (auto& r : runs) {
         const int64_t s = (int64_t)r.first, e = (int64_t)r.second, k = K, x = E;
-        iv.emplace_back(s - k + 1, s - k + x);                 // the window's tail overlaps the head of the run
-        iv.emplace_back(e - x, e - 1);                         // the window's head overlaps the tail of the run
-        if (e - s <= x) iv.emplace_back(s - k + 1, e - 1);     // the whole run inside the window
+        iv.emplace_back(s - k + 1, std::min(s - k + x, e - 1));   // the window's tail overlaps the head of the run (and it does touch it)
+        iv.emplace_back(std::max(e - x, s - k + 1), e - 1);       // the window's head overlaps the tail of the run
+        if (std::min(e - s, k) <= x) iv.emplace_back(s - k + 1, e - 1);   // no window can hold more than E letters of this run (short run, or K <= E)
     }
     std::sort(iv.begin(), iv.end());
     size_t sq = 0;

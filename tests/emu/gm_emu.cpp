@@ -274,6 +274,18 @@ static int run(const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nse
     return 0;
 }
 
+// gm_host.h: n_window_intervals on a host text (runs of N found here): returns the number of [begin, end) pairs written (at most cap)
+extern "C" uint64_t gm_emu_n_window_intervals(const uint8_t* codes, const uint64_t* cum, uint32_t nSeq, uint32_t K, uint32_t E, uint64_t* out, uint64_t cap)
+{
+    const uint64_t n = cum[nSeq];
+    std::vector<std::pair<uint64_t, uint64_t>> runs;
+    for (uint64_t i = 0; i < n; ) { if (codes[i] != SYM_N) { ++i; continue; } uint64_t e = i; while (e < n && codes[e] == SYM_N) ++e; runs.emplace_back(i, e); i = e; }
+    std::vector<uint64_t> cumv(cum, cum + nSeq + 1), iv;
+    n_window_intervals(runs, cumv, K, E, iv);
+    for (size_t k = 0; k < iv.size() && k < 2 * cap; ++k) out[k] = iv[k];
+    return iv.size() / 2;
+}
+
 // jumpCap: longest jump (0 = the plain tree walk from the root); nless != 0: the main pass never follows the text letter N and the
 // correction pass adds the occurrences with N in the text (needs sa, allCodes, allCum).  stats: 6 entries.
 extern "C" int gm_emu_map2(int wpp, const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nseqTotal, const uint8_t* text,
