@@ -479,12 +479,18 @@ def main():
         # rank blocks + one q-mer table entry per root + text read once per strand (4-bit packed) + 8-bit output
         # + verification: one 32-byte record per row and 8 needle symbols per chunk -- or, without the records, the SA entry
         # per row and 8 needle + 8 text symbols per chunk
-        ver = 32 * d["verify_items"] + 8 * d["verify_chunks"] if info["verify_records"] else 4 * d["verify_items"] + 16 * d["verify_chunks"]
+        vi = d["verify_items"]
+        ver = 32 * vi + 8 * d["verify_chunks"] if info["verify_records"] else 4 * vi + 16 * d["verify_chunks"]
         # (a root that jumps reads one 16-byte table entry per pattern instead of the single q-mer entry: counted as jump_lookups)
         alg = bb * sp["rank_lines"] + 16 * (d.get("jump_lookups", 0) or sp["roots"]) + n + n + ver
         # N > 1: per GPU -- a rank's share of the bytes over the slowest rank's kernel time, against one GPU's peak
         ach = alg / world / (rec["kernel_ms"] * 1e-3) / 1e9
+        # random requests the kernel issues (rank blocks, table entries, records) against the measured ceiling of the memory system
+        # for random reads over a large footprint (48.3 G/s whatever the concurrency: profiles/r03/gather2_concurrency.txt); L2 hits
+        # are included, so the figure can exceed the ceiling -- the lines actually fetched are in profiles/<round>/final/pmc_by_config.txt
+        issued = sp["rank_lines"] + (d.get("jump_lookups", 0) or sp["roots"]) + vi
         return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "random_requests_issued_per_s": issued / world / (rec["kernel_ms"] * 1e-3), "random_read_ceiling_per_s": 4.83e10,
                 "traffic": None,   # PMC FETCH_SIZE/WRITE_SIZE need rocprofv3 around the process: tools/profile_round.sh -> profiles/
                 "per_gpu": True, "kernel": "search_kernel", "kernel_ms": rec["kernel_ms"], "algorithmic_bytes": alg, "rank_lines": sp["rank_lines"],
                 "roots": sp["roots"], "node_steps": sp["node_steps"], "node_steps_per_kmer": sp["node_steps"] / rec["num_kmers"],

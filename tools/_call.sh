@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-(timeout 1200 python tools/sweep_tuning.py --workload grch38 --reps 2 --cfg 30,0,1.0 30,1,0.2 30,2,0.03 100,1,0.5 -- "" "prefetch_rec=0" 2>&1 | grep -v amdgpu.ids) > gpurun_out/c17_sweep_pf.txt
-(timeout 600 bash tools/cli_c5_check.sh 2>&1 | tail -40) > gpurun_out/c17_cli_c5.txt
+(timeout 600 ./tools/gather_bench2 32 1 more 2>&1 | grep "footprint= 32768\|footprint=  8192\|device") > gpurun_out/c18_gather.txt

@@ -143,6 +143,14 @@ int main(int argc, char** argv)
         run<4, 2, false>(T, sz, cus * 8, iters, d_out, "g");
         run<4, 2, true>(T, sz, cus * 8, iters, d_out, "g");
         run<8, 2, true>(T, sz, cus * 8, iters, d_out, "g");
+        if (argc > 3) {   // more requests in flight: is the ~48 G/s of the rows above a limit of the memory system or of the concurrency?
+            run<1, 4, false>(T, sz, cus * 8, iters, d_out, "ch4");
+            run<2, 4, true>(T, sz, cus * 8, iters, d_out, "ch4");
+            run<1, 8, false>(T, sz, cus * 8, iters, d_out, "ch8");
+            run<2, 8, true>(T, sz, cus * 8, iters, d_out, "ch8");
+            run<1, 2, false>(T, sz, cus * 16, iters, d_out, "b16");
+            run<2, 2, true>(T, sz, cus * 16, iters, d_out, "b16");
+        }
     }
     return 0;
 }
