@@ -931,6 +931,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     A.probation = p->E == 0 ? 0u : 2u;   // 3.09 Gbp: e=1 +8.5 %, e=2 +4 % over 0 (profiles/r02/sweep_grch38_retune.txt); K=100: no difference
     if (ix->tune.probation >= 0) A.probation = (uint32_t)ix->tune.probation;
     A.verifyCost = (uint32_t)std::max(0, ix->tune.verifyCost);
+    A.selfHit = ix->tune.selfHit != 0 ? 1u : 0u;
     A.chunkBlocks = chunked ? p->chunk_blocks : 0u; A.chunkStride = p->chunk_stride; A.chunkIndex = p->chunk_index;
     A.skipDup = ix->tune.skipDup >= 0 ? (uint32_t)(ix->tune.skipDup != 0) : 1u;   // profiles/r02: +3..8 % on 3.09 Gbp, +1..5 % on 249 Mbp
     // groups of lanes read the rank blocks (rank2_coop): +4..12 % with 32-byte blocks on 249 Mbp and 3.09 Gbp (profiles/r02)
@@ -1490,7 +1491,7 @@ int gm_index_set_tuning(gm_index* ix, const char* name, int64_t value)
         {"skip_dup", &ix->tune.skipDup, dflt.skipDup, 0, 1}, {"coop", &ix->tune.coop, dflt.coop, 0, 1}, {"use_ctx", &ix->tune.useCtx, dflt.useCtx, 0, 1},
         {"steal", &ix->tune.steal, dflt.steal, 0, 64}, {"part_bias", &ix->tune.partBias, dflt.partBias, -255, 255},
         {"child_tables", &ix->tune.childTables, dflt.childTables, 0, 1}, {"oss_weights", &ix->tune.ossWeights, dflt.ossWeights, 0, 0xFFFFFF},   // (-1: 5,4,7,8 at e = 2, the even split elsewhere)
-        {"jump", &ix->tune.jump, dflt.jump, 0, 15},
+        {"jump", &ix->tune.jump, dflt.jump, 0, 15}, {"self_hit", &ix->tune.selfHit, dflt.selfHit, 0, 1},
     };
     for (auto& t : tab) if (!strcmp(t.n, name)) {
         const bool isBias = t.f == &ix->tune.partBias;

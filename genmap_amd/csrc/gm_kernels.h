@@ -60,6 +60,7 @@ struct SearchArgs {
     uint32_t satMinW;               // saturation is looked up (a global read per covered k-mer) only for nodes at least this wide
     uint32_t probation;             // a single-row node that has spent every error is stepped this many times before it is verified
     uint32_t verifyCost;            // ... when width * verifyCost <= estimated rank steps left below the node
+    uint32_t selfHit;               // 1: a single error-free row on the forward strand is the window's own location -- no lookup at all
     // ---- LDS staging (per wavefront): verification queue | top of the lane stacks | packed needle windows ----
     const uint4* text4;             // whole text, 4 bits per symbol (32 symbols per 16-byte chunk), sentinel-free
     uint64_t textBegin;             // slice offset inside the text (symbols)
@@ -201,6 +202,7 @@ template <int WPP> struct EnvBase {
     static constexpr bool NLESS = false;        // the text letter N is never followed (gm_engine.h); a correction pass adds those occurrences
     static constexpr bool JUMPS = false;        // regular roots start from the jump patterns of their search (gm_oss.h)
     static constexpr bool LEAFQ = false;        // leaves are queued per wavefront and located 64 rows at a time (LeafQueueEnv)
+    static constexpr bool SELF_HIT = false;     // frequency policies: a lone error-free row on the forward strand is the window itself
     typedef typename BlockGeom<WPP>::row_t row_t;
     typedef NodeT<row_t> Node;
     typedef RootT<row_t> Root;
@@ -478,6 +480,8 @@ template <int WPP, bool JUMP = false> struct CountEnv : EnvBase<WPP> {
     typedef typename EnvBase<WPP>::row_t row_t;
     typedef typename EnvBase<WPP>::Root Root;
     static constexpr bool NLESS = JUMP, JUMPS = JUMP;   // the tables of the jump hold A,C,G,T strings only
+    // (SELF_HIT stays off here: measured on 3.09 Gbp the per-k-mer atomics of the shortcut cost more than the verification round
+    //  they replace -- e1 -5 %, K=100 e1 -10 %, profiles/r03/sweep_self_hit.txt -- while the miss-bound e = 0 kernel gains 9 %)
     uint32_t leafSum = 0;
     uint32_t rootHits = 0;   // hits this lane has added for its current root (gates the saturation check)
     __device__ __forceinline__ CountEnv(const SearchArgs& a, uint4* s, uint32_t k) : EnvBase<WPP>(a, s, k) {}
@@ -521,6 +525,7 @@ template <int WPP, typename TPlane> struct StoreEnv : EnvBase<WPP> {
     typedef typename EnvBase<WPP>::row_t row_t;
     typedef typename EnvBase<WPP>::Root Root;
     static constexpr bool EXACT_ONLY = true;    // launched for E = 0 only (gm_api.hip: `store`)
+    static constexpr bool SELF_HIT = true;
     static constexpr uint32_t CAP = sizeof(TPlane) == 1 ? 0xFFu : 0xFFFFu;   // min(MAX, f + r) == min(MAX, min(MAX, f) + min(MAX, r))
     __device__ __forceinline__ StoreEnv(const SearchArgs& a, uint4* s, uint32_t k) : EnvBase<WPP>(a, s, k) {}
     __device__ __forceinline__ void leaf(const Root& rt, uint32_t kmer, row_t, row_t w)
@@ -1070,6 +1075,31 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
         }
         GM_LAP2(tSt1);
         // ---- defer narrow nodes: one queue entry per SA row ----
+        if constexpr (EnvT::SELF_HIT) {
+            // Forward strand, no error spent, ONE row left: it is the window's own location (a string always matches itself), so every
+            // k-mer the node still covers gains exactly one occurrence -- without reading the suffix array, a record or another rank
+            // block.  Nothing else can be found below the node: the text there IS the needle, no mismatching child exists.  In the OSS
+            // phase the self hit belongs to the search whose remaining lower bounds are all zero (find2:389-392): the others drop the
+            // node.  (k-mers that cross a sequence end are zeroed by resetLimits whatever is added here; a window with an N anywhere
+            // takes the ordinary path, which knows which k-mers the N spoils.)
+            if (A.selfHit && have && nd.w == 1u && rt.strand == 0u && meta_errs(nd.meta) == 0u) {
+                const uint32_t W = A.K + rt.n - 1u, nch = (env.woff + W + 31u) >> 5;
+                uint32_t anyN = 0;
+                for (uint32_t c = 0; c < nch; ++c) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(env.lwin + c * 1024u);
+                    anyN |= (v.x | v.y | v.z | v.w) & 0x44444444u;   // (nibbles of the neighbouring text in the first / last chunk count too: harmless)
+                }
+                if (anyN == 0u) {
+                    const bool counts = meta_mode(nd.meta) != M_OSS || oss_l(rt.rec, oss_nb(rt.rec) - 1u) == 0u;   // cumulative bounds: the last is the largest
+                    if (counts) {
+                        uint32_t smin, smax;
+                        covered_kmers(nd.meta, rt.n, A.K, smin, smax);
+                        for (uint32_t k = smin; k <= smax; ++k) env.leaf_at(rt, k, (row_t)0);
+                    }
+                    have = false;
+                }
+            }
+        }
         if (A.verifyT) {
             bool narrow = have && nd.w <= A.verifyT;
             if (narrow) {   // is the subtree below worth one SA read + one text comparison per row?

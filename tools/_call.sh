@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-(timeout 600 ./tools/gather_bench2 32 1 more 2>&1 | grep "footprint= 32768\|footprint=  8192\|device") > gpurun_out/c18_gather.txt
+(timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q --timeout 600 -k "gtest or baseline_settings_small or fixture or midsize or chr1 or ecoli or interleaved or 62mbp or e2_vs_blank" 2>&1 | tail -8) > gpurun_out/c20_pytest.txt
+(timeout 1200 python tools/sweep_tuning.py --workload grch38 --reps 2 --cfg 30,0,1.0 30,1,0.2 30,2,0.03 100,1,0.5 -- "" "self_hit=0" 2>&1 | grep -v amdgpu.ids) > gpurun_out/c20_sweep_self.txt
