@@ -593,18 +593,21 @@ static int get_qtable(gm_index* ix, uint32_t* qio, const uint4** out)
         if (q == 0) { *qio = 0; *out = nullptr; return GM_OK; }
         size_t freeB = 0, totalB = 0;
         const uint64_t bytes = (1ull << (2 * q)) * sizeof(uint4) * (ix->wide ? 2 : 1);
-        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && bytes > freeB / 2) { ix->qtableCap = q - 1; continue; }
+        // (tables up to 4^15 entries leave half of the free memory alone; the 69 GB of 4^16 ask for 16 GiB of slack instead)
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && (q >= 16 ? bytes + (16ull << 30) > freeB : bytes > freeB / 2)) { ix->qtableCap = q - 1; continue; }
         if (hipMalloc(&d, bytes) == hipSuccess) break;
         (void)hipGetLastError();
         ix->qtableCap = q - 1;
     }
     const uint64_t n = 1ull << (2 * q);
+    const uint64_t qblocks = (n + 255) / 256;   // one thread per string: up to 2^24 blocks of 256 (HIP refuses 2^32 threads in one grid dimension)
+    const dim3 qgrid((unsigned)std::min<uint64_t>(qblocks, 1u << 22), (unsigned)((qblocks + (1u << 22) - 1) >> 22));
     if (!ix->d_C) { GM_HIP(hipMalloc(&ix->d_C, sizeof(ix->C))); GM_HIP(hipMemcpy(ix->d_C, ix->C, sizeof(ix->C), hipMemcpyHostToDevice)); }
     switch (ix->wpp) {
-        case 1: hipLaunchKernelGGL(qmer_table_kernel<1>, dim3(grid_for(n)), dim3(256), 0, 0, ix->d_blk[1], ix->d_C, ix->nRows, q, d); break;
-        case 2: hipLaunchKernelGGL(qmer_table_kernel<2>, dim3(grid_for(n)), dim3(256), 0, 0, ix->d_blk[1], ix->d_C, ix->nRows, q, d); break;
-        case 3: hipLaunchKernelGGL(qmer_table_kernel<3>, dim3(grid_for(n)), dim3(256), 0, 0, ix->d_blk[1], ix->d_C, ix->nRows, q, d); break;
-        default: hipLaunchKernelGGL(qmer_table_kernel<9>, dim3(grid_for(n)), dim3(256), 0, 0, ix->d_blk[1], ix->d_C, ix->nRows, q, d); break;
+        case 1: hipLaunchKernelGGL(qmer_table_kernel<1>, qgrid, dim3(256), 0, 0, ix->d_blk[1], ix->d_C, ix->nRows, q, d); break;
+        case 2: hipLaunchKernelGGL(qmer_table_kernel<2>, qgrid, dim3(256), 0, 0, ix->d_blk[1], ix->d_C, ix->nRows, q, d); break;
+        case 3: hipLaunchKernelGGL(qmer_table_kernel<3>, qgrid, dim3(256), 0, 0, ix->d_blk[1], ix->d_C, ix->nRows, q, d); break;
+        default: hipLaunchKernelGGL(qmer_table_kernel<9>, qgrid, dim3(256), 0, 0, ix->d_blk[1], ix->d_C, ix->nRows, q, d); break;
     }
     GM_HIP(hipGetLastError());
     GM_HIP(hipDeviceSynchronize());
@@ -822,8 +825,9 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     if (S->jump) {
         const uint32_t L = plan.infix;
         uint32_t J = 1;   // longest tabulated string: as for the q-mer tables below
-        while (J < 15 && (1ull << (2 * J)) < 4ull * ix->nRows) ++J;
-        if (ix->tune.jump > 0) J = std::min<uint32_t>(J, (uint32_t)ix->tune.jump);
+        // (3.09 Gbp, 16 against 15 characters: K=30 e=1 -10 %, e=2 -4.7 %, K=100 e=1 -6.5 % kernel time, profiles/r03/sweep_qtable16.txt)
+        while (J < (ix->nRows > (1ull << 30) ? 16u : 15u) && (1ull << (2 * J)) < 4ull * ix->nRows) ++J;
+        if (ix->tune.jump > 0) J = (uint32_t)ix->tune.jump;   // forced (sweeps, tests)
         if (ix->tune.qtable >= 0) J = std::min<uint32_t>(J, (uint32_t)ix->tune.qtable);
         J = L >= 2 ? std::min(J, L - 1u) : 0u;
         if (J) { rc = get_qtable(ix, &J, &jtab); if (rc) return rc; }   // (shorter when the device is short of memory)
@@ -891,11 +895,14 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         // (ceil(log4 rows) + 1), at most 15: 4^15 entries x 16 B = 17 GB of the 288 GB -- every tabulated symbol
         // replaces a bidirectional step (1-2 random rank reads) by a share of ONE table read
         // (profiles/r01h_qtable_sweep.txt: e=0 +27 % on 249 Mbp, +30 % on 3.1 Gbp going from 12 to 15).
+        // Beyond 2^30 rows the average 15-mer still has ~3 occurrences: 16 symbols (4^16 entries x 16 B = 69 GB) leave most k-mers of a
+        // genome with their single row straight from the table (profiles/r03/sweep_qtable16.txt)
         uint32_t qmax = 1;
-        while (qmax < 15 && (1ull << (2 * qmax)) < 4ull * ix->nRows) ++qmax;
+        const uint32_t qcap = ix->tune.qtable >= 0 ? (uint32_t)ix->tune.qtable : (ix->nRows > (1ull << 30) ? 16u : 15u);
+        while (qmax < qcap && (1ull << (2 * qmax)) < 4ull * ix->nRows) ++qmax;
         if (ix->wide) qmax = std::min(qmax, 14u);   // 32-byte entries
-        if (ix->tune.qtable >= 0) qmax = (uint32_t)std::min(ix->tune.qtable, 15);
-        A.qtabA = A.qtabB = nullptr; A.qlenPacked = 0; A.qselMask = 0; A.startPacked[0] = A.startPacked[1] = 0;
+        if (ix->tune.qtable >= 0) qmax = (uint32_t)std::min(ix->tune.qtable, 16);
+        A.qtabA = A.qtabB = nullptr; A.qlenPacked[0] = A.qlenPacked[1] = 0; A.qselMask = 0; A.startPacked[0] = A.startPacked[1] = 0;
         uint32_t qA = 0, qB = 0;
         for (uint32_t s = 0; s < plan.nSearches; ++s) {
             const OssRecord& r = plan.table[(size_t)(plan.stepSize - 1) * 8 + s];
@@ -908,8 +915,9 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
             else if (qB == 0 || qB == q) { if (qB == 0) { rc = get_qtable(ix, &q, &A.qtabB); if (rc) return rc; qB = q; } A.qselMask |= 1u << s; }
             else continue;   // a third distinct prefix length: this search starts from the root
             if (q == 0) continue;
-            A.qlenPacked |= q << (4u * s);
+            A.qlenPacked[s >> 2] |= q << (8u * (s & 3u));
         }
+        ix->lastQ = std::max(qA, qB) | jumpJ << 8;
     }
     A.text4 = ix->d_text4; A.textBegin = text_begin; A.vqCap = vqCap; A.ldsDepth = ldsDepth; A.winChunks = winChunks; A.lqCap = lqCap;
     A.workCounter = reinterpret_cast<unsigned long long*>(ix->d_small);
@@ -1484,14 +1492,14 @@ int gm_index_set_tuning(gm_index* ix, const char* name, int64_t value)
     const Tuning dflt;   // -1 restores these (for part_bias, which may be negative, -1 is a value: 0 is its default)
     struct { const char* n; int* f; int d; int64_t lo, hi; } tab[] = {
         {"verify_t", &ix->tune.verifyT, dflt.verifyT, 0, (int64_t)VERIFY_TMAX}, {"lds_stack", &ix->tune.ldsStack, dflt.ldsStack, 0, 64},
-        {"blocks_per_cu", &ix->tune.blocksPerCU, dflt.blocksPerCU, 1, 8}, {"qtable", &ix->tune.qtable, dflt.qtable, 0, 15},
+        {"blocks_per_cu", &ix->tune.blocksPerCU, dflt.blocksPerCU, 1, 8}, {"qtable", &ix->tune.qtable, dflt.qtable, 0, 16},
         {"sat_min_w", &ix->tune.satMinW, dflt.satMinW, 1, 0x7FFFFFFF}, {"fetch_batch", &ix->tune.fetchBatch, dflt.fetchBatch, 1, 64},
         {"probation", &ix->tune.probation, dflt.probation, 0, 255}, {"verify_cost", &ix->tune.verifyCost, dflt.verifyCost, 0, 1 << 20},
         {"no_store", &ix->tune.noStore, dflt.noStore, 0, 1}, {"no_saturate", &ix->tune.noSaturate, dflt.noSaturate, 0, 1},
         {"skip_dup", &ix->tune.skipDup, dflt.skipDup, 0, 1}, {"coop", &ix->tune.coop, dflt.coop, 0, 1}, {"use_ctx", &ix->tune.useCtx, dflt.useCtx, 0, 1},
         {"steal", &ix->tune.steal, dflt.steal, 0, 64}, {"part_bias", &ix->tune.partBias, dflt.partBias, -255, 255},
         {"child_tables", &ix->tune.childTables, dflt.childTables, 0, 1}, {"oss_weights", &ix->tune.ossWeights, dflt.ossWeights, 0, 0xFFFFFF},   // (-1: 5,4,7,8 at e = 2, the even split elsewhere)
-        {"jump", &ix->tune.jump, dflt.jump, 0, 15}, {"self_hit", &ix->tune.selfHit, dflt.selfHit, 0, 1},
+        {"jump", &ix->tune.jump, dflt.jump, 0, 16}, {"self_hit", &ix->tune.selfHit, dflt.selfHit, 0, 1},
     };
     for (auto& t : tab) if (!strcmp(t.n, name)) {
         const bool isBias = t.f == &ix->tune.partBias;
@@ -1548,6 +1556,7 @@ int gm_last_map_stats(const gm_index* cix, gm_map_stats* out)
     GM_HIP(hipMemcpy(cnt, reinterpret_cast<char*>(ix->d_small) + 16, sizeof(cnt), hipMemcpyDeviceToHost));
     ix->stats.node_steps = cnt[0]; ix->stats.rank_lines = cnt[1];
     for (int i = 0; i < 40; ++i) ix->stats.detail[i] = cnt[2 + i];
+    ix->stats.detail[38] = ix->lastQ;   // longest q-mer table of the call | jump length << 8
     if (ix->corrTimed) { float c = 0; GM_HIP(hipEventElapsedTime(&c, ix->ev[1], ix->ev[2])); ix->stats.detail[37] = (uint64_t)(c * 1000.0f); }   // correction pass, microseconds
     int rc = check_device_error(ix);
     *out = ix->stats;

@@ -45,7 +45,9 @@ inline uint32_t tuned_infix_length(uint32_t K, uint32_t E)
     auto clampu = [](uint32_t v, uint32_t lo, uint32_t hi) { return v < lo ? lo : (v > hi ? hi : v); };
     uint32_t n;
     switch (E) {
-        case 0: n = K > 15 ? clampu(K - 15, 1, 31) : 1; break;
+        // the exact infix is one table read plus one step: 17 characters for the 4^16 table of indexes beyond 2^30 rows
+        // (profiles/r03/sweep_qtable16.txt: K=30 n=14 54.1 ms, n=13 54.7; with the 4^15 table n=14 61.5, n=15 62.6)
+        case 0: n = K > 16 ? clampu(K - 16, 1, 31) : 1; break;
         case 1:
             // re-measured on the 3.09 Gbp index with cooperative reads and verification records (profiles/r02/sweep_grch38_steps.txt):
             // the longest block whose first (exact) part still has >= 17 characters (infix >= 35), and whose window K + n - 1

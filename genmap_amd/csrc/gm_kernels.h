@@ -71,7 +71,7 @@ struct SearchArgs {
     // ---- q-mer range tables: the first (always exact) OSS block of a root starts from a lookup instead of q steps ----
     const uint4* qtabA;             // {fwd lo, rev lo, width, 0} of every ACGT string of length q (two tables at most per call)
     const uint4* qtabB;
-    uint32_t qlenPacked;            // 4 bits per search: table prefix length q_s (0 = no table for that search)
+    uint32_t qlenPacked[2];         // 8 bits per search: table prefix length q_s (0 = no table for that search), at most 16
     uint32_t qselMask;              // bit s: search s uses qtabB
     uint32_t startPacked[2];        // 8 bits per search: startPos of the regular block shape (n == stepSize)
     uint32_t skipDup;               // 1: the range-hi block is not loaded when it is the range-lo block (saves a translation per shared step)
@@ -1047,7 +1047,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                         fql = (frt.n == A.stepSize) ? A.jumpJ : 0u;
                         startPos = (A.jumpAPacked[frt.search >> 2] >> (8u * (frt.search & 3u))) & 0xFFu;
                     } else {
-                    fql = (A.qlenPacked >> (4u * frt.search)) & 15u;
+                    fql = (A.qlenPacked[frt.search >> 2] >> (8u * (frt.search & 3u))) & 0xFFu;
                     if (frt.n == A.stepSize) startPos = (A.startPacked[frt.search >> 2] >> (8u * (frt.search & 3u))) & 0xFFu;
                     else { const uint4 q = *recp; startPos = (q.y >> 16) & 0xFFu; }   // odd block shape (end of text / interval): rare
                     }
@@ -1247,8 +1247,9 @@ __global__ __launch_bounds__(256) void qmer_table_kernel(const uint32_t* __restr
                                                          uint4* __restrict__ out)
 {
     typedef typename BlockGeom<WPP>::row_t row_t;
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (1u << (2u * q))) return;
+    const uint64_t idx64 = ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;   // q = 16: 2^32 strings (HIP: < 2^32 threads per grid row)
+    if (idx64 >= (1ull << (2u * q))) return;
+    const uint32_t idx = (uint32_t)idx64;
     constexpr uint32_t SPB = BlockGeom<WPP>::SPB, WPB = BlockGeom<WPP>::WPB;
     row_t flo = 0, rlo = 0, w = (row_t)nRows;
     for (uint32_t i = 0; i < q && w; ++i) {

@@ -115,7 +115,7 @@ struct JumpSearch {
 inline bool oss_jump_patterns(uint32_t E, const OssRecord& rec, uint32_t L, uint32_t J, size_t maxPatterns, JumpSearch* out)
 {
     out->J = 0; out->pat.clear();
-    if (J == 0 || J >= L || J > 15u) return false;
+    if (J == 0 || J >= L || J > 16u) return false;   // (offsets inside the J-mer have 4 bits)
     // the exact path through the first J characters: position, block and "block ends here" of every character
     uint32_t a = oss_start(rec), bx = a, t = 0;    // coordinates relative to the infix start
     uint32_t pos[16], blk[16]; bool endsBlock[16];

@@ -237,6 +237,30 @@ def test_gpu_baseline_settings_small(K, E):
         ix.close()
 
 
+def test_gpu_sixteen_symbol_table_on_a_small_text():
+    """Indexes beyond 2^30 rows start their searches from the table of all 16-mers (69 GB); forced here on a small text so that the
+    oracle can check it: q-mer table at e = 0 (infix 17 and longer), jump patterns of 16 characters at e = 1 and 2."""
+    g = _gm()
+    import torch
+    if torch.cuda.mem_get_info()[0] < (90 << 30):
+        pytest.skip("needs 69 GB of device memory for the table")
+    rng = np.random.default_rng(1616)
+    lens = [50000, 900, 20000, 16, 17]
+    codes = _repeat_text(rng, sum(lens), True)
+    ora = H.OracleIndex(codes, lens, keep_sa=False)
+    ix = g.Index.build(codes, lens, sampling=1)
+    try:
+        for K, E, infix in ((30, 0, 0), (30, 0, 20), (17, 0, 17), (100, 0, 0), (30, 1, 0), (30, 2, 0), (100, 1, 0)):
+            exp = ora.mappability(K, E, value_bits=8, threads=8)
+            ix.set_tuning(qtable=16, jump=16)
+            out = ix.map(K, E, infix=infix, value_bits=8)
+            tq = ix.last_stats()["detail"]["table_q"]
+            assert np.array_equal(out, exp), (K, E, infix)
+            assert (tq & 255) == 16 if E == 0 else (tq >> 8) == 16, (K, E, infix, tq)
+    finally:
+        ix.close()
+
+
 def test_gpu_shards_and_device_output():
     """kmer_begin/kmer_end shards written into a torch device buffer add up to the unsharded result."""
     g = _gm()

@@ -48,6 +48,7 @@ for cfg in a.cfg:
         chk = int(out[:n].to(torch.int64).sum().item())
         if base is None: base = chk
         best = min(ms)
-        corr = ix.last_stats()["detail"].get("correction_us", 0) / 1e3
-        print(f"K={K} E={E} frac={frac:<5} {st or '(default)':45s} {best:10.2f} ms (correction pass {corr:8.2f})  {(span if rng else nk)/best*1e3:10.4g} k-mers/s  checksum {'ok' if chk == base else 'DIFFERS'}", flush=True)
+        det = ix.last_stats()["detail"]
+        corr = det.get("correction_us", 0) / 1e3; tq = det.get("table_q", 0)
+        print(f"K={K} E={E} frac={frac:<5} {st or '(default)':45s} {best:10.2f} ms (correction pass {corr:8.2f})  {(span if rng else nk)/best*1e3:10.4g} k-mers/s  checksum {'ok' if chk == base else 'DIFFERS'}  q={tq & 255} J={tq >> 8}", flush=True)
 ix.close()
