@@ -995,6 +995,33 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
             }
         }
         GM_LAP2(tSt32);
+        // ---- self hits, BEFORE the draw below: a lane whose root ends here (most roots of a large e = 0 call: the table leaves them one
+        // row) takes its next root in this very iteration (3.09 Gbp K=30 e=0: 51.6 against 54.1 ms) ----
+        if constexpr (EnvT::SELF_HIT) {
+            // Forward strand, no error spent, ONE row left: it is the window's own location (a string always matches itself), so every
+            // k-mer the node still covers gains exactly one occurrence -- without reading the suffix array, a record or another rank
+            // block.  Nothing else can be found below the node: the text there IS the needle, no mismatching child exists.  In the OSS
+            // phase the self hit belongs to the search whose remaining lower bounds are all zero (find2:389-392): the others drop the
+            // node.  (k-mers that cross a sequence end are zeroed by resetLimits whatever is added here; a window with an N anywhere
+            // takes the ordinary path, which knows which k-mers the N spoils.)
+            if (A.selfHit && have && nd.w == 1u && rt.strand == 0u && meta_errs(nd.meta) == 0u) {
+                const uint32_t W = A.K + rt.n - 1u, nch = (env.woff + W + 31u) >> 5;
+                uint32_t anyN = 0;
+                for (uint32_t c = 0; c < nch; ++c) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(env.lwin + c * 1024u);
+                    anyN |= (v.x | v.y | v.z | v.w) & 0x44444444u;   // (nibbles of the neighbouring text in the first / last chunk count too: harmless)
+                }
+                if (anyN == 0u) {
+                    const bool counts = meta_mode(nd.meta) != M_OSS || oss_l(rt.rec, oss_nb(rt.rec) - 1u) == 0u;   // cumulative bounds: the last is the largest
+                    if (counts) {
+                        uint32_t smin, smax;
+                        covered_kmers(nd.meta, rt.n, A.K, smin, smax);
+                        for (uint32_t k = smin; k <= smax; ++k) env.leaf_at(rt, k, (row_t)0);
+                    }
+                    have = false;
+                }
+            }
+        }
         // stage 1: lanes without node, stack or fetch in flight draw a root (ballot rank) and issue its loads
 #pragma unroll 1
         for (int round = 0; round < 2; ++round) {
@@ -1075,31 +1102,6 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
         }
         GM_LAP2(tSt1);
         // ---- defer narrow nodes: one queue entry per SA row ----
-        if constexpr (EnvT::SELF_HIT) {
-            // Forward strand, no error spent, ONE row left: it is the window's own location (a string always matches itself), so every
-            // k-mer the node still covers gains exactly one occurrence -- without reading the suffix array, a record or another rank
-            // block.  Nothing else can be found below the node: the text there IS the needle, no mismatching child exists.  In the OSS
-            // phase the self hit belongs to the search whose remaining lower bounds are all zero (find2:389-392): the others drop the
-            // node.  (k-mers that cross a sequence end are zeroed by resetLimits whatever is added here; a window with an N anywhere
-            // takes the ordinary path, which knows which k-mers the N spoils.)
-            if (A.selfHit && have && nd.w == 1u && rt.strand == 0u && meta_errs(nd.meta) == 0u) {
-                const uint32_t W = A.K + rt.n - 1u, nch = (env.woff + W + 31u) >> 5;
-                uint32_t anyN = 0;
-                for (uint32_t c = 0; c < nch; ++c) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(env.lwin + c * 1024u);
-                    anyN |= (v.x | v.y | v.z | v.w) & 0x44444444u;   // (nibbles of the neighbouring text in the first / last chunk count too: harmless)
-                }
-                if (anyN == 0u) {
-                    const bool counts = meta_mode(nd.meta) != M_OSS || oss_l(rt.rec, oss_nb(rt.rec) - 1u) == 0u;   // cumulative bounds: the last is the largest
-                    if (counts) {
-                        uint32_t smin, smax;
-                        covered_kmers(nd.meta, rt.n, A.K, smin, smax);
-                        for (uint32_t k = smin; k <= smax; ++k) env.leaf_at(rt, k, (row_t)0);
-                    }
-                    have = false;
-                }
-            }
-        }
         if (A.verifyT) {
             bool narrow = have && nd.w <= A.verifyT;
             if (narrow) {   // is the subtree below worth one SA read + one text comparison per row?
