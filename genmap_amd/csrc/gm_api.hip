@@ -602,12 +602,14 @@ static int get_qtable(gm_index* ix, uint32_t* qio, const uint4** out)
     const uint64_t n = 1ull << (2 * q);
     const uint64_t qblocks = (n + 255) / 256;   // one thread per string: up to 2^24 blocks of 256 (HIP refuses 2^32 threads in one grid dimension)
     const dim3 qgrid((unsigned)std::min<uint64_t>(qblocks, 1u << 22), (unsigned)((qblocks + (1u << 22) - 1) >> 22));
+    // one-row entries carry the text next to their occurrence when the suffix array is at hand (gm_kernels.h: qmer_table_kernel)
+    const uint32_t* nbSa = (!ix->wide && ix->d_sa && ix->d_textS) ? reinterpret_cast<const uint32_t*>(ix->d_sa) : nullptr;
     if (!ix->d_C) { GM_HIP(hipMalloc(&ix->d_C, sizeof(ix->C))); GM_HIP(hipMemcpy(ix->d_C, ix->C, sizeof(ix->C), hipMemcpyHostToDevice)); }
     switch (ix->wpp) {
-        case 1: hipLaunchKernelGGL(qmer_table_kernel<1>, qgrid, dim3(256), 0, 0, ix->d_blk[1], ix->d_C, ix->nRows, q, d); break;
-        case 2: hipLaunchKernelGGL(qmer_table_kernel<2>, qgrid, dim3(256), 0, 0, ix->d_blk[1], ix->d_C, ix->nRows, q, d); break;
-        case 3: hipLaunchKernelGGL(qmer_table_kernel<3>, qgrid, dim3(256), 0, 0, ix->d_blk[1], ix->d_C, ix->nRows, q, d); break;
-        default: hipLaunchKernelGGL(qmer_table_kernel<9>, qgrid, dim3(256), 0, 0, ix->d_blk[1], ix->d_C, ix->nRows, q, d); break;
+        case 1: hipLaunchKernelGGL(qmer_table_kernel<1>, qgrid, dim3(256), 0, 0, ix->d_blk[1], ix->d_C, ix->nRows, q, d, nbSa, ix->d_textS); break;
+        case 2: hipLaunchKernelGGL(qmer_table_kernel<2>, qgrid, dim3(256), 0, 0, ix->d_blk[1], ix->d_C, ix->nRows, q, d, nbSa, ix->d_textS); break;
+        case 3: hipLaunchKernelGGL(qmer_table_kernel<3>, qgrid, dim3(256), 0, 0, ix->d_blk[1], ix->d_C, ix->nRows, q, d, nbSa, ix->d_textS); break;
+        default: hipLaunchKernelGGL(qmer_table_kernel<9>, qgrid, dim3(256), 0, 0, ix->d_blk[1], ix->d_C, ix->nRows, q, d, nbSa, ix->d_textS); break;
     }
     GM_HIP(hipGetLastError());
     GM_HIP(hipDeviceSynchronize());
@@ -847,7 +849,15 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
             jumpJ = J;
             jinfoHost.assign(8, make_uint4(0, 0, 0, 0));
             for (uint32_t s2 = 0; s2 < plan.nSearches; ++s2) {
-                jinfoHost[s2] = make_uint4((uint32_t)patHost.size() | (uint32_t)js[s2].pat.size() << 16, js[s2].meta0, js[s2].pat[0], 0u);
+                // neighbour filter (gm_kernels.h): how many infix characters right / left of the J-mer a one-row table entry is compared with
+                uint32_t nbWord = 0;
+                if (ix->tune.jumpFilter != 0 && !ix->wide && ix->d_sa && ix->d_textS) {
+                    const uint32_t nr = std::min<uint32_t>(NB_SYMS, L - js[s2].regionA - J), nl = std::min<uint32_t>(NB_SYMS, js[s2].regionA);
+                    for (uint32_t i = 0; i < nr; ++i) nbWord |= 1u << (2u * i);
+                    for (uint32_t i = 0; i < nl; ++i) nbWord |= 1u << (16u + 2u * i);
+                    nbWord |= nr << 12 | nl << 28 | 1u << 31;
+                }
+                jinfoHost[s2] = make_uint4((uint32_t)patHost.size() | (uint32_t)js[s2].pat.size() << 16, js[s2].meta0, js[s2].pat[0], nbWord);
                 jumpAPacked[s2 >> 2] |= js[s2].regionA << (8u * (s2 & 3u));
                 patHost.insert(patHost.end(), js[s2].pat.begin(), js[s2].pat.end());
             }
@@ -862,7 +872,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         // host-device synchronisation
         uint64_t h = 1469598103934665603ull;
         auto mix = [&h](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
-        mix(p->K); mix(p->E); mix(plan.infix); mix((uint64_t)(int64_t)ix->tune.partBias); mix((uint64_t)(int64_t)ix->tune.ossWeights); mix(jumpJ); mix(patHost.size()); mix(text_begin); mix(text_len); mix(first_seq); mix(n_seq); mix(n_intervals);
+        mix(p->K); mix(p->E); mix(plan.infix); mix((uint64_t)(int64_t)ix->tune.partBias); mix((uint64_t)(int64_t)ix->tune.ossWeights); mix(jumpJ); mix((uint64_t)ix->tune.jumpFilter); mix(patHost.size()); mix(text_begin); mix(text_len); mix(first_seq); mix(n_seq); mix(n_intervals);
         for (uint64_t k = 0; k < 2 * n_intervals; ++k) mix(intervals[k]);
         if (!ix->sigValid || ix->sig != h) {
             GM_HIP(hipMemcpyAsync(ix->d_table, plan.table.data(), plan.table.size() * sizeof(OssRecord), hipMemcpyHostToDevice, st));
@@ -1501,7 +1511,7 @@ int gm_index_set_tuning(gm_index* ix, const char* name, int64_t value)
         {"skip_dup", &ix->tune.skipDup, dflt.skipDup, 0, 1}, {"coop", &ix->tune.coop, dflt.coop, 0, 1}, {"use_ctx", &ix->tune.useCtx, dflt.useCtx, 0, 1},
         {"steal", &ix->tune.steal, dflt.steal, 0, 64}, {"part_bias", &ix->tune.partBias, dflt.partBias, -255, 255},
         {"child_tables", &ix->tune.childTables, dflt.childTables, 0, 1}, {"oss_weights", &ix->tune.ossWeights, dflt.ossWeights, 0, 0xFFFFFF},   // (-1: 5,4,7,8 at e = 2, the even split elsewhere)
-        {"jump", &ix->tune.jump, dflt.jump, 0, 16}, {"self_hit", &ix->tune.selfHit, dflt.selfHit, 0, 1},
+        {"jump", &ix->tune.jump, dflt.jump, 0, 16}, {"self_hit", &ix->tune.selfHit, dflt.selfHit, 0, 1}, {"jump_filter", &ix->tune.jumpFilter, dflt.jumpFilter, 0, 1},
     };
     for (auto& t : tab) if (!strcmp(t.n, name)) {
         const bool isBias = t.f == &ix->tune.partBias;

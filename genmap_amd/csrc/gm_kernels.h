@@ -144,7 +144,9 @@ template <> struct NodeIO<uint32_t> {
     static __device__ __forceinline__ void load_item(const uint4* p, uint32_t& row, uint32_t& meta, uint32_t& win, uint32_t& nss) { const uint4 v = p[0]; row = v.x; meta = v.y; win = v.z; nss = v.w; }
     // q-mer table entry {fwd lo, rev lo, width}
     static __device__ __forceinline__ void load_qentry(const uint4* tab, uint32_t idx, uint32_t& flo, uint32_t& rlo, uint32_t& w) { const uint4 v = tab[idx]; flo = v.x; rlo = v.y; w = v.z; }
-    static __device__ __forceinline__ void store_qentry(uint4* tab, uint32_t idx, uint32_t flo, uint32_t rlo, uint32_t w) { tab[idx] = make_uint4(flo, rlo, w, 0u); }
+    static __device__ __forceinline__ void load_qentry(const uint4* tab, uint32_t idx, uint32_t& flo, uint32_t& rlo, uint32_t& w, uint32_t& nb) { const uint4 v = tab[idx]; flo = v.x; rlo = v.y; w = v.z; nb = v.w; }
+    // nb: the text next to the string's ONLY occurrence (qmer_table_kernel), 0 for every other entry
+    static __device__ __forceinline__ void store_qentry(uint4* tab, uint32_t idx, uint32_t flo, uint32_t rlo, uint32_t w, uint32_t nb = 0u) { tab[idx] = make_uint4(flo, rlo, w, nb); }
 };
 template <> struct NodeIO<uint64_t> {
     static constexpr uint32_t NU = 2;
@@ -170,7 +172,8 @@ template <> struct NodeIO<uint64_t> {
     {
         const uint4 a = tab[2 * (size_t)idx], b = tab[2 * (size_t)idx + 1]; flo = (uint64_t)a.y << 32 | a.x; rlo = (uint64_t)a.w << 32 | a.z; w = (uint64_t)b.y << 32 | b.x;
     }
-    static __device__ __forceinline__ void store_qentry(uint4* tab, uint32_t idx, uint64_t flo, uint64_t rlo, uint64_t w)
+    static __device__ __forceinline__ void load_qentry(const uint4* tab, uint32_t idx, uint64_t& flo, uint64_t& rlo, uint64_t& w, uint32_t& nb) { load_qentry(tab, idx, flo, rlo, w); nb = 0u; }
+    static __device__ __forceinline__ void store_qentry(uint4* tab, uint32_t idx, uint64_t flo, uint64_t rlo, uint64_t w, uint32_t = 0u)
     {
         tab[2 * (size_t)idx] = make_uint4((uint32_t)flo, (uint32_t)(flo >> 32), (uint32_t)rlo, (uint32_t)(rlo >> 32));
         tab[2 * (size_t)idx + 1] = make_uint4((uint32_t)w, (uint32_t)(w >> 32), 0u, 0u);
@@ -216,7 +219,7 @@ template <int WPP> struct EnvBase {
     uint32_t sbase;      // raised when a neighbour takes the bottom entry (work sharing), back to 0 when the stack runs empty
     uint32_t K;
 #ifdef GM_COUNTERS
-    uint32_t steps = 0, lines = 0, stOss = 0, stExt = 0, stExtW1 = 0, stExtW4 = 0, stOssW1 = 0, pushes = 0, vItems = 0, vItemsOss = 0, vChunks = 0, jumps = 0;
+    uint32_t steps = 0, lines = 0, stOss = 0, stExt = 0, stExtW1 = 0, stExtW4 = 0, stOssW1 = 0, pushes = 0, vItems = 0, vItemsOss = 0, vChunks = 0, jumps = 0, jumpDrops = 0;
     uint32_t whit[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // a wavefront passed here (counted by its first enabled lane): the dynamic cost of a region = passes x its instructions
     __device__ __forceinline__ void note_wave(int i) { const unsigned long long m = __ballot(true); if (__lane_id() == (unsigned)(__ffsll((long long)m) - 1)) whit[i]++; }
@@ -816,6 +819,9 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     // the next pattern's descriptor (prefetched), meta of the node at depth J (with the errors of the pattern whose table entry
     // is in flight; bit 30 marks the first pattern of a root: the root context is installed with it)
     uint32_t jb = 0, jpp = 0, jd = 0, jm = 0;   // jm: errs field = errors of the pattern in flight, bit 30 = first pattern of its root
+    // neighbour filter: jn = the needle's characters next to the J-mer inside the infix, packed like the table's 4th word (bit 15: the
+    // filter applies to this root), ftNb = that word of the entry in flight
+    uint32_t jn = 0, ftNb = 0;
     unsigned long long poolCur = 0, poolEnd = 0, poolBase = 0, poolBlock = 0;   // wave-uniform
     uint32_t poolRem = 0;
     bool globalDone = false;                        // wave-uniform
@@ -905,7 +911,20 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                 if (first) { rt = frt; env.on_root(); jm &= 0x3FFFFFFFu; }
                 // every k-mer of the block at MAX: nothing a further pattern finds can change the result
                 const bool sat = !first && env.root_hits() >= A.maxVal && env.saturated(rt, 0u, rt.n - 1u);
-                if (ftW != 0u && !sat) {
+                bool take = ftW != 0u && !sat;
+                if (take && ftW == 1u && (jn & ftNb & 0x8000u) != 0u) {
+                    // The substituted J-mer occurs once.  Whatever this node could still find lies at that one place and contains the whole
+                    // infix, so the infix characters next to the J-mer must agree with the text there up to the errors the pattern has
+                    // left; a text N or a sequence end within them ends it too (N-less pass).  No memory request is spent on the rest.
+                    const uint32_t h = jl[rt.search].w;     // bits 2i / 16 + 2i: neighbour i counts; bits 12..14 / 28..30: how many do
+                    const uint32_t x = ftNb ^ jn;
+                    const uint32_t differ = (x | x >> 1) & h & 0x05550555u;
+                    take = ((ftNb >> 12) & 7u) >= ((h >> 12) & 7u) && ((ftNb >> 28) & 7u) >= ((h >> 28) & 7u) && meta_errs(jm) + (uint32_t)__popc(differ) <= A.E;
+#ifdef GM_COUNTERS
+                    env.jumpDrops += take ? 0u : 1u;
+#endif
+                }
+                if (take) {
                     nd.flo = ftFlo; nd.rlo = ftRlo; nd.w = ftW; nd.meta = jm;
                     have = true; w1run = 0;
                 }
@@ -917,7 +936,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                         const uint32_t f = (jd >> (3u + 6u * k)) & 63u, sh = 2u * (A.jumpJ - 1u - (f & 15u)), old = (idx >> sh) & 3u;
                         idx ^= (old ^ ((old + (f >> 4)) & 3u)) << sh;
                     }
-                    IO::load_qentry(A.jtab, idx, ftFlo, ftRlo, ftW);
+                    IO::load_qentry(A.jtab, idx, ftFlo, ftRlo, ftW, ftNb);
                     jm = (jm & ~(7u << META_ERRS_SHIFT)) | (jd & 7u) << META_ERRS_SHIFT;
                     jpp += 1u;
                     if (jp + 1u < jpe) jd = A.patterns[jp + 1u];
@@ -980,7 +999,16 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                             const uint32_t f = (fji.z >> (3u + 6u * k)) & 63u, sh = 2u * (A.jumpJ - 1u - (f & 15u)), old = (x >> sh) & 3u;
                             x ^= (old ^ ((old + (f >> 4)) & 3u)) << sh;
                         }
-                        IO::load_qentry(A.jtab, x, ftFlo, ftRlo, ftW);
+                        IO::load_qentry(A.jtab, x, ftFlo, ftRlo, ftW, ftNb);
+                        jn = 0u;
+                        if (fji.w >> 31) {   // the needle's neighbours of the J-mer, once per root
+                            uint32_t notLetter = 0u;
+#pragma unroll 1
+                            for (uint32_t i = 0; i < ((fji.w >> 12) & 7u); ++i) { const uint32_t c = env.text_char(frt, fa0 + A.jumpJ + i); notLetter |= c >> 2; jn |= (c & 3u) << (2u * i); }
+#pragma unroll 1
+                            for (uint32_t i = 0; i < ((fji.w >> 28) & 7u); ++i) { const uint32_t c = env.text_char(frt, fa0 - 1u - i); notLetter |= c >> 2; jn |= (c & 3u) << (16u + 2u * i); }
+                            jn = notLetter ? 0u : (jn | 0x8000u);   // a needle N mismatches everything: leave such roots to the ordinary path
+                        }
                         jpp = ((fji.x & 0xFFFFu) + 1u) | ((fji.x & 0xFFFFu) + (fji.x >> 16)) << 16;
                         if ((fji.x >> 16) > 1u) jd = A.patterns[(fji.x & 0xFFFFu) + 1u];
                         fs = 2u;
@@ -1216,6 +1244,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     atomicAdd(&A.counters[10], (unsigned long long)env.vChunks);
     atomicAdd(&A.counters[21], (unsigned long long)nSteals);
     atomicAdd(&A.counters[38], (unsigned long long)env.jumps);   // detail[36]: table reads of jump patterns
+    atomicAdd(&A.counters[41], (unsigned long long)env.jumpDrops);   // detail[39]: one-row entries ended by the neighbour filter
 #pragma unroll
     for (int i = 0; i < 16; ++i) if (env.whit[i]) atomicAdd(&A.counters[22 + i], (unsigned long long)env.whit[i]);
     if (lane == 0) {
@@ -1244,9 +1273,15 @@ __global__ __launch_bounds__(256) void search_kernel_w4(const SearchArgs A) { se
 
 // SA ranges of every ACGT string of length q in both indexes (right extensions from the root): the top of the search
 // tree, tabulated once per index and q.
+// Entries with exactly ONE row additionally carry the text next to that only occurrence (when the suffix array is resident; 32-bit rows):
+//   bits 0..11  the 6 symbols to its right (2 bits each, nearest first), bits 12..14 how many of them are letters A,C,G,T inside the sequence,
+//   bits 16..27 the 6 symbols to its left (nearest first), bits 28..30 their count, bits 15 and 31 = 1.
+// A search that lands on such an entry compares its own neighbouring characters with them before it spends a single memory request on the
+// node (search_body, jump patterns): on a genome most one-row entries are chance hits of a substituted string.
+constexpr uint32_t NB_SYMS = 6;
 template <int WPP>
 __global__ __launch_bounds__(256) void qmer_table_kernel(const uint32_t* __restrict__ blkRev, const uint64_t* __restrict__ Cin, uint64_t nRows, uint32_t q,
-                                                         uint4* __restrict__ out)
+                                                         uint4* __restrict__ out, const uint32_t* __restrict__ sa, const uint8_t* __restrict__ textS)
 {
     typedef typename BlockGeom<WPP>::row_t row_t;
     const uint64_t idx64 = ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;   // q = 16: 2^32 strings (HIP: < 2^32 threads per grid row)
@@ -1266,7 +1301,15 @@ __global__ __launch_bounds__(256) void qmer_table_kernel(const uint32_t* __restr
         rlo = (row_t)Cin[c] + rl[c];
         w = rh[c] - rl[c];
     }
-    NodeIO<row_t>::store_qentry(out, idx, flo, rlo, w);
+    uint32_t nb = 0;
+    if (sizeof(row_t) == 4 && w == 1u && sa != nullptr) {
+        const uint8_t* t = textS + sa[flo];            // the occurrence; the sentinel text has 512 sentinels of padding on either side
+        uint32_t nr = 0, nl = 0;
+        while (nr < NB_SYMS && t[q + nr] < (uint8_t)SYM_N) { nb |= (uint32_t)t[q + nr] << (2u * nr); ++nr; }
+        while (nl < NB_SYMS && t[-1 - (int)nl] < (uint8_t)SYM_N) { nb |= (uint32_t)t[-1 - (int)nl] << (16u + 2u * nl); ++nl; }
+        nb |= nr << 12 | nl << 28 | 0x80008000u;
+    }
+    NodeIO<row_t>::store_qentry(out, idx, flo, rlo, w, nb);
 }
 
 // store planes -> c[]: 16 bytes per lane where the three arrays are aligned alike (the planes are; `out` is the caller's)

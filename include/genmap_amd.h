@@ -254,7 +254,7 @@ int gm_map_kernel_times(const gm_index *idx, double *ms, uint32_t n, uint32_t *n
 int gm_index_sync(gm_index *idx);
 
 /* scheduling knobs of the search kernel, for sweeps and tests.  Names: verify_t, lds_stack, blocks_per_cu, qtable,
- * sat_min_w, fetch_batch, probation, verify_cost, skip_dup, coop, use_ctx, jump, self_hit, steal (0: no work sharing inside a
+ * sat_min_w, fetch_batch, probation, verify_cost, skip_dup, coop, use_ctx, jump, jump_filter, self_hit, steal (0: no work sharing inside a
  * wavefront, n > 0: an exchange when at least n lanes are idle), part_bias (e = 1: characters moved from the second OSS block
  * to the first; every split gives the same result; may be negative, default 0), oss_weights (e >= 1: nibble i = relative length of
  * OSS block i, left to right; 0 = the reference's equal split).  Results never depend on these.
