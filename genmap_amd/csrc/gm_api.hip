@@ -952,6 +952,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     if (ix->tune.probation >= 0) A.probation = (uint32_t)ix->tune.probation;
     A.verifyCost = (uint32_t)std::max(0, ix->tune.verifyCost);
     A.selfHit = ix->tune.selfHit != 0 ? 1u : 0u;
+    A.nbFilter = ix->tune.jumpFilter != 0 ? 1u : 0u;
     A.chunkBlocks = chunked ? p->chunk_blocks : 0u; A.chunkStride = p->chunk_stride; A.chunkIndex = p->chunk_index;
     A.skipDup = ix->tune.skipDup >= 0 ? (uint32_t)(ix->tune.skipDup != 0) : 1u;   // profiles/r02: +3..8 % on 3.09 Gbp, +1..5 % on 249 Mbp
     // groups of lanes read the rank blocks (rank2_coop): +4..12 % with 32-byte blocks on 249 Mbp and 3.09 Gbp (profiles/r02)

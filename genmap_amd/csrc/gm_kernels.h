@@ -60,6 +60,7 @@ struct SearchArgs {
     uint32_t satMinW;               // saturation is looked up (a global read per covered k-mer) only for nodes at least this wide
     uint32_t probation;             // a single-row node that has spent every error is stepped this many times before it is verified
     uint32_t verifyCost;            // ... when width * verifyCost <= estimated rank steps left below the node
+    uint32_t nbFilter;              // 1: one-row table entries are compared with the needle's next characters before they become nodes
     uint32_t selfHit;               // 1: a single error-free row on the forward strand is the window's own location -- no lookup at all
     // ---- LDS staging (per wavefront): verification queue | top of the lane stacks | packed needle windows ----
     const uint4* text4;             // whole text, 4 bits per symbol (32 symbols per 16-byte chunk), sentinel-free
@@ -195,6 +196,7 @@ __device__ __forceinline__ void covered_kmers(uint32_t meta, uint32_t n, uint32_
 // One aligned 32-byte read replaces the dependent pair "SA entry, then text around it" (two to three random requests).
 constexpr int32_t CTX_LEFT = 24, CTX_SYMS = 56;
 
+constexpr uint32_t NB_SYMS = 6;       // neighbour symbols per side carried by one-row q-mer table entries (qmer_table_kernel)
 constexpr uint32_t STEAL_LEVELS = 16;  // a lane gives away at most this many bottom entries before its stack has run empty once
 
 constexpr uint32_t WORK_CHUNK = 256;   // roots taken from the global counter per atomic
@@ -948,7 +950,19 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
         } else if (fs == 2u) {
             env.note_wave(3);
             fs = 0u;
-            if (ftW != 0u) {
+            bool take = ftW != 0u;
+            if (ftW == 1u && (ftNb >> 31) != 0u && A.nbFilter) {
+                // The q-mer occurs once, and the rest of the search's first block must follow it without an error (u[0] = 0 in every
+                // scheme, gm_oss.h; a needle N, a text N and a sequence end all end an exact block): compare up to 6 of those characters
+                // with the text next to that occurrence, which the table entry carries -- a chance hit of the reverse strand ends here
+                // instead of after a rank step or a record read.  (The forward strand's own location passes, of course.)
+                uint32_t R = oss_bl(frt.rec, 0u) - fql;
+                R = R < NB_SYMS ? R : NB_SYMS;
+                take = ((ftNb >> 12) & 7u) >= R;
+#pragma unroll 1
+                for (uint32_t i = 0; i < R && take; ++i) take = env.text_char(frt, fa0 + fql + i) == ((ftNb >> (2u * i)) & 3u);
+            }
+            if (take) {
                 rt = frt; env.on_root();
                 nd.flo = ftFlo; nd.rlo = ftRlo; nd.w = ftW; nd.meta = meta_pack(fa0, fa0 + fql, 0, 0, M_OSS);
                 have = true; w1run = 0;
@@ -1018,7 +1032,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                     }
                 } else {
                 if (bad) fs = 0u;   // a pattern N never matches in an exact block (find2:330): this root finds nothing
-                else { IO::load_qentry(((A.qselMask >> frt.search) & 1u) ? A.qtabB : A.qtabA, idx, ftFlo, ftRlo, ftW); fs = 2u; }
+                else { IO::load_qentry(((A.qselMask >> frt.search) & 1u) ? A.qtabB : A.qtabA, idx, ftFlo, ftRlo, ftW, ftNb); fs = 2u; }
                 }
             }
         }
@@ -1278,7 +1292,6 @@ __global__ __launch_bounds__(256) void search_kernel_w4(const SearchArgs A) { se
 //   bits 16..27 the 6 symbols to its left (nearest first), bits 28..30 their count, bits 15 and 31 = 1.
 // A search that lands on such an entry compares its own neighbouring characters with them before it spends a single memory request on the
 // node (search_body, jump patterns): on a genome most one-row entries are chance hits of a substituted string.
-constexpr uint32_t NB_SYMS = 6;
 template <int WPP>
 __global__ __launch_bounds__(256) void qmer_table_kernel(const uint32_t* __restrict__ blkRev, const uint64_t* __restrict__ Cin, uint64_t nRows, uint32_t q,
                                                          uint4* __restrict__ out, const uint32_t* __restrict__ sa, const uint8_t* __restrict__ textS)
