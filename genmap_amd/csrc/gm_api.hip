@@ -611,8 +611,11 @@ static int get_qtable(gm_index* ix, uint32_t* qio, const uint4** out)
         case 3: hipLaunchKernelGGL(qmer_table_kernel<3>, qgrid, dim3(256), 0, 0, ix->d_blk[1], ix->d_C, ix->nRows, q, d, nbSa, ix->d_textS); break;
         default: hipLaunchKernelGGL(qmer_table_kernel<9>, qgrid, dim3(256), 0, 0, ix->d_blk[1], ix->d_C, ix->nRows, q, d, nbSa, ix->d_textS); break;
     }
-    GM_HIP(hipGetLastError());
-    GM_HIP(hipDeviceSynchronize());
+    {   // (a failed build must not leave 69 GB behind)
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) { hipFree(d); GM_HIP(e); }
+    }
     ix->qtables[q] = d;
     ix->qtableBytes += n * sizeof(uint4) * (ix->wide ? 2 : 1);
     *qio = q;

@@ -239,7 +239,10 @@ typedef struct gm_map_stats {
                                  [20..35]: how often a WAVEFRONT executed a code region (any lane enabled): pop, saturation
                                  test, work-sharing exchange, fetch stage 3, 2, 1, deferral round, split, mismatch round,
                                  leaf, leaf flush, verification: OSS block, 8-symbol chunk, mismatch event, k-mer loop
-                                 iteration; stack push past the LDS levels */
+                                 iteration; stack push past the LDS levels;
+                                 [36] table reads of jump patterns; [37] correction pass in microseconds, [38] longest q-mer table of
+                                 the call | jump length << 8 (both set by the host in every build); [39] one-row table entries ended
+                                 by the neighbour filter */
     double   search_ms;       /* HIP-event time of the search kernel alone */
     double   total_ms;        /* memset + search + finalize, HIP events on the call's stream */
 } gm_map_stats;
@@ -257,7 +260,9 @@ int gm_index_sync(gm_index *idx);
  * sat_min_w, fetch_batch, probation, verify_cost, skip_dup, coop, use_ctx, jump, jump_filter, self_hit, steal (0: no work sharing inside a
  * wavefront, n > 0: an exchange when at least n lanes are idle), part_bias (e = 1: characters moved from the second OSS block
  * to the first; every split gives the same result; may be negative, default 0), oss_weights (e >= 1: nibble i = relative length of
- * OSS block i, left to right; 0 = the reference's equal split).  Results never depend on these.
+ * OSS block i, left to right; 0 = the reference's equal split); qtable / jump = 1..16 force the length of the q-mer table / of the jump
+ * patterns (16: the 69 GB table of all 16-mers, the default beyond 2^30 rows), jump_filter = 0 switches the neighbour test of one-row
+ * table entries off.  Results never depend on these.
  * Two TEST-ONLY knobs do change the output: no_saturate = 1 counts without the min(total, MAX) clamp and stores the low bits,
  * no_store = 1 only switches e = 0 from plain stores to the atomic accumulators (same result).
  * value -1 restores the library default of any knob except part_bias; values outside a knob's range are GM_ERR_BAD_ARG.

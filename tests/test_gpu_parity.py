@@ -231,7 +231,7 @@ def test_gpu_baseline_settings_small(K, E):
                 # idle lanes steal from their neighbours' stacks or not
                 # ... jump patterns + N-less pass + correction pass (default), short jumps, or the plain tree walk with N children
                 for coop, ctx, steal, jump in (((1, 1, 0, -1), (0, 0, 0, 0), (1, 0, 1, 7), (0, 1, 1, -1)) if bb in (32, 64) else ((0, 1, 0, -1), (0, 0, 1, 0))):
-                    ix.set_tuning(verify_t=T, coop=coop, use_ctx=ctx, steal=steal, jump=jump)
+                    ix.set_tuning(verify_t=T, coop=coop, use_ctx=ctx, steal=steal, jump=jump, jump_filter=1 - (T & 1))   # neighbour filter on / off
                     out = ix.map(K, E, value_bits=bits)
                     assert np.array_equal(out, exp), (K, E, bits, bb, T, coop, ctx, steal, jump)
         ix.close()
@@ -252,7 +252,9 @@ def test_gpu_sixteen_symbol_table_on_a_small_text():
     try:
         for K, E, infix in ((30, 0, 0), (30, 0, 20), (17, 0, 17), (100, 0, 0), (30, 1, 0), (30, 2, 0), (100, 1, 0)):
             exp = ora.mappability(K, E, value_bits=8, threads=8)
-            ix.set_tuning(qtable=16, jump=16)
+            ix.set_tuning(qtable=16, jump=16, jump_filter=0)
+            assert np.array_equal(ix.map(K, E, infix=infix, value_bits=8), exp), (K, E, infix, "no neighbour filter")
+            ix.set_tuning(qtable=16, jump=16, jump_filter=1)
             out = ix.map(K, E, infix=infix, value_bits=8)
             tq = ix.last_stats()["detail"]["table_q"]
             assert np.array_equal(out, exp), (K, E, infix)
