@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-(timeout 900 python tools/first_call_cost.py 2>&1 | grep -v amdgpu.ids) > gpurun_out/c40_first_call.txt
-(timeout 1500 python tools/sweep_tuning.py --workload grch38 --reps 2 --cfg 30,1,0.2 30,2,0.03 100,1,0.5 -- "" "lds_stack=3" "lds_stack=2" 2>&1 | grep -v amdgpu.ids) > gpurun_out/c40_sweep_lds.txt
+(timeout 900 python -m pytest tests/test_gpu_parity.py -x -q --timeout 300 -k "sixteen or baseline_settings_small or gtest_matrix or fixture" 2>&1 | tail -12) > gpurun_out/c44_pytest.txt
+(timeout 600 python tools/sweep_tuning.py --workload grch38 --reps 2 --cfg 30,0,1.0 30,1,0.2 30,2,0.03 100,1,0.5 -- "" "steal=4" 2>&1 | grep -v amdgpu.ids) > gpurun_out/c44_sweep.txt
