@@ -262,7 +262,7 @@ def test_jump_patterns_and_n_correction_baseline_settings(K, E):
     codes[n - 40:n - 10] = codes[10:40]
     ix = H.OracleIndex(codes, lens, keep_sa=True)
     exp = ix.mappability(K, E, value_bits=16, threads=4)
-    for T, jump in ((0, 15), (1, 15), (4, 7), (1 << 30, 15)):
+    for T, jump in ((0, 15), (1, 15), (4, 7), (1 << 30, 15), (1, 16)):   # 16: the jump length of indexes beyond 2^30 rows (offsets up to 15)
         out, st = emu_map2(ix, 1, K, E, value_bits=16, verify_t=T, jump=jump)
         assert np.array_equal(out, exp), (K, E, T, jump, np.flatnonzero(out != exp)[:10], out[out != exp][:10], exp[out != exp][:10])
         assert st[4] > 0 and st[5] > 0
