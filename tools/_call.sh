@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-(timeout 900 python -m pytest tests/test_gpu_parity.py -x -q --timeout 300 -k "sixteen or baseline_settings_small or gtest_matrix or fixture" 2>&1 | tail -12) > gpurun_out/c44_pytest.txt
-(timeout 600 python tools/sweep_tuning.py --workload grch38 --reps 2 --cfg 30,0,1.0 30,1,0.2 30,2,0.03 100,1,0.5 -- "" "steal=4" 2>&1 | grep -v amdgpu.ids) > gpurun_out/c44_sweep.txt
+(timeout 1200 python tools/wide_rows_smoke.py 0.7 14,15,16 2>&1 | grep -v amdgpu.ids | tail -14) > gpurun_out/c46_wide.txt

@@ -64,6 +64,16 @@ print(f"whole text K=30 e=0 through gm_map (host vector, PCIe included): {len(fu
 # doubling property on the whole vector: the two copies agree position by position and nothing is odd except saturation
 a, b = out[:nh - K + 1], out[nh:2 * nh - K + 1]
 ok &= bool(np.array_equal(a, b)) and bool(((out % 2 == 0) | (out == 255)).all())
+if len(sys.argv) > 2:   # e.g. "14,15,16": forced lengths of the q-mer table (32-byte entries with 64-bit rows; the default stops at 14)
+    import torch
+    dev = torch.zeros(len(full) + 16, dtype=torch.uint8, device="cuda:0")
+    for q in map(int, sys.argv[2].split(",")):
+        ix.set_tuning(qtable=q)
+        for _ in range(2):
+            ix.map_device(dev.data_ptr(), K, 0, value_bits=8, stream=torch.cuda.current_stream().cuda_stream)
+        same = bool(np.array_equal(dev[:len(out)].cpu().numpy(), out))
+        ok &= same
+        print(f"qtable={q}: search kernel {ix.kernel_times(1)[0]:.1f} ms, table_q {ix.last_stats()['detail']['table_q'] & 255}, same result: {same}", flush=True)
 print("WIDE_ROWS_OK" if ok else "WIDE_ROWS_FAILED", flush=True)
 ix.close()
 sys.exit(0 if ok else 1)
