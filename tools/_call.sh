@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-(timeout 1200 python tools/wide_rows_smoke.py 0.7 14,15,16 2>&1 | grep -v amdgpu.ids | tail -14) > gpurun_out/c46_wide.txt
+(timeout 1500 bash tools/cli_scale_check.sh grch38 1.0 0 2>&1 | grep -v amdgpu.ids | tail -40) > gpurun_out/c47_cli_scale.txt
