@@ -358,7 +358,7 @@ def main():
         for _, recs in files5:
             tl = sum(len(c) for _, c in recs)
             slices.append((first, len(recs), tl)); first += len(recs)
-        infix = args.infix or g.tuned_infix_length(K, E)
+        infix = args.infix or g.tuned_infix_length(K, E, locating=True)   # --exclude-pseudo and csv locate: the library's block shape for those calls
         step_size = K - infix + 1
         total_kmers = sum(tl - K + 1 for _, _, tl in slices)
         bufs = []

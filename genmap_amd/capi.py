@@ -52,7 +52,7 @@ class Locations(C.Structure):
 MAP_FLAG_RANGE = 1
 WIDE_ROWS = 0x10000   # GM_BLOCK_WIDE_ROWS: OR into block_bytes to force 64-bit rows
 
-EXPORTS = ["gm_device_alloc", "gm_device_free", "gm_ipc_export", "gm_ipc_open", "gm_ipc_close", "gm_push_pieces", "gm_map_shard", "gm_host_pin", "gm_host_unpin", "gm_index_set_tuning", "gm_index_sync", "gm_map_kernel_times", "gm_map_runs", "gm_runs_free", "gm_tuned_infix_length", "gm_index_export_sa", "gm_locate", "gm_locations_free", "gm_status_string", "gm_last_error", "gm_device_count", "gm_index_build", "gm_index_import", "gm_index_import_sampled", "gm_index_export_sa_sampled",
+EXPORTS = ["gm_device_alloc", "gm_device_free", "gm_ipc_export", "gm_ipc_open", "gm_ipc_close", "gm_push_pieces", "gm_map_shard", "gm_host_pin", "gm_host_unpin", "gm_index_set_tuning", "gm_index_sync", "gm_map_kernel_times", "gm_map_runs", "gm_runs_free", "gm_tuned_infix_length", "gm_tuned_infix_length_locating", "gm_index_export_sa", "gm_locate", "gm_locations_free", "gm_status_string", "gm_last_error", "gm_device_count", "gm_index_build", "gm_index_import", "gm_index_import_sampled", "gm_index_export_sa_sampled",
            "gm_index_export_bwt", "gm_index_get_info", "gm_index_free", "gm_map", "gm_map_device",
            "gm_last_map_stats", "gm_default_infix_length"]
 
@@ -136,6 +136,8 @@ def load_library(profiling=False):
     lib.gm_map_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.c_uint32, C.POINTER(C.c_uint32)]
     lib.gm_tuned_infix_length.restype = C.c_uint32
     lib.gm_tuned_infix_length.argtypes = [C.c_uint32, C.c_uint32]
+    lib.gm_tuned_infix_length_locating.restype = C.c_uint32
+    lib.gm_tuned_infix_length_locating.argtypes = [C.c_uint32, C.c_uint32]
     lib.gm_default_infix_length.restype = C.c_uint32
     lib.gm_default_infix_length.argtypes = [C.c_uint32, C.c_uint32, C.c_int32]
     _LIB, _LIB_NAME = lib, str(path)
@@ -156,8 +158,10 @@ def default_infix_length(K, E, xo=None):
     return int(load_library().gm_default_infix_length(K, E, -1 if xo is None else xo))
 
 
-def tuned_infix_length(K, E):
-    return int(load_library().gm_tuned_infix_length(K, E))
+def tuned_infix_length(K, E, locating=False):
+    """common-infix length the library schedules with by default; locating: --exclude-pseudo / gm_locate calls"""
+    lib = load_library()
+    return int(lib.gm_tuned_infix_length_locating(K, E) if locating else lib.gm_tuned_infix_length(K, E))
 
 
 def _ptr(a):

@@ -325,6 +325,7 @@ int gm_device_count(void)
 
 uint32_t gm_default_infix_length(uint32_t K, uint32_t E, int32_t xo) { return default_infix_length(K, E, xo); }
 uint32_t gm_tuned_infix_length(uint32_t K, uint32_t E) { return (K < 1 || K > MAX_K || E > MAX_ERRORS) ? 0u : tuned_infix_length(K, E); }
+uint32_t gm_tuned_infix_length_locating(uint32_t K, uint32_t E) { return (K < 1 || K > MAX_K || E > MAX_ERRORS) ? 0u : tuned_infix_length(K, E, true); }
 
 void gm_index_free(gm_index* ix)
 {
@@ -722,7 +723,8 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     if (ix->doneValid) GM_HIP(hipStreamWaitEvent(st, ix->evDone, 0));
 
     if (p->K < 1 || p->K > MAX_K) return GM_ERR_BAD_K;
-    const uint32_t infix = p->infix > 0 ? (uint32_t)p->infix : (p->overlap >= 0 ? default_infix_length(p->K, p->E, p->overlap) : tuned_infix_length(p->K, p->E));
+    // (frequency calls ask for jump patterns; --exclude-pseudo and gm_locate do not: gm_tuned_infix_length_locating)
+    const uint32_t infix = p->infix > 0 ? (uint32_t)p->infix : (p->overlap >= 0 ? default_infix_length(p->K, p->E, p->overlap) : tuned_infix_length(p->K, p->E, !wantJump));
     if (infix == 0) return GM_ERR_BAD_OVERLAP;
     MapPlan& plan = S->plan;
     int rc = make_map_plan(p->K, p->E, infix, p->revcompl, text_len, intervals, n_intervals, &plan, ix->tune.partBias, oss_weights_for(ix, p->E));
@@ -951,7 +953,10 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     if (ix->tune.fetchBatch > 0) A.fetchBatch = (uint32_t)std::min(ix->tune.fetchBatch, 64);
     // e = 0: a single row is almost always the k-mer's own location.  Beyond ~1 G rows a lone-row step is an HBM miss
     // like the verification reads it postpones, and no longer pays (3.09 Gbp e = 2: 90.7 vs 86.7 M k-mers/s without).
-    A.probation = p->E == 0 ? 0u : 2u;   // 3.09 Gbp: e=1 +8.5 %, e=2 +4 % over 0 (profiles/r02/sweep_grch38_retune.txt); K=100: no difference
+    // 3.09 Gbp: e=1 +8.5 %, e=2 +4 % over 0 (profiles/r02/sweep_grch38_retune.txt); K=100: no difference.  With the neighbour filter the
+    // chance hits the two steps used to kill are mostly gone before they become nodes: e=2 one step 371-373 ms against 376-379 with
+    // two, e=1 no difference (profiles/r03/sweep_neighbour_filter.txt, sweep_knobs_after_filter.txt)
+    A.probation = p->E == 0 ? 0u : p->E == 1 ? 2u : 1u;
     if (ix->tune.probation >= 0) A.probation = (uint32_t)ix->tune.probation;
     A.verifyCost = (uint32_t)std::max(0, ix->tune.verifyCost);
     A.selfHit = ix->tune.selfHit != 0 ? 1u : 0u;
@@ -1337,7 +1342,7 @@ int gm_map_shard(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t 
     const bool chunked = p->chunk_blocks > 0 && p->chunk_stride > 1;
     if (n_intervals > 0 || !chunked) {
         // a selection, or a plain contiguous share (gm_map is the share "everything")
-        const uint32_t infix = p->infix > 0 ? (uint32_t)p->infix : (p->overlap >= 0 ? default_infix_length(p->K, p->E, p->overlap) : tuned_infix_length(p->K, p->E));
+        const uint32_t infix = p->infix > 0 ? (uint32_t)p->infix : (p->overlap >= 0 ? default_infix_length(p->K, p->E, p->overlap) : tuned_infix_length(p->K, p->E, p->exclude_pseudo != 0));
         if (infix == 0 || infix > p->K) return GM_ERR_BAD_OVERLAP;
         const uint64_t step = p->K - infix + 1;
         // whole blocks: the share ends where the next one begins; the tail past the last k-mer is all zeros (resetLimits)
@@ -1378,7 +1383,7 @@ int gm_map_shard(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t 
         GM_HIP(hipStreamSynchronize(ix->stCompute));
         return check_device_error(ix);
     }
-    const uint32_t infix = p->infix > 0 ? (uint32_t)p->infix : (p->overlap >= 0 ? default_infix_length(p->K, p->E, p->overlap) : tuned_infix_length(p->K, p->E));
+    const uint32_t infix = p->infix > 0 ? (uint32_t)p->infix : (p->overlap >= 0 ? default_infix_length(p->K, p->E, p->overlap) : tuned_infix_length(p->K, p->E, p->exclude_pseudo != 0));
     if (infix == 0 || infix > p->K) return GM_ERR_BAD_OVERLAP;
     const uint64_t step = p->K - infix + 1, chunkLen = (uint64_t)p->chunk_blocks * step, rowLen = chunkLen * p->chunk_stride;
     const uint64_t base = (kb + step - 1) / step * step;                       // first block of the range

@@ -40,7 +40,9 @@ inline uint32_t default_infix_length(uint32_t K, uint32_t E, int32_t xo)
 // measured fastest on MI355X (profiles/r01e_infix_sweeps.txt): with a q-mer table and verification of narrow nodes,
 // e = 0 wants a 16-character infix (one lookup + ~4 steps per half) and blocks of at most 31 k-mers; e >= 1 wants
 // the infix long enough that the OSS search ends on narrow ranges.
-inline uint32_t tuned_infix_length(uint32_t K, uint32_t E)
+// locating: the call locates its occurrences (--exclude-pseudo, csv): those kernels walk the tree from its root (no jump patterns), and
+// the shorter blocks of round 2 stay the optimum there (C5, K = 24 e = 1 -ep on 21 Mbp: n = 5 109 ms, 6 128, 7 151, 8 165)
+inline uint32_t tuned_infix_length(uint32_t K, uint32_t E, bool locating = false)
 {
     auto clampu = [](uint32_t v, uint32_t lo, uint32_t hi) { return v < lo ? lo : (v > hi ? hi : v); };
     uint32_t n;
@@ -58,9 +60,9 @@ inline uint32_t tuned_infix_length(uint32_t K, uint32_t E)
             else if (K >= 44) n = std::min<uint32_t>(16, K - 34);
             // K <= 43, re-measured in round 3 with jump patterns (profiles/r03/sweep_shapes.txt): the jump makes the top of the
             // tree cheap, so longer blocks pay: K=30 n=8 +10 % over n=5 (flat up to 12), K=24 n=8 +13 %
-            else n = clampu(K / 3, 5, 8);
+            else n = locating ? clampu(K / 6, 5, 16) : clampu(K / 3, 5, 8);
             break;
-        case 2: n = clampu(K / 6, 6, 16); break;   // K=30: n=6 +4 % over 7 with jump patterns and blocks of 5,4,7,8 (r03)
+        case 2: n = clampu(K / 6, locating ? 7 : 6, 16); break;   // K=30: n=6 +4 % over 7 with jump patterns and blocks of 5,4,7,8 (r03)
         case 3: n = clampu(K / 4, 9, 16); break;
         default: n = clampu(K / 4, 11, 16); break;
     }

@@ -341,7 +341,7 @@ int map_main(int argc, const char** argv)
                     // into the one result vector -- nothing is merged on the CPU (gm_map_shard).  A selection is small: contiguous shares.
                     const uint64_t numKmers = textLen >= K ? textLen - K + 1 : 0;
                     const size_t nd = replicas.size();
-                    const uint32_t tuned = gm_tuned_infix_length(K, E);
+                    const uint32_t tuned = ep ? gm_tuned_infix_length_locating(K, E) : gm_tuned_infix_length(K, E);
                     const uint64_t stepSize = K - (xo >= 0 ? infix : tuned) + 1, nBlocks = (numKmers + stepSize - 1) / stepSize;
                     const uint32_t chunkBlocks = (uint32_t)std::max<uint64_t>(1, (nBlocks + nd * 64 - 1) / (nd * 64));
                     const bool pinned = gm_host_pin(c.data(), c.size()) == GM_OK;

@@ -274,6 +274,9 @@ int gm_index_set_tuning(gm_index *idx, const char *name, int64_t value);
 uint32_t gm_default_infix_length(uint32_t K, uint32_t E, int32_t xo);
 /* common-infix length this build schedules with when neither -xo nor params.infix is given (0 for invalid K/E) */
 uint32_t gm_tuned_infix_length(uint32_t K, uint32_t E);
+/* ... for the calls that locate their occurrences: gm_map* with params.exclude_pseudo, gm_locate (shorter blocks: those kernels walk the
+ * search tree from its root).  A caller that cuts such a call into shares of whole blocks (kmer_begin / kmer_end) aligns them with this one. */
+uint32_t gm_tuned_infix_length_locating(uint32_t K, uint32_t E);
 
 #ifdef __cplusplus
 }

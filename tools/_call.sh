@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-(timeout 900 python -m pytest tests/test_gpu_parity.py -x -q --timeout 300 -k "sixteen or baseline_settings_small or gtest_matrix or fixture or chr1" 2>&1 | tail -6) > gpurun_out/c48_pytest.txt
-(timeout 900 python tools/sweep_tuning.py --workload grch38 --reps 2 --cfg 30,1,0.2 30,2,0.03 100,1,0.5 150,1,0.5 50,2,0.05 -- "self_hit=0" "" 2>&1 | grep -v amdgpu.ids) > gpurun_out/c48_sweep.txt
+(timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_cli_end_to_end.py -x -q --timeout 900 -k "exclude or five_bacteria or fixture or csv or cli or alignment or sampled or two_ranks or three_ranks or locations" 2>&1 | tail -5) > gpurun_out/c51_pytest.txt
+(timeout 600 python bench.py --workload bacteria5 --steps 10 2>/dev/null | tail -1) > gpurun_out/c51_bench_c5.json
