@@ -40,12 +40,20 @@ inline uint32_t default_infix_length(uint32_t K, uint32_t E, int32_t xo)
 // measured fastest on MI355X (profiles/r01e_infix_sweeps.txt): with a q-mer table and verification of narrow nodes,
 // e = 0 wants a 16-character infix (one lookup + ~4 steps per half) and blocks of at most 31 k-mers; e >= 1 wants
 // the infix long enough that the OSS search ends on narrow ranges.
-// locating: the call locates its occurrences (--exclude-pseudo, csv): those kernels walk the tree from its root (no jump patterns), and
-// the shorter blocks of round 2 stay the optimum there (C5, K = 24 e = 1 -ep on 21 Mbp: n = 5 109 ms, 6 128, 7 151, 8 165)
+// locating: the call locates its occurrences (--exclude-pseudo, csv).  Those kernels walk the tree from its root (no jump patterns), nothing
+// saturates (every occurrence is wanted), and on a multi-genome index -- what these options are for -- nearly every k-mer has a handful
+// of occurrences: sharing the infix search between the k-mers of a block does not pay for the extension phase it adds.  C5's index
+// (five bacteria, 21 Mbp), -ep pass in ms for n = 1 / 3-4 / round-2 shape: K=24 e=1 43 / 74 / 109 (n=5; 165 with the n=8 of the jumping
+// kernels), K=30 e=1 42 / 69 / 97, K=30 e=2 131 / 145 / 227, K=50 e=1 52 / 72 / 186, K=100 e=1 91 / 68 / 190 (profiles/r03/c5_block_shape.txt)
 inline uint32_t tuned_infix_length(uint32_t K, uint32_t E, bool locating = false)
 {
     auto clampu = [](uint32_t v, uint32_t lo, uint32_t hi) { return v < lo ? lo : (v > hi ? hi : v); };
     uint32_t n;
+    if (locating && E >= 1) {
+        n = K < 64 ? 1 : 4;
+        const uint32_t minInfixL = std::min(K, std::max<uint32_t>(E + 2, oss_scheme(E > MAX_ERRORS ? 0 : E).s[0].nb));
+        return std::max(K - std::min(n, K) + 1, minInfixL);
+    }
     switch (E) {
         // the exact infix is one table read plus one step: 17 characters for the 4^16 table of indexes beyond 2^30 rows
         // (profiles/r03/sweep_qtable16.txt: K=30 n=14 54.1 ms, n=13 54.7; with the 4^15 table n=14 61.5, n=15 62.6)
@@ -60,9 +68,9 @@ inline uint32_t tuned_infix_length(uint32_t K, uint32_t E, bool locating = false
             else if (K >= 44) n = std::min<uint32_t>(16, K - 34);
             // K <= 43, re-measured in round 3 with jump patterns (profiles/r03/sweep_shapes.txt): the jump makes the top of the
             // tree cheap, so longer blocks pay: K=30 n=8 +10 % over n=5 (flat up to 12), K=24 n=8 +13 %
-            else n = locating ? clampu(K / 6, 5, 16) : clampu(K / 3, 5, 8);
+            else n = clampu(K / 3, 5, 8);
             break;
-        case 2: n = clampu(K / 6, locating ? 7 : 6, 16); break;   // K=30: n=6 +4 % over 7 with jump patterns and blocks of 5,4,7,8 (r03)
+        case 2: n = clampu(K / 6, 6, 16); break;   // K=30: n=6 +4 % over 7 with jump patterns and blocks of 5,4,7,8 (r03)
         case 3: n = clampu(K / 4, 9, 16); break;
         default: n = clampu(K / 4, 11, 16); break;
     }
