@@ -77,7 +77,7 @@ def test_tuned_block_shape_at_one_error_follows_the_measured_rule():
     n = lambda K: K - g.tuned_infix_length(K, 1) + 1
     assert (n(24), n(30), n(50), n(64), n(100), n(150), n(250)) == (8, 8, 16, 16, 24, 48, 48)   # K <= 43: re-measured with jump patterns (r03)
     assert g.tuned_infix_length(24, 1, locating=True) == 24 and g.tuned_infix_length(30, 2, locating=True) == 30 and g.tuned_infix_length(100, 1, locating=True) == 97
-    assert g.tuned_infix_length(30, 0, locating=True) == g.tuned_infix_length(30, 0) and g.tuned_infix_length(3, 2, locating=True) >= 3
+    assert g.tuned_infix_length(30, 0, locating=True) == 30 and g.tuned_infix_length(100, 0, locating=True) == 97 and g.tuned_infix_length(3, 2, locating=True) >= 3
     assert g.tuned_infix_length(30, 0) == 17 and g.tuned_infix_length(30, 2) == 25 and g.tuned_infix_length(24, 1) == 17
     for K in range(44, 256):
         assert g.tuned_infix_length(K, 1) >= 35, K

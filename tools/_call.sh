@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-(timeout 2400 python -m pytest tests/ -x -q -m gpu --timeout 1200 2>&1 | tail -6) > gpurun_out/c55_pytest_gpu_full.txt
-(timeout 600 python bench.py --workload bacteria5 --steps 10 2>/dev/null | tail -1) > gpurun_out/c55_bench_c5.json
+(timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_cli_end_to_end.py -x -q --timeout 900 -k "exclude or five_bacteria or fixture or csv or cli or alignment or sampled or locations or extremes" 2>&1 | tail -5) > gpurun_out/c57_pytest.txt
