@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-(timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_cli_end_to_end.py -x -q --timeout 900 -k "exclude or five_bacteria or fixture or csv or cli or alignment or sampled or locations or extremes" 2>&1 | tail -5) > gpurun_out/c57_pytest.txt
+(timeout 900 bash tools/cli_c5_check.sh 1.0 0 2>&1 | grep -v amdgpu.ids | tail -45) > gpurun_out/c58_cli_c5.txt
+(timeout 1200 python bench.py 2> gpurun_out/c58_bench_default.log | tail -1) > gpurun_out/c58_bench_default.json
