@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-export MASTER_ADDR=127.0.0.1
-(timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29547 bench.py --gpus 2 --workload bacteria5 --same-device --backend gloo --steps 2 --warmup 1 --verify --no-cpu-baseline 2>&1 | grep -v "Warning\|amdgpu.ids\|socket.cpp\|OMP_NUM\|\*\*\*\*\|^$" | cut -c1-1200 | tail -12) > gpurun_out/c59_c5_2rank.txt
+(timeout 600 python tools/sweep_tuning.py --workload bacteria5 --reps 2 --cfg 24,1,1.0 30,2,1.0 24,0,1.0 -- "" "STEP=1" "STEP=2" "STEP=4" "STEP=6" 2>&1 | grep -v amdgpu.ids) > gpurun_out/c60_sweep_bact.txt
