@@ -129,6 +129,15 @@ __device__ __forceinline__ uint32_t sat_add_u16x2(uint32_t x, uint32_t y)
 // (seqPos is reported in 32 bits: csv / --exclude-pseudo need every single sequence to be shorter than 2^32, gm_api.hip checks)
 __device__ __forceinline__ uint2 locate_position(const uint64_t* __restrict__ cum, uint32_t nSeq, uint64_t p)
 {
+    if (nSeq <= 32u) {
+        // few sequences (a handful of genomes: what --exclude-pseudo and csv are used on): one pass over the sequence starts with
+        // wave-uniform addresses (scalar loads) instead of log2(nSeq) DEPENDENT vector loads per located row -- the drain of the leaf
+        // queue spent most of its time in that chain (profiles/r03/c5_block_shape.txt)
+        uint32_t s = 0; uint64_t base = 0;
+#pragma unroll 4
+        for (uint32_t i = 1; i < nSeq; ++i) { const uint64_t st = cum[i] + i; if (st <= p) { s = i; base = st; } }
+        return make_uint2(s, (uint32_t)(p - base));
+    }
     uint32_t lo = 0, hi = nSeq;
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cum[mid] + mid <= p) lo = mid; else hi = mid; }
     return make_uint2(lo, (uint32_t)(p - (cum[lo] + lo)));

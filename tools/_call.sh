@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT
-(timeout 600 python tools/sweep_tuning.py --workload bacteria5 --reps 2 --cfg 24,1,1.0 30,2,1.0 24,0,1.0 -- "" "STEP=1" "STEP=2" "STEP=4" "STEP=6" 2>&1 | grep -v amdgpu.ids) > gpurun_out/c60_sweep_bact.txt
+run() { (timeout 300 python bench.py --workload bacteria5 --steps 5 --K 24 --E 1 --infix $1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('infix', $1, 'ep ms/step', round(d['ms_per_step'],1), 'csv pass ms', round(d['csv']['ms_per_pass'],1), 'locate', round(d['csv']['locate_ms'],1))") >> gpurun_out/c62_c5.txt 2>&1; }
+run 0; run 20; run 17
+(timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_cli_end_to_end.py -x -q --timeout 600 -k "exclude or five_bacteria or fixture or csv or cli or locations or sampled" 2>&1 | tail -4) > gpurun_out/c62_pytest.txt
