@@ -795,8 +795,16 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         if (ix->tune.verifyT >= 0) t = ix->tune.verifyT;
         verifyT = (uint32_t)std::max(0, std::min(t, (int)VERIFY_TMAX));
     }
+    // extension-phase nodes (infix complete) may be wider: each row costs one record and two short scans against ~n log n steps
+    // (3.09 Gbp K=100 e=1: 4 rows -11 % kernel time over 2, 8 and 16 the same; profiles/r04/sweep_verify_t_ext.txt)
+    uint32_t verifyTExt = verifyT;
+    if (verifyT && p->E >= 1) {
+        int t = 4;   // K=30: e=1 -2 %, e=2 -0.7 % kernel time over 1 (2 rows: no gain)
+        if (ix->tune.verifyTExt >= 0) t = ix->tune.verifyTExt;
+        verifyTExt = (uint32_t)std::max((int)verifyT, std::min(t, (int)VERIFY_TMAX));
+    }
     const uint32_t depth = stack_bound(p->E, plan.stepSize) + STEAL_LEVELS;   // room for the levels work sharing may vacate at the bottom
-    const uint32_t vqCap = verifyT ? 64u + 64u * verifyT : 1u;
+    const uint32_t vqCap = verifyT ? 64u + 64u * std::min(verifyTExt, VERIFY_ROWS) : 1u;   // a lane queues at most VERIFY_ROWS rows per iteration (search_body)
     const uint32_t winChunks = (31u + p->K + plan.stepSize - 1u + 31u) / 32u;
     const uint32_t nu = ix->wide ? 2u : 1u;
     const int wantPerCU = std::max(1, ix->tune.blocksPerCU);   // default 4 = 4 waves/SIMD, what the kernel's VGPR count allows
@@ -945,6 +953,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     A.textS = ix->d_textS;
     A.ctx = ix->tune.useCtx ? ix->d_ctx : nullptr;
     A.verifyT = verifyT;
+    A.verifyTExt = verifyTExt;   // (== verifyT at e = 0: the plain stores rely on one row per k-mer and strand)
     A.satMinW = (uint32_t)std::max(1, ix->tune.satMinW);   // default 256: narrow nodes finish sooner than the lookup takes (r01h sweep: 128-256 best)
     // profiles/r01e_infix_sweeps.txt (r01h): 16 / 8 / 4 on the 249 Mbp index; beyond 2^30 rows the fetch loads are HBM
     // misses and larger batches pay (3.09 Gbp: e=0 82.6 vs 90.2 ms, K100 e=1 861 vs 900 ms with 32)
@@ -956,7 +965,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     // 3.09 Gbp: e=1 +8.5 %, e=2 +4 % over 0 (profiles/r02/sweep_grch38_retune.txt); K=100: no difference.  With the neighbour filter the
     // chance hits the two steps used to kill are mostly gone before they become nodes: e=2 one step 371-373 ms against 376-379 with
     // two, e=1 no difference (profiles/r03/sweep_neighbour_filter.txt, sweep_knobs_after_filter.txt)
-    A.probation = p->E == 0 ? 0u : p->E == 1 ? 2u : 1u;
+    A.probation = p->E == 0 ? 0u : p->E == 1 ? (p->K >= 64 ? 0u : 2u) : 1u;   // (K=100 e=1: 0 -> -1.3 % kernel time, r04)
     if (ix->tune.probation >= 0) A.probation = (uint32_t)ix->tune.probation;
     A.verifyCost = (uint32_t)std::max(0, ix->tune.verifyCost);
     A.selfHit = ix->tune.selfHit != 0 ? 1u : 0u;
@@ -970,7 +979,10 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     // the wavefront is idle gains 1.5 % (3.09 Gbp) to 5 % (249 Mbp) (profiles/r02/sweep_steal_e2.txt, sweep_chr1_steal_*.txt)
     uint32_t stealDefault = 0u;
     if ((p->E <= 1 && p->K < 64 && ix->nRows >= (1ull << 30)) || S->numRoots < 64ull * 4ull * 1024ull) stealDefault = 1u;
-    else if (p->E >= 2) stealDefault = p->K < 64 ? 16u : 8u;   // K=100 e=2: 8 -> +5.7 %, 16 -> 0 (sweep_steal_longk.txt); e=1 at K >= 64: sharing loses 5..9 %
+    else if (p->E >= 2) stealDefault = p->K < 64 ? 16u : 8u;   // K=100 e=2: 8 -> +5.7 %, 16 -> 0 (sweep_steal_longk.txt)
+    // e=1 at K >= 64: sharing used to lose 5..9 % (r02); with verified runs added in two atomics the balance turned: an exchange when a
+    // quarter of the wavefront is idle gains 2-6 % on 3.09 Gbp (profiles/r04/sweep_k100_knobs.txt, sweep_verify_t_ext.txt)
+    else if (p->E == 1 && p->K >= 64) stealDefault = 16u;
     A.steal = ix->tune.steal >= 0 ? (uint32_t)std::min(ix->tune.steal, 64) : stealDefault;
     A.coop = ix->tune.coop >= 0 ? (uint32_t)(ix->tune.coop != 0) : (ix->wpp == 1 ? 1u : 0u);
     if (ix->wide) A.coop = 0u;
@@ -1017,6 +1029,9 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
     // E = 0 with single-row verification: plain stores into one plane per strand instead of atomics
     const bool store = !ep && p->E == 0 && A.verifyT <= 1 && !ix->tune.noStore;
     const uint64_t plane = (text_len + 4 + 15) & ~15ull;   // both planes aligned alike: finalize2 reads 16 bytes per lane
+    // counting kernels on the regular partition: verified runs of k-mers go into a difference plane behind acc (gm_kernels.h: CountEnv::leaf_range)
+    const bool useDiff = !ep && !store && !S.plan.useList && ix->tune.rangeAdd != 0;
+    const uint64_t diffOff = (text_len + 4 + 3) & ~3ull;
     // kernels over positions: blockIdx.y walks the shard's own chunk ranges (one range without chunks), blockIdx.x one range
     auto range_grid = [](const ChunkSel& c, uint64_t n, uint32_t perThread) {
         uint64_t nr = 1, span = n;
@@ -1044,11 +1059,19 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
                 GM_HIP(hipMemsetAsync((uint8_t*)ix->d_acc + r0 * pb, 0, rn * pb, st));
                 GM_HIP(hipMemsetAsync((uint8_t*)ix->d_acc + (plane + r0) * pb, 0, rn * pb, st));
             }
-        } else if (sel.len) hipLaunchKernelGGL(clear_chunks_kernel, range_grid(sel, rn, 4), dim3(256), 0, st, (uint8_t*)(ix->d_acc + r0), 4u, rn, sel);
-        else GM_HIP(hipMemsetAsync(ix->d_acc + r0, 0, rn * sizeof(uint32_t), st));
+        } else if (sel.len) {
+            hipLaunchKernelGGL(clear_chunks_kernel, range_grid(sel, rn, 4), dim3(256), 0, st, (uint8_t*)(ix->d_acc + r0), 4u, rn, sel);
+            if (useDiff) hipLaunchKernelGGL(clear_chunks_kernel, range_grid(sel, rn, 4), dim3(256), 0, st, (uint8_t*)(ix->d_acc + diffOff + r0), 4u, rn, sel);
+        } else {
+            GM_HIP(hipMemsetAsync(ix->d_acc + r0, 0, rn * sizeof(uint32_t), st));
+            if (useDiff) GM_HIP(hipMemsetAsync(ix->d_acc + diffOff + r0, 0, rn * sizeof(uint32_t), st));
+        }
     }
     GM_HIP(hipMemsetAsync(ix->d_small, 0, ix->pieceIndex == 0 ? SMALL_ZEROED : 16, st));   // later pieces of one call keep adding to the statistics
     A.acc = ix->d_acc; A.accPlane = plane; A.fileBits = ix->d_bits;
+    A.diff = useDiff ? ix->d_acc + diffOff : nullptr;
+    // self hits of the counting kernels pay only with the difference plane (one atomic per block instead of one per k-mer)
+    if (!store && !useDiff) A.selfHit = 0u;
     A.maxVal = ix->tune.noSaturate ? 0xFFFFFFFFu : (p->value_bits == 8 ? 255u : 65535u); A.wordsPerKmer = wordsPerKmer; A.seqFile = ix->d_seqFile;
 
     const uint32_t slot = (uint32_t)(ix->evCount % gm_index::EV_RING);
@@ -1075,7 +1098,7 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
     GM_HIP(hipEventRecord(ix->evRing[slot][1], st));
     ix->evCount++;
     if (text_len > 0) {
-        const dim3 g4 = range_grid(sel, rn, 4), g1 = range_grid(sel, rn, 1), g16 = range_grid(sel, rn, 16);
+        const dim3 g4 = range_grid(sel, rn, 4), g1 = range_grid(sel, rn, 1), g16 = range_grid(sel, rn, 16), g8 = range_grid(sel, rn, 8);
         const uint16_t* pf = (const uint16_t*)ix->d_acc + r0;
         const uint8_t* pf8 = (const uint8_t*)ix->d_acc + r0;
         if (p->value_bits == 8) {
@@ -1083,6 +1106,7 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
             if (rn == 0) {}
             else if (ep) hipLaunchKernelGGL(finalize_fileset_kernel<uint8_t>, g1, dim3(256), 0, st, ix->d_bits + r0 * wordsPerKmer, wordsPerKmer, o, rn, sel);
             else if (store) hipLaunchKernelGGL((finalize2_kernel<uint8_t, uint8_t>), g16, dim3(256), 0, st, pf8, pf8 + plane, o, rn, 255u, sel);
+            else if (useDiff) hipLaunchKernelGGL(finalize_diff_kernel<uint8_t>, g8, dim3(256), 0, st, ix->d_acc + r0, ix->d_acc + diffOff + r0, o, rn, 255u, sel, S.plan.stepSize);
             else hipLaunchKernelGGL(finalize_kernel<uint8_t>, g4, dim3(256), 0, st, ix->d_acc + r0, o, rn, 255u, sel);
             rc = launch_reset_limits(ix, (uint8_t*)d_out, n_seq, p->K, st);
         } else {
@@ -1090,6 +1114,7 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
             if (rn == 0) {}
             else if (ep) hipLaunchKernelGGL(finalize_fileset_kernel<uint16_t>, g1, dim3(256), 0, st, ix->d_bits + r0 * wordsPerKmer, wordsPerKmer, o, rn, sel);
             else if (store) hipLaunchKernelGGL((finalize2_kernel<uint16_t, uint16_t>), g16, dim3(256), 0, st, pf, pf + plane, o, rn, 65535u, sel);
+            else if (useDiff) hipLaunchKernelGGL(finalize_diff_kernel<uint16_t>, g8, dim3(256), 0, st, ix->d_acc + r0, ix->d_acc + diffOff + r0, o, rn, 65535u, sel, S.plan.stepSize);
             else hipLaunchKernelGGL(finalize_kernel<uint16_t>, g4, dim3(256), 0, st, ix->d_acc + r0, o, rn, 65535u, sel);
             rc = launch_reset_limits(ix, (uint16_t*)d_out, n_seq, p->K, st);
         }
@@ -1521,6 +1546,7 @@ int gm_index_set_tuning(gm_index* ix, const char* name, int64_t value)
         {"steal", &ix->tune.steal, dflt.steal, 0, 64}, {"part_bias", &ix->tune.partBias, dflt.partBias, -255, 255},
         {"child_tables", &ix->tune.childTables, dflt.childTables, 0, 1}, {"oss_weights", &ix->tune.ossWeights, dflt.ossWeights, 0, 0xFFFFFF},   // (-1: 5,4,7,8 at e = 2, the even split elsewhere)
         {"jump", &ix->tune.jump, dflt.jump, 0, 16}, {"self_hit", &ix->tune.selfHit, dflt.selfHit, 0, 1}, {"jump_filter", &ix->tune.jumpFilter, dflt.jumpFilter, 0, 1},
+        {"range_add", &ix->tune.rangeAdd, dflt.rangeAdd, 0, 1}, {"verify_t_ext", &ix->tune.verifyTExt, dflt.verifyTExt, 0, (int64_t)VERIFY_TMAX},
     };
     for (auto& t : tab) if (!strcmp(t.n, name)) {
         const bool isBias = t.f == &ix->tune.partBias;

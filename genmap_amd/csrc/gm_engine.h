@@ -306,6 +306,34 @@ GM_HD uint32_t scan_side(Env& env, const RootT<typename Env::row_t>& rt, const t
     return need;
 }
 
+// k-mers s0..s1 of the root's block all hit at the verified location (p0 is aligned with needle coordinate a0).  Leaf policies that
+// only count (Env::RANGE_ADD) take the run whole: void leaf_range(const Root&, uint32_t s0, uint32_t s1); the others get one
+// leaf_at per k-mer with its text position.
+template <class Env>
+GM_HD void emit_kmer_run(Env& env, const RootT<typename Env::row_t>& rt, uint32_t s0, uint32_t s1, typename Env::row_t p0, uint32_t a0)
+{
+    if constexpr (Env::RANGE_ADD) env.leaf_range(rt, s0, s1);
+    else for (uint32_t s = s0; s <= s1; ++s) env.leaf_at(rt, s, p0 - (a0 - s));
+}
+
+// Self hit (gm_kernels.h: search_body).  A forward-strand node with no error spent and ONE row left is the window's own location (a
+// string always matches itself) and nothing else can be found below it: the text there IS the needle, no mismatching child exists.
+// So every k-mer the node still covers gains exactly one occurrence -- without a suffix-array read, a record or another rank block.
+// In the OSS phase the self hit belongs to the search whose remaining lower bounds are all zero (find2:389-392; the bounds are
+// cumulative, the last is the largest): the other searches drop the node.  The caller has checked that the window holds no N (such
+// windows take the ordinary path, which knows which k-mers the N spoils); k-mers that cross a sequence end are zeroed by resetLimits
+// whatever is added.  Returns whether [smin, smax] gain their occurrence (false: the node is dropped without a hit).
+template <typename R>
+GM_HD bool self_hit_kmers(uint32_t meta, const RootT<R>& rt, uint32_t K, uint32_t& smin, uint32_t& smax)
+{
+    const uint32_t a = meta_a(meta), bx = meta_bx(meta), t = meta_t(meta), md = meta_mode(meta);
+    if (md == M_OSS) { smin = 0u; smax = rt.n - 1u; return oss_l(rt.rec, oss_nb(rt.rec) - 1u) == 0u; }
+    if (md == M_EXT_R) { smin = t - K; smax = a; }
+    else if (md == M_EXT_L) { smin = bx - K; smax = t; }
+    else { smin = bx - K; smax = a; }
+    return true;
+}
+
 template <class Env>
 GM_HD void verify_item(typename Env::row_t row, uint32_t meta, const RootT<typename Env::row_t>& rt, uint32_t K, uint32_t E, Env& env)
 {
@@ -340,19 +368,34 @@ GM_HD void verify_item(typename Env::row_t row, uint32_t meta, const RootT<typen
     uint32_t rc = 0, lc = 0;
     const uint32_t rlim = scan_side(env, rt, it, a0, bx, false, smax + K - bx, budget, rc, rp);
     const uint32_t llim = scan_side(env, rt, it, a0, a - 1u, true, a - smin, budget, lc, lp);
-    // only the k-mers the two scans reach: a - s <= llim and s + K - bx <= rlim (a chance hit reaches none: no loop at all)
+    // only the k-mers the two scans reach: a - s <= llim and s + K - bx <= rlim (a chance hit reaches none: nothing below runs)
     if (bx + rlim < K) return;
     if (a > llim && a - llim > smin) smin = a - llim;
     if (bx + rlim - K < smax) smax = bx + rlim - K;
-    for (uint32_t s = smin; s <= smax; ++s) {
-        env.note_wave(14);
-        const uint32_t lenL = a - s, lenR = s + K - bx;
-        if (lenL > llim || lenR > rlim) continue;
-        uint32_t d = 0;
+    if (smin > smax) return;
+    // k-mer s holds L(s) = #{j : lp[j] <= a - s} mismatches on the left and R(s) = #{j : rp[j] <= s + K - bx} on the right; it is a hit
+    // iff L(s) + R(s) <= budget.  L falls and R rises with s, so the hits are the union over i = 0..budget of the RUNS
+    //   { s : L(s) <= i } and { s : R(s) <= budget - i }  =  [a + 1 - lp[i], rp[budget - i] + bx - K - 1]
+    // (a mismatch that does not exist -- entry 0xFFFF, or index budget: the scans stop in front of mismatch budget + 1 -- bounds nothing).
+    // Both ends grow as i falls: the runs are merged in one ordered pass and handed to the leaf policy whole -- a frequency call adds a
+    // run with two memory operations instead of one per k-mer (K = 100: 24 k-mers per block).
+    int32_t curLo = 1, curHi = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) d += (lp[j] <= lenL ? 1u : 0u) + (rp[j] <= lenR ? 1u : 0u);
-        if (d <= budget) env.leaf_at(rt, s, p0 - (a0 - s));
+    for (uint32_t step = 0; step <= MAX_ERRORS; ++step) {
+        if (step > budget) break;
+        env.note_wave(14);
+        const uint32_t i = budget - step, r = step;   // i left mismatches allowed, r = budget - i right ones
+        const uint32_t lpi = i == 0 ? lp[0] : i == 1 ? lp[1] : i == 2 ? lp[2] : i == 3 ? lp[3] : 0xFFFFu;
+        const uint32_t rpr = r == 0 ? rp[0] : r == 1 ? rp[1] : r == 2 ? rp[2] : r == 3 ? rp[3] : 0xFFFFu;
+        int32_t lo = (int32_t)a + 1 - (int32_t)(i < budget ? lpi : 0xFFFFu), hi = (int32_t)(r < budget ? rpr : 0xFFFFu) + (int32_t)bx - (int32_t)K - 1;
+        if (lo < (int32_t)smin) lo = (int32_t)smin;
+        if (hi > (int32_t)smax) hi = (int32_t)smax;
+        if (lo > hi) continue;
+        if (curLo <= curHi && lo <= curHi + 1) { if (hi > curHi) curHi = hi; continue; }
+        if (curLo <= curHi) emit_kmer_run(env, rt, (uint32_t)curLo, (uint32_t)curHi, p0, a0);
+        curLo = lo; curHi = hi;
     }
+    if (curLo <= curHi) emit_kmer_run(env, rt, (uint32_t)curLo, (uint32_t)curHi, p0, a0);
 }
 
 // upper bound of simultaneously stacked nodes of one lane (DESIGN.md "stack bound")

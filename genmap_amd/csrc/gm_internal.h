@@ -27,7 +27,7 @@ namespace gm {
 // -1 = "library default for this call" (depends on K, E and the index size, see prepare_search)
 struct Tuning {
     int verifyT = -1, ldsStack = -1, blocksPerCU = 4, qtable = -1, satMinW = 256, fetchBatch = -1, probation = -1, verifyCost = 3;
-    int noStore = 0, noSaturate = 0, skipDup = -1, coop = -1, useCtx = 1, steal = -1, partBias = 0, childTables = -1, ossWeights = -1, jump = -1, selfHit = 1, jumpFilter = 1;
+    int noStore = 0, noSaturate = 0, skipDup = -1, coop = -1, useCtx = 1, steal = -1, partBias = 0, childTables = -1, ossWeights = -1, jump = -1, selfHit = 1, jumpFilter = 1, rangeAdd = 1, verifyTExt = -1;
 };
 }  // namespace gm
 

@@ -23,6 +23,9 @@ struct SearchArgs {
     uint64_t nRows;
     const uint8_t* text;        // slice base, one code per byte
     uint32_t* acc;              // per slice position, zeroed by the caller (two planes of accPlane entries with StoreEnv)
+    uint32_t* diff;             // CountEnv: difference plane of the verified runs (nullptr: runs are added k-mer by k-mer into acc).  A run of
+                                // k-mers [lo, hi] of ONE block adds +1 at lo and -1 at hi + 1 (nothing when hi is the block's last k-mer);
+                                // finalize_diff_kernel sums the plane inside each block and adds it to acc.  Regular partition only.
     uint64_t accPlane;
     uint32_t maxVal;            // 255 or 65535: the result is min(total, maxVal), so saturated k-mers need no further hits
     uint32_t K, E;
@@ -56,6 +59,7 @@ struct SearchArgs {
     const uint8_t* textS;           // sentinel text (one code per byte, 5 = sentinel), nRows bytes
     const uint4* ctx;               // optional: per forward SA row one 32-byte record {SA[row], 56 symbols around it} (CTX_* below)
     uint32_t verifyT;               // nodes with range width <= verifyT are resolved by verification (0 = off)
+    uint32_t verifyTExt;            // ... and this wide once the infix is complete (extension phase)
     uint32_t fetchBatch;            // roots are drawn when this many lanes are idle (or nothing else is left): the fetch code runs per batch
     uint32_t satMinW;               // saturation is looked up (a global read per covered k-mer) only for nodes at least this wide
     uint32_t probation;             // a single-row node that has spent every error is stepped this many times before it is verified
@@ -209,7 +213,8 @@ constexpr uint32_t NB_SYMS = 6;       // neighbour symbols per side carried by o
 constexpr uint32_t STEAL_LEVELS = 16;  // a lane gives away at most this many bottom entries before its stack has run empty once
 
 constexpr uint32_t WORK_CHUNK = 256;   // roots taken from the global counter per atomic
-constexpr uint32_t VERIFY_TMAX = 4;    // widest range resolved by verification
+constexpr uint32_t VERIFY_TMAX = 16;   // widest range resolved by verification
+constexpr uint32_t VERIFY_ROWS = 2;    // rows of one node queued per iteration (the rest waits on the lane's stack)
 
 template <int WPP> struct EnvBase {
     static constexpr bool EXACT_ONLY = false;   // StoreEnv: the kernel only ever runs with E = 0
@@ -217,6 +222,7 @@ template <int WPP> struct EnvBase {
     static constexpr bool JUMPS = false;        // regular roots start from the jump patterns of their search (gm_oss.h)
     static constexpr bool LEAFQ = false;        // leaves are queued per wavefront and located 64 rows at a time (LeafQueueEnv)
     static constexpr bool SELF_HIT = false;     // frequency policies: a lone error-free row on the forward strand is the window itself
+    static constexpr bool RANGE_ADD = false;    // the policy takes a run of hit k-mers whole (leaf_range) instead of one leaf_at per k-mer
     typedef typename BlockGeom<WPP>::row_t row_t;
     typedef NodeT<row_t> Node;
     typedef RootT<row_t> Root;
@@ -494,8 +500,11 @@ template <int WPP, bool JUMP = false> struct CountEnv : EnvBase<WPP> {
     typedef typename EnvBase<WPP>::row_t row_t;
     typedef typename EnvBase<WPP>::Root Root;
     static constexpr bool NLESS = JUMP, JUMPS = JUMP;   // the tables of the jump hold A,C,G,T strings only
-    // (SELF_HIT stays off here: measured on 3.09 Gbp the per-k-mer atomics of the shortcut cost more than the verification round
-    //  they replace -- e1 -5 %, K=100 e1 -10 %, profiles/r03/sweep_self_hit.txt -- while the miss-bound e = 0 kernel gains 9 %)
+    // Verified hits come as RUNS of k-mers of one block (gm_engine.h: verify_item): with the difference plane a run costs two
+    // fire-and-forget atomics whatever its length instead of one returning device-scope atomic per k-mer (3.09 Gbp K=100 e=1: a third
+    // of all memory requests of the pass were those atomics, WRITE_SIZE 98x the result, profiles/r03/final/pmc_by_config.txt).
+    // That also makes the self hit pay at e >= 1 (one atomic for the whole block instead of n; r03 measured -5..-10 % with n).
+    static constexpr bool RANGE_ADD = true, SELF_HIT = true;
     uint32_t leafSum = 0;
     uint32_t rootHits = 0;   // hits this lane has added for its current root (gates the saturation check)
     __device__ __forceinline__ CountEnv(const SearchArgs& a, uint4* s, uint32_t k) : EnvBase<WPP>(a, s, k) {}
@@ -528,6 +537,18 @@ template <int WPP, bool JUMP = false> struct CountEnv : EnvBase<WPP> {
         uint32_t* p = &A.acc[this->slice_pos(rt, kmer)];
         if (atomicAdd(p, 1u) == 0xFFFFFFFFu) atomicOr(p, 0x80000000u);
         // (verified hits are not added to rootHits: the verifying lane is not the root's lane)
+    }
+    // k-mers s0..s1 of the block each gain one occurrence
+    __device__ __forceinline__ void leaf_range(const Root& rt, uint32_t s0, uint32_t s1)
+    {
+        const row_t lo = rt.win + (rt.strand ? rt.n - 1u - s1 : s0), hi = lo + (s1 - s0);   // slice positions of the run
+        if (A.diff) {   // wave-uniform
+            // the sums are taken modulo 2^32 inside one block: a position's true count is below 2^32 (rows of the index)
+            __hip_atomic_fetch_add(&A.diff[lo], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (hi + 1u < rt.win + rt.n) __hip_atomic_fetch_add(&A.diff[hi + 1u], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            for (row_t p = lo; p <= hi; ++p) if (atomicAdd(&A.acc[p], 1u) == 0xFFFFFFFFu) atomicOr(&A.acc[p], 0x80000000u);
+        }
     }
 };
 
@@ -1055,7 +1076,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
             // phase the self hit belongs to the search whose remaining lower bounds are all zero (find2:389-392): the others drop the
             // node.  (k-mers that cross a sequence end are zeroed by resetLimits whatever is added here; a window with an N anywhere
             // takes the ordinary path, which knows which k-mers the N spoils.)
-            if (A.selfHit && have && nd.w == 1u && rt.strand == 0u && meta_errs(nd.meta) == 0u) {
+            if (A.selfHit && have && nd.w == 1u && rt.strand == 0u && meta_errs(nd.meta) == 0u && nd.rlo != ~(row_t)0) {   // (not the left-over rows of a wider node)
                 const uint32_t W = A.K + rt.n - 1u, nch = (env.woff + W + 31u) >> 5;
                 uint32_t anyN = 0;
                 for (uint32_t c = 0; c < nch; ++c) {
@@ -1063,11 +1084,10 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                     anyN |= (v.x | v.y | v.z | v.w) & 0x44444444u;   // (nibbles of the neighbouring text in the first / last chunk count too: harmless)
                 }
                 if (anyN == 0u) {
-                    const bool counts = meta_mode(nd.meta) != M_OSS || oss_l(rt.rec, oss_nb(rt.rec) - 1u) == 0u;   // cumulative bounds: the last is the largest
-                    if (counts) {
-                        uint32_t smin, smax;
-                        covered_kmers(nd.meta, rt.n, A.K, smin, smax);
-                        for (uint32_t k = smin; k <= smax; ++k) env.leaf_at(rt, k, (row_t)0);
+                    uint32_t smin, smax;
+                    if (self_hit_kmers(nd.meta, rt, A.K, smin, smax)) {   // gm_engine.h
+                        if constexpr (EnvT::RANGE_ADD) env.leaf_range(rt, smin, smax);
+                        else for (uint32_t k = smin; k <= smax; ++k) env.leaf_at(rt, k, (row_t)0);
                     }
                     have = false;
                 }
@@ -1154,9 +1174,12 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
         GM_LAP2(tSt1);
         // ---- defer narrow nodes: one queue entry per SA row ----
         if (A.verifyT) {
-            bool narrow = have && nd.w <= A.verifyT;
-            if (narrow) {   // is the subtree below worth one SA read + one text comparison per row?
-                const uint32_t m = nd.meta, a = meta_a(m), bx = meta_bx(m), t = meta_t(m), md = meta_mode(m);
+            const uint32_t md0 = meta_mode(nd.meta);
+            // (extension-phase nodes have the whole infix behind them: one row there costs a record read and two short scans, while the
+            //  walk still has ~n log n steps to go -- they may be wider than the nodes verified inside the infix)
+            bool narrow = have && nd.w <= (md0 == M_OSS ? A.verifyT : A.verifyTExt);
+            if (narrow && nd.rlo != ~(row_t)0) {   // is the subtree below worth one SA read + one text comparison per row?
+                const uint32_t m = nd.meta, a = meta_a(m), bx = meta_bx(m), t = meta_t(m), md = md0;
                 const uint32_t covered = md == M_OSS ? rt.n : md == M_EXT_R ? a + A.K - t + 1u : md == M_EXT_L ? t + A.K - bx + 1u : a + A.K - bx + 1u;
                 const uint32_t est = (A.K - (bx - a)) + covered - 1u;   // lower bound of the steps still needed
                 narrow = nd.w * A.verifyCost <= est;
@@ -1168,8 +1191,10 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                 // reverse-strand chance hits their SA + text reads (5.31 vs 5.46 ms, profiles/r01e_infix_sweeps.txt)
                 if (A.E == 0u && md == M_OSS) narrow = false;
             }
+            // At most VERIFY_ROWS rows of a node are queued per iteration (the queue holds 64 + 64 * VERIFY_ROWS entries); the rows left
+            // over go back onto the lane's stack as a rows-only node (rlo = all ones: never stepped, queued the moment it is popped).
 #pragma unroll 1
-            for (uint32_t r = 0; r < VERIFY_TMAX; ++r) {
+            for (uint32_t r = 0; r < VERIFY_ROWS; ++r) {
                 const bool e = narrow && r < nd.w;
                 const unsigned long long m = __ballot(e);
                 if (m == 0ull) break;
@@ -1180,9 +1205,12 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                 }
                 qsize += (uint32_t)__popcll(m);
             }
-            if (narrow) have = false;
+            if (narrow) {
+                have = false;
+                if (nd.w > VERIFY_ROWS) { nd.flo += VERIFY_ROWS; nd.w -= VERIFY_ROWS; nd.rlo = ~(row_t)0; env.push(nd); }
+            }
             // a partial round only when the wavefront has nothing else left to do
-            const bool finishing = (__ballot(have || fs != 0u) == 0ull) && (__ballot(!exhausted) == 0ull);
+            const bool finishing = (__ballot(have || fs != 0u || env.sp != 0u) == 0ull) && (__ballot(!exhausted) == 0ull);
             while (qsize >= 64u || (finishing && qsize > 0u)) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -1387,6 +1415,37 @@ __global__ __launch_bounds__(256) void finalize_kernel(const uint32_t* __restric
                            (TValue)(v.z < maxVal ? v.z : maxVal), (TValue)(v.w < maxVal ? v.w : maxVal)};
             if (sizeof(TValue) == 1) *reinterpret_cast<uint32_t*>(out + bb + g * 4) = *reinterpret_cast<uint32_t*>(r);
             else *reinterpret_cast<uint2*>(out + bb + g * 4) = *reinterpret_cast<uint2*>(r);
+        }
+    }
+}
+
+// acc + difference plane of the verified runs -> c[] (CountEnv::leaf_range).  The runs of a block never leave it and blocks start at
+// multiples of stepSize from the range's first position (regular partition; a shard's chunks are whole blocks), so the running sum
+// restarts at every block: count(j) = acc[j] + sum of diff over [block start of j, j].  A workgroup stages a tile of whole blocks of the
+// plane in LDS; every position sums its block's entries up to itself from there (stepSize / 2 LDS reads on average).
+template <typename TValue>
+__global__ __launch_bounds__(256) void finalize_diff_kernel(const uint32_t* __restrict__ acc, const uint32_t* __restrict__ diff, TValue* __restrict__ out, uint64_t n, uint32_t maxVal,
+                                                            ChunkSel sel, uint32_t stepSize)
+{
+    constexpr uint32_t TILE = 2048;
+    __shared__ uint32_t sd[TILE];
+    const uint32_t tile = TILE / stepSize * stepSize;   // whole blocks (stepSize <= MAX_K)
+    const uint64_t nr = own_ranges(sel, n);
+    for (uint64_t q = blockIdx.y; q < nr; q += gridDim.y) {
+        uint64_t b, e;
+        own_range(sel, n, q, b, e);
+        for (uint64_t t0 = b + (uint64_t)blockIdx.x * tile; t0 < e; t0 += (uint64_t)gridDim.x * tile) {
+            const uint32_t len = e - t0 < tile ? (uint32_t)(e - t0) : tile;
+            for (uint32_t k = threadIdx.x; k < len; k += 256u) sd[k] = diff[t0 + k];
+            __syncthreads();
+            for (uint32_t k = threadIdx.x; k < len; k += 256u) {
+                const uint32_t off = k % stepSize;
+                uint32_t s = 0;
+                for (uint32_t i = 0; i <= off; ++i) s += sd[k - i];
+                const uint64_t tot = (uint64_t)acc[t0 + k] + s;   // (a sticky top bit of acc stays above MAX)
+                out[t0 + k] = (TValue)(tot < maxVal ? tot : maxVal);
+            }
+            __syncthreads();
         }
     }
 }

@@ -14,6 +14,8 @@ using namespace gm;
 
 static uint32_t g_ossWeights = 0;   // relative OSS block lengths for the plans below (gm_host.h: make_map_plan), 0 = even split
 extern "C" void gm_emu_set_oss_weights(uint32_t w) { g_ossWeights = w; }
+static int g_selfHit = 1;           // self hits of the counting pass (gm_engine.h: self_hit_kmers)
+extern "C" void gm_emu_set_self_hit(int on) { g_selfHit = on; }
 
 template <int WPP> struct HostIndex {
     std::vector<uint32_t> blk[2];
@@ -39,10 +41,21 @@ template <int WPP> struct HostIndex {
     }
 };
 
-template <int WPP, bool NL = false> struct EmuEnv {
+template <int WPP, bool NL = false, bool RA = false> struct EmuEnv {
     typedef uint32_t row_t;
     static constexpr bool EXACT_ONLY = false;
     static constexpr bool NLESS = NL;
+    // the main pass takes verified runs of k-mers whole, like the device's CountEnv: +1 / -1 in a difference plane that the end of run()
+    // sums inside each block (regular partition), or k-mer by k-mer into acc (selections)
+    static constexpr bool RANGE_ADD = RA;
+    std::vector<uint32_t>* diff = nullptr;
+    uint64_t selfHits = 0;
+    void leaf_range(const Root& rt, uint32_t s0, uint32_t s1)
+    {
+        const uint32_t lo = rt.win + (rt.strand ? rt.n - 1 - s1 : s0), hi = lo + (s1 - s0);
+        if (diff) { (*diff)[lo] += 1u; if (hi + 1u < rt.win + rt.n) (*diff)[hi + 1u] -= 1u; }
+        else for (uint32_t p = lo; p <= hi; ++p) { uint32_t& v = (*acc)[p]; if (v != 0xFFFFFFFFu) ++v; }
+    }
     // correction pass (scatter): a located occurrence adds one to ITS OWN slice position (the needle is a text window with N)
     bool scatter = false;
     const uint64_t* cumAll = nullptr; uint32_t nSeqAll = 0; uint64_t sliceBegin = 0, sliceLen = 0;
@@ -168,6 +181,15 @@ static void search_plan(const MapPlan& plan, const HostIndex<WPP>& ix, Env& env,
         bool have = true;
         for (;;) {
             if (!have) { if (env.stack.empty()) break; nd = env.stack.back(); env.stack.pop_back(); have = true; }
+            if (Env::RANGE_ADD && g_selfHit && nd.w == 1u && rt.strand == 0u && meta_errs(nd.meta) == 0u) {   // gm_kernels.h: self hits
+                bool anyN = false;
+                for (uint32_t i = 0; i < K + rt.n - 1u; ++i) anyN |= env.text_char(rt, i) >= SYM_N;
+                if (!anyN) {
+                    uint32_t smin, smax;
+                    if (self_hit_kmers(nd.meta, rt, K, smin, smax)) { if constexpr (Env::RANGE_ADD) env.leaf_range(rt, smin, smax); }
+                    env.selfHits++; have = false; continue;
+                }
+            }
             if (env.saArr && verifyT && nd.w <= verifyT) {   // the device defers these to a wave-wide verification round
                 for (uint32_t r2 = 0; r2 < nd.w; ++r2) verify_item(nd.flo + r2, nd.meta, rt, K, E, env);
                 env.verified += nd.w; have = false; continue;
@@ -225,7 +247,9 @@ static int run(const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nse
     if (rc) return rc;
     HostIndex<WPP> ix; ix.build(bf, br, rows, nseqTotal);
     std::vector<uint32_t> acc(textLen ? textLen : 1, 0);
-    EmuEnv<WPP, NL> env; env.ix = &ix; env.text = text; env.K = K; env.acc = &acc;
+    EmuEnv<WPP, NL, true> env; env.ix = &ix; env.text = text; env.K = K; env.acc = &acc;
+    std::vector<uint32_t> diff(textLen + 1, 0);
+    if (!plan.useList) env.diff = &diff;
     std::vector<uint8_t> textS;
     if (sa && (verifyT || NL)) {   // sentinel text: sequence s occupies [cum[s] + s, cum[s+1] + s), sentinel after it
         textS.resize(rows);
@@ -262,15 +286,19 @@ static int run(const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nse
         }
     }
     uint32_t maxv = valueBits == 8 ? 255u : 65535u;
+    uint32_t run = 0;
     for (uint64_t j = 0; j < textLen; ++j) {
-        uint32_t v = acc[j] < maxv ? acc[j] : maxv;
+        if (j % plan.stepSize == 0) run = 0;               // gm_kernels.h: finalize_diff_kernel
+        run += diff[j];
+        const uint64_t tot = (uint64_t)acc[j] + (env.diff ? run : 0u);
+        uint32_t v = tot < maxv ? (uint32_t)tot : maxv;
         if (valueBits == 8) ((uint8_t*)out)[j] = (uint8_t)v; else ((uint16_t*)out)[j] = (uint16_t)v;
     }
     for (uint32_t s = 1; s <= nseqLocal; ++s) {   // resetLimits, algo.hpp:10-22
         uint64_t lim = std::min<uint64_t>(K, seqCum[s] - seqCum[s - 1] + 1);
         for (uint64_t j = 1; j < lim; ++j) { if (valueBits == 8) ((uint8_t*)out)[seqCum[s] - j] = 0; else ((uint16_t*)out)[seqCum[s] - j] = 0; }
     }
-    if (stats) { stats[0] = env.maxDepth; stats[1] = bound; stats[2] = env.steps; stats[3] = env.verified; stats[4] = nPatterns; stats[5] = corrRoots; }
+    if (stats) { stats[0] = env.maxDepth; stats[1] = bound; stats[2] = env.steps; stats[3] = env.verified; stats[4] = nPatterns; stats[5] = corrRoots; stats[6] = env.selfHits; }
     return 0;
 }
 
@@ -287,7 +315,7 @@ extern "C" uint64_t gm_emu_n_window_intervals(const uint8_t* codes, const uint64
 }
 
 // jumpCap: longest jump (0 = the plain tree walk from the root); nless != 0: the main pass never follows the text letter N and the
-// correction pass adds the occurrences with N in the text (needs sa, allCodes, allCum).  stats: 6 entries.
+// correction pass adds the occurrences with N in the text (needs sa, allCodes, allCum).  stats: 7 entries.
 extern "C" int gm_emu_map2(int wpp, const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nseqTotal, const uint8_t* text,
                            uint64_t textLen, const uint64_t* seqCum, uint32_t nseqLocal, uint32_t K, uint32_t E, int32_t xo,
                            int32_t infixOverride, int revcompl, int valueBits, const uint64_t* intervals, uint64_t nIntervals,
@@ -312,7 +340,7 @@ extern "C" int gm_emu_map(int wpp, const uint8_t* bf, const uint8_t* br, uint64_
                           int32_t infixOverride, int revcompl, int valueBits, const uint64_t* intervals, uint64_t nIntervals,
                           void* out, uint64_t* stats, const uint32_t* sa, uint32_t verifyT, const uint8_t* allCodes, const uint64_t* allCum)
 {
-    uint64_t st[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t st[7] = {0, 0, 0, 0, 0, 0, 0};
     const int rc = gm_emu_map2(wpp, bf, br, rows, nseqTotal, text, textLen, seqCum, nseqLocal, K, E, xo, infixOverride, revcompl, valueBits, intervals, nIntervals,
                                out, st, sa, verifyT, allCodes, allCum, 0, 0);
     if (stats) for (int i = 0; i < 4; ++i) stats[i] = st[i];

@@ -190,7 +190,7 @@ def emu_map2(ix, wpp, K, E, first_seq=0, n_seq=None, xo=None, infix=0, revcompl=
     cum = np.ascontiguousarray(ix.cum[first_seq:first_seq + n_seq + 1] - ix.cum[first_seq]).astype(np.uint64)
     out = np.zeros(tl, dtype=np.uint8 if value_bits == 8 else np.uint16)
     iv = np.ascontiguousarray(np.asarray(intervals, dtype=np.uint64).reshape(-1)) if intervals else None
-    stats = np.zeros(6, dtype=np.uint64)
+    stats = np.zeros(7, dtype=np.uint64)
     sa = ix.sa()
     rc = e.gm_emu_map2(wpp, H._ptr(bf), H._ptr(br), ix.n, len(ix.seq_len), C.c_void_p(allcodes.ctypes.data + tb), tl, H._ptr(cum), n_seq, K, E,
                        -1 if xo is None else xo, infix, int(revcompl), value_bits, H._ptr(iv), 0 if iv is None else len(iv) // 2,

@@ -29,6 +29,12 @@ def _repeat_text(rng, n, dna5):
         mut = rng.random(300) < 0.05
         cp[mut] = rng.integers(0, 4, size=int(mut.sum()), dtype=np.uint8)
         codes[s:s + 300] = cp[:max(0, min(300, n - s))]
+    if n > 20000:   # a family of EXACT copies, and copies one substitution away (wide extension-phase nodes: verify_t_ext, left-over rows)
+        fam2 = rng.integers(0, 4, size=400, dtype=np.uint8)
+        for i, s in enumerate(rng.integers(0, n - 400, size=9)):
+            cp = fam2.copy()
+            if i >= 6: cp[rng.integers(0, 400)] ^= 1
+            codes[s:s + 400] = cp
     if dna5:
         a = n // 3
         codes[a:a + max(1, n // 50)] = 4
@@ -230,10 +236,12 @@ def test_gpu_baseline_settings_small(K, E):
                 # rank blocks read by one lane / by groups of lanes; verification from the 32-byte row records / from SA + text;
                 # idle lanes steal from their neighbours' stacks or not
                 # ... jump patterns + N-less pass + correction pass (default), short jumps, or the plain tree walk with N children
-                for coop, ctx, steal, jump in (((1, 1, 0, -1), (0, 0, 0, 0), (1, 0, 1, 7), (0, 1, 1, -1)) if bb in (32, 64) else ((0, 1, 0, -1), (0, 0, 1, 0))):
-                    ix.set_tuning(verify_t=T, coop=coop, use_ctx=ctx, steal=steal, jump=jump, jump_filter=1 - (T & 1))   # neighbour filter on / off
+                # ... verified runs of k-mers through the difference plane + self hits (default) or k-mer by k-mer; extension-phase
+                # nodes verified up to 16 / 3 rows wide (their left-over rows wait on the lane's stack), the library's default, or as the others
+                for coop, ctx, steal, jump, ra, text in (((1, 1, 0, -1, 1, 16), (0, 0, 0, 0, 0, -1), (1, 0, 1, 7, 1, 3), (0, 1, 1, -1, 1, -1)) if bb in (32, 64) else ((0, 1, 0, -1, 1, 5), (0, 0, 1, 0, 0, -1))):
+                    ix.set_tuning(verify_t=T, coop=coop, use_ctx=ctx, steal=steal, jump=jump, jump_filter=1 - (T & 1), range_add=ra, self_hit=1 if T else ra, verify_t_ext=text)   # neighbour filter on / off
                     out = ix.map(K, E, value_bits=bits)
-                    assert np.array_equal(out, exp), (K, E, bits, bb, T, coop, ctx, steal, jump)
+                    assert np.array_equal(out, exp), (K, E, bits, bb, T, coop, ctx, steal, jump, ra, text)
         ix.close()
 
 
