@@ -12,8 +12,9 @@ frequencies), raw output; the map computation alone is timed, index resident (lo
 A "step" is one complete computeMappability pass (src/algo.hpp:405-483) over the text with the index already in HBM:
 clear of the accumulators, the search kernel, finalize/resetLimits, and -- for N > 1 -- the gather of the ranks' chunks of
 the frequency vector to rank 0.  Each rank holds a full index replica and computes interleaved chunks of whole k-mer
-blocks (strong scaling: the genome is fixed).  The headline line is K=30, e=0; the same JSON line carries sub-records
-for (30,1), (30,2) and (100,1) -- config C3 and C4 of BASELINE.json -- measured in the same run AT EVERY N, each with its
+blocks (strong scaling: the genome is fixed).  The headline line is K=30, e=2 -- BASELINE.json's one-GPU configuration on the
+3.1 Gbp index (C3); the same JSON line carries sub-records for (30,0), (30,1) and (100,1) = config C4, measured in the same
+run AT EVERY N, each with its
 own roofline (numerator counted by the instrumented twin library after the timed part, shard by shard for N > 1;
 denominator = HIP-event time of the search kernel over the timed steps, the slowest rank's for N > 1) and CPU baseline.
 
@@ -51,31 +52,51 @@ def mark(*a):
         print(f"[bench r{os.environ.get('RANK', '0')} +{time.time() - _T0:7.1f}s]", *a, file=sys.stderr, flush=True)
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 class CpuBaseline:
-    """The oracle (a port of the reference algorithm, kind="port") on this box's host cores, on a bounded sample:
-    whole k-mer blocks from the start of the text, sized so that the timed run takes roughly 10 s."""
+    """The oracle (a port of the reference algorithm, kind="port") on this box's host cores, on a bounded sample: whole k-mer
+    blocks from the start of the text, sized so that the timed run takes roughly 10 s.  Built for THIS host with -O3 -march=native
+    (POPCNT, as the reference ships it: README.rst:60-62), 64-byte rank blocks (one cache line per query), rank arrays built and
+    first touched by the threads that use them; timed with every hardware thread and with ONE thread."""
 
     def __init__(self, codes, lens, bwt, threads):
         sys.path.insert(0, str(ROOT / "tests"))
         import helpers as H
         t0 = time.time()
-        self.ora = H.OracleIndex(codes, lens, keep_sa=False, bwt=bwt)
-        self.n, self.threads = len(codes), threads
-        log(f"cpu_baseline: oracle adopted the GPU-built BWTs in {time.time() - t0:.1f} s")
+        so = H.build_oracle_native()
+        self.build = "-O3 -march=native" if so else "-O3 -mpopcnt (portable build: the native build failed on this host)"
+        self.ora = H.OracleIndex(codes, lens, keep_sa=False, bwt=bwt, lib=H.oracle_lib(so))
+        self.n, self.threads, self.model = len(codes), threads, cpu_model()
+        log(f"cpu_baseline: oracle ({self.build}) adopted the GPU-built BWTs in {time.time() - t0:.1f} s on {self.model}, {threads} threads")
 
-    def run(self, K, E, first_guess):
+    def _timed(self, K, E, first_guess, threads, target):
         n = self.n
         skip = min(n // 10, 20_000)               # stay clear of the leading N block
         avail = n - skip - K
         sample, dt = min(first_guess, avail), 0.0
-        while True:                                # grow the sample until the timed run takes >= 8 s (or covers the text)
+        while True:                                # grow the sample until the timed run takes >= target s (or covers the text)
             t0 = time.time()
-            self.ora.mappability(K, E, value_bits=8, threads=self.threads, intervals=[(skip, skip + sample)])
+            self.ora.mappability(K, E, value_bits=8, threads=threads, intervals=[(skip, skip + sample)])
             dt = time.time() - t0
-            if dt >= 8.0 or sample >= avail:
+            if dt >= target or sample >= avail:
                 break
-            sample = int(min(avail, max(sample * 2, sample * 11.0 / max(dt, 1e-3))))
-        return {"value": sample / dt, "unit": "k-mers/s", "cores": self.threads, "kind": "port",
+            sample = int(min(avail, max(sample * 2, sample * (target * 1.4) / max(dt, 1e-3))))
+        return sample, dt, skip
+
+    def run(self, K, E, first_guess):
+        sample, dt, skip = self._timed(K, E, first_guess, self.threads, 8.0)
+        s1, dt1, _ = self._timed(K, E, max(1000, first_guess // max(1, self.threads // 2)), 1, 4.0)
+        return {"value": sample / dt, "unit": "k-mers/s", "cores": self.threads, "kind": "port", "build": self.build, "cpu_model": self.model,
+                "threads_1": {"value": s1 / dt1, "unit": "k-mers/s", "sample": f"{s1} positions, {dt1:.1f} s"},
                 "sample": f"{sample} consecutive k-mer positions from offset {skip} of the same index, K={K} E={E}, both strands, {dt:.1f} s"}
 
 
@@ -99,14 +120,14 @@ def read_fasta(path):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="grch38", help="grch38 | chr1 | ecoli (one FASTA, frequency pass) | bacteria5 (config C5: five FASTA files, --exclude-pseudo, csv)")
     ap.add_argument("--scale", type=float, default=1.0)
     ap.add_argument("--fasta", default=None, help="real FASTA file instead of the synthetic workload")
     ap.add_argument("--K", type=int, default=0, help="default 30 (24 for bacteria5)")
-    ap.add_argument("--E", type=int, default=-1, help="default 0 (1 for bacteria5)")
-    ap.add_argument("--sub", default="30,1:2;30,2:1;100,1:2", help="sub-records 'K,E:steps;...' measured after the headline; '' = none")
+    ap.add_argument("--E", type=int, default=-1, help="default 2 = BASELINE.json's one-GPU 3.1 Gbp configuration C3 (1 for bacteria5)")
+    ap.add_argument("--sub", default="30,0:20;30,1:3;100,1:3", help="sub-records 'K,E:steps;...' measured after the headline (one warm-up step each); '' = none")
     ap.add_argument("--block-bytes", type=int, default=0)
     ap.add_argument("--infix", type=int, default=0, help="common-infix length (SearchParams.overlap); 0 = library default")
     ap.add_argument("--sampling", type=int, default=1, help="1: keep the suffix array resident (narrow nodes are verified against the text); 0: rank queries only; "
@@ -122,7 +143,17 @@ def main():
     ap.add_argument("--no-counters", action="store_true")
     ap.add_argument("--no-csv", action="store_true", help="bacteria5: skip the csv location lists (gm_locate), time the --exclude-pseudo frequencies only")
     ap.add_argument("--trace", type=float, default=0.0, help="print stage markers from every rank and, after this many seconds, every thread's Python stack (diagnosis of a stalled multi-rank run)")
+    ap.add_argument("--allow-mixed-features", action="store_true", help="N > 1: time the run even if the ranks' index replicas differ (records, table length)")
+    ap.add_argument("--no-preflight", action="store_true", help="N > 1: skip the verified (100,1) step through both transports that precedes every timing")
+    ap.add_argument("--no-traffic", action="store_true", help="skip roofline.traffic (two extra processes under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE after the timed part, N = 1 only)")
+    ap.add_argument("--protocol", default="", choices=["", "reference"], help="reference: the reference's own benchmark protocol (benchmarks/bench.sh:35-43: (5,0), (6,0), (101,0..4)) "
+                    "on the same index, one pass each -- tools/protocol_reference.py; E = 4 takes minutes, never part of the default line")
     args = ap.parse_args()
+    if args.protocol == "reference":
+        import runpy
+        sys.argv = [str(ROOT / "tools" / "protocol_reference.py"), "--workload", args.workload, "--scale", str(args.scale)]
+        runpy.run_path(sys.argv[0], run_name="__main__")
+        return
     if args.trace > 0:
         global TRACE
         TRACE = True
@@ -130,7 +161,7 @@ def main():
         faulthandler.dump_traceback_later(args.trace, repeat=True, file=sys.stderr)
     c5 = args.workload == "bacteria5" and not args.fasta
     args.K = args.K or (24 if c5 else 30)
-    args.E = args.E if args.E >= 0 else (1 if c5 else 0)
+    args.E = args.E if args.E >= 0 else (1 if c5 else 2)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -153,6 +184,7 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
     cdev = dev if args.backend == "nccl" else "cpu"   # where the small control tensors of the collectives live
+    rccl_ranks = dist.get_world_size() if (world > 1 and args.backend == "nccl") else 0
 
     t0 = time.time()
     files5 = fid = None
@@ -231,9 +263,29 @@ def main():
                 self.t.cancel()
             return False
 
-    def measure(K, E, steps, warmup):
+    features = {"per_rank": None}
+
+    def check_features(K, E):
+        """N > 1: every rank reports what its index replica got (verification records, suffix array, the q-mer table / jump length of this
+        call -- the 69 GB table of all 16-mers shrinks by itself when a device is short of memory); ranks with different features compute the
+        same result at different speeds, which would look like a scaling problem: refuse to time such a mix"""
+        if world == 1:
+            return
+        tq = ix.last_stats()["detail"].get("table_q", 0)
+        mine = {"rank": rank, "verify_records": info["verify_records"], "sampling": info["sampling"], "q": tq & 255, "J": tq >> 8, "device_gib": round(ix.info()["device_bytes"] / 2**30, 2)}
+        allf = [None] * world
+        dist.all_gather_object(allf, mine)
+        features["per_rank"] = allf
+        log(f"index features per rank for K={K} E={E}: {allf}")
+        key = lambda f: (f["verify_records"], f["sampling"], f["q"], f["J"])
+        if len({key(f) for f in allf}) > 1 and not args.allow_mixed_features:
+            raise SystemExit(f"ranks got different index features {allf}: not timing a mix (--allow-mixed-features overrides)")
+
+    def measure(K, E, steps, warmup, verify=None, comm_mode=None):
         """W warm-up steps, then exactly `steps` timed steps between barrier + synchronize; returns the record."""
         nonlocal out
+        verify = args.verify if verify is None else verify
+        comm_mode = comm_mode or args.comm
         infix = args.infix or g.tuned_infix_length(K, E)
         num_kmers = n - K + 1
         plan = ShardPlan(num_kmers, K - infix + 1, world)
@@ -242,7 +294,7 @@ def main():
         comm = {"wait_s": 0.0, "mode": "none", "note": None}
         pg = None
         mark(f"measure K={K} E={E}: plan {plan.nchunks} chunks of {plan.chunk_len} positions")
-        if world > 1 and args.comm == "p2p":
+        if world > 1 and comm_mode == "p2p":
             pg = PeerGather(plan, n, 1, rank, local_rank, dist, mark=mark)
             mark(f"PeerGather ready: ok={pg.ok} launches={pg.launches}")
             if not pg.ok:
@@ -294,6 +346,8 @@ def main():
             mark(f"warm-up step {i} issued")
         sync()
         mark("warm-up done")
+        if warmup > 0 or pg is not None:
+            check_features(K, E)
         warm_wait = comm["wait_s"]
         t0 = time.perf_counter()
         for i in range(steps):
@@ -305,7 +359,8 @@ def main():
         launches = pg.launches if pg else 1
         kms = ix.kernel_times(min(steps * launches, 64 // launches * launches))   # HIP events around the search kernel of each timed launch, on the launch stream
         kms = [float(np.sum(kms[i * launches:(i + 1) * launches])) for i in range(len(kms) // launches)]
-        if args.verify and world > 1:
+        verified = None
+        if verify and world > 1:
             sync()
             if rank == 0:
                 if pg:
@@ -319,10 +374,12 @@ def main():
                 torch.cuda.synchronize()
                 same = bool(torch.equal(got, ref[:n]))
                 log(f"verify K={K} E={E}: gathered vector {'==' if same else '!='} single-rank vector ({comm['mode']})")
-                if not same:
+                if not same and verify != "report":
                     raise SystemExit("gathered result differs from the single-rank result")
                 del got, ref
+                verified = same
             sync()
+            verified = bool(max_over_ranks(1.0 if verified else 0.0)) if verified is not None or rank != 0 else None
         if pg:
             pg.close()
         dt = max_over_ranks(dt)
@@ -330,7 +387,7 @@ def main():
         pr = per_rank_of([my_ms, (comm["wait_s"] - warm_wait) / max(1, steps) * 1e3])
         return {"K": K, "E": E, "infix": infix, "num_kmers": num_kmers, "steps": steps, "warmup": warmup, "dt": dt,
                 "kernel_ms": max(r[0] for r in pr) if pr else my_ms, "kernel_ms_min": float(np.min(kms)), "plan": plan,
-                "comm_mode": comm["mode"], "comm_note": comm["note"], "per_rank": pr}
+                "comm_mode": comm["mode"], "comm_note": comm["note"], "per_rank": pr, "verified": verified}
 
     def host_rate(K, E):
         """PCIe-inclusive rates of the drop-in call gm_map (host result vector), never `value`: into ordinary (pageable) memory,
@@ -395,7 +452,7 @@ def main():
         my_ms = float(np.sum(kms)) / max(1, len(kms) // len(slices))
         pr = per_rank_of([my_ms, 0.0])
         rec = {"K": K, "E": E, "infix": infix, "num_kmers": total_kmers, "steps": steps, "warmup": warmup, "dt": dt, "kernel_ms": max(r[0] for r in pr) if pr else my_ms,
-               "per_rank": pr, "csv": None}
+               "per_rank": pr, "csv": None, "slices": slices, "ranges": [rg for rg, _ in bufs]}
         if not args.no_csv:
             sync()
             t0 = time.perf_counter()
@@ -409,26 +466,48 @@ def main():
     if c5:
         with Watchdog():
             head = measure_c5(args.K, args.E, args.steps, args.warmup)
-        subs, value_host, value_host_pinned = [], None, None
+        subs, value_host, value_host_pinned, host_cfg = [], None, None, None
     else:
+        preflight = None
+        if world > 1 and not args.no_preflight:
+            # Before anything is timed: ONE step of config C4 (K=100, e=1) through each transport, the gathered vector compared with rank 0's
+            # own single-rank computation.  A transport that fails (or cannot be set up) is not timed; if both fail the run stops here.
+            preflight = {}
+            for mode in ("p2p", "collective"):
+                with Watchdog():
+                    r = measure(100, 1, 1, 0, verify="report", comm_mode=mode)
+                ok = bool(r["verified"]) and (mode == "collective" or r["comm_mode"].startswith("peer"))
+                preflight[mode] = "verified" if ok else ("not available: " + (r["comm_note"] or "fell back") if r["verified"] else "WRONG RESULT")
+            log(f"preflight (K=100 e=1, one verified step per transport): {preflight}")
+            if preflight["p2p"] != "verified" and args.comm == "p2p":
+                args.comm = "collective"
+            if preflight["collective"] == "WRONG RESULT" and args.comm == "collective":
+                raise SystemExit("preflight: no transport delivers the single-rank result")
+            log(f"timing with --comm {args.comm}")
         with Watchdog():
             head = measure(args.K, args.E, args.steps, args.warmup)
         subs = []
         for item in filter(None, args.sub.split(";")):
             ke, st = item.split(":")
             K, E = map(int, ke.split(","))
+            if (K, E) == (args.K, args.E):
+                continue
             with Watchdog():
-                subs.append(measure(K, E, int(st), 1 if E < 2 else 0))
+                subs.append(measure(K, E, int(st), 1))
             log(f"sub-record K={K} E={E}: {subs[-1]['dt'] / subs[-1]['steps'] * 1e3:.1f} ms/step")
-        value_host, value_host_pinned = host_rate(args.K, args.E) if (world == 1 and not args.no_host_rate) else (None, None)
+        # PCIe-inclusive rate of the drop-in call gm_map, measured where the transfer weighs most: the cheapest pass (e = 0)
+        host_cfg = (args.K, 0) if any((r["K"], r["E"]) == (args.K, 0) for r in [head] + subs) else (args.K, args.E)
+        value_host, value_host_pinned = host_rate(*host_cfg) if (world == 1 and not args.no_host_rate) else (None, None)
 
     # ---- the multi-rank part ends here: every rank but 0 releases its index and leaves; rank 0 counts and prints ----
     bwt_host = sa_host = None
-    want_twin = not args.no_counters and g.lib_path(True).exists() and not c5
+    want_twin = not args.no_counters and g.lib_path(True).exists()
     if rank == 0 and (not args.no_cpu_baseline or want_twin):
         bwt_host = ix.export_bwt()
         if want_twin and args.sampling == 1:
             sa_host = ix.export_sa()
+        elif want_twin and args.sampling > 1:
+            sa_host = ix.export_sa_sampled()   # (mark words, samples)
     ix.close()
     out = None
     torch.cuda.empty_cache()
@@ -445,13 +524,33 @@ def main():
     if want_twin:
         try:
             bf, br = bwt_host
-            ixp = g.Index.from_bwt(bf, br, codes, lens, sa_fwd=sa_host, sampling=args.sampling,
-                                   block_bytes=info["block_bytes"], device=local_rank, profiling=True)
+            if args.sampling > 1:
+                ixp = g.Index.from_sampled(bf, br, sa_host[0], sa_host[1], codes, lens, args.sampling, block_bytes=info["block_bytes"], device=local_rank, profiling=True)
+            else:
+                ixp = g.Index.from_bwt(bf, br, codes, lens, sa_fwd=sa_host, sampling=args.sampling,
+                                       block_bytes=info["block_bytes"], device=local_rank, profiling=True)
             sa_host = None
             if ixp.info()["verify_records"] != info["verify_records"]:
                 log("warning: the instrumented twin did not get the same verification records as the timed index")
-            tmp = torch.zeros(max(r["plan"].padded_len(n) for r in [head] + subs), dtype=torch.uint8, device=dev)
-            for rec in [head] + subs:
+            if c5:   # the --exclude-pseudo pass of every file, share by share, with the arguments the ranks used
+                tot = None
+                tmp = torch.zeros(max(tl for _, _, tl in head["slices"]) + 16 + max(max_shard_len(rg) for rg in head["ranges"]), dtype=torch.uint16, device=dev)
+                for (fs, ns, tl), rg in zip(head["slices"], head["ranges"]):
+                    for r in range(world):
+                        ixp.map_device(tmp.data_ptr(), head["K"], head["E"], first_seq=fs, n_seq=ns, infix=args.infix, value_bits=16, exclude_pseudo=True, seq_file_id=fid,
+                                       kmer_range=rg[r] if world > 1 else None, stream=stream)
+                        sp = ixp.last_stats()
+                        if tot is None:
+                            tot = sp
+                        else:
+                            for k in ("rank_lines", "roots", "node_steps", "kmers"):
+                                tot[k] += sp[k]
+                            for k in tot["detail"]:
+                                tot["detail"][k] = max(tot["detail"][k], sp["detail"][k]) if k in ("max_stack", "table_q") else tot["detail"][k] + sp["detail"][k]
+                counted[(head["K"], head["E"])] = tot
+            else:
+                tmp = torch.zeros(max(r["plan"].padded_len(n) for r in [head] + subs), dtype=torch.uint8, device=dev)
+            for rec in ([] if c5 else [head] + subs):
                 tot = None
                 for r in range(world):
                     ixp.map_device(tmp.data_ptr(), rec["K"], rec["E"], infix=args.infix, value_bits=8, chunks=rec["plan"].chunk_arg(r), stream=stream)
@@ -462,7 +561,7 @@ def main():
                         for k in ("rank_lines", "roots", "node_steps", "kmers"):
                             tot[k] += sp[k]
                         for k in tot["detail"]:
-                            tot["detail"][k] += sp["detail"][k]
+                            tot["detail"][k] = max(tot["detail"][k], sp["detail"][k]) if k in ("max_stack", "table_q") else tot["detail"][k] + sp["detail"][k]
                 counted[(rec["K"], rec["E"])] = tot
             ixp.close()
             del tmp
@@ -489,13 +588,70 @@ def main():
         # for random reads over a large footprint (48.3 G/s whatever the concurrency: profiles/r03/gather2_concurrency.txt); L2 hits
         # are included, so the figure can exceed the ceiling -- the lines actually fetched are in profiles/<round>/final/pmc_by_config.txt
         issued = sp["rank_lines"] + (d.get("jump_lookups", 0) or sp["roots"]) + vi
+        tr = traffic.get((rec["K"], rec["E"]), {})
+        tsum = (tr.get("FETCH_SIZE", 0.0) + tr.get("WRITE_SIZE", 0.0)) if len(tr) == 2 else None
         return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "random_requests_issued_per_s": issued / world / (rec["kernel_ms"] * 1e-3), "random_read_ceiling_per_s": 4.83e10,
-                "traffic": None,   # PMC FETCH_SIZE/WRITE_SIZE need rocprofv3 around the process: tools/profile_round.sh -> profiles/
+                # bytes per launch of the same configuration under rocprofv3 --pmc (FETCH_SIZE + WRITE_SIZE, separate passes, KB x 1024; the
+                # counters tally 64 B per request at the fabric side of the L2, whatever the request's width); null when not collected
+                "traffic": tsum, "traffic_fetch_bytes": tr.get("FETCH_SIZE"), "traffic_write_bytes": tr.get("WRITE_SIZE"),
+                "traffic_over_algorithmic": (tsum / alg) if tsum else None,
                 "per_gpu": True, "kernel": "search_kernel", "kernel_ms": rec["kernel_ms"], "algorithmic_bytes": alg, "rank_lines": sp["rank_lines"],
                 "roots": sp["roots"], "node_steps": sp["node_steps"], "node_steps_per_kmer": sp["node_steps"] / rec["num_kmers"],
                 "verify_items": d["verify_items"], "verify_chunks": d["verify_chunks"], "jump_lookups": d.get("jump_lookups", 0),
                 "lanes_with_node_per_iteration": d["active_lane_sum"] / max(1, d["wave_iterations"])}
+
+    def roofline_c5(rec):
+        """--exclude-pseudo pass (FileSetEnv): rank blocks + one table entry per root + every located row (a 4-byte suffix-array entry, or with a
+        sampled array an 8-byte mark word per visit, a 32-byte rank block per LF step and the 4-byte sample) + one 4-byte word of the file
+        set per located row + the text once per strand + the 16-bit result"""
+        sp = counted.get((rec["K"], rec["E"]))
+        base = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "kernel": "search_kernel (FileSetEnv), one launch per FASTA file",
+                "kernel_ms": rec["kernel_ms"], "per_gpu": True}
+        if not sp or not sp["rank_lines"]:
+            return dict(base, achieved=None, frac=None)
+        d = sp["detail"]
+        loc, lf = d.get("located_rows", 0), d.get("lf_steps", 0)
+        loc_bytes = 4 * loc if args.sampling == 1 else 8 * (loc + lf) + info["block_bytes"] * lf + 4 * loc
+        alg = info["block_bytes"] * sp["rank_lines"] + 16 * sp["roots"] + loc_bytes + 4 * loc + 2 * n + 2 * n
+        ach = alg / world / (rec["kernel_ms"] * 1e-3) / 1e9
+        return dict(base, achieved=ach, frac=ach / HBM_PEAK_GBS, algorithmic_bytes=alg, rank_lines=sp["rank_lines"], roots=sp["roots"], node_steps=sp["node_steps"],
+                    located_rows=loc, lf_steps=lf, random_requests_issued_per_s=(sp["rank_lines"] + sp["roots"] + 2 * loc + 2 * lf) / world / (rec["kernel_ms"] * 1e-3),
+                    random_read_ceiling_per_s=4.83e10, lanes_with_node_per_iteration=d["active_lane_sum"] / max(1, d["wave_iterations"]))
+
+    # ---- roofline.traffic: FETCH_SIZE and WRITE_SIZE of the search kernel, one rocprofv3 --pmc pass each (they do not fit one pass:
+    # MI355X_MICROARCH.md, "rocprofv3 PMC slots"), of the same configurations on the same synthetic text in a child process ----
+    def pmc_traffic(cfgs):
+        import csv, glob, shutil, subprocess, tempfile
+        if world != 1 or args.no_traffic or args.fasta or c5 or not shutil.which("rocprofv3"):
+            return {}
+        res = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="gm_pmc_", dir="/tmp")
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable, str(ROOT / "tools" / "sweep_tuning.py"),
+                   "--workload", args.workload, "--scale", str(args.scale), "--sampling", str(args.sampling), "--reps", "1", "--cfg"] + [f"{K},{E},1.0" for K, E in cfgs] + ["--", ""]
+            try:
+                subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900, env=dict(os.environ, TMPDIR="/tmp"), cwd=str(ROOT))
+                acc = {}
+                for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
+                    for r in csv.DictReader(open(f)):
+                        if "search_kernel" in r["Kernel_Name"] and "ScatterEnv" not in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                            acc[int(r["Dispatch_Id"])] = acc.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
+                vals = [acc[k] for k in sorted(acc)]
+                for i, ke in enumerate(cfgs):   # two dispatches per configuration (a warm-up and one more): the second
+                    if 2 * i + 1 < len(vals):
+                        res.setdefault(ke, {})[counter] = vals[2 * i + 1] * 1024.0   # the counter is reported in KB
+            except Exception as e:
+                log(f"roofline.traffic: rocprofv3 --pmc {counter} failed: {e}")
+            shutil.rmtree(d, ignore_errors=True)
+        return res
+
+    traffic = {}
+    if not c5:
+        t0 = time.time()
+        traffic = pmc_traffic([(r["K"], r["E"]) for r in [head] + subs])
+        if traffic:
+            log(f"roofline.traffic: FETCH_SIZE / WRITE_SIZE passes under rocprofv3 took {time.time() - t0:.0f} s")
 
     cpu = None
     if not args.no_cpu_baseline:
@@ -540,12 +696,17 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32 ranks / u8 counts" if not c5 else "u32 ranks / u16 counts", "data": data,
         "config": {"workload": wl(head), "K": head["K"], "E": head["E"], "text_len": n, "block_bytes": info["block_bytes"],
                    "parallelism": parallelism, "index_build_s": round(t_build, 2), "index_device_gib": round(info["device_bytes"] / 2**30, 2)},
-        "value_host": value_host,   # gm_map with the result vector delivered to host memory (PCIe-inclusive); never `value`
-        "value_host_pinned": value_host_pinned,   # the same into a page-locked vector
     }
+    if world > 1:
+        result["rccl_ranks"] = rccl_ranks   # dist.get_world_size() of the nccl (= RCCL) process group the gathers ran on (0: another backend)
+        result["backend"] = args.backend
+        result["rank_features"] = features["per_rank"]
+        if not c5:
+            result["preflight"] = preflight
+    if value_host is not None:   # gm_map with the result vector delivered to host memory (PCIe-inclusive); never `value`
+        result["value_host"] = {"K": host_cfg[0], "E": host_cfg[1], "pageable": value_host, "pinned": value_host_pinned, "unit": "k-mers/s"}
     if c5:
-        result["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "kernel": "search_kernel (FileSetEnv)",
-                              "kernel_ms": head["kernel_ms"], "note": "locate-bound pass; the byte roofline is reported for the frequency workloads"}
+        result["roofline"] = roofline_c5(head)
         result["csv"] = head["csv"]
     else:
         result["roofline"] = roofline(head)

@@ -29,7 +29,7 @@ void set_error(const char* fmt, ...)
 // dimension and wide indexes have more rows than that
 static inline unsigned grid_for(uint64_t n, unsigned bs = 256) { return (unsigned)std::min<uint64_t>((n + bs - 1) / bs, 1u << 22); }
 
-// d_small: work counter (8 B) | pad | statistics counters (42 x 8 B at +16), zeroed by every call  ||  +512: sticky error flag
+// d_small: work counter (8 B) | pad | statistics counters (50 x 8 B at +16), zeroed by every call  ||  +512: sticky error flag
 // (set by a device-side invariant check, surfaced and cleared by the next host-side check: gm_map, gm_index_sync, gm_last_map_stats)
 constexpr size_t SMALL_BYTES = 1024, SMALL_ZEROED = 512, SMALL_ERR_OFF = 512;   // [0,16) work counter, [16,512) statistics, 512: sticky error flag
 
@@ -1599,10 +1599,10 @@ int gm_last_map_stats(const gm_index* cix, gm_map_stats* out)
     }
     GM_HIP(hipEventElapsedTime(&b, ix->ev[0], ix->ev[3]));
     ix->stats.search_ms = a; ix->stats.total_ms = b;
-    unsigned long long cnt[42] = {0};
+    unsigned long long cnt[50] = {0};
     GM_HIP(hipMemcpy(cnt, reinterpret_cast<char*>(ix->d_small) + 16, sizeof(cnt), hipMemcpyDeviceToHost));
     ix->stats.node_steps = cnt[0]; ix->stats.rank_lines = cnt[1];
-    for (int i = 0; i < 40; ++i) ix->stats.detail[i] = cnt[2 + i];
+    for (int i = 0; i < 48; ++i) ix->stats.detail[i] = cnt[2 + i];
     ix->stats.detail[38] = ix->lastQ;   // longest q-mer table of the call | jump length << 8
     if (ix->corrTimed) { float c = 0; GM_HIP(hipEventElapsedTime(&c, ix->ev[1], ix->ev[2])); ix->stats.detail[37] = (uint64_t)(c * 1000.0f); }   // correction pass, microseconds
     int rc = check_device_error(ix);

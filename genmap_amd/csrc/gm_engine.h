@@ -312,6 +312,7 @@ GM_HD uint32_t scan_side(Env& env, const RootT<typename Env::row_t>& rt, const t
 template <class Env>
 GM_HD void emit_kmer_run(Env& env, const RootT<typename Env::row_t>& rt, uint32_t s0, uint32_t s1, typename Env::row_t p0, uint32_t a0)
 {
+    env.note_run();
     if constexpr (Env::RANGE_ADD) env.leaf_range(rt, s0, s1);
     else for (uint32_t s = s0; s <= s1; ++s) env.leaf_at(rt, s, p0 - (a0 - s));
 }

@@ -238,9 +238,12 @@ template <int WPP> struct EnvBase {
 #ifdef GM_COUNTERS
     uint32_t steps = 0, lines = 0, stOss = 0, stExt = 0, stExtW1 = 0, stExtW4 = 0, stOssW1 = 0, pushes = 0, vItems = 0, vItemsOss = 0, vChunks = 0, jumps = 0, jumpDrops = 0;
     uint32_t whit[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    mutable uint32_t locRows = 0, lfSteps = 0;   // rows located (one suffix-array or mark-word read each), LF steps of sampled walks
+    uint32_t maxSp = 0, selfHits = 0, runs = 0;  // deepest lane stack, self hits, verified runs of k-mers handed to the leaf policy
     // a wavefront passed here (counted by its first enabled lane): the dynamic cost of a region = passes x its instructions
     __device__ __forceinline__ void note_wave(int i) { const unsigned long long m = __ballot(true); if (__lane_id() == (unsigned)(__ffsll((long long)m) - 1)) whit[i]++; }
     __device__ __forceinline__ void note_chunk() { vChunks++; }
+    __device__ __forceinline__ void note_run() { runs++; }
     __device__ __forceinline__ void note_item(uint32_t mode) { vItems++; vItemsOss += (mode == M_OSS); }
     __device__ __forceinline__ void note_step(uint32_t mode, row_t w)
     {
@@ -249,6 +252,7 @@ template <int WPP> struct EnvBase {
 #else
     __device__ __forceinline__ void note_step(uint32_t, row_t) {}
     __device__ __forceinline__ void note_chunk() {}
+    __device__ __forceinline__ void note_run() {}
     __device__ __forceinline__ void note_item(uint32_t) {}
     __device__ __forceinline__ void note_wave(int) {}
 #endif
@@ -380,10 +384,10 @@ template <int WPP> struct EnvBase {
     }
     __device__ __forceinline__ void push(const Node& nd)
     {
-#ifdef GM_COUNTERS
-        pushes++;
-#endif
         const uint32_t lv = sbase + sp;
+#ifdef GM_COUNTERS
+        pushes++; maxSp = lv + 1u > maxSp ? lv + 1u : maxSp;
+#endif
         // wave-uniform fast path (scalar branch, no exec-mask juggling): nobody in the wavefront is past the LDS levels
         if (__ballot(lv >= A.ldsDepth) == 0ull) { IO::store(lstk + (size_t)lv * IO::NU * 64u, 64u, nd); ++sp; return; }
         note_wave(15);
@@ -403,6 +407,9 @@ template <int WPP> struct EnvBase {
     // (one rank block each: the symbol in front of the suffix and its rank) until a marked row (src/seqan_libdivsufsort.h:129-143)
     __device__ __forceinline__ row_t locate(row_t row) const
     {
+#ifdef GM_COUNTERS
+        locRows++;
+#endif
         if (A.sa) return sa(row);
         constexpr uint32_t SPB = BlockGeom<WPP>::SPB, WPB = BlockGeom<WPP>::WPB, H = BlockGeom<WPP>::HDRW;
         row_t r = row; uint32_t k = 0;
@@ -423,6 +430,9 @@ template <int WPP> struct EnvBase {
             for (uint32_t i = 0; i < NLET; ++i) nx = c == i ? (row_t)(A.C[i] + rk[i]) : nx;   // selects, not an indexed array (scratch)
             r = nx;
             ++k;
+#ifdef GM_COUNTERS
+            lfSteps++;
+#endif
         }
     }
     struct Item { row_t p0; uint32_t w[7]; };
@@ -1085,6 +1095,9 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                 }
                 if (anyN == 0u) {
                     uint32_t smin, smax;
+#ifdef GM_COUNTERS
+                    env.selfHits++;
+#endif
                     if (self_hit_kmers(nd.meta, rt, A.K, smin, smax)) {   // gm_engine.h
                         if constexpr (EnvT::RANGE_ADD) env.leaf_range(rt, smin, smax);
                         else for (uint32_t k = smin; k <= smax; ++k) env.leaf_at(rt, k, (row_t)0);
@@ -1296,6 +1309,11 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     atomicAdd(&A.counters[21], (unsigned long long)nSteals);
     atomicAdd(&A.counters[38], (unsigned long long)env.jumps);   // detail[36]: table reads of jump patterns
     atomicAdd(&A.counters[41], (unsigned long long)env.jumpDrops);   // detail[39]: one-row entries ended by the neighbour filter
+    atomicAdd(&A.counters[42], (unsigned long long)env.locRows);     // detail[40]: rows located (locating policies, correction pass)
+    atomicAdd(&A.counters[43], (unsigned long long)env.lfSteps);     // detail[41]: LF steps of sampled suffix-array walks
+    atomicMax(&A.counters[44], (unsigned long long)env.maxSp);       // detail[42]: deepest lane stack of the call
+    atomicAdd(&A.counters[45], (unsigned long long)env.selfHits);    // detail[43]: self hits (nodes settled without a lookup)
+    atomicAdd(&A.counters[46], (unsigned long long)env.runs);        // detail[44]: verified runs of k-mers
 #pragma unroll
     for (int i = 0; i < 16; ++i) if (env.whit[i]) atomicAdd(&A.counters[22 + i], (unsigned long long)env.whit[i]);
     if (lane == 0) {

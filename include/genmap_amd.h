@@ -230,7 +230,7 @@ typedef struct gm_map_stats {
     uint64_t roots;           /* (block, strand, search) work items */
     uint64_t node_steps;      /* bidirectional extensions evaluated (0 unless the library was built with GM_COUNTERS) */
     uint64_t rank_lines;      /* distinct rank blocks those steps read (same) */
-    uint64_t detail[40];      /* GM_COUNTERS only: steps in OSS phase, in extension phase, extension steps at range
+    uint64_t detail[48];      /* GM_COUNTERS only: steps in OSS phase, in extension phase, extension steps at range
                                  width 1, at width 2..4, OSS steps at width 1, nodes pushed to lane stacks,
                                  verification items, of which in OSS phase, 8-symbol comparison chunks,
                                  wavefront iterations, lanes holding a node summed over iterations, verification rounds,
@@ -242,7 +242,9 @@ typedef struct gm_map_stats {
                                  iteration; stack push past the LDS levels;
                                  [36] table reads of jump patterns; [37] correction pass in microseconds, [38] longest q-mer table of
                                  the call | jump length << 8 (both set by the host in every build); [39] one-row table entries ended
-                                 by the neighbour filter */
+                                 by the neighbour filter; [40] rows located (one suffix-array or mark-word read each: --exclude-pseudo, csv,
+                                 correction pass), [41] LF steps of sampled suffix-array walks, [42] deepest lane stack of the call,
+                                 [43] self hits, [44] verified runs of k-mers; [45..47] spare */
     double   search_ms;       /* HIP-event time of the search kernel alone */
     double   total_ms;        /* memset + search + finalize, HIP events on the call's stream */
 } gm_map_stats;

@@ -3,6 +3,7 @@
  * See gm_oracle.h for scope and pinning.  Every function that restates reference code cites it.
  * All citations are relative to /root/reference/.
  */
+#define _POSIX_C_SOURCE 200809L   /* posix_memalign */
 #include "gm_oracle.h"
 #include <stdlib.h>
 #include <string.h>
@@ -17,7 +18,8 @@ enum { SYM_N = 4, SYM_SENT = 5, NLET = 5 };
 /* stands in the reference: src/common.hpp:38-52)                                               */
 /* ------------------------------------------------------------------------------------------ */
 
-typedef struct { uint32_t cnt[NLET]; uint32_t pad; uint64_t pl[3]; } rankblk; /* 64 symbols */
+/* one cache line per block: a rank query touches exactly one line (the CPU baseline of bench.py is timed on this layout) */
+typedef struct { uint32_t cnt[NLET]; uint32_t pad; uint64_t pl[3]; uint64_t pad2[2]; } rankblk; /* 64 symbols, 64 bytes */
 
 struct gmo_index {
     uint64_t n;           /* symbols incl. sentinels */
@@ -37,29 +39,49 @@ void gmo_last_counters(uint64_t *v, uint64_t *l) { if (v) *v = g_visits; if (l) 
 
 static void build_rank(gmo_index *ix, int d)
 {
+    /* two passes over chunks of blocks, both under OpenMP with the same static schedule: letter totals per chunk, then the blocks.
+     * The thread that will later share the array also touches its pages first (NUMA first touch on a many-core host). */
     uint64_t n = ix->n, nb = n / 64 + 1;
-    rankblk *rb = (rankblk *)calloc(nb, sizeof(rankblk));
-    uint32_t run[NLET] = {0, 0, 0, 0, 0};
+    rankblk *rb = NULL;
+    if (posix_memalign((void **)&rb, 64, nb * sizeof(rankblk)) != 0) { ix->rb[d] = NULL; return; }
     const uint8_t *bwt = ix->bwt[d];
-    for (uint64_t b = 0; b < nb; ++b) {
-        for (int c = 0; c < NLET; ++c) rb[b].cnt[c] = run[c];
-        uint64_t p0 = 0, p1 = 0, p2 = 0;
-        for (uint64_t j = 0; j < 64; ++j) {
-            uint64_t i = b * 64 + j;
-            uint8_t c = (i < n) ? bwt[i] : SYM_SENT;
-            if (c & 1) p0 |= 1ULL << j;
-            if (c & 2) p1 |= 1ULL << j;
-            if (c & 4) p2 |= 1ULL << j;
-            if (i < n && c < NLET) run[c]++;
+    int nt = omp_get_max_threads();
+    if (nt < 1) nt = 1;
+    uint64_t nchunks = (uint64_t)nt * 8, per = (nb + nchunks - 1) / nchunks;
+    uint64_t *tot = (uint64_t *)calloc((nchunks + 1) * NLET, sizeof(uint64_t));
+#pragma omp parallel for schedule(static)
+    for (uint64_t c = 0; c < nchunks; ++c) {
+        uint64_t b0 = c * per, b1 = b0 + per < nb ? b0 + per : nb, cnt[NLET] = {0, 0, 0, 0, 0};
+        for (uint64_t i = b0 * 64; i < b1 * 64 && i < n; ++i) if (bwt[i] < NLET) cnt[bwt[i]]++;
+        for (int x = 0; x < NLET; ++x) tot[(c + 1) * NLET + x] = cnt[x];
+    }
+    for (uint64_t c = 1; c <= nchunks; ++c) for (int x = 0; x < NLET; ++x) tot[c * NLET + x] += tot[(c - 1) * NLET + x];
+#pragma omp parallel for schedule(static)
+    for (uint64_t c = 0; c < nchunks; ++c) {
+        uint64_t b0 = c * per, b1 = b0 + per < nb ? b0 + per : nb;
+        uint32_t run[NLET];
+        for (int x = 0; x < NLET; ++x) run[x] = (uint32_t)tot[c * NLET + x];
+        for (uint64_t b = b0; b < b1; ++b) {
+            for (int x = 0; x < NLET; ++x) rb[b].cnt[x] = run[x];
+            uint64_t p0 = 0, p1 = 0, p2 = 0;
+            for (uint64_t j = 0; j < 64; ++j) {
+                uint64_t i = b * 64 + j;
+                uint8_t ch = (i < n) ? bwt[i] : SYM_SENT;
+                if (ch & 1) p0 |= 1ULL << j;
+                if (ch & 2) p1 |= 1ULL << j;
+                if (ch & 4) p2 |= 1ULL << j;
+                if (i < n && ch < NLET) run[ch]++;
+            }
+            rb[b].pad = 0; rb[b].pl[0] = p0; rb[b].pl[1] = p1; rb[b].pl[2] = p2; rb[b].pad2[0] = rb[b].pad2[1] = 0;
         }
-        rb[b].pl[0] = p0; rb[b].pl[1] = p1; rb[b].pl[2] = p2;
     }
     ix->rb[d] = rb;
     if (d == 0) {
         uint64_t acc = ix->nseq; /* sentinel suffixes occupy rows [0, nseq) */
-        for (int c = 0; c < NLET; ++c) { ix->C[c] = acc; acc += run[c]; }
+        for (int x = 0; x < NLET; ++x) { ix->C[x] = acc; acc += tot[nchunks * NLET + x]; }
         ix->C[NLET] = acc;
     }
+    free(tot);
 }
 
 static inline void rank5(const rankblk *rb, uint64_t i, uint32_t out[NLET])

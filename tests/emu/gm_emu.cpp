@@ -127,6 +127,7 @@ template <int WPP, bool NL = false, bool RA = false> struct EmuEnv {
     void note_step(uint32_t, uint32_t) {}
     bool any(bool b) const { return b; }
     void note_chunk() {}
+    void note_run() {}
     void note_wave(int) {}
     void note_item(uint32_t) {}
     uint32_t leafSum = 0;

@@ -159,21 +159,31 @@ class _Locations(C.Structure):
                 ("minus_seq", C.POINTER(C.c_uint32)), ("minus_pos", C.POINTER(C.c_uint64))]
 
 
-_lib = None
+_libs = {}
 
 
 def build_oracle():
     subprocess.check_call(["make", "-s", "-C", str(ROOT / "oracle")])
 
 
-def oracle_lib():
-    global _lib
-    if _lib is not None:
-        return _lib
-    so = ROOT / "oracle" / "libgmoracle.so"
-    src = ROOT / "oracle" / "gm_oracle.c"
-    if not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
-        build_oracle()
+def build_oracle_native():
+    """-march=native build for the machine this runs on (bench.py's cpu_baseline leg); returns its path or None"""
+    try:
+        subprocess.check_call(["make", "-s", "-B", "-C", str(ROOT / "oracle"), "native"], timeout=300)
+    except Exception:
+        return None
+    so = ROOT / "oracle" / "_native" / "libgmoracle.so"
+    return so if so.exists() else None
+
+
+def oracle_lib(so=None):
+    if so is None:
+        so = ROOT / "oracle" / "libgmoracle.so"
+        src = ROOT / "oracle" / "gm_oracle.c"
+        if not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
+            build_oracle()
+    if str(so) in _libs:
+        return _libs[str(so)]
     lib = C.CDLL(str(so))
     vp, u8p, u64p, u32p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
     lib.gmo_index_build.restype = vp
@@ -202,7 +212,7 @@ def oracle_lib():
     lib.gmo_default_infix_length.argtypes = [C.c_uint32, C.c_uint32, C.c_int32]
     lib.gmo_last_counters.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.gmo_set_line_symbols.argtypes = [C.c_uint32]
-    _lib = lib
+    _libs[str(so)] = lib
     return lib
 
 
@@ -211,8 +221,8 @@ def _ptr(a):
 
 
 class OracleIndex:
-    def __init__(self, codes, seq_len, keep_sa=True, bwt=None, sa=None):
-        self.lib = oracle_lib()
+    def __init__(self, codes, seq_len, keep_sa=True, bwt=None, sa=None, lib=None):
+        self.lib = lib if lib is not None else oracle_lib()
         self.codes = np.ascontiguousarray(codes, dtype=np.uint8)
         self.seq_len = np.ascontiguousarray(seq_len, dtype=np.uint64)
         self.cum = np.concatenate([[0], np.cumsum(self.seq_len)]).astype(np.uint64)

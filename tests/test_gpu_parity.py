@@ -956,7 +956,7 @@ def test_gpu_bench_two_ranks_on_one_device_at_0p77_gbp():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29611",
            os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "grch38", "--scale", "0.25", "--sampling", "0", "--same-device", "--backend", "gloo",
-           "--comm", "p2p", "--watchdog", "400", "--steps", "2", "--warmup", "1", "--verify", "--sub", "100,1:1", "--no-cpu-baseline"]
+           "--comm", "p2p", "--watchdog", "400", "--E", "0", "--steps", "2", "--warmup", "1", "--verify", "--sub", "100,1:1", "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     for K, E in ((30, 0), (100, 1)):

@@ -5,7 +5,7 @@
 SC=${1:-1.0}; SA=${2:-0}; CM=${3:-p2p}; LIM=${4:-420}; SUB=${5-100,1:1}
 export MASTER_ADDR=127.0.0.1
 mkdir -p gpurun_out
-timeout $LIM python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --workload grch38 --scale $SC --sampling $SA \
+timeout $LIM python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --E 0 --workload grch38 --scale $SC --sampling $SA \
   --same-device --backend gloo --comm $CM --watchdog 250 --steps 3 --warmup 1 --verify --trace 150 --sub "$SUB" --no-cpu-baseline > gpurun_out/diag_${CM}.txt 2>&1
 echo "rc=$?" >> gpurun_out/diag_${CM}.txt
 grep -v "Warning\|amdgpu.ids\|socket.cpp\|OMP_NUM\|\*\*\*\*\|^$" gpurun_out/diag_${CM}.txt | cut -c1-2000 | tail -70
