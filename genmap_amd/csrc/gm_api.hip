@@ -7,6 +7,7 @@
 #include <rocprim/device/device_select.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
@@ -256,10 +257,22 @@ static int index_common_setup(gm_index* ix, const uint8_t* codes, const uint64_t
     return GM_OK;
 }
 
+// number of suffix array rows a sampling rate keeps: the offsets 0, s, 2s, .. of every sequence
+static uint64_t expected_samples(const gm_index* ix)
+{
+    uint64_t t = 0;
+    const uint64_t s = std::max<uint32_t>(ix->sampling, 1u);
+    for (uint32_t i = 0; i < ix->nSeq; ++i) t += (ix->cum[i + 1] - ix->cum[i] + s - 1) / s;
+    return t;
+}
+
 // the sampled form of a full forward suffix array (device): marks + "samples before this word" per 32 rows, and the kept values
 static int sample_sa(gm_index* ix, const void* d_saFull)   // entries as wide as the index's rows
 {
     const uint64_t n = ix->nRows, words = (n + 31) / 32;
+    // The marked rows are the in-sequence offsets that are multiples of the rate: their number is known exactly on the host, in 64
+    // bits -- the device-side counts below are 32-bit and would wrap silently
+    if (expected_samples(ix) >= (1ull << 32)) { set_error("more than 2^32 suffix array samples: use a larger sampling rate"); return GM_ERR_TOO_LONG; }
     GM_HIP(hipMalloc(&ix->d_saMark, words * sizeof(uint2)));   // (owned by the index: gm_index_free releases it on every path)
     if (ix->wide) hipLaunchKernelGGL(sa_mark_kernel<uint64_t>, dim3(grid_for(words)), dim3(256), 0, 0, (const uint64_t*)d_saFull, ix->d_cum, ix->nSeq, n, ix->sampling, ix->d_saMark);
     else hipLaunchKernelGGL(sa_mark_kernel<uint32_t>, dim3(grid_for(words)), dim3(256), 0, 0, (const uint32_t*)d_saFull, ix->d_cum, ix->nSeq, n, ix->sampling, ix->d_saMark);
@@ -280,7 +293,7 @@ static int sample_sa(gm_index* ix, const void* d_saFull)   // entries as wide as
     hipFree(d_cnt); hipFree(d_before); hipFree(d_tmp);
     if (rc) return rc;
     ix->nSamples = (uint64_t)last[0] + last[1];
-    if (ix->nSamples >= (1ull << 32)) { set_error("more than 2^32 suffix array samples: use a larger sampling rate"); return GM_ERR_TOO_LONG; }   // (the mark words count them in 32 bits)
+    if (ix->nSamples != expected_samples(ix)) { set_error("suffix array sampling: %llu rows marked, %llu expected", (unsigned long long)ix->nSamples, (unsigned long long)expected_samples(ix)); return GM_ERR_HIP; }
     GM_HIP(hipMalloc(&ix->d_saSamples, std::max<uint64_t>(ix->nSamples, 1) * (ix->wide ? 8 : 4)));
     if (ix->wide) hipLaunchKernelGGL(sa_compact_kernel<uint64_t>, dim3(grid_for(n)), dim3(256), 0, 0, (const uint64_t*)d_saFull, ix->d_saMark, n, (uint64_t*)ix->d_saSamples);
     else hipLaunchKernelGGL(sa_compact_kernel<uint32_t>, dim3(grid_for(n)), dim3(256), 0, 0, (const uint32_t*)d_saFull, ix->d_saMark, n, (uint32_t*)ix->d_saSamples);
@@ -333,7 +346,8 @@ void gm_index_free(gm_index* ix)
     hipSetDevice(ix->device);
     hipFree(ix->d_blk[0]); hipFree(ix->d_blk[1]); hipFree(ix->d_textAlloc); hipFree(ix->d_text4); hipFree(ix->d_cum); hipFree(ix->d_sa); hipFree(ix->d_textSAlloc); hipFree(ix->d_C); hipFree(ix->d_ctx);
     hipFree(ix->d_saMark); hipFree(ix->d_saSamples);
-    for (auto& kv : ix->qtables) hipFree(kv.second); hipFree(ix->d_seqFile); hipFree(ix->d_bits);
+    for (auto& kv : ix->qtables) hipFree(kv.second);
+    for (auto& kv : ix->jbits) hipFree(kv.second); hipFree(ix->d_seqFile); hipFree(ix->d_bits);
     hipFree(ix->d_acc); hipFree(ix->d_stack); hipFree(ix->d_small); hipFree(ix->d_table); hipFree(ix->d_blocks); hipFree(ix->d_cumLocal);
     for (int i = 0; i < 4; ++i) if (ix->ev[i]) hipEventDestroy(ix->ev[i]);
     for (uint32_t i = 0; i < gm_index::EV_RING; ++i) for (int j = 0; j < 2; ++j) if (ix->evRing[i][j]) hipEventDestroy(ix->evRing[i][j]);
@@ -433,6 +447,7 @@ int gm_index_import_sampled(const uint8_t* bwt_fwd, const uint8_t* bwt_rev, cons
         set_error("sampled suffix array: %llu marks for %llu samples", (unsigned long long)run, (unsigned long long)n_samples);
         gm_index_free(ix); return GM_ERR_BAD_ARG;
     }
+    if (n_samples >= (1ull << 32)) { set_error("more than 2^32 suffix array samples: use a larger sampling rate"); gm_index_free(ix); return GM_ERR_TOO_LONG; }   // (the mark words count them in 32 bits)
     if (hipMalloc(&ix->d_saMark, words * sizeof(uint2)) != hipSuccess || hipMalloc(&ix->d_saSamples, std::max<uint64_t>(n_samples, 1) * sa_entry_bytes) != hipSuccess) rc = GM_ERR_OOM;
     if (!rc && (hipMemcpy(ix->d_saMark, mk.data(), words * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess ||
                 hipMemcpy(ix->d_saSamples, samples, n_samples * sa_entry_bytes, hipMemcpyHostToDevice) != hipSuccess)) rc = GM_ERR_HIP;
@@ -522,7 +537,7 @@ template <typename T> static int grow(T** p, uint64_t* cap, uint64_t need)
 enum LeafMode { LEAF_COUNT = 0, LEAF_FILESET = 1, LEAF_OCC_COUNT = 2, LEAF_OCC_EMIT = 3, LEAF_STORE = 4, LEAF_STORE8 = 5, LEAF_COUNT_JUMP = 6, LEAF_SCATTER = 7 };
 
 // nu = 16-byte units per stored node / queue entry: 1, or 2 with 64-bit rows (gm_kernels.h: NodeIO)
-static inline size_t search_lds_bytes(const SearchArgs& A, uint32_t nu) { return (size_t)(4u * A.vqCap * nu + 4u * 64u * (A.ldsDepth * nu + A.winChunks)) * 16u + 4u * 128u * 4u + 128u + (A.lqCap ? 4u * (A.lqCap * 16u + 80u * 4u) : 0u); }
+static inline size_t search_lds_bytes(const SearchArgs& A, uint32_t nu) { return (size_t)(4u * A.vqCap * nu + 4u * 64u * (A.ldsDepth * nu + A.winChunks)) * 16u + 4u * 128u * 4u + 192u + (A.lqCap ? 4u * (A.lqCap * 16u + 80u * 4u) : 0u); }
 
 template <int WPP, class EnvT>
 static int launch_one(const SearchArgs& A, unsigned blocks, hipStream_t st)
@@ -624,6 +639,31 @@ static int get_qtable(gm_index* ix, uint32_t* qio, const uint4** out)
     return GM_OK;
 }
 
+// existence bitmap of the q-mers (cached; built from the table of all q-mers).  *out stays null when the device is short of memory:
+// the call then keeps plain pattern lists.
+static int get_jbits(gm_index* ix, uint32_t q, const uint4* tab, const unsigned long long** out)
+{
+    *out = nullptr;
+    if (q < GROUP_SYMS || ix->wide || !tab) return GM_OK;
+    auto it = ix->jbits.find(q);
+    if (it != ix->jbits.end()) { *out = it->second; return GM_OK; }
+    const uint64_t n = 1ull << (2 * q), bytes = n / 8;
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && bytes + (8ull << 30) > freeB && bytes > (1ull << 20)) return GM_OK;
+    unsigned long long* d = nullptr;
+    if (hipMalloc(&d, bytes) != hipSuccess) { (void)hipGetLastError(); return GM_OK; }
+    const uint64_t blocks = (n + 255) / 256;
+    const dim3 grid((unsigned)std::min<uint64_t>(blocks, 1u << 22), (unsigned)((blocks + (1u << 22) - 1) >> 22));
+    hipLaunchKernelGGL(jbits_kernel, grid, dim3(256), 0, 0, tab, n, d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { hipFree(d); GM_HIP(e); }
+    ix->jbits[q] = d;
+    ix->qtableBytes += bytes;
+    *out = d;
+    return GM_OK;
+}
+
 // maximal runs of the letter N in the whole text (needed once per index, by the correction pass of N-less calls)
 __global__ __launch_bounds__(256) void n_run_bounds_kernel(const uint8_t* __restrict__ text, uint64_t n, uint64_t* __restrict__ starts, uint64_t* __restrict__ ends,
                                                             unsigned long long* __restrict__ counts, uint64_t cap)
@@ -665,7 +705,7 @@ static int ensure_n_runs(gm_index* ix)
     return GM_OK;
 }
 // block list of the correction pass: the text windows with 1..E letters N of a run (gm_host.h: n_window_intervals), cached per (K, E, infix)
-static int ensure_correction_blocks(gm_index* ix, uint32_t K, uint32_t E, uint32_t infix)
+static int ensure_correction_blocks(gm_index* ix, uint32_t K, uint32_t E, uint32_t infix, hipStream_t st)
 {
     if (ix->corrValid && ix->corrK == K && ix->corrE == E && ix->corrInfix == infix) return GM_OK;
     int rc = ensure_n_runs(ix); if (rc) return rc;
@@ -678,7 +718,10 @@ static int ensure_correction_blocks(gm_index* ix, uint32_t K, uint32_t E, uint32
         if (rc) return rc;
         if (!cp.blocks.empty()) {
             rc = grow(&ix->d_cblocks, &ix->cblocksCap, (uint64_t)cp.blocks.size()); if (rc) return rc;
-            GM_HIP(hipMemcpy(ix->d_cblocks, cp.blocks.data(), cp.blocks.size() * sizeof(uint2), hipMemcpyHostToDevice));
+            // on the call's stream, which already waits for the end of the previous call on this index (prepare_search): a correction
+            // kernel of that call, on another stream, may still be reading the list this one replaces
+            GM_HIP(hipMemcpyAsync(ix->d_cblocks, cp.blocks.data(), cp.blocks.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
+            GM_HIP(hipStreamSynchronize(st));   // the host list goes out of scope
             ix->nCBlocks = cp.blocks.size();
         }
     }
@@ -808,7 +851,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     const uint32_t winChunks = (31u + p->K + plan.stepSize - 1u + 31u) / 32u;
     const uint32_t nu = ix->wide ? 2u : 1u;
     const int wantPerCU = std::max(1, ix->tune.blocksPerCU);   // default 4 = 4 waves/SIMD, what the kernel's VGPR count allows
-    auto lds_bytes_for = [&](uint32_t d) { return (size_t)(4u * vqCap * nu + 4u * 64u * (d * nu + winChunks)) * 16u + 4u * 128u * 4u + 128u + (lqCap ? 4u * (lqCap * 16u + 80u * 4u) : 0u); };   // == search_lds_bytes
+    auto lds_bytes_for = [&](uint32_t d) { return (size_t)(4u * vqCap * nu + 4u * 64u * (d * nu + winChunks)) * 16u + 4u * 128u * 4u + 192u + (lqCap ? 4u * (lqCap * 16u + 80u * 4u) : 0u); };   // == search_lds_bytes
     auto blocks_for = [&](uint32_t d, int* nb) {
         switch (ix->wpp) { case 1: return occupancy_blocks<1>(nb, lds_bytes_for(d)); case 2: return occupancy_blocks<2>(nb, lds_bytes_for(d)); case 3: return occupancy_blocks<3>(nb, lds_bytes_for(d)); default: return occupancy_blocks<9>(nb, lds_bytes_for(d)); }
     };
@@ -837,6 +880,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
 
     // ---- jump patterns (frequency calls with errors on an index that can locate): one J for every search ----
     std::vector<uint32_t> patHost; std::vector<uint4> jinfoHost; uint32_t jumpJ = 0, jumpAPacked[2] = {0, 0};
+    const unsigned long long* jbitsCall = nullptr; unsigned long long gmaskCall[GROUP_MAX_MASKS] = {0, 0, 0, 0, 0, 0, 0, 0};
     const uint4* jtab = nullptr;
     S->jump = wantJump && p->E >= 1 && (ix->d_sa || ix->d_saMark) && ix->tune.jump != 0 && !ix->wide;
     if (S->jump) {
@@ -861,6 +905,24 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         if (J >= 1) {
             jumpJ = J;
             jinfoHost.assign(8, make_uint4(0, 0, 0, 0));
+            // Groups of patterns (gm_oss.h): patterns that differ in the last three characters only share one word of the existence bitmap.
+            // A search is grouped when that saves table reads: groups + (share of J-mers that occur) x their patterns against one read
+            // per pattern (3.09 Gbp, J = 16: 51 % occur; K = 30 e = 2, search 1: 211 reads -> 13 words + 54 + ~80 reads).
+            const unsigned long long* jbits = nullptr;
+            if (ix->tune.jumpGroups != 0) { rc = get_jbits(ix, J, jtab, &jbits); if (rc) return rc; }
+            const double occur = 1.0 - std::exp(-(double)ix->nRows / std::ldexp(1.0, 2 * (int)J));
+            std::vector<uint64_t> masks;
+            for (uint32_t s2 = 0; s2 < plan.nSearches && jbits; ++s2) {
+                GroupedSearch gs;
+                std::vector<uint64_t> m2 = masks;
+                if (!oss_group_patterns(js[s2], &m2, &gs) || gs.groups == 0) continue;
+                const double inGroups = (double)(gs.patterns - (gs.items.size() - gs.groups));
+                if (ix->tune.jumpGroups < 0 && gs.groups + occur * inGroups > 0.9 * inGroups) continue;
+                masks = m2;
+                js[s2].pat = gs.items;   // (the lane tells groups from plain patterns by bit 31)
+            }
+            jbitsCall = masks.empty() ? nullptr : jbits;
+            for (size_t k = 0; k < masks.size(); ++k) gmaskCall[k] = masks[k];
             for (uint32_t s2 = 0; s2 < plan.nSearches; ++s2) {
                 // neighbour filter (gm_kernels.h): how many infix characters right / left of the J-mer a one-row table entry is compared with
                 uint32_t nbWord = 0;
@@ -885,7 +947,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         // host-device synchronisation
         uint64_t h = 1469598103934665603ull;
         auto mix = [&h](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
-        mix(p->K); mix(p->E); mix(plan.infix); mix((uint64_t)(int64_t)ix->tune.partBias); mix((uint64_t)(int64_t)ix->tune.ossWeights); mix(jumpJ); mix((uint64_t)ix->tune.jumpFilter); mix(patHost.size()); mix(text_begin); mix(text_len); mix(first_seq); mix(n_seq); mix(n_intervals);
+        mix(p->K); mix(p->E); mix(plan.infix); mix((uint64_t)(int64_t)ix->tune.partBias); mix((uint64_t)(int64_t)ix->tune.ossWeights); mix(jumpJ); mix((uint64_t)ix->tune.jumpFilter); mix(patHost.size()); for (uint32_t v : patHost) mix(v); mix(text_begin); mix(text_len); mix(first_seq); mix(n_seq); mix(n_intervals);
         for (uint64_t k = 0; k < 2 * n_intervals; ++k) mix(intervals[k]);
         if (!ix->sigValid || ix->sig != h) {
             GM_HIP(hipMemcpyAsync(ix->d_table, plan.table.data(), plan.table.size() * sizeof(OssRecord), hipMemcpyHostToDevice, st));
@@ -987,7 +1049,8 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     A.coop = ix->tune.coop >= 0 ? (uint32_t)(ix->tune.coop != 0) : (ix->wpp == 1 ? 1u : 0u);
     if (ix->wide) A.coop = 0u;
     A.jumpJ = jumpJ; A.jumpAPacked[0] = jumpAPacked[0]; A.jumpAPacked[1] = jumpAPacked[1];
-    A.patterns = ix->d_patterns; A.jinfo = ix->d_jinfo; A.jtab = jtab;
+    A.patterns = ix->d_patterns; A.jinfo = ix->d_jinfo; A.jtab = jtab; A.jbits = jbitsCall;
+    for (uint32_t k = 0; k < GROUP_MAX_MASKS; ++k) A.gmask[k] = gmaskCall[k];
     A.sliceBegin = text_begin; A.sliceLen = text_len; A.ownBegin = 0; A.ownEnd = text_len; A.ownChunkLen = 0; A.selBlocks = nullptr; A.nSelBlocks = 0;
     *Aout = A;
     return GM_OK;
@@ -1011,7 +1074,7 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
     int rc = prepare_search(ix, text_begin, text_len, first_seq, n_seq, p, intervals, n_intervals, st, &S, &A, /*wantJump=*/p->exclude_pseudo == 0, /*leaf queue*/p->exclude_pseudo ? 128u : 0u);
     if (rc) return rc;
     const bool ep = p->exclude_pseudo != 0;
-    if (S.jump) { rc = ensure_correction_blocks(ix, p->K, p->E, S.plan.infix); if (rc) return rc; }
+    if (S.jump) { rc = ensure_correction_blocks(ix, p->K, p->E, S.plan.infix, st); if (rc) return rc; }
     uint32_t wordsPerKmer = 0;
     if (ep) {
         if (!ix->d_sa && !ix->d_saMark) { set_error("--exclude-pseudo needs an index with suffix array samples (sampling >= 1)"); return GM_ERR_NEED_LOCATE; }
@@ -1547,6 +1610,7 @@ int gm_index_set_tuning(gm_index* ix, const char* name, int64_t value)
         {"child_tables", &ix->tune.childTables, dflt.childTables, 0, 1}, {"oss_weights", &ix->tune.ossWeights, dflt.ossWeights, 0, 0xFFFFFF},   // (-1: 5,4,7,8 at e = 2, the even split elsewhere)
         {"jump", &ix->tune.jump, dflt.jump, 0, 16}, {"self_hit", &ix->tune.selfHit, dflt.selfHit, 0, 1}, {"jump_filter", &ix->tune.jumpFilter, dflt.jumpFilter, 0, 1},
         {"range_add", &ix->tune.rangeAdd, dflt.rangeAdd, 0, 1}, {"verify_t_ext", &ix->tune.verifyTExt, dflt.verifyTExt, 0, (int64_t)VERIFY_TMAX},
+        {"jump_groups", &ix->tune.jumpGroups, dflt.jumpGroups, 0, 1},   // groups of jump patterns behind the existence bitmap: 0 never, 1 wherever possible, -1 where they save table reads
     };
     for (auto& t : tab) if (!strcmp(t.n, name)) {
         const bool isBias = t.f == &ix->tune.partBias;

@@ -27,7 +27,7 @@ namespace gm {
 // -1 = "library default for this call" (depends on K, E and the index size, see prepare_search)
 struct Tuning {
     int verifyT = -1, ldsStack = -1, blocksPerCU = 4, qtable = -1, satMinW = 256, fetchBatch = -1, probation = -1, verifyCost = 3;
-    int noStore = 0, noSaturate = 0, skipDup = -1, coop = -1, useCtx = 1, steal = -1, partBias = 0, childTables = -1, ossWeights = -1, jump = -1, selfHit = 1, jumpFilter = 1, rangeAdd = 1, verifyTExt = -1;
+    int noStore = 0, noSaturate = 0, skipDup = -1, coop = -1, useCtx = 1, steal = -1, partBias = 0, childTables = -1, ossWeights = -1, jump = -1, selfHit = 1, jumpFilter = 1, rangeAdd = 1, verifyTExt = -1, jumpGroups = -1;
 };
 }  // namespace gm
 
@@ -52,6 +52,7 @@ struct gm_index {
     uint8_t* d_textS = nullptr;       // sentinel text (verification of narrow nodes), present with d_sa
     uint4* d_ctx = nullptr;           // verification records {SA[row], 56 symbols around it}, 32 B per row, when HBM allows (gm_kernels.h: CTX_*)
     std::map<uint32_t, uint4*> qtables;   // q -> device table of 4^q entries (built on first use)
+    std::map<uint32_t, unsigned long long*> jbits;   // q -> existence bitmap of the q-mers, 4^q bits (groups of jump patterns, gm_oss.h)
     uint64_t sig = 0; bool sigValid = false;   // signature of the call whose tables are on the device
     uint32_t lastQ = 0;                   // longest q-mer table of the last call | jump length << 8 (statistics)
     uint32_t qtableCap = 0;               // != 0: longest prefix that fitted the device so far

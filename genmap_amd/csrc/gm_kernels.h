@@ -88,6 +88,8 @@ struct SearchArgs {
     const uint32_t* patterns;       // descriptors of every search, back to back
     const uint4* jinfo;             // per search {first pattern | patterns << 16, meta at depth J relative to n - 1, first descriptor, 0}
     const uint4* jtab;              // table of all J-mers
+    const unsigned long long* jbits;   // one bit per J-mer: does it occur (word = the 64 J-mers sharing their first J - 3 characters); groups of patterns
+    unsigned long long gmask[8];    // masks of the groups (gm_oss.h: GROUP_MAX_MASKS)
     uint32_t jumpJ;                 // 0: no jumps in this call (every root starts at the tree's root)
     uint32_t jumpAPacked[2];        // 8 bits per search: window coordinate of the J-mer's first character, minus (n - 1)
     // ---- correction pass (ScatterEnv): occurrences are added at THEIR OWN position if the main pass computes that position ----
@@ -212,6 +214,7 @@ constexpr int32_t CTX_LEFT = 24, CTX_SYMS = 56;
 constexpr uint32_t NB_SYMS = 6;       // neighbour symbols per side carried by one-row q-mer table entries (qmer_table_kernel)
 constexpr uint32_t STEAL_LEVELS = 16;  // a lane gives away at most this many bottom entries before its stack has run empty once
 
+constexpr uint32_t JF_ENTRY = 4u, JF_WORD = 8u, JF_ITEM = 16u;   // fetch-state flags of a lane with jump patterns: table entry in flight, bitmap word in flight, jd holds an item
 constexpr uint32_t WORK_CHUNK = 256;   // roots taken from the global counter per atomic
 constexpr uint32_t VERIFY_TMAX = 16;   // widest range resolved by verification
 constexpr uint32_t VERIFY_ROWS = 2;    // rows of one node queued per iteration (the rest waits on the lane's stack)
@@ -237,8 +240,9 @@ template <int WPP> struct EnvBase {
     uint32_t K;
 #ifdef GM_COUNTERS
     uint32_t steps = 0, lines = 0, stOss = 0, stExt = 0, stExtW1 = 0, stExtW4 = 0, stOssW1 = 0, pushes = 0, vItems = 0, vItemsOss = 0, vChunks = 0, jumps = 0, jumpDrops = 0;
-    uint32_t whit[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t whit[17] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // (16: part B of the jump patterns; not exported)
     mutable uint32_t locRows = 0, lfSteps = 0;   // rows located (one suffix-array or mark-word read each), LF steps of sampled walks
+    uint32_t jumpWords = 0;                       // words of the existence bitmap read for groups of jump patterns
     uint32_t maxSp = 0, selfHits = 0, runs = 0;  // deepest lane stack, self hits, verified runs of k-mers handed to the leaf policy
     // a wavefront passed here (counted by its first enabled lane): the dynamic cost of a region = passes x its instructions
     __device__ __forceinline__ void note_wave(int i) { const unsigned long long m = __ballot(true); if (__lane_id() == (unsigned)(__ffsll((long long)m) - 1)) whit[i]++; }
@@ -759,6 +763,11 @@ template <int WPP> struct ScatterEnv : LeafQueueEnv<WPP, ScatterEnv<WPP>> {
         uint32_t* p = &A.acc[q];
         if (atomicAdd(p, 1u) == 0xFFFFFFFFu) atomicOr(p, 0x80000000u);
     }
+    // INVARIANT the two shortcuts below rest on: the main pass computes a position's count as a pure function of the k-mer AT that
+    // position (no duplicate shortcut, no per-position early exit other than "the count has reached MAX"), and acc only ever grows.  So
+    // all rows of a leaf (same k-mer) end at the same value, acc[q] >= MAX of one owned row means MAX for all of them, and a count that
+    // the difference plane still holds back (CountEnv::leaf_range) only makes the test conservative.  With no_saturate the caller
+    // passes maxVal = 2^32 - 1 and neither shortcut fires.  (test_gpu_correction_pass_near_the_8_bit_maximum_under_chunks_and_selections)
     __device__ __forceinline__ void leaf(const Root&, uint32_t, row_t flo, row_t w)
     {
         if (w >= (row_t)A.maxVal) {
@@ -826,14 +835,16 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     // that lane's needle window (wlane) and the owner may not stage a new window while users[owner] != 0
     uint32_t* const users = reinterpret_cast<uint32_t*>(smem + 4u * A.vqCap * NU + 4u * 64u * (A.ldsDepth * NU + A.winChunks)) + wv * 128u;   // [64] users | [64] pairing
     uint32_t* const pairing = users + 64;
-    // the searches' jump records (Env::JUMPS), 8 x 16 bytes per block behind the work-sharing bookkeeping
+    // the searches' jump records (Env::JUMPS), 8 x 16 bytes (+ 64 bytes of group masks) per block behind the work-sharing bookkeeping
     uint4* const jl = smem + 4u * A.vqCap * NU + 4u * 64u * (A.ldsDepth * NU + A.winChunks) + (4u * 128u * 4u) / 16u;
     if constexpr (EnvT::JUMPS) {
         if (threadIdx.x < 8u) jl[threadIdx.x] = A.jumpJ ? A.jinfo[threadIdx.x] : make_uint4(0, 0, 0, 0);
+        // ... and the masks of its groups of patterns (gm_oss.h), 8 x 8 bytes behind them
+        if (threadIdx.x < GROUP_MAX_MASKS) reinterpret_cast<unsigned long long*>(jl + 8)[threadIdx.x] = A.gmask[threadIdx.x];
         __syncthreads();
     }
     if constexpr (EnvT::LEAFQ) {   // leaf queue behind everything else: [4 x lqCap entries] [4 x 80 control words]
-        uint4* const lqBase = jl + 8;
+        uint4* const lqBase = jl + 12;
         env.lq = lqBase + wv * A.lqCap;
         env.lqCtl = reinterpret_cast<uint32_t*>(lqBase + 4u * A.lqCap) + wv * 80u;
         if (lane == 0u) env.lqCtl[0] = 0u;
@@ -854,13 +865,20 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     uint32_t w1run = 0;                             // consecutive steps this lane has taken on a single-row node
     // root fetch pipeline of this lane: 0 idle, 1 window/record loads in flight, 2 q-mer table lookup in flight
     uint32_t fs = 0, fa0 = 0, fql = 0, fnch = 0;
-    Root frt; frt.win = 0; frt.n = 1; frt.strand = 0; frt.search = 0; frt.rec = OssRecord{0, 0, 0, 0};
+    // The root a lane fetches IS its next root: a lane draws only when it has no node, no stack and no fetch in flight, nobody takes work
+    // from such a lane (work sharing robs lanes that hold a node) and it cannot become a thief while its fetch is in flight -- so the
+    // fetch writes the root context in place (8 VGPRs less than a staged copy).
+    Root& frt = rt;
     row_t ftFlo = 0, ftRlo = 0, ftW = 0;
     const uint4* fsrc = A.text4;
     // jump patterns of the lane's current root (Env::JUMPS): 2-bit packed J-mer of the needle, cursor | end << 16 into A.patterns,
     // the next pattern's descriptor (prefetched), meta of the node at depth J (with the errors of the pattern whose table entry
     // is in flight; bit 30 marks the first pattern of a root: the root context is installed with it)
-    uint32_t jb = 0, jpp = 0, jd = 0, jm = 0;   // jm: errs field = errors of the pattern in flight, bit 30 = first pattern of its root
+    uint32_t jb = 0, jpp = 0, jd = 0, jm = 0;   // jpp: next item | end << 16; jd: the current item (JF_ITEM); jm: errs field = errors of the pattern in flight
+    // groups of patterns (gm_oss.h): rotations of the current group that exist and are still to be looked up, the group's J-mer prefix,
+    // the bitmap word in flight (JF_WORD).  fs of a lane with pattern work = 2 | JF_* flags.
+    unsigned long long galive = 0ull, pw = 0ull;
+    uint32_t gpre = 0;
     // neighbour filter: jn = the needle's characters next to the J-mer inside the infix, packed like the table's 4th word (bit 15: the
     // filter applies to this root), ftNb = that word of the entry in flight
     uint32_t jn = 0, ftNb = 0;
@@ -946,13 +964,12 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
         // ---- root fetch, pipelined over iterations so that the wavefront never waits for it ----
         // stage 3: the q-mer table entry has arrived -> the root becomes the lane's node (or turns out empty)
         if constexpr (EnvT::JUMPS) {
-            // the table entry of the current pattern has arrived, and the lane has finished the subtree of the one before
-            if (fs == 2u && !have && env.sp == 0u) {
+            // (A) the table entry of the pattern in flight has arrived, and the lane has finished the subtree of the one before
+            if ((fs & (3u | JF_ENTRY)) == (2u | JF_ENTRY) && !have && env.sp == 0u) {
                 env.note_wave(3);
-                const bool first = (jm >> 30) != 0u;
-                if (first) { rt = frt; env.on_root(); jm &= 0x3FFFFFFFu; }
+                fs &= ~JF_ENTRY;
                 // every k-mer of the block at MAX: nothing a further pattern finds can change the result
-                const bool sat = !first && env.root_hits() >= A.maxVal && env.saturated(rt, 0u, rt.n - 1u);
+                const bool sat = env.root_hits() >= A.maxVal && env.saturated(rt, 0u, rt.n - 1u);
                 bool take = ftW != 0u && !sat;
                 if (take && ftW == 1u && (jn & ftNb & 0x8000u) != 0u) {
                     // The substituted J-mer occurs once.  Whatever this node could still find lies at that one place and contains the whole
@@ -970,22 +987,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                     nd.flo = ftFlo; nd.rlo = ftRlo; nd.w = ftW; nd.meta = jm;
                     have = true; w1run = 0;
                 }
-                const uint32_t jp = jpp & 0xFFFFu, jpe = jpp >> 16;
-                if (!sat && jp < jpe) {   // the next pattern: substituted J-mer -> table read; the descriptor after it is prefetched
-                    uint32_t idx = jb;
-#pragma unroll 1
-                    for (uint32_t k = 0; k < (jd & 7u); ++k) {
-                        const uint32_t f = (jd >> (3u + 6u * k)) & 63u, sh = 2u * (A.jumpJ - 1u - (f & 15u)), old = (idx >> sh) & 3u;
-                        idx ^= (old ^ ((old + (f >> 4)) & 3u)) << sh;
-                    }
-                    IO::load_qentry(A.jtab, idx, ftFlo, ftRlo, ftW, ftNb);
-                    jm = (jm & ~(7u << META_ERRS_SHIFT)) | (jd & 7u) << META_ERRS_SHIFT;
-                    jpp += 1u;
-                    if (jp + 1u < jpe) jd = A.patterns[jp + 1u];
-#ifdef GM_COUNTERS
-                    env.jumps++;
-#endif
-                } else fs = 0u;
+                if (sat) { galive = 0ull; jpp = (jpp >> 16) * 0x10001u; fs = 2u; }   // the remaining items are skipped (part B ends the root)
             }
         } else if (fs == 2u) {
             env.note_wave(3);
@@ -1045,15 +1047,8 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                     if (bad) { rt = frt; env.on_root(); nd = root_node(rt, (row_t)A.nRows); have = true; fs = 0u; w1run = 0; }
                     else {
                         jb = idx;
-                        const uint4 fji = jl[frt.search];   // {first pattern | patterns << 16, meta at depth J relative to n - 1, first descriptor}
-                        jm = meta_pack((fji.y & 0x1FFu) + frt.n - 1u, ((fji.y >> 9) & 0x1FFu) + frt.n - 1u, fji.y >> 18, fji.z & 7u, 1u);   // "mode" bit 30: first pattern
-                        uint32_t x = idx;   // the first pattern's descriptor travels with the search's record
-#pragma unroll 1
-                        for (uint32_t k = 0; k < (fji.z & 7u); ++k) {
-                            const uint32_t f = (fji.z >> (3u + 6u * k)) & 63u, sh = 2u * (A.jumpJ - 1u - (f & 15u)), old = (x >> sh) & 3u;
-                            x ^= (old ^ ((old + (f >> 4)) & 3u)) << sh;
-                        }
-                        IO::load_qentry(A.jtab, x, ftFlo, ftRlo, ftW, ftNb);
+                        const uint4 fji = jl[frt.search];   // {first item | items << 16, meta at depth J relative to n - 1, first item, neighbour-filter mask}
+                        jm = meta_pack((fji.y & 0x1FFu) + frt.n - 1u, ((fji.y >> 9) & 0x1FFu) + frt.n - 1u, fji.y >> 18, 0u, M_OSS);
                         jn = 0u;
                         if (fji.w >> 31) {   // the needle's neighbours of the J-mer, once per root
                             uint32_t notLetter = 0u;
@@ -1063,16 +1058,67 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                             for (uint32_t i = 0; i < ((fji.w >> 28) & 7u); ++i) { const uint32_t c = env.text_char(frt, fa0 - 1u - i); notLetter |= c >> 2; jn |= (c & 3u) << (16u + 2u * i); }
                             jn = notLetter ? 0u : (jn | 0x8000u);   // a needle N mismatches everything: leave such roots to the ordinary path
                         }
+                        // the first item travels with the search's record; part (B) below issues its read in this very iteration
+                        jd = fji.z; galive = 0ull;
                         jpp = ((fji.x & 0xFFFFu) + 1u) | ((fji.x & 0xFFFFu) + (fji.x >> 16)) << 16;
-                        if ((fji.x >> 16) > 1u) jd = A.patterns[(fji.x & 0xFFFFu) + 1u];
-                        fs = 2u;
-#ifdef GM_COUNTERS
-                        env.jumps++;
-#endif
+                        env.on_root();
+                        fs = 2u | JF_ITEM;
                     }
                 } else {
                 if (bad) fs = 0u;   // a pattern N never matches in an exact block (find2:330): this root finds nothing
                 else { IO::load_qentry(((A.qselMask >> frt.search) & 1u) ? A.qtabB : A.qtabA, idx, ftFlo, ftRlo, ftW, ftNb); fs = 2u; }
+                }
+            }
+        }
+        if constexpr (EnvT::JUMPS) {
+            // (B) the next table read of the lane's root, as soon as the previous entry has been consumed.  Items (gm_oss.h) are plain
+            // patterns -- substituted J-mer -> ONE 16-byte read of the table of all J-mers -- or GROUPS of patterns that differ in the last
+            // three characters only: one 8-byte word of the existence bitmap tells which of up to 64 such J-mers occur at all, and only
+            // those are looked up (on a genome half of the substituted 16-mers do not exist).  A group's word is requested as soon as its
+            // item is known, i.e. while the lane still works through the group before it.
+            if ((fs & 3u) == 2u) {
+                env.note_wave(16);
+                // (an item loaded in this iteration is not looked at before the next one: nothing waits for that load)
+                bool fresh = false;
+                if ((fs & (JF_ITEM | JF_WORD)) == JF_ITEM && (jd >> 31) != 0u) {   // a group item: request its word now
+                    pw = A.jbits[jump_apply(jb, jd & 0x07FFFFFFu, A.jumpJ) >> 6];
+                    fs |= JF_WORD;
+                    fresh = true;
+#ifdef GM_COUNTERS
+                    env.jumpWords++;
+#endif
+                }
+                if (galive == 0ull && (fs & JF_WORD) && !fresh) {   // the word of group jd has arrived: its patterns that exist
+                    gpre = jump_apply(jb, jd & 0x07FFFFFFu, A.jumpJ);
+                    const uint2 mk = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint32_t*>(jl + 8) + 2u * ((jd >> 27) & 7u));
+                    galive = word_to_rotations(pw, jb & 63u) & ((unsigned long long)mk.y << 32 | mk.x);
+                    fs &= ~(JF_WORD | JF_ITEM);
+                    const uint32_t jp = jpp & 0xFFFFu;
+                    if (jp < (jpp >> 16)) { jd = A.patterns[jp]; jpp += 1u; fs |= JF_ITEM; fresh = true; }
+                }
+                if (!(fs & JF_ENTRY)) {
+                    uint32_t idx = 0u, er = 0u; bool go = false;
+                    if (galive != 0ull) {
+                        const uint32_t rot = ctz64(galive);
+                        galive &= galive - 1ull;
+                        idx = (gpre & ~63u) | rotations_to_low6(jb & 63u, rot);
+                        const uint32_t px = (gpre ^ jb) >> 6;
+                        er = (uint32_t)__popc((px | px >> 1) & 0x01555555u) + rotations_errors(rot);
+                        go = true;
+                    } else if ((fs & (JF_ITEM | JF_WORD)) == JF_ITEM && !fresh) {   // (jd is a plain pattern here: a group has JF_WORD set by now)
+                        idx = jump_apply(jb, jd, A.jumpJ); er = jd & 7u; go = true;
+                        fs &= ~JF_ITEM;
+                        const uint32_t jp = jpp & 0xFFFFu;
+                        if (jp < (jpp >> 16)) { jd = A.patterns[jp]; jpp += 1u; fs |= JF_ITEM; }
+                    }
+                    if (go) {
+                        IO::load_qentry(A.jtab, idx, ftFlo, ftRlo, ftW, ftNb);
+                        jm = (jm & ~(7u << META_ERRS_SHIFT)) | er << META_ERRS_SHIFT;
+                        fs |= JF_ENTRY;
+#ifdef GM_COUNTERS
+                        env.jumps++;
+#endif
+                    } else if (fs == 2u) fs = 0u;   // no entry in flight, no item, no word, nothing alive: the root's patterns are done
                 }
             }
         }
@@ -1314,6 +1360,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     atomicMax(&A.counters[44], (unsigned long long)env.maxSp);       // detail[42]: deepest lane stack of the call
     atomicAdd(&A.counters[45], (unsigned long long)env.selfHits);    // detail[43]: self hits (nodes settled without a lookup)
     atomicAdd(&A.counters[46], (unsigned long long)env.runs);        // detail[44]: verified runs of k-mers
+    atomicAdd(&A.counters[47], (unsigned long long)env.jumpWords);   // detail[45]: bitmap words read for groups of jump patterns
 #pragma unroll
     for (int i = 0; i < 16; ++i) if (env.whit[i]) atomicAdd(&A.counters[22 + i], (unsigned long long)env.whit[i]);
     if (lane == 0) {
@@ -1378,6 +1425,16 @@ __global__ __launch_bounds__(256) void qmer_table_kernel(const uint32_t* __restr
         nb |= nr << 12 | nl << 28 | 0x80008000u;
     }
     NodeIO<row_t>::store_qentry(out, idx, flo, rlo, w, nb);
+}
+
+// existence bitmap of the J-mers (groups of jump patterns, gm_oss.h): bit idx & 63 of word idx >> 6 = table entry idx holds a row.
+// One wavefront per word: coalesced 16-byte reads of the table, one ballot.  (32-bit rows: 16-byte entries)
+__global__ __launch_bounds__(256) void jbits_kernel(const uint4* __restrict__ tab, uint64_t nEntries, unsigned long long* __restrict__ bits)
+{
+    const uint64_t i = ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+    const bool alive = i < nEntries && tab[i].z != 0u;
+    const unsigned long long m = __ballot(alive);
+    if ((threadIdx.x & 63u) == 0u && i < nEntries) bits[i >> 6] = m;
 }
 
 // store planes -> c[]: 16 bytes per lane where the three arrays are aligned alike (the planes are; `out` is the caller's)

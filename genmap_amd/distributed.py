@@ -141,13 +141,21 @@ class PeerGather:
         mark(f"PeerGather: {self.nbytes} bytes in {len(self.piece_off)} pieces of at most {max(self.piece_len)} bytes")
         good = 1
         handles = [None]
-        try:
-            if rank == 0:
+        if rank == 0:
+            try:   # only the root's allocation and export may fail here; the broadcast below ALWAYS runs (a root that skipped it left
+                   # the other ranks inside it while it went on to the all_reduce: mismatched collectives)
                 self.piece_ptr = [capi.device_alloc(device, n) for n in self.piece_len]
                 handles = [[capi.ipc_export(device, q) for q in self.piece_ptr]]
-            dist.broadcast_object_list(handles, src=0)
-            mark("PeerGather: handles exchanged")
-            if rank != 0:
+            except Exception as e:   # noqa: BLE001
+                mark(f"PeerGather: the root cannot allocate / export its pieces: {e}")
+                handles = [None]
+                good = 0
+        dist.broadcast_object_list(handles, src=0)
+        mark("PeerGather: handles exchanged")
+        if handles[0] is None:      # the root failed: every rank falls back
+            good = 0
+        try:
+            if rank != 0 and good:
                 box = {}
 
                 def _open():

@@ -14,6 +14,8 @@ using namespace gm;
 
 static uint32_t g_ossWeights = 0;   // relative OSS block lengths for the plans below (gm_host.h: make_map_plan), 0 = even split
 extern "C" void gm_emu_set_oss_weights(uint32_t w) { g_ossWeights = w; }
+static int g_jumpGroups = 0;        // 1: patterns that differ in their last three characters only are read through one word of an existence bitmap (gm_oss.h)
+extern "C" void gm_emu_set_jump_groups(int on) { g_jumpGroups = on; }
 static int g_selfHit = 1;           // self hits of the counting pass (gm_engine.h: self_hit_kmers)
 extern "C" void gm_emu_set_self_hit(int on) { g_selfHit = on; }
 
@@ -176,6 +178,9 @@ static void search_plan(const MapPlan& plan, const HostIndex<WPP>& ix, Env& env,
             for (auto& j : jumps) j = JumpSearch();
         }
     }
+    std::vector<uint64_t> gmasks;
+    if (g_jumpGroups)
+        for (auto& j : jumps) { GroupedSearch gs; if (j.J && oss_group_patterns(j, &gmasks, &gs)) j.pat = gs.items; }
     uint64_t roots = plan.numRoots();
     uint32_t rpb = plan.nSearches * plan.nStrands;
     auto walk = [&](Node nd, const Root& rt) {
@@ -215,21 +220,27 @@ static void search_plan(const MapPlan& plan, const HostIndex<WPP>& ix, Env& env,
             for (uint32_t i = 0; i < js.J; ++i) { const uint32_t c = env.text_char(rt, a0 + i); if (c >= SYM_N) bad = true; base2 = base2 << 2 | (c & 3u); }
             if (!bad) {
                 jumped = true;
-                for (uint32_t d : js.pat) {
-                    uint32_t idx = base2;
-                    const uint32_t nsub = d & 7u;
-                    for (uint32_t k = 0; k < nsub; ++k) {
-                        const uint32_t f = (d >> (3u + 6u * k)) & 63u, off = f & 15u, rot = f >> 4;
-                        const uint32_t sh = 2u * (js.J - 1u - off), old = (idx >> sh) & 3u;
-                        idx ^= (old ^ ((old + rot) & 3u)) << sh;
-                    }
+                auto lookup = [&](uint32_t idx, uint32_t nsub) {
                     Node nd;
                     table_entry<WPP>(ix, idx, js.J, nd.flo, nd.rlo, nd.w);
                     if (nPatterns) ++*nPatterns;
-                    if (!nd.w) continue;
+                    if (!nd.w) return;
                     const uint32_t off = rt.n - 1u;
                     nd.meta = meta_pack((js.meta0 & 0x1FFu) + off, ((js.meta0 >> 9) & 0x1FFu) + off, js.meta0 >> 18, nsub, M_OSS);
                     walk(nd, rt);
+                };
+                for (uint32_t d : js.pat) {
+                    if (!(d & GROUP_FLAG)) { lookup(jump_apply(base2, d, js.J), d & 7u); continue; }
+                    // a group: the word of the existence bitmap (built here from the table), in rotation space, masked; only J-mers that exist are looked up
+                    const uint32_t pre = jump_apply(base2, d & 0x07FFFFFFu, js.J);
+                    uint64_t word = 0;
+                    for (uint32_t c = 0; c < 64u; ++c) { uint32_t f, r, w; table_entry<WPP>(ix, (pre & ~63u) | c, js.J, f, r, w); if (w) word |= 1ull << c; }
+                    uint64_t alive = word_to_rotations(word, base2 & 63u) & gmasks[(d >> 27) & 7u];
+                    while (alive) {
+                        const uint32_t rot = (uint32_t)__builtin_ctzll(alive); alive &= alive - 1ull;
+                        const uint32_t px = (pre ^ base2) >> 6;
+                        lookup((pre & ~63u) | rotations_to_low6(base2 & 63u, rot), (uint32_t)__builtin_popcount((px | px >> 1) & 0x01555555u) + rotations_errors(rot));
+                    }
                 }
             }
         }

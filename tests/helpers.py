@@ -330,6 +330,49 @@ def check_sa_against_bwt(codes, seq_len, bwt_fwd, sa):
     assert np.array_equal(sa[lf[m]], sa[m] - 1)
 
 
+def check_sa_against_bwt_device(codes, seq_len, bwt_fwd, sa, device="cuda:0", chunk=1 << 27):
+    """check_sa_against_bwt with torch on a device, in chunks of rows (indexes of billions of rows): the suffix array is a permutation of
+    the sentinel-text positions, the symbols in front of its suffixes are the BWT, and sa[LF(i)] == sa[i] - 1 for every row with a letter"""
+    import torch
+    seq_len = np.asarray(seq_len, dtype=np.int64)
+    n = int(seq_len.sum()) + len(seq_len)
+    assert len(sa) == n and len(bwt_fwd) == n and np.asarray(sa).dtype == np.uint32
+    textS = torch.full((n,), 5, dtype=torch.uint8, device=device)
+    host = torch.from_numpy(np.ascontiguousarray(codes))
+    off = s = 0
+    for ln in seq_len.tolist():
+        textS[s:s + ln] = host[off:off + ln].to(device)
+        off += ln
+        s += ln + 1
+    b = torch.from_numpy(np.ascontiguousarray(bwt_fwd)).to(device)
+    sa32 = torch.from_numpy(np.ascontiguousarray(sa).view(np.int32)).to(device)      # (values beyond 2^31 come back through the mask below)
+    cnt = torch.zeros(6, dtype=torch.int64, device=device)
+    for i in range(0, n, chunk):
+        cnt += torch.bincount(b[i:i + chunk].long(), minlength=6)
+    cnt = cnt.tolist()
+    Cc = [cnt[5]]
+    for c in range(1, 5):
+        Cc.append(Cc[-1] + cnt[c - 1])
+    seen = torch.zeros(n, dtype=torch.bool, device=device)
+    base = [0] * 5
+    for i in range(0, n, chunk):
+        sac = sa32[i:i + chunk].long() & 0xFFFFFFFF
+        assert int(sac.max()) < n
+        seen[sac] = True
+        bc = b[i:i + chunk]
+        assert torch.equal(textS[(sac - 1) % n], bc), ("preceding symbols", i)       # row 0's suffix wraps to the last sentinel
+        for c in range(5):
+            m = bc == c
+            k = int(m.sum())
+            if k == 0:
+                continue
+            lf = Cc[c] + base[c] + torch.arange(k, device=device)
+            assert torch.equal(sa32[lf].long() & 0xFFFFFFFF, sac[m] - 1), ("LF walk", i, c)
+            base[c] += k
+        del sac, bc
+    assert bool(seen.all()), "not a permutation"
+
+
 def _unpack_locations(L):
     n = int(L.n_entries)
     ent = []

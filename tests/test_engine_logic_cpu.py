@@ -272,6 +272,39 @@ def test_jump_patterns_and_n_correction_baseline_settings(K, E):
     assert np.array_equal(out2, exp2), (K, E, "slice")
 
 
+@pytest.mark.parametrize("K,E", [(30, 1), (30, 2), (24, 1), (24, 2), (50, 3), (36, 4), (100, 1)])
+def test_groups_of_jump_patterns_read_through_the_existence_bitmap(K, E):
+    """gm_oss.h: patterns that differ in their last three characters only form a group answered by one word of the bitmap "which J-mers
+    occur" (word_to_rotations, rotations_to_low6, rotations_errors, oss_group_patterns): grouped == plain patterns == oracle, for the jump
+    lengths the device uses (15, 16) and short ones, on a text with repeats and N"""
+    rng = np.random.default_rng(K * 10 + E + 77)
+    lens = [1800, 600, K + 2, 1000]
+    n = sum(lens)
+    codes = rng.integers(0, 4, size=n, dtype=np.uint8)
+    fam = rng.integers(0, 4, size=150, dtype=np.uint8)
+    for s in (30, 500, 1900, 2500, 3100):
+        cp = fam.copy()
+        mut = rng.random(150) < 0.04
+        cp[mut] = rng.integers(0, 4, size=int(mut.sum()), dtype=np.uint8)
+        codes[s:s + 150] = cp
+    codes[800:830] = 4
+    codes[2000] = 4
+    codes[1200:1290] = 1
+    ix = H.OracleIndex(codes, lens, keep_sa=True)
+    exp = ix.mappability(K, E, value_bits=16, threads=4)
+    e = emu()
+    try:
+        for T, jump in ((0, 16), (1, 15), (4, 9), (1, 5)):
+            e.gm_emu_set_jump_groups(0)
+            plain, st0 = emu_map2(ix, 1, K, E, value_bits=16, verify_t=T, jump=jump)
+            e.gm_emu_set_jump_groups(1)
+            out, st1 = emu_map2(ix, 1, K, E, value_bits=16, verify_t=T, jump=jump)
+            assert np.array_equal(plain, exp) and np.array_equal(out, exp), (K, E, T, jump, np.flatnonzero(out != exp)[:10])
+            assert 0 < st1[4] <= st0[4]          # only J-mers that occur are looked up
+    finally:
+        e.gm_emu_set_jump_groups(0)
+
+
 def test_n_window_intervals_list_exactly_the_windows_that_can_match():
     """gm_host.h: n_window_intervals against brute force on random texts with runs of N of every kind (isolated letters, short and
     long runs, runs across sequence boundaries, at both ends of the text): every window with 1..E letters N inside one sequence is

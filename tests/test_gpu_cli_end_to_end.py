@@ -4,6 +4,7 @@ every output format and every -xo rerun; all produced files must equal tests/gol
 import filecmp
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 import pytest
 
@@ -52,6 +53,7 @@ def test_cli_reproduces_reference_outputs(case, sampling, tmp_path):
     flags = ["-E", str(fl["E"]), "-K", str(fl["K"])] + (["-nc"] if fl.get("nc") else []) + (["-ep"] if fl.get("ep") else [])
     if (d / "subset.bed").exists():
         flags += ["-S", str(d / "subset.bed")]
+    runs = []
     for sub, ff in FORMAT_FLAGS.items():
         if not (d / sub).is_dir():
             continue
@@ -60,9 +62,14 @@ def test_cli_reproduces_reference_outputs(case, sampling, tmp_path):
         for xo in H.xo_variants(case):
             out = tmp_path / f"out_{sub}_{xo}"
             out.mkdir()
-            cmd = [str(GENMAP), "map", "-I", str(idx), "-O", str(out)] + flags + ff + (["-xo", str(xo)] if xo is not None else [])
-            subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
-            _same_tree(out, d / sub)
+            runs.append((sub, out, [str(GENMAP), "map", "-I", str(idx), "-O", str(out)] + flags + ff + (["-xo", str(xo)] if xo is not None else [])))
+    # the map runs of one case are independent processes reading one index directory: six at a time (a run is mostly process start
+    # and HIP initialisation -- one after the other they were half of the GPU suite's wall time)
+    with ThreadPoolExecutor(max_workers=6) as pool:
+        rcs = list(pool.map(lambda r: subprocess.run(r[2], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True), runs))
+    for (sub, out, cmd), r in zip(runs, rcs):
+        assert r.returncode == 0, (cmd, r.returncode, r.stderr[-2000:])
+        _same_tree(out, d / sub)
 
 
 def test_cli_error_paths(tmp_path):
