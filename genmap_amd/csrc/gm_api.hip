@@ -912,14 +912,17 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
             if (ix->tune.jumpGroups != 0) { rc = get_jbits(ix, J, jtab, &jbits); if (rc) return rc; }
             const double occur = 1.0 - std::exp(-(double)ix->nRows / std::ldexp(1.0, 2 * (int)J));
             std::vector<uint64_t> masks;
-            for (uint32_t s2 = 0; s2 < plan.nSearches && jbits; ++s2) {
-                GroupedSearch gs;
+            std::vector<SearchItems> items(plan.nSearches);
+            for (uint32_t s2 = 0; s2 < plan.nSearches; ++s2) {
+                SearchItems gs;
                 std::vector<uint64_t> m2 = masks;
-                if (!oss_group_patterns(js[s2], &m2, &gs) || gs.groups == 0) continue;
-                const double inGroups = (double)(gs.patterns - (gs.items.size() - gs.groups));
-                if (ix->tune.jumpGroups < 0 && gs.groups + occur * inGroups > 0.9 * inGroups) continue;
-                masks = m2;
-                js[s2].pat = gs.items;   // (the lane tells groups from plain patterns by bit 31)
+                bool grouped = jbits && oss_make_items(js[s2], true, &m2, &gs) && gs.groups > 0;
+                if (grouped && ix->tune.jumpGroups < 0) {
+                    const double inGroups = (double)(gs.patterns - (gs.items.size() - gs.groups));
+                    grouped = gs.groups + occur * inGroups <= 0.9 * inGroups;
+                }
+                if (grouped) { masks = m2; items[s2] = gs; }
+                else oss_make_items(js[s2], false, nullptr, &items[s2]);
             }
             jbitsCall = masks.empty() ? nullptr : jbits;
             for (size_t k = 0; k < masks.size(); ++k) gmaskCall[k] = masks[k];
@@ -932,9 +935,9 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
                     for (uint32_t i = 0; i < nl; ++i) nbWord |= 1u << (16u + 2u * i);
                     nbWord |= nr << 12 | nl << 28 | 1u << 31;
                 }
-                jinfoHost[s2] = make_uint4((uint32_t)patHost.size() | (uint32_t)js[s2].pat.size() << 16, js[s2].meta0, js[s2].pat[0], nbWord);
+                jinfoHost[s2] = make_uint4((uint32_t)patHost.size() | (uint32_t)items[s2].items.size() << 16, js[s2].meta0 | items[s2].groups << 24, items[s2].items[0], nbWord);
                 jumpAPacked[s2 >> 2] |= js[s2].regionA << (8u * (s2 & 3u));
-                patHost.insert(patHost.end(), js[s2].pat.begin(), js[s2].pat.end());
+                patHost.insert(patHost.end(), items[s2].items.begin(), items[s2].items.end());
             }
             const void *p0 = ix->d_patterns, *j0 = ix->d_jinfo;
             rc = grow(&ix->d_patterns, &ix->patternsCap, (uint64_t)patHost.size()); if (rc) return rc;
@@ -1031,7 +1034,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     if (ix->tune.probation >= 0) A.probation = (uint32_t)ix->tune.probation;
     A.verifyCost = (uint32_t)std::max(0, ix->tune.verifyCost);
     A.selfHit = ix->tune.selfHit != 0 ? 1u : 0u;
-    A.nbFilter = ix->tune.jumpFilter != 0 ? 1u : 0u;
+    A.nbFilter = (uint32_t)std::max(0, ix->tune.jumpFilter);   // 0 off, 1 one- and two-row entries, 2 one-row entries only
     A.chunkBlocks = chunked ? p->chunk_blocks : 0u; A.chunkStride = p->chunk_stride; A.chunkIndex = p->chunk_index;
     A.skipDup = ix->tune.skipDup >= 0 ? (uint32_t)(ix->tune.skipDup != 0) : 1u;   // profiles/r02: +3..8 % on 3.09 Gbp, +1..5 % on 249 Mbp
     // groups of lanes read the rank blocks (rank2_coop): +4..12 % with 32-byte blocks on 249 Mbp and 3.09 Gbp (profiles/r02)
@@ -1192,6 +1195,12 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
     return GM_OK;
 }
 
+static int staged_copy_to_host(gm_index* ix, uint8_t* h_dst, const uint8_t* d_src, uint64_t bytes, hipStream_t st);
+__global__ __launch_bounds__(256) void narrow_offsets_kernel(const uint64_t* __restrict__ in, uint64_t n, uint32_t* __restrict__ out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = (uint32_t)in[i];
+}
+
 // ---- gm_locate: per-position occurrence lists for csv (algo.hpp:311-348) -------------------------------------
 static int locate_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t first_seq, uint32_t n_seq, const gm_map_params* p,
                        const uint64_t* intervals, uint64_t n_intervals, gm_locations* L)
@@ -1222,8 +1231,10 @@ static int locate_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uin
         LC(rocprim::exclusive_scan(nullptr, tmpBytes, d_cnt, d_offs, (uint64_t)0, slots + 1, rocprim::plus<uint64_t>()));
         LC(hipMalloc(&d_tmp, tmpBytes ? tmpBytes : 16));
         { size_t tb = tmpBytes; LC(rocprim::exclusive_scan(d_tmp, tb, d_cnt, d_offs, (uint64_t)0, slots + 1, rocprim::plus<uint64_t>())); }
+        // (every device -> host transfer of this call goes through the page-locked ring: the plain hipMemcpy into pageable memory was
+        //  most of the second that config C5's csv window took, profiles/r03/final/bench_c5_bacteria5.json)
         std::vector<uint64_t> offs(slots + 1);
-        LC(hipMemcpy(offs.data(), d_offs, (slots + 1) * 8, hipMemcpyDeviceToHost));
+        rc = staged_copy_to_host(ix, (uint8_t*)offs.data(), (const uint8_t*)d_offs, (slots + 1) * 8, st); if (rc) goto done;
         const uint64_t total = offs[slots];
         if (total >= (1ull << 31)) { set_error("%llu occurrences in one gm_locate window; use a smaller k-mer range", (unsigned long long)total); rc = GM_ERR_TOO_LONG; goto done; }
         for (uint64_t j = 0; j <= W; ++j) { L->plus_off[j] = offs[j]; L->minus_off[j] = offs[W + j] - offs[W]; }
@@ -1238,16 +1249,15 @@ static int locate_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uin
             rc = launch_search(ix, LEAF_OCC_EMIT, A, S.blocks, st); if (rc) goto done;
             // std::sort of every list (algo.hpp:336,348): segmented radix sort, segments = (position, strand) slots
             LC(hipMalloc(&d_segB, (slots + 1) * 4));
-            std::vector<uint32_t> seg(slots + 1);
-            for (uint64_t j = 0; j <= slots; ++j) seg[j] = (uint32_t)offs[j];
-            LC(hipMemcpy(d_segB, seg.data(), (slots + 1) * 4, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(narrow_offsets_kernel, dim3(grid_for(slots + 1)), dim3(256), 0, st, d_offs, slots + 1, d_segB);   // (total < 2^31)
+            LC(hipGetLastError());
             d_segE = d_segB + 1;
             size_t sb = 0;
             LC(rocprim::segmented_radix_sort_keys(nullptr, sb, d_emit, d_sorted, (unsigned int)total, (unsigned int)slots, d_segB, d_segE, 0, 64));
             if (sb > tmpBytes) { hipFree(d_tmp); d_tmp = nullptr; LC(hipMalloc(&d_tmp, sb)); tmpBytes = sb; }
             { size_t tb = tmpBytes; LC(rocprim::segmented_radix_sort_keys(d_tmp, tb, d_emit, d_sorted, (unsigned int)total, (unsigned int)slots, d_segB, d_segE, 0, 64)); }
-            LC(hipMemcpy(L->plus, d_sorted, offs[W] * 8, hipMemcpyDeviceToHost));
-            LC(hipMemcpy(L->minus, d_sorted + offs[W], (total - offs[W]) * 8, hipMemcpyDeviceToHost));
+            if (offs[W]) { rc = staged_copy_to_host(ix, (uint8_t*)L->plus, (const uint8_t*)d_sorted, offs[W] * 8, st); if (rc) goto done; }
+            if (total > offs[W]) { rc = staged_copy_to_host(ix, (uint8_t*)L->minus, (const uint8_t*)(d_sorted + offs[W]), (total - offs[W]) * 8, st); if (rc) goto done; }
         }
         LC(hipDeviceSynchronize());
     }
@@ -1608,7 +1618,7 @@ int gm_index_set_tuning(gm_index* ix, const char* name, int64_t value)
         {"skip_dup", &ix->tune.skipDup, dflt.skipDup, 0, 1}, {"coop", &ix->tune.coop, dflt.coop, 0, 1}, {"use_ctx", &ix->tune.useCtx, dflt.useCtx, 0, 1},
         {"steal", &ix->tune.steal, dflt.steal, 0, 64}, {"part_bias", &ix->tune.partBias, dflt.partBias, -255, 255},
         {"child_tables", &ix->tune.childTables, dflt.childTables, 0, 1}, {"oss_weights", &ix->tune.ossWeights, dflt.ossWeights, 0, 0xFFFFFF},   // (-1: 5,4,7,8 at e = 2, the even split elsewhere)
-        {"jump", &ix->tune.jump, dflt.jump, 0, 16}, {"self_hit", &ix->tune.selfHit, dflt.selfHit, 0, 1}, {"jump_filter", &ix->tune.jumpFilter, dflt.jumpFilter, 0, 1},
+        {"jump", &ix->tune.jump, dflt.jump, 0, 16}, {"self_hit", &ix->tune.selfHit, dflt.selfHit, 0, 1}, {"jump_filter", &ix->tune.jumpFilter, dflt.jumpFilter, 0, 2},
         {"range_add", &ix->tune.rangeAdd, dflt.rangeAdd, 0, 1}, {"verify_t_ext", &ix->tune.verifyTExt, dflt.verifyTExt, 0, (int64_t)VERIFY_TMAX},
         {"jump_groups", &ix->tune.jumpGroups, dflt.jumpGroups, 0, 1},   // groups of jump patterns behind the existence bitmap: 0 never, 1 wherever possible, -1 where they save table reads
     };

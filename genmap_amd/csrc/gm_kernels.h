@@ -64,7 +64,7 @@ struct SearchArgs {
     uint32_t satMinW;               // saturation is looked up (a global read per covered k-mer) only for nodes at least this wide
     uint32_t probation;             // a single-row node that has spent every error is stepped this many times before it is verified
     uint32_t verifyCost;            // ... when width * verifyCost <= estimated rank steps left below the node
-    uint32_t nbFilter;              // 1: one-row table entries are compared with the needle's next characters before they become nodes
+    uint32_t nbFilter;              // != 0: one-row table entries are compared with the needle's next characters before they become nodes; 1: two-row entries too
     uint32_t selfHit;               // 1: a single error-free row on the forward strand is the window's own location -- no lookup at all
     // ---- LDS staging (per wavefront): verification queue | top of the lane stacks | packed needle windows ----
     const uint4* text4;             // whole text, 4 bits per symbol (32 symbols per 16-byte chunk), sentinel-free
@@ -212,9 +212,10 @@ __device__ __forceinline__ void covered_kmers(uint32_t meta, uint32_t n, uint32_
 constexpr int32_t CTX_LEFT = 24, CTX_SYMS = 56;
 
 constexpr uint32_t NB_SYMS = 6;       // neighbour symbols per side carried by one-row q-mer table entries (qmer_table_kernel)
+constexpr uint32_t NB_SYMS2 = 3;      // ... and per side and row by two-row entries
 constexpr uint32_t STEAL_LEVELS = 16;  // a lane gives away at most this many bottom entries before its stack has run empty once
 
-constexpr uint32_t JF_ENTRY = 4u, JF_WORD = 8u, JF_ITEM = 16u;   // fetch-state flags of a lane with jump patterns: table entry in flight, bitmap word in flight, jd holds an item
+constexpr uint32_t JF_ENTRY = 4u, JF_WORD = 8u, JF_ITEM = 16u, JF_GROUP = 32u;   // fetch-state flags of a lane with jump patterns: table entry in flight, bitmap word in flight, jd holds an item, that item is a group
 constexpr uint32_t WORK_CHUNK = 256;   // roots taken from the global counter per atomic
 constexpr uint32_t VERIFY_TMAX = 16;   // widest range resolved by verification
 constexpr uint32_t VERIFY_ROWS = 2;    // rows of one node queued per iteration (the rest waits on the lane's stack)
@@ -242,7 +243,7 @@ template <int WPP> struct EnvBase {
     uint32_t steps = 0, lines = 0, stOss = 0, stExt = 0, stExtW1 = 0, stExtW4 = 0, stOssW1 = 0, pushes = 0, vItems = 0, vItemsOss = 0, vChunks = 0, jumps = 0, jumpDrops = 0;
     uint32_t whit[17] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // (16: part B of the jump patterns; not exported)
     mutable uint32_t locRows = 0, lfSteps = 0;   // rows located (one suffix-array or mark-word read each), LF steps of sampled walks
-    uint32_t jumpWords = 0;                       // words of the existence bitmap read for groups of jump patterns
+    uint32_t jumpWords = 0, jumpDrops2 = 0;       // words of the existence bitmap read for groups of jump patterns; rows of two-row entries ended by the neighbour filter
     uint32_t maxSp = 0, selfHits = 0, runs = 0;  // deepest lane stack, self hits, verified runs of k-mers handed to the leaf policy
     // a wavefront passed here (counted by its first enabled lane): the dynamic cost of a region = passes x its instructions
     __device__ __forceinline__ void note_wave(int i) { const unsigned long long m = __ballot(true); if (__lane_id() == (unsigned)(__ffsll((long long)m) - 1)) whit[i]++; }
@@ -875,10 +876,10 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     // the next pattern's descriptor (prefetched), meta of the node at depth J (with the errors of the pattern whose table entry
     // is in flight; bit 30 marks the first pattern of a root: the root context is installed with it)
     uint32_t jb = 0, jpp = 0, jd = 0, jm = 0;   // jpp: next item | end << 16; jd: the current item (JF_ITEM); jm: errs field = errors of the pattern in flight
-    // groups of patterns (gm_oss.h): rotations of the current group that exist and are still to be looked up, the group's J-mer prefix,
+    // groups of patterns (gm_oss.h): rotations of the current group that exist and are still to be looked up, the group's own rotations,
     // the bitmap word in flight (JF_WORD).  fs of a lane with pattern work = 2 | JF_* flags.
     unsigned long long galive = 0ull, pw = 0ull;
-    uint32_t gpre = 0;
+    uint32_t gcur = 0;
     // neighbour filter: jn = the needle's characters next to the J-mer inside the infix, packed like the table's 4th word (bit 15: the
     // filter applies to this root), ftNb = that word of the entry in flight
     uint32_t jn = 0, ftNb = 0;
@@ -983,8 +984,31 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                     env.jumpDrops += take ? 0u : 1u;
 #endif
                 }
+                bool rowsOnly = false;
+                if (take && ftW == 2u && (jn & 0x8000u) != 0u && A.nbFilter == 1u) {
+                    // The substituted J-mer occurs TWICE: the same test with 3 + 3 neighbours for either row.  Neither passes: no node.  One
+                    // passes: the node is that row alone, and a lone row of which only the forward position is known is never stepped --
+                    // it goes to the verification queue (rows-only node, rlo = all ones).
+                    const uint32_t h = jl[rt.search].w;
+                    const uint32_t needR = min((h >> 12) & 7u, NB_SYMS2), needL = min((h >> 28) & 7u, NB_SYMS2);
+                    const uint32_t mR = h & 0x15u, mL = (h >> 16) & 0x15u, budget = A.E - meta_errs(jm);
+                    bool pass[2];
+#pragma unroll
+                    for (uint32_t r = 0; r < 2u; ++r) {
+                        const uint32_t x = (ftNb >> (16u * r)) & 0xFFFFu;
+                        const uint32_t dr = (x ^ jn) & 0x3Fu, dl = ((x >> 6) ^ (jn >> 16)) & 0x3Fu;
+                        const uint32_t mism = (uint32_t)__popc((dr | dr >> 1) & mR) + (uint32_t)__popc((dl | dl >> 1) & mL);
+                        pass[r] = ((x >> 12) & 3u) >= needR && (x >> 14) >= needL && mism <= budget;
+                    }
+                    take = pass[0] || pass[1];
+                    if (take && pass[0] != pass[1] && A.verifyT != 0u) { rowsOnly = true; ftFlo += pass[1] ? 1u : 0u; }
+#ifdef GM_COUNTERS
+                    env.jumpDrops2 += take ? (rowsOnly ? 1u : 0u) : 2u;
+#endif
+                }
                 if (take) {
                     nd.flo = ftFlo; nd.rlo = ftRlo; nd.w = ftW; nd.meta = jm;
+                    if (rowsOnly) { nd.rlo = ~(row_t)0; nd.w = 1u; }
                     have = true; w1run = 0;
                 }
                 if (sat) { galive = 0ull; jpp = (jpp >> 16) * 0x10001u; fs = 2u; }   // the remaining items are skipped (part B ends the root)
@@ -1047,8 +1071,8 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                     if (bad) { rt = frt; env.on_root(); nd = root_node(rt, (row_t)A.nRows); have = true; fs = 0u; w1run = 0; }
                     else {
                         jb = idx;
-                        const uint4 fji = jl[frt.search];   // {first item | items << 16, meta at depth J relative to n - 1, first item, neighbour-filter mask}
-                        jm = meta_pack((fji.y & 0x1FFu) + frt.n - 1u, ((fji.y >> 9) & 0x1FFu) + frt.n - 1u, fji.y >> 18, 0u, M_OSS);
+                        const uint4 fji = jl[frt.search];   // {first item | items << 16, meta at depth J relative to n - 1 | groups << 24, first item, neighbour-filter mask}
+                        jm = meta_pack((fji.y & 0x1FFu) + frt.n - 1u, ((fji.y >> 9) & 0x1FFu) + frt.n - 1u, (fji.y >> 18) & 63u, 0u, M_OSS);
                         jn = 0u;
                         if (fji.w >> 31) {   // the needle's neighbours of the J-mer, once per root
                             uint32_t notLetter = 0u;
@@ -1063,6 +1087,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                         jpp = ((fji.x & 0xFFFFu) + 1u) | ((fji.x & 0xFFFFu) + (fji.x >> 16)) << 16;
                         env.on_root();
                         fs = 2u | JF_ITEM;
+                        if (fji.y >> 24) fs += JF_GROUP + ((fji.y >> 24) - 1u) * 256u;   // bits 8..15: groups that follow the item in jd
                     }
                 } else {
                 if (bad) fs = 0u;   // a pattern N never matches in an exact block (find2:330): this root finds nothing
@@ -1080,8 +1105,8 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                 env.note_wave(16);
                 // (an item loaded in this iteration is not looked at before the next one: nothing waits for that load)
                 bool fresh = false;
-                if ((fs & (JF_ITEM | JF_WORD)) == JF_ITEM && (jd >> 31) != 0u) {   // a group item: request its word now
-                    pw = A.jbits[jump_apply(jb, jd & 0x07FFFFFFu, A.jumpJ) >> 6];
+                if ((fs & (JF_ITEM | JF_WORD | JF_GROUP)) == (JF_ITEM | JF_GROUP)) {   // a group item: request its word now
+                    pw = A.jbits[rot_add(jb, jd & ~63u) >> 6];
                     fs |= JF_WORD;
                     fresh = true;
 #ifdef GM_COUNTERS
@@ -1089,31 +1114,28 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
 #endif
                 }
                 if (galive == 0ull && (fs & JF_WORD) && !fresh) {   // the word of group jd has arrived: its patterns that exist
-                    gpre = jump_apply(jb, jd & 0x07FFFFFFu, A.jumpJ);
-                    const uint2 mk = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint32_t*>(jl + 8) + 2u * ((jd >> 27) & 7u));
+                    const uint2 mk = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint32_t*>(jl + 8) + 2u * (jd & 7u));
                     galive = word_to_rotations(pw, jb & 63u) & ((unsigned long long)mk.y << 32 | mk.x);
-                    fs &= ~(JF_WORD | JF_ITEM);
+                    gcur = jd & ~63u;
+                    fs &= ~(JF_WORD | JF_ITEM | JF_GROUP);
                     const uint32_t jp = jpp & 0xFFFFu;
-                    if (jp < (jpp >> 16)) { jd = A.patterns[jp]; jpp += 1u; fs |= JF_ITEM; fresh = true; }
+                    if (jp < (jpp >> 16)) { jd = A.patterns[jp]; jpp += 1u; fs |= JF_ITEM; fresh = true; if (fs >> 8) fs += JF_GROUP - 256u; }
                 }
                 if (!(fs & JF_ENTRY)) {
-                    uint32_t idx = 0u, er = 0u; bool go = false;
-                    if (galive != 0ull) {
-                        const uint32_t rot = ctz64(galive);
+                    uint32_t rw = 0u; bool go = false;
+                    if (galive != 0ull) {   // the next pattern of the current group that exists
+                        rw = gcur | ctz64(galive);
                         galive &= galive - 1ull;
-                        idx = (gpre & ~63u) | rotations_to_low6(jb & 63u, rot);
-                        const uint32_t px = (gpre ^ jb) >> 6;
-                        er = (uint32_t)__popc((px | px >> 1) & 0x01555555u) + rotations_errors(rot);
                         go = true;
-                    } else if ((fs & (JF_ITEM | JF_WORD)) == JF_ITEM && !fresh) {   // (jd is a plain pattern here: a group has JF_WORD set by now)
-                        idx = jump_apply(jb, jd, A.jumpJ); er = jd & 7u; go = true;
+                    } else if ((fs & (JF_ITEM | JF_WORD | JF_GROUP)) == JF_ITEM && !fresh) {   // a plain pattern
+                        rw = jd; go = true;
                         fs &= ~JF_ITEM;
                         const uint32_t jp = jpp & 0xFFFFu;
-                        if (jp < (jpp >> 16)) { jd = A.patterns[jp]; jpp += 1u; fs |= JF_ITEM; }
+                        if (jp < (jpp >> 16)) { jd = A.patterns[jp]; jpp += 1u; fs |= JF_ITEM; if (fs >> 8) fs += JF_GROUP - 256u; }
                     }
                     if (go) {
-                        IO::load_qentry(A.jtab, idx, ftFlo, ftRlo, ftW, ftNb);
-                        jm = (jm & ~(7u << META_ERRS_SHIFT)) | er << META_ERRS_SHIFT;
+                        IO::load_qentry(A.jtab, rot_add(jb, rw), ftFlo, ftRlo, ftW, ftNb);
+                        jm = (jm & ~(7u << META_ERRS_SHIFT)) | rot_errors(rw) << META_ERRS_SHIFT;
                         fs |= JF_ENTRY;
 #ifdef GM_COUNTERS
                         env.jumps++;
@@ -1361,6 +1383,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     atomicAdd(&A.counters[45], (unsigned long long)env.selfHits);    // detail[43]: self hits (nodes settled without a lookup)
     atomicAdd(&A.counters[46], (unsigned long long)env.runs);        // detail[44]: verified runs of k-mers
     atomicAdd(&A.counters[47], (unsigned long long)env.jumpWords);   // detail[45]: bitmap words read for groups of jump patterns
+    atomicAdd(&A.counters[48], (unsigned long long)env.jumpDrops2);  // detail[46]: rows of two-row table entries ended by the neighbour filter
 #pragma unroll
     for (int i = 0; i < 16; ++i) if (env.whit[i]) atomicAdd(&A.counters[22 + i], (unsigned long long)env.whit[i]);
     if (lane == 0) {
@@ -1423,6 +1446,17 @@ __global__ __launch_bounds__(256) void qmer_table_kernel(const uint32_t* __restr
         while (nr < NB_SYMS && t[q + nr] < (uint8_t)SYM_N) { nb |= (uint32_t)t[q + nr] << (2u * nr); ++nr; }
         while (nl < NB_SYMS && t[-1 - (int)nl] < (uint8_t)SYM_N) { nb |= (uint32_t)t[-1 - (int)nl] << (16u + 2u * nl); ++nl; }
         nb |= nr << 12 | nl << 28 | 0x80008000u;
+    }
+    if (sizeof(row_t) == 4 && w == 2u && sa != nullptr) {
+        // TWO rows: 3 + 3 symbols next to either occurrence, 16 bits per row (row flo in the low half): bits 0..5 the symbols to its right,
+        // 6..11 to its left (nearest first), 12..13 / 14..15 how many of them are letters inside the sequence
+        for (uint32_t r = 0; r < 2u; ++r) {
+            const uint8_t* t = textS + sa[flo + r];
+            uint32_t x = 0, nr = 0, nl = 0;
+            while (nr < NB_SYMS2 && t[q + nr] < (uint8_t)SYM_N) { x |= (uint32_t)t[q + nr] << (2u * nr); ++nr; }
+            while (nl < NB_SYMS2 && t[-1 - (int)nl] < (uint8_t)SYM_N) { x |= (uint32_t)t[-1 - (int)nl] << (6u + 2u * nl); ++nl; }
+            nb |= (x | nr << 12 | nl << 14) << (16u * r);
+        }
     }
     NodeIO<row_t>::store_qentry(out, idx, flo, rlo, w, nb);
 }

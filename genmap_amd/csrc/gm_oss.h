@@ -143,69 +143,68 @@ inline bool oss_jump_patterns(uint32_t E, const OssRecord& rec, uint32_t L, uint
     return true;
 }
 
-// ---- grouped jump patterns: many patterns answered by ONE word of an existence bitmap ---------------------------------------
+// ---- items of a search: rotation words, and groups of patterns answered by ONE word of an existence bitmap --------------------
+// What a lane reads is not the descriptor above but its ROTATION WORD: 2-bit field at index bits 2(J-1-off) = r, i.e. the rotations laid
+// out like the table index itself, so that "apply the substitutions" is one carry-less field-wise addition (rot_add) and "count them"
+// one population count (rot_errors) -- no loop over the substitutions in the kernel.
+//
 // On a genome about half of the substituted J-mers of a search do not occur at all (3 Gbp, J = 16: the average 16-mer has 0.72
 // occurrences), yet each of them costs a 16-byte table read -- an HBM fetch -- to find that out.  A bitmap with one bit per J-mer
 // (4^16 bits = 512 MB) answers "does it occur" for the 64 J-mers that share their first J - 3 characters with ONE 8-byte read.
 // Patterns that differ only in their last GROUP_SYMS = 3 characters (the lowest 6 bits of the table index) therefore form a GROUP:
-//   item (u32), bit 31 set:  bits 0..26 the substitutions in front of the last three characters (same layout as a pattern descriptor),
-//                            bits 27..29 which of at most 8 distinct MASKS the group uses
-//   mask (u64): bit (r0 << 4 | r1 << 2 | r2) set = the pattern that rotates the last three characters by r0, r1, r2 (0 = kept) belongs
-//               to the search; its error count is the group's plus the number of non-zero rotations.
+//   group item (u32): the rotations in front of the last three characters (bits 6..31) | which of at most 8 distinct MASKS it uses (bits 0..2)
+//   mask (u64): bit (r0 << 4 | r1 << 2 | r2) set = the pattern that additionally rotates the last three characters by r0, r1, r2 belongs
+//               to the search.
 // The lane reads the group's word, brings it into "rotation space" (word_to_rotations) and walks the set bits of word & mask: only
-// J-mers that exist are looked up in the table.  Patterns whose group would hold a single pattern stay plain descriptors (bit 31
-// clear): a probe plus half a table read costs more than the table read.
+// J-mers that exist are looked up in the table.  A search's items are its groups first, then its plain patterns (a pattern whose
+// group would hold it alone stays plain: a probe plus half a table read costs more than the table read).
 constexpr uint32_t GROUP_SYMS = 3;
-constexpr uint32_t GROUP_FLAG = 0x80000000u;
 constexpr uint32_t GROUP_MAX_MASKS = 8;
 
-struct GroupedSearch {
-    std::vector<uint32_t> items;   // plain pattern descriptors and group items, in processing order
+struct SearchItems {
+    std::vector<uint32_t> items;   // groups first, then plain rotation words
+    uint32_t groups = 0;           // at most 255
     uint32_t patterns = 0;         // patterns covered (== JumpSearch::pat.size())
-    uint32_t groups = 0;
 };
 
-// splits a descriptor into the part in front of the last GROUP_SYMS characters and the rotation triple of those characters
-inline void oss_split_descriptor(uint32_t d, uint32_t J, uint32_t* prefix, uint32_t* rot)
+inline uint32_t oss_rotation_word(uint32_t d, uint32_t J)
 {
-    uint32_t pre = 0, np = 0, r = 0;
-    for (uint32_t k = 0; k < (d & 7u); ++k) {
-        const uint32_t f = (d >> (3u + 6u * k)) & 63u, off = f & 15u;
-        if (off + GROUP_SYMS >= J) r |= (f >> 4) << (2u * (J - 1u - off));
-        else { pre |= f << (3u + 6u * np); ++np; }
-    }
-    *prefix = pre | np; *rot = r;
+    uint32_t rw = 0;
+    for (uint32_t k = 0; k < (d & 7u); ++k) { const uint32_t f = (d >> (3u + 6u * k)) & 63u; rw |= (f >> 4) << (2u * (J - 1u - (f & 15u))); }
+    return rw;
 }
 
-// (host) Groups the patterns of one search.  masks: the distinct masks of the call so far (shared by its searches); returns false when
-// grouping is impossible (J too short, too many masks) -- the search then keeps its plain pattern list.
-inline bool oss_group_patterns(const JumpSearch& js, std::vector<uint64_t>* masks, GroupedSearch* out)
+// (host) Items of one search.  group: form groups where possible (masks: the distinct masks of the call so far, shared by its searches);
+// returns false when grouping was asked for and is impossible (J too short, too many masks or groups) -- call again without.
+inline bool oss_make_items(const JumpSearch& js, bool group, std::vector<uint64_t>* masks, SearchItems* out)
 {
     out->items.clear(); out->patterns = (uint32_t)js.pat.size(); out->groups = 0;
+    if (!group) { for (uint32_t d : js.pat) out->items.push_back(oss_rotation_word(d, js.J)); return true; }
     if (js.J <= GROUP_SYMS) return false;
-    std::vector<uint32_t> keys; std::vector<uint64_t> km; std::vector<uint32_t> single;   // per prefix: mask, and the one descriptor if it stays alone
+    std::vector<uint32_t> keys; std::vector<uint64_t> km; std::vector<uint32_t> single;   // per prefix: mask, and the one pattern if it stays alone
     for (uint32_t d : js.pat) {
-        uint32_t pre, rot;
-        oss_split_descriptor(d, js.J, &pre, &rot);
+        const uint32_t rw = oss_rotation_word(d, js.J), pre = rw & ~63u;
         size_t g = 0;
         while (g < keys.size() && keys[g] != pre) ++g;
-        if (g == keys.size()) { keys.push_back(pre); km.push_back(0); single.push_back(d); }
-        km[g] |= 1ull << rot;
+        if (g == keys.size()) { keys.push_back(pre); km.push_back(0); single.push_back(rw); }
+        km[g] |= 1ull << (rw & 63u);
     }
     std::vector<uint64_t> m2 = *masks;
+    std::vector<uint32_t> plain;
     for (size_t g = 0; g < keys.size(); ++g) {
-        if ((km[g] & (km[g] - 1)) == 0) { out->items.push_back(single[g]); continue; }   // one pattern: a plain descriptor
+        if ((km[g] & (km[g] - 1)) == 0) { plain.push_back(single[g]); continue; }
         size_t id = 0;
         while (id < m2.size() && m2[id] != km[g]) ++id;
         if (id == m2.size()) { if (m2.size() == GROUP_MAX_MASKS) return false; m2.push_back(km[g]); }
-        out->items.push_back(GROUP_FLAG | (uint32_t)id << 27 | keys[g]);
-        out->groups++;
+        out->items.push_back(keys[g] | (uint32_t)id);
+        if (++out->groups > 255u) return false;
     }
+    out->items.insert(out->items.end(), plain.begin(), plain.end());
     *masks = m2;
     return true;
 }
 
-// the J-mer index with a descriptor's substitutions applied (pattern descriptors and the prefix part of group items alike)
+// the J-mer index with a descriptor's substitutions applied (descriptor form: tests and the emulator's reference path)
 GM_HD uint32_t jump_apply(uint32_t idx, uint32_t d, uint32_t J)
 {
     for (uint32_t k = 0; k < (d & 7u); ++k) {
@@ -213,6 +212,20 @@ GM_HD uint32_t jump_apply(uint32_t idx, uint32_t d, uint32_t J)
         idx ^= (old ^ ((old + (f >> 4)) & 3u)) << sh;
     }
     return idx;
+}
+// the same with a rotation word: every 2-bit letter of idx advanced by the rotation in the same field, without carries between fields
+GM_HD uint32_t rot_add(uint32_t idx, uint32_t rw)
+{
+    return (((idx & 0x33333333u) + (rw & 0x33333333u)) & 0x33333333u) | (((idx & 0xCCCCCCCCu) + (rw & 0xCCCCCCCCu)) & 0xCCCCCCCCu);
+}
+GM_HD uint32_t rot_errors(uint32_t rw)   // substitutions of a rotation word
+{
+    const uint32_t nz = (rw | rw >> 1) & 0x55555555u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__popc(nz);
+#else
+    return (uint32_t)__builtin_popcount(nz);
+#endif
 }
 
 // Bitmap word of the 64 J-mers that share the first J - 3 characters: bit (c0 << 4 | c1 << 2 | c2) = the J-mer ending in letters c0 c1 c2
@@ -228,15 +241,4 @@ GM_HD uint64_t word_to_rotations(uint64_t w, uint32_t low6)
     w = ((w >> s2) & lo2) | ((w << (4u - s2)) & ~lo2);
     return w;
 }
-// the last three letters (6 index bits) of the J-mer that rotation triple `rot` turns the needle's low6 into, and its substitutions
-GM_HD uint32_t rotations_to_low6(uint32_t low6, uint32_t rot)
-{
-    return (((low6 & 0x33u) + (rot & 0x33u)) & 0x33u) | (((low6 & 0x0Cu) + (rot & 0x0Cu)) & 0x0Cu);
-}
-GM_HD uint32_t rotations_errors(uint32_t rot)
-{
-    const uint32_t nz = (rot | rot >> 1) & 0x15u;
-    return (nz & 1u) + ((nz >> 2) & 1u) + ((nz >> 4) & 1u);
-}
-
 }  // namespace gm

@@ -178,9 +178,11 @@ static void search_plan(const MapPlan& plan, const HostIndex<WPP>& ix, Env& env,
             for (auto& j : jumps) j = JumpSearch();
         }
     }
+    // what a lane reads: rotation words, groups first (gm_oss.h: oss_make_items)
     std::vector<uint64_t> gmasks;
-    if (g_jumpGroups)
-        for (auto& j : jumps) { GroupedSearch gs; if (j.J && oss_group_patterns(j, &gmasks, &gs)) j.pat = gs.items; }
+    std::vector<SearchItems> items(plan.nSearches);
+    for (uint32_t s = 0; s < plan.nSearches; ++s)
+        if (jumps[s].J && !(g_jumpGroups && oss_make_items(jumps[s], true, &gmasks, &items[s]))) oss_make_items(jumps[s], false, nullptr, &items[s]);
     uint64_t roots = plan.numRoots();
     uint32_t rpb = plan.nSearches * plan.nStrands;
     auto walk = [&](Node nd, const Root& rt) {
@@ -229,17 +231,18 @@ static void search_plan(const MapPlan& plan, const HostIndex<WPP>& ix, Env& env,
                     nd.meta = meta_pack((js.meta0 & 0x1FFu) + off, ((js.meta0 >> 9) & 0x1FFu) + off, js.meta0 >> 18, nsub, M_OSS);
                     walk(nd, rt);
                 };
-                for (uint32_t d : js.pat) {
-                    if (!(d & GROUP_FLAG)) { lookup(jump_apply(base2, d, js.J), d & 7u); continue; }
+                const SearchItems& it = items[rt.search];
+                for (size_t q = 0; q < it.items.size(); ++q) {
+                    const uint32_t d = it.items[q];
+                    if (q >= it.groups) { lookup(rot_add(base2, d), rot_errors(d)); continue; }
                     // a group: the word of the existence bitmap (built here from the table), in rotation space, masked; only J-mers that exist are looked up
-                    const uint32_t pre = jump_apply(base2, d & 0x07FFFFFFu, js.J);
+                    const uint32_t pre = rot_add(base2, d & ~63u);
                     uint64_t word = 0;
                     for (uint32_t c = 0; c < 64u; ++c) { uint32_t f, r, w; table_entry<WPP>(ix, (pre & ~63u) | c, js.J, f, r, w); if (w) word |= 1ull << c; }
-                    uint64_t alive = word_to_rotations(word, base2 & 63u) & gmasks[(d >> 27) & 7u];
+                    uint64_t alive = word_to_rotations(word, base2 & 63u) & gmasks[d & 7u];
                     while (alive) {
-                        const uint32_t rot = (uint32_t)__builtin_ctzll(alive); alive &= alive - 1ull;
-                        const uint32_t px = (pre ^ base2) >> 6;
-                        lookup((pre & ~63u) | rotations_to_low6(base2 & 63u, rot), (uint32_t)__builtin_popcount((px | px >> 1) & 0x01555555u) + rotations_errors(rot));
+                        const uint32_t rw = (d & ~63u) | (uint32_t)__builtin_ctzll(alive); alive &= alive - 1ull;
+                        lookup(rot_add(base2, rw), rot_errors(rw));
                     }
                 }
             }
