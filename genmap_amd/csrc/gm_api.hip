@@ -347,7 +347,9 @@ void gm_index_free(gm_index* ix)
     hipFree(ix->d_blk[0]); hipFree(ix->d_blk[1]); hipFree(ix->d_textAlloc); hipFree(ix->d_text4); hipFree(ix->d_cum); hipFree(ix->d_sa); hipFree(ix->d_textSAlloc); hipFree(ix->d_C); hipFree(ix->d_ctx);
     hipFree(ix->d_saMark); hipFree(ix->d_saSamples);
     for (auto& kv : ix->qtables) hipFree(kv.second);
-    for (auto& kv : ix->jbits) hipFree(kv.second); hipFree(ix->d_seqFile); hipFree(ix->d_bits);
+    for (auto& kv : ix->jbits) hipFree(kv.second);
+    for (auto& m : ix->jbits1) for (auto& kv : m) hipFree(kv.second);
+    hipFree(ix->d_jinfo2); hipFree(ix->d_seqFile); hipFree(ix->d_bits);
     hipFree(ix->d_acc); hipFree(ix->d_stack); hipFree(ix->d_small); hipFree(ix->d_table); hipFree(ix->d_blocks); hipFree(ix->d_cumLocal);
     for (int i = 0; i < 4; ++i) if (ix->ev[i]) hipEventDestroy(ix->ev[i]);
     for (uint32_t i = 0; i < gm_index::EV_RING; ++i) for (int j = 0; j < 2; ++j) if (ix->evRing[i][j]) hipEventDestroy(ix->evRing[i][j]);
@@ -537,7 +539,7 @@ template <typename T> static int grow(T** p, uint64_t* cap, uint64_t need)
 enum LeafMode { LEAF_COUNT = 0, LEAF_FILESET = 1, LEAF_OCC_COUNT = 2, LEAF_OCC_EMIT = 3, LEAF_STORE = 4, LEAF_STORE8 = 5, LEAF_COUNT_JUMP = 6, LEAF_SCATTER = 7 };
 
 // nu = 16-byte units per stored node / queue entry: 1, or 2 with 64-bit rows (gm_kernels.h: NodeIO)
-static inline size_t search_lds_bytes(const SearchArgs& A, uint32_t nu) { return (size_t)(4u * A.vqCap * nu + 4u * 64u * (A.ldsDepth * nu + A.winChunks)) * 16u + 4u * 128u * 4u + 192u + (A.lqCap ? 4u * (A.lqCap * 16u + 80u * 4u) : 0u); }
+static inline size_t search_lds_bytes(const SearchArgs& A, uint32_t nu) { return (size_t)(4u * A.vqCap * nu + 4u * 64u * (A.ldsDepth * nu + A.winChunks)) * 16u + 4u * 128u * 4u + 320u + (A.lqCap ? 4u * (A.lqCap * 16u + 80u * 4u) : 0u); }
 
 template <int WPP, class EnvT>
 static int launch_one(const SearchArgs& A, unsigned blocks, hipStream_t st)
@@ -661,6 +663,36 @@ static int get_jbits(gm_index* ix, uint32_t q, const uint4* tab, const unsigned 
     ix->jbits[q] = d;
     ix->qtableBytes += bytes;
     *out = d;
+    return GM_OK;
+}
+
+// bitmaps of kind 1 (gm_oss.h), both layouts, built from the sentinel text (cached).  Null when the device is short of memory.
+static int get_jbits1(gm_index* ix, uint32_t q, const unsigned long long** low, const unsigned long long** mid)
+{
+    *low = *mid = nullptr;
+    if (q <= GROUP_SYMS || ix->wide || !ix->d_textS) return GM_OK;
+    auto it = ix->jbits1[0].find(q);
+    if (it != ix->jbits1[0].end()) { *low = it->second; auto im = ix->jbits1[1].find(q); *mid = im != ix->jbits1[1].end() ? im->second : nullptr; return GM_OK; }
+    const uint64_t words = (1ull << (2 * q)) / 64, bytes = 16 * words * 8;
+    const bool wantMid = q >= 2 * GROUP_SYMS;
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && bytes * (wantMid ? 2 : 1) + (8ull << 30) > freeB && bytes > (1ull << 24)) return GM_OK;
+    unsigned long long *dl = nullptr, *dm = nullptr;
+    if (hipMalloc(&dl, bytes) != hipSuccess) { (void)hipGetLastError(); return GM_OK; }
+    if (wantMid && hipMalloc(&dm, bytes) != hipSuccess) { (void)hipGetLastError(); hipFree(dl); return GM_OK; }
+    hipError_t e = hipMemset(dl, 0, bytes);
+    if (e == hipSuccess && dm) e = hipMemset(dm, 0, bytes);
+    if (e == hipSuccess) {
+        const uint64_t threads = (ix->nRows + 63) / 64, blocks = (threads + 255) / 256;
+        const dim3 grid((unsigned)std::min<uint64_t>(blocks, 1u << 22), (unsigned)((blocks + (1u << 22) - 1) >> 22));
+        hipLaunchKernelGGL(jbits1_kernel, grid, dim3(256), 0, 0, ix->d_textS, ix->nRows, q, dl, dm, words);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    if (e != hipSuccess) { hipFree(dl); hipFree(dm); GM_HIP(e); }
+    ix->jbits1[0][q] = dl; if (dm) ix->jbits1[1][q] = dm;
+    ix->qtableBytes += bytes * (dm ? 2 : 1);
+    *low = dl; *mid = dm;
     return GM_OK;
 }
 
@@ -851,7 +883,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     const uint32_t winChunks = (31u + p->K + plan.stepSize - 1u + 31u) / 32u;
     const uint32_t nu = ix->wide ? 2u : 1u;
     const int wantPerCU = std::max(1, ix->tune.blocksPerCU);   // default 4 = 4 waves/SIMD, what the kernel's VGPR count allows
-    auto lds_bytes_for = [&](uint32_t d) { return (size_t)(4u * vqCap * nu + 4u * 64u * (d * nu + winChunks)) * 16u + 4u * 128u * 4u + 192u + (lqCap ? 4u * (lqCap * 16u + 80u * 4u) : 0u); };   // == search_lds_bytes
+    auto lds_bytes_for = [&](uint32_t d) { return (size_t)(4u * vqCap * nu + 4u * 64u * (d * nu + winChunks)) * 16u + 4u * 128u * 4u + 320u + (lqCap ? 4u * (lqCap * 16u + 80u * 4u) : 0u); };   // == search_lds_bytes
     auto blocks_for = [&](uint32_t d, int* nb) {
         switch (ix->wpp) { case 1: return occupancy_blocks<1>(nb, lds_bytes_for(d)); case 2: return occupancy_blocks<2>(nb, lds_bytes_for(d)); case 3: return occupancy_blocks<3>(nb, lds_bytes_for(d)); default: return occupancy_blocks<9>(nb, lds_bytes_for(d)); }
     };
@@ -881,6 +913,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     // ---- jump patterns (frequency calls with errors on an index that can locate): one J for every search ----
     std::vector<uint32_t> patHost; std::vector<uint4> jinfoHost; uint32_t jumpJ = 0, jumpAPacked[2] = {0, 0};
     const unsigned long long* jbitsCall = nullptr; unsigned long long gmaskCall[GROUP_MAX_MASKS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long* jb1Call[2] = {nullptr, nullptr}; uint64_t jbitsWords = 0; std::vector<uint4> jinfo2Host(8, make_uint4(0, 0, 0, 0));
     const uint4* jtab = nullptr;
     S->jump = wantJump && p->E >= 1 && (ix->d_sa || ix->d_saMark) && ix->tune.jump != 0 && !ix->wide;
     if (S->jump) {
@@ -908,23 +941,22 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
             // Groups of patterns (gm_oss.h): patterns that differ in the last three characters only share one word of the existence bitmap.
             // A search is grouped when that saves table reads: groups + (share of J-mers that occur) x their patterns against one read
             // per pattern (3.09 Gbp, J = 16: 51 % occur; K = 30 e = 2, search 1: 211 reads -> 13 words + 54 + ~80 reads).
-            const unsigned long long* jbits = nullptr;
-            if (ix->tune.jumpGroups != 0) { rc = get_jbits(ix, J, jtab, &jbits); if (rc) return rc; }
+            const unsigned long long *jbits = nullptr, *jb1Low = nullptr, *jb1Mid = nullptr;
+            if (ix->tune.jumpGroups != 0) {
+                rc = get_jbits(ix, J, jtab, &jbits); if (rc) return rc;
+                if (jbits) { rc = get_jbits1(ix, J, &jb1Low, &jb1Mid); if (rc) return rc; }
+            }
             const double occur = 1.0 - std::exp(-(double)ix->nRows / std::ldexp(1.0, 2 * (int)J));
+            const double occur1 = 1.0 - std::exp(-(double)ix->nRows / std::ldexp(1.0, 2 * (int)J + 4));
             std::vector<uint64_t> masks;
             std::vector<SearchItems> items(plan.nSearches);
+            jinfo2Host.assign(8, make_uint4(0, 0, 0, 0));
             for (uint32_t s2 = 0; s2 < plan.nSearches; ++s2) {
-                SearchItems gs;
-                std::vector<uint64_t> m2 = masks;
-                bool grouped = jbits && oss_make_items(js[s2], true, &m2, &gs) && gs.groups > 0;
-                if (grouped && ix->tune.jumpGroups < 0) {
-                    const double inGroups = (double)(gs.patterns - (gs.items.size() - gs.groups));
-                    grouped = gs.groups + occur * inGroups <= 0.9 * inGroups;
-                }
-                if (grouped) { masks = m2; items[s2] = gs; }
-                else oss_make_items(js[s2], false, nullptr, &items[s2]);
+                // kind 1 needs two more infix characters to the right of the J-mer (and, for MID groups, its second bitmap family)
+                const bool ext = jb1Low && (jb1Mid || J < 2 * GROUP_SYMS) && js[s2].regionA + J + 2u <= L;
+                oss_make_items(js[s2], p->E, jbits ? (ix->tune.jumpGroups < 0 ? 2 : 1) : 0, ext, occur, occur1, &masks, &items[s2]);
             }
-            jbitsCall = masks.empty() ? nullptr : jbits;
+            jbitsCall = masks.empty() ? nullptr : jbits; jb1Call[0] = jb1Low; jb1Call[1] = jb1Mid; jbitsWords = (1ull << (2 * J)) / 64;
             for (size_t k = 0; k < masks.size(); ++k) gmaskCall[k] = masks[k];
             for (uint32_t s2 = 0; s2 < plan.nSearches; ++s2) {
                 // neighbour filter (gm_kernels.h): how many infix characters right / left of the J-mer a one-row table entry is compared with
@@ -935,13 +967,15 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
                     for (uint32_t i = 0; i < nl; ++i) nbWord |= 1u << (16u + 2u * i);
                     nbWord |= nr << 12 | nl << 28 | 1u << 31;
                 }
-                jinfoHost[s2] = make_uint4((uint32_t)patHost.size() | (uint32_t)items[s2].items.size() << 16, js[s2].meta0 | items[s2].groups << 24, items[s2].items[0], nbWord);
+                jinfoHost[s2] = make_uint4((uint32_t)patHost.size() | (uint32_t)items[s2].items.size() << 16, js[s2].meta0, items[s2].items[0], nbWord);
+                jinfo2Host[s2] = make_uint4((uint32_t)patHost.size() + items[s2].low, (uint32_t)patHost.size() + items[s2].low + items[s2].mid, items[s2].ext ? 1u : 0u, 0u);
                 jumpAPacked[s2 >> 2] |= js[s2].regionA << (8u * (s2 & 3u));
                 patHost.insert(patHost.end(), items[s2].items.begin(), items[s2].items.end());
             }
             const void *p0 = ix->d_patterns, *j0 = ix->d_jinfo;
             rc = grow(&ix->d_patterns, &ix->patternsCap, (uint64_t)patHost.size()); if (rc) return rc;
             rc = grow(&ix->d_jinfo, &ix->jinfoCap, 8); if (rc) return rc;
+            if (!ix->d_jinfo2) { GM_HIP(hipMalloc(&ix->d_jinfo2, 8 * sizeof(uint4))); ix->sigValid = false; }
             if (p0 != ix->d_patterns || j0 != ix->d_jinfo) ix->sigValid = false;   // reallocated: contents are gone
         }
     }
@@ -950,7 +984,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         // host-device synchronisation
         uint64_t h = 1469598103934665603ull;
         auto mix = [&h](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
-        mix(p->K); mix(p->E); mix(plan.infix); mix((uint64_t)(int64_t)ix->tune.partBias); mix((uint64_t)(int64_t)ix->tune.ossWeights); mix(jumpJ); mix((uint64_t)ix->tune.jumpFilter); mix(patHost.size()); for (uint32_t v : patHost) mix(v); mix(text_begin); mix(text_len); mix(first_seq); mix(n_seq); mix(n_intervals);
+        mix(p->K); mix(p->E); mix(plan.infix); mix((uint64_t)(int64_t)ix->tune.partBias); mix((uint64_t)(int64_t)ix->tune.ossWeights); mix(jumpJ); mix((uint64_t)ix->tune.jumpFilter); mix(patHost.size()); for (uint32_t v : patHost) mix(v); for (const uint4& v : jinfo2Host) { mix(v.x); mix(v.y); mix(v.z); } mix(text_begin); mix(text_len); mix(first_seq); mix(n_seq); mix(n_intervals);
         for (uint64_t k = 0; k < 2 * n_intervals; ++k) mix(intervals[k]);
         if (!ix->sigValid || ix->sig != h) {
             GM_HIP(hipMemcpyAsync(ix->d_table, plan.table.data(), plan.table.size() * sizeof(OssRecord), hipMemcpyHostToDevice, st));
@@ -959,6 +993,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
             if (jumpJ) {
                 GM_HIP(hipMemcpyAsync(ix->d_patterns, patHost.data(), patHost.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
                 GM_HIP(hipMemcpyAsync(ix->d_jinfo, jinfoHost.data(), 8 * sizeof(uint4), hipMemcpyHostToDevice, st));
+                GM_HIP(hipMemcpyAsync(ix->d_jinfo2, jinfo2Host.data(), 8 * sizeof(uint4), hipMemcpyHostToDevice, st));
             }
             std::vector<uint64_t> cumLocal((size_t)n_seq + 1);
             for (uint32_t s = 0; s <= n_seq; ++s) cumLocal[s] = ix->cum[first_seq + s] - text_begin;
@@ -1052,7 +1087,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     A.coop = ix->tune.coop >= 0 ? (uint32_t)(ix->tune.coop != 0) : (ix->wpp == 1 ? 1u : 0u);
     if (ix->wide) A.coop = 0u;
     A.jumpJ = jumpJ; A.jumpAPacked[0] = jumpAPacked[0]; A.jumpAPacked[1] = jumpAPacked[1];
-    A.patterns = ix->d_patterns; A.jinfo = ix->d_jinfo; A.jtab = jtab; A.jbits = jbitsCall;
+    A.patterns = ix->d_patterns; A.jinfo = ix->d_jinfo; A.jinfo2 = ix->d_jinfo2; A.jtab = jtab; A.jbits = jbitsCall; A.jbits1[0] = jb1Call[0]; A.jbits1[1] = jb1Call[1]; A.jbitsWords = jbitsWords;
     for (uint32_t k = 0; k < GROUP_MAX_MASKS; ++k) A.gmask[k] = gmaskCall[k];
     A.sliceBegin = text_begin; A.sliceLen = text_len; A.ownBegin = 0; A.ownEnd = text_len; A.ownChunkLen = 0; A.selBlocks = nullptr; A.nSelBlocks = 0;
     *Aout = A;

@@ -53,6 +53,8 @@ struct gm_index {
     uint4* d_ctx = nullptr;           // verification records {SA[row], 56 symbols around it}, 32 B per row, when HBM allows (gm_kernels.h: CTX_*)
     std::map<uint32_t, uint4*> qtables;   // q -> device table of 4^q entries (built on first use)
     std::map<uint32_t, unsigned long long*> jbits;   // q -> existence bitmap of the q-mers, 4^q bits (groups of jump patterns, gm_oss.h)
+    std::map<uint32_t, unsigned long long*> jbits1[2];   // q -> "q-mer followed by two given letters occurs", 16 x 4^q bits; [1]: MID layout
+    uint4* d_jinfo2 = nullptr;
     uint64_t sig = 0; bool sigValid = false;   // signature of the call whose tables are on the device
     uint32_t lastQ = 0;                   // longest q-mer table of the last call | jump length << 8 (statistics)
     uint32_t qtableCap = 0;               // != 0: longest prefix that fitted the device so far

@@ -89,6 +89,9 @@ struct SearchArgs {
     const uint4* jinfo;             // per search {first pattern | patterns << 16, meta at depth J relative to n - 1, first descriptor, 0}
     const uint4* jtab;              // table of all J-mers
     const unsigned long long* jbits;   // one bit per J-mer: does it occur (word = the 64 J-mers sharing their first J - 3 characters); groups of patterns
+    const unsigned long long* jbits1[2];   // per pair of following letters (16 x jbitsWords words): does the J-mer occur followed by them; [1]: MID layout
+    uint64_t jbitsWords;            // 4^J / 64
+    const uint4* jinfo2;            // per search {first item behind the LOW groups, first item behind the MID groups, groups of kind 1?, 0}
     unsigned long long gmask[8];    // masks of the groups (gm_oss.h: GROUP_MAX_MASKS)
     uint32_t jumpJ;                 // 0: no jumps in this call (every root starts at the tree's root)
     uint32_t jumpAPacked[2];        // 8 bits per search: window coordinate of the J-mer's first character, minus (n - 1)
@@ -215,7 +218,9 @@ constexpr uint32_t NB_SYMS = 6;       // neighbour symbols per side carried by o
 constexpr uint32_t NB_SYMS2 = 3;      // ... and per side and row by two-row entries
 constexpr uint32_t STEAL_LEVELS = 16;  // a lane gives away at most this many bottom entries before its stack has run empty once
 
-constexpr uint32_t JF_ENTRY = 4u, JF_WORD = 8u, JF_ITEM = 16u, JF_GROUP = 32u;   // fetch-state flags of a lane with jump patterns: table entry in flight, bitmap word in flight, jd holds an item, that item is a group
+// fetch state of a lane with jump patterns: fs = 2 | flags.  Table entry in flight, bitmap word in flight, jd holds an item, that item is a
+// group / a MID group, the current set of live rotations belongs to a MID group; bits 8..11 the two letters behind the J-mer, bit 12: both are letters
+constexpr uint32_t JF_ENTRY = 4u, JF_WORD = 8u, JF_ITEM = 16u, JF_GROUP = 32u, JF_MID = 64u, JF_CURMID = 128u, JF_EXT_SHIFT = 8u, JF_EXTOK = 1u << 12;
 constexpr uint32_t WORK_CHUNK = 256;   // roots taken from the global counter per atomic
 constexpr uint32_t VERIFY_TMAX = 16;   // widest range resolved by verification
 constexpr uint32_t VERIFY_ROWS = 2;    // rows of one node queued per iteration (the rest waits on the lane's stack)
@@ -836,16 +841,17 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     // that lane's needle window (wlane) and the owner may not stage a new window while users[owner] != 0
     uint32_t* const users = reinterpret_cast<uint32_t*>(smem + 4u * A.vqCap * NU + 4u * 64u * (A.ldsDepth * NU + A.winChunks)) + wv * 128u;   // [64] users | [64] pairing
     uint32_t* const pairing = users + 64;
-    // the searches' jump records (Env::JUMPS), 8 x 16 bytes (+ 64 bytes of group masks) per block behind the work-sharing bookkeeping
+    // the searches' jump records (Env::JUMPS), 8 x 16 bytes (+ 64 bytes of group masks + 8 x 16 bytes of group counts) per block behind the work-sharing bookkeeping
     uint4* const jl = smem + 4u * A.vqCap * NU + 4u * 64u * (A.ldsDepth * NU + A.winChunks) + (4u * 128u * 4u) / 16u;
     if constexpr (EnvT::JUMPS) {
         if (threadIdx.x < 8u) jl[threadIdx.x] = A.jumpJ ? A.jinfo[threadIdx.x] : make_uint4(0, 0, 0, 0);
         // ... and the masks of its groups of patterns (gm_oss.h), 8 x 8 bytes behind them
         if (threadIdx.x < GROUP_MAX_MASKS) reinterpret_cast<unsigned long long*>(jl + 8)[threadIdx.x] = A.gmask[threadIdx.x];
+        if (threadIdx.x < 8u) jl[12u + threadIdx.x] = A.jumpJ ? A.jinfo2[threadIdx.x] : make_uint4(0, 0, 0, 0);   // ... and where its groups end
         __syncthreads();
     }
     if constexpr (EnvT::LEAFQ) {   // leaf queue behind everything else: [4 x lqCap entries] [4 x 80 control words]
-        uint4* const lqBase = jl + 12;
+        uint4* const lqBase = jl + 20;
         env.lq = lqBase + wv * A.lqCap;
         env.lqCtl = reinterpret_cast<uint32_t*>(lqBase + 4u * A.lqCap) + wv * 80u;
         if (lane == 0u) env.lqCtl[0] = 0u;
@@ -1071,8 +1077,8 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                     if (bad) { rt = frt; env.on_root(); nd = root_node(rt, (row_t)A.nRows); have = true; fs = 0u; w1run = 0; }
                     else {
                         jb = idx;
-                        const uint4 fji = jl[frt.search];   // {first item | items << 16, meta at depth J relative to n - 1 | groups << 24, first item, neighbour-filter mask}
-                        jm = meta_pack((fji.y & 0x1FFu) + frt.n - 1u, ((fji.y >> 9) & 0x1FFu) + frt.n - 1u, (fji.y >> 18) & 63u, 0u, M_OSS);
+                        const uint4 fji = jl[frt.search];   // {first item | items << 16, meta at depth J relative to n - 1, first item, neighbour-filter mask}
+                        jm = meta_pack((fji.y & 0x1FFu) + frt.n - 1u, ((fji.y >> 9) & 0x1FFu) + frt.n - 1u, fji.y >> 18, 0u, M_OSS);
                         jn = 0u;
                         if (fji.w >> 31) {   // the needle's neighbours of the J-mer, once per root
                             uint32_t notLetter = 0u;
@@ -1086,8 +1092,15 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                         jd = fji.z; galive = 0ull;
                         jpp = ((fji.x & 0xFFFFu) + 1u) | ((fji.x & 0xFFFFu) + (fji.x >> 16)) << 16;
                         env.on_root();
-                        fs = 2u | JF_ITEM;
-                        if (fji.y >> 24) fs += JF_GROUP + ((fji.y >> 24) - 1u) * 256u;   // bits 8..15: groups that follow the item in jd
+                        {
+                            const uint4 lim = jl[12u + frt.search];
+                            const uint32_t first = fji.x & 0xFFFFu;
+                            fs = 2u | JF_ITEM | (first < lim.x ? JF_GROUP : first < lim.y ? (JF_GROUP | JF_MID) : 0u);
+                            if (lim.z) {   // groups of kind 1 ask whether the J-mer occurs followed by the needle's next two letters
+                                const uint32_t e0 = env.text_char(frt, fa0 + A.jumpJ), e1 = env.text_char(frt, fa0 + A.jumpJ + 1u);
+                                if ((e0 | e1) < SYM_N) fs |= JF_EXTOK | (e0 << 2 | e1) << JF_EXT_SHIFT;
+                            }
+                        }
                     }
                 } else {
                 if (bad) fs = 0u;   // a pattern N never matches in an exact block (find2:330): this root finds nothing
@@ -1103,35 +1116,52 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
             // item is known, i.e. while the lane still works through the group before it.
             if ((fs & 3u) == 2u) {
                 env.note_wave(16);
-                // (an item loaded in this iteration is not looked at before the next one: nothing waits for that load)
+                // the next item of the lane's root into jd (not looked at before the next iteration: nothing waits for that load)
                 bool fresh = false;
-                if ((fs & (JF_ITEM | JF_WORD | JF_GROUP)) == (JF_ITEM | JF_GROUP)) {   // a group item: request its word now
-                    pw = A.jbits[rot_add(jb, jd & ~63u) >> 6];
-                    fs |= JF_WORD;
-                    fresh = true;
-#ifdef GM_COUNTERS
-                    env.jumpWords++;
-#endif
-                }
-                if (galive == 0ull && (fs & JF_WORD) && !fresh) {   // the word of group jd has arrived: its patterns that exist
-                    const uint2 mk = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint32_t*>(jl + 8) + 2u * (jd & 7u));
-                    galive = word_to_rotations(pw, jb & 63u) & ((unsigned long long)mk.y << 32 | mk.x);
-                    gcur = jd & ~63u;
-                    fs &= ~(JF_WORD | JF_ITEM | JF_GROUP);
+                auto next_item = [&]() {
                     const uint32_t jp = jpp & 0xFFFFu;
-                    if (jp < (jpp >> 16)) { jd = A.patterns[jp]; jpp += 1u; fs |= JF_ITEM; fresh = true; if (fs >> 8) fs += JF_GROUP - 256u; }
+                    if (jp < (jpp >> 16)) {
+                        jd = A.patterns[jp]; jpp += 1u; fresh = true;
+                        const uint4 lim = jl[12u + rt.search];
+                        fs |= JF_ITEM | (jp < lim.x ? JF_GROUP : jp < lim.y ? (JF_GROUP | JF_MID) : 0u);
+                    }
+                };
+                if ((fs & (JF_ITEM | JF_WORD | JF_GROUP)) == (JF_ITEM | JF_GROUP)) {   // a group item: request its word now
+                    const uint32_t sh = (fs & JF_MID) ? 6u : 0u, kind = (jd >> (sh + 3u)) & 1u;
+                    if (kind && !(fs & JF_EXTOK)) {   // a needle N behind the J-mer: no pattern without budget can match
+                        fs &= ~(JF_ITEM | JF_GROUP | JF_MID);
+                        next_item();
+                    } else {
+                        const uint32_t idxp = rot_add(jb, jd & ~(63u << sh));
+                        const uint32_t widx = ((fs & JF_MID) ? jump_swap_mid(idxp) : idxp) >> 6;
+                        const unsigned long long* base = A.jbits;
+                        if (kind) base = ((fs & JF_MID) ? A.jbits1[1] : A.jbits1[0]) + (size_t)((fs >> JF_EXT_SHIFT) & 15u) * A.jbitsWords;
+                        pw = base[widx];
+                        fs |= JF_WORD;
+                        fresh = true;
+#ifdef GM_COUNTERS
+                        env.jumpWords++;
+#endif
+                    }
+                }
+                if (galive == 0ull && (fs & JF_WORD) && !fresh) {   // the word of group jd has arrived: its patterns that pass
+                    const uint32_t sh = (fs & JF_MID) ? 6u : 0u;
+                    const uint2 mk = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint32_t*>(jl + 8) + 2u * ((jd >> sh) & 7u));
+                    galive = word_to_rotations(pw, (jb >> sh) & 63u) & ((unsigned long long)mk.y << 32 | mk.x);
+                    gcur = jd & ~(63u << sh);
+                    fs = (fs & ~(JF_WORD | JF_ITEM | JF_GROUP | JF_MID | JF_CURMID)) | ((fs & JF_MID) ? JF_CURMID : 0u);
+                    next_item();
                 }
                 if (!(fs & JF_ENTRY)) {
                     uint32_t rw = 0u; bool go = false;
-                    if (galive != 0ull) {   // the next pattern of the current group that exists
-                        rw = gcur | ctz64(galive);
+                    if (galive != 0ull) {   // the next pattern of the current group that passed
+                        rw = gcur | ctz64(galive) << ((fs & JF_CURMID) ? 6u : 0u);
                         galive &= galive - 1ull;
                         go = true;
                     } else if ((fs & (JF_ITEM | JF_WORD | JF_GROUP)) == JF_ITEM && !fresh) {   // a plain pattern
                         rw = jd; go = true;
                         fs &= ~JF_ITEM;
-                        const uint32_t jp = jpp & 0xFFFFu;
-                        if (jp < (jpp >> 16)) { jd = A.patterns[jp]; jpp += 1u; fs |= JF_ITEM; if (fs >> 8) fs += JF_GROUP - 256u; }
+                        next_item();
                     }
                     if (go) {
                         IO::load_qentry(A.jtab, rot_add(jb, rw), ftFlo, ftRlo, ftW, ftNb);
@@ -1140,7 +1170,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
 #ifdef GM_COUNTERS
                         env.jumps++;
 #endif
-                    } else if (fs == 2u) fs = 0u;   // no entry in flight, no item, no word, nothing alive: the root's patterns are done
+                    } else if (!(fs & (JF_ENTRY | JF_WORD | JF_ITEM))) fs = 0u;   // no entry in flight, no item, no word, nothing alive: the root's patterns are done
                 }
             }
         }
@@ -1469,6 +1499,26 @@ __global__ __launch_bounds__(256) void jbits_kernel(const uint4* __restrict__ ta
     const bool alive = i < nEntries && tab[i].z != 0u;
     const unsigned long long m = __ballot(alive);
     if ((threadIdx.x & 63u) == 0u && i < nEntries) bits[i >> 6] = m;
+}
+
+// bitmaps of kind 1 (gm_oss.h): for every run of J + 2 letters of the sentinel text (no N, no sequence end inside) the bit of its first J
+// letters in the array of its last two.  low / mid: the two index layouts (either may be null).  One thread per 64 text positions.
+__global__ __launch_bounds__(256) void jbits1_kernel(const uint8_t* __restrict__ textS, uint64_t n, uint32_t J, unsigned long long* __restrict__ low,
+                                                     unsigned long long* __restrict__ mid, uint64_t words)
+{
+    const uint64_t p0 = (((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x) * 64ull;
+    if (p0 >= n) return;
+    const uint64_t keep = (1ull << (2u * (J + 2u))) - 1ull;
+    uint64_t code = 0; uint32_t run = 0;
+    for (uint64_t q = p0; q < p0 + 64u + J + 1u && q < n; ++q) {
+        const uint32_t c = textS[q];
+        if (c < SYM_N) { code = ((code << 2) | c) & keep; ++run; } else run = 0;
+        if (run >= J + 2u && q - (J + 1u) >= p0) {
+            const uint32_t idx = (uint32_t)(code >> 4), ext = (uint32_t)code & 15u;
+            if (low) atomicOr(&low[(size_t)ext * words + (idx >> 6)], 1ull << (idx & 63u));
+            if (mid) { const uint32_t sw = jump_swap_mid(idx); atomicOr(&mid[(size_t)ext * words + (sw >> 6)], 1ull << (sw & 63u)); }
+        }
+    }
 }
 
 // store planes -> c[]: 16 bytes per lane where the three arrays are aligned alike (the planes are; `out` is the caller's)

@@ -149,22 +149,28 @@ inline bool oss_jump_patterns(uint32_t E, const OssRecord& rec, uint32_t L, uint
 // one population count (rot_errors) -- no loop over the substitutions in the kernel.
 //
 // On a genome about half of the substituted J-mers of a search do not occur at all (3 Gbp, J = 16: the average 16-mer has 0.72
-// occurrences), yet each of them costs a 16-byte table read -- an HBM fetch -- to find that out.  A bitmap with one bit per J-mer
-// (4^16 bits = 512 MB) answers "does it occur" for the 64 J-mers that share their first J - 3 characters with ONE 8-byte read.
-// Patterns that differ only in their last GROUP_SYMS = 3 characters (the lowest 6 bits of the table index) therefore form a GROUP:
-//   group item (u32): the rotations in front of the last three characters (bits 6..31) | which of at most 8 distinct MASKS it uses (bits 0..2)
-//   mask (u64): bit (r0 << 4 | r1 << 2 | r2) set = the pattern that additionally rotates the last three characters by r0, r1, r2 belongs
-//               to the search.
-// The lane reads the group's word, brings it into "rotation space" (word_to_rotations) and walks the set bits of word & mask: only
-// J-mers that exist are looked up in the table.  A search's items are its groups first, then its plain patterns (a pattern whose
-// group would hold it alone stays plain: a probe plus half a table read costs more than the table read).
+// occurrences), and most of those that do occur are chance hits which the neighbour filter drops right after their 16-byte table entry
+// has been read -- an HBM fetch and a turn of the lane each.  Bitmaps answer for 64 patterns at once, with ONE 8-byte read:
+//   kind 0  "does the J-mer occur"                                              4^J bits      (from the table of all J-mers)
+//   kind 1  "does the J-mer occur FOLLOWED BY the needle's next two letters"    16 x 4^J bits (from the text; 3 Gbp: 4 % of the 18-mers occur)
+// Kind 1 is a necessary condition for every pattern that has spent the whole error budget (the rest of the infix must follow
+// exactly) when two more infix characters lie to the right of the J-mer.  64 patterns that differ only in three adjacent characters form
+// a GROUP; two layouts: LOW = the last three characters of the J-mer (index bits 0..5), MID = the three before them (bits 6..11; its
+// bitmap is indexed with those two 6-bit fields swapped, jump_swap_mid).
+//   group item (u32): the rotations of all other characters | in the 6 bits of the group's own characters: mask id (bits 0..2), kind (bit 3)
+//   mask (u64): bit (r0 << 4 | r1 << 2 | r2) set = the pattern that additionally rotates the group's three characters by r0, r1, r2
+//               belongs to the search.
+// The lane reads the group's word, brings it into "rotation space" (word_to_rotations) and walks the set bits of word & mask: only those
+// patterns are looked up in the table.  A search's items are its LOW groups, then its MID groups, then its plain patterns.
 constexpr uint32_t GROUP_SYMS = 3;
 constexpr uint32_t GROUP_MAX_MASKS = 8;
+inline uint32_t rot_errors_host(uint32_t rw) { return (uint32_t)__builtin_popcount((rw | rw >> 1) & 0x55555555u); }
 
 struct SearchItems {
-    std::vector<uint32_t> items;   // groups first, then plain rotation words
-    uint32_t groups = 0;           // at most 255
+    std::vector<uint32_t> items;   // LOW groups, MID groups, plain rotation words
+    uint32_t low = 0, mid = 0;     // groups of either layout
     uint32_t patterns = 0;         // patterns covered (== JumpSearch::pat.size())
+    bool ext = false;              // some group is of kind 1: the lane needs the two letters behind the J-mer
 };
 
 inline uint32_t oss_rotation_word(uint32_t d, uint32_t J)
@@ -174,34 +180,59 @@ inline uint32_t oss_rotation_word(uint32_t d, uint32_t J)
     return rw;
 }
 
-// (host) Items of one search.  group: form groups where possible (masks: the distinct masks of the call so far, shared by its searches);
-// returns false when grouping was asked for and is impossible (J too short, too many masks or groups) -- call again without.
-inline bool oss_make_items(const JumpSearch& js, bool group, std::vector<uint64_t>* masks, SearchItems* out)
+// (host) Items of one search of a call with E errors.
+//   group:  0 plain patterns only, 1 groups wherever two patterns share a word, 2 groups where they are expected to save table reads
+//           (occur0 / occur1 = share of the J-mers / of the (J+2)-mers that occur in the text)
+//   ext:    kind 1 bitmaps are at hand and two more infix characters lie to the right of the J-mer
+// masks: the distinct masks of the call so far (shared by its searches).  Falls back to plain patterns when the masks run out.
+inline void oss_make_items(const JumpSearch& js, uint32_t E, int group, bool ext, double occur0, double occur1, std::vector<uint64_t>* masks, SearchItems* out)
 {
-    out->items.clear(); out->patterns = (uint32_t)js.pat.size(); out->groups = 0;
-    if (!group) { for (uint32_t d : js.pat) out->items.push_back(oss_rotation_word(d, js.J)); return true; }
-    if (js.J <= GROUP_SYMS) return false;
-    std::vector<uint32_t> keys; std::vector<uint64_t> km; std::vector<uint32_t> single;   // per prefix: mask, and the one pattern if it stays alone
-    for (uint32_t d : js.pat) {
-        const uint32_t rw = oss_rotation_word(d, js.J), pre = rw & ~63u;
-        size_t g = 0;
-        while (g < keys.size() && keys[g] != pre) ++g;
-        if (g == keys.size()) { keys.push_back(pre); km.push_back(0); single.push_back(rw); }
-        km[g] |= 1ull << (rw & 63u);
-    }
+    out->items.clear(); out->patterns = (uint32_t)js.pat.size(); out->low = out->mid = 0; out->ext = false;
+    std::vector<uint32_t> rws;
+    for (uint32_t d : js.pat) rws.push_back(oss_rotation_word(d, js.J));
+    if (!group || js.J <= GROUP_SYMS || !masks) { out->items = rws; return; }
+    struct G { uint32_t key; uint64_t mask; uint32_t kind; uint32_t one; };
     std::vector<uint64_t> m2 = *masks;
-    std::vector<uint32_t> plain;
-    for (size_t g = 0; g < keys.size(); ++g) {
-        if ((km[g] & (km[g] - 1)) == 0) { plain.push_back(single[g]); continue; }
+    bool fail = false;
+    // members that may share a word: same rotations outside the layout's three characters, same kind
+    auto collect = [&](const std::vector<uint32_t>& in, uint32_t shift, std::vector<G>* gs) {
+        for (uint32_t rw : in) {
+            const uint32_t key = rw & ~(63u << shift), kind = (ext && rot_errors_host(rw) == E) ? 1u : 0u;
+            size_t g = 0;
+            while (g < gs->size() && !((*gs)[g].key == key && (*gs)[g].kind == kind)) ++g;
+            if (g == gs->size()) gs->push_back(G{key, 0, kind, rw});
+            (*gs)[g].mask |= 1ull << ((rw >> shift) & 63u);
+        }
+    };
+    auto worth = [&](const G& g) {
+        const int m = __builtin_popcountll(g.mask);
+        if (m < 2) return false;
+        if (group == 1) return true;
+        return m * (1.0 - (g.kind ? occur1 : occur0)) >= 1.5;   // one word + the members that pass it, against one table read per member
+    };
+    auto emit = [&](const G& g, uint32_t shift) {
         size_t id = 0;
-        while (id < m2.size() && m2[id] != km[g]) ++id;
-        if (id == m2.size()) { if (m2.size() == GROUP_MAX_MASKS) return false; m2.push_back(km[g]); }
-        out->items.push_back(keys[g] | (uint32_t)id);
-        if (++out->groups > 255u) return false;
+        while (id < m2.size() && m2[id] != g.mask) ++id;
+        if (id == m2.size()) { if (m2.size() == GROUP_MAX_MASKS) { fail = true; return; } m2.push_back(g.mask); }
+        out->items.push_back(g.key | ((uint32_t)id | g.kind << 3) << shift);
+        out->ext = out->ext || g.kind != 0u;
+    };
+    std::vector<G> lowG, midG; std::vector<uint32_t> rest, plain;
+    collect(rws, 0u, &lowG);
+    for (const G& g : lowG) {
+        if (worth(g)) { emit(g, 0u); out->low++; }
+        else for (uint32_t r = 0; r < 64u; ++r) if ((g.mask >> r) & 1ull) rest.push_back(g.key | r);
     }
+    if (js.J >= 2u * GROUP_SYMS && ext) {   // what stayed alone: the same with the three characters in front (kind 1 only: one more bitmap family)
+        collect(rest, 6u, &midG);
+        for (const G& g : midG) {
+            if (g.kind == 1u && worth(g)) { emit(g, 6u); out->mid++; }
+            else for (uint32_t r = 0; r < 64u; ++r) if ((g.mask >> r) & 1ull) plain.push_back(g.key | r << 6);
+        }
+    } else plain = rest;
     out->items.insert(out->items.end(), plain.begin(), plain.end());
+    if (fail || out->low > 255u || out->mid > 255u) { out->items = rws; out->low = out->mid = 0; out->ext = false; return; }
     *masks = m2;
-    return true;
 }
 
 // the J-mer index with a descriptor's substitutions applied (descriptor form: tests and the emulator's reference path)
@@ -227,6 +258,9 @@ GM_HD uint32_t rot_errors(uint32_t rw)   // substitutions of a rotation word
     return (uint32_t)__builtin_popcount(nz);
 #endif
 }
+
+// index of a MID group's bitmaps: the J-mer index with its two lowest 6-bit fields swapped (the group's characters become the bit number)
+GM_HD uint32_t jump_swap_mid(uint32_t idx) { return (idx & ~0xFFFu) | (idx & 63u) << 6 | ((idx >> 6) & 63u); }
 
 // Bitmap word of the 64 J-mers that share the first J - 3 characters: bit (c0 << 4 | c1 << 2 | c2) = the J-mer ending in letters c0 c1 c2
 // occurs.  Returns the same bits indexed by ROTATIONS relative to the needle's last three letters low6 = n0 << 4 | n1 << 2 | n2:

@@ -149,12 +149,12 @@ template <int WPP, bool NL = false, bool RA = false> struct EmuEnv {
 // SA range of an ACGT string (most significant symbol first in idx) by right extensions from the root: what the device reads from
 // its table of all J-mers (gm_kernels.h: qmer_table_kernel)
 template <int WPP>
-static void table_entry(const HostIndex<WPP>& ix, uint32_t idx, uint32_t J, uint32_t& flo, uint32_t& rlo, uint32_t& w)
+static void table_entry(const HostIndex<WPP>& ix, uint64_t idx, uint32_t J, uint32_t& flo, uint32_t& rlo, uint32_t& w)
 {
     constexpr uint32_t SPB = BlockGeom<WPP>::SPB, WPB = BlockGeom<WPP>::WPB;
     flo = 0; rlo = 0; w = (uint32_t)ix.n;
     for (uint32_t i = 0; i < J && w; ++i) {
-        const uint32_t c = (idx >> (2u * (J - 1u - i))) & 3u;
+        const uint32_t c = (uint32_t)(idx >> (2u * (J - 1u - i))) & 3u;
         uint32_t rl[NLET], rh[NLET];
         block_rank<WPP>(ix.blk[1].data() + (size_t)(rlo / SPB) * WPB, rlo % SPB, rl);
         block_rank<WPP>(ix.blk[1].data() + (size_t)((rlo + w) / SPB) * WPB, (rlo + w) % SPB, rh);
@@ -178,11 +178,11 @@ static void search_plan(const MapPlan& plan, const HostIndex<WPP>& ix, Env& env,
             for (auto& j : jumps) j = JumpSearch();
         }
     }
-    // what a lane reads: rotation words, groups first (gm_oss.h: oss_make_items)
+    // what a lane reads: rotation words and groups (gm_oss.h: oss_make_items); with g_jumpGroups every group two patterns can form
     std::vector<uint64_t> gmasks;
     std::vector<SearchItems> items(plan.nSearches);
     for (uint32_t s = 0; s < plan.nSearches; ++s)
-        if (jumps[s].J && !(g_jumpGroups && oss_make_items(jumps[s], true, &gmasks, &items[s]))) oss_make_items(jumps[s], false, nullptr, &items[s]);
+        if (jumps[s].J) oss_make_items(jumps[s], E, g_jumpGroups ? 1 : 0, jumps[s].regionA + jumps[s].J + 2u <= L, 0.5, 0.05, &gmasks, &items[s]);
     uint64_t roots = plan.numRoots();
     uint32_t rpb = plan.nSearches * plan.nStrands;
     auto walk = [&](Node nd, const Root& rt) {
@@ -232,16 +232,26 @@ static void search_plan(const MapPlan& plan, const HostIndex<WPP>& ix, Env& env,
                     walk(nd, rt);
                 };
                 const SearchItems& it = items[rt.search];
+                // the two letters behind the J-mer (groups of kind 1); a needle N there ends every pattern that may not err any more
+                uint32_t e0 = SYM_N, e1 = SYM_N;
+                if (it.ext) { e0 = env.text_char(rt, a0 + js.J); e1 = env.text_char(rt, a0 + js.J + 1u); }
+                const bool extValid = e0 < SYM_N && e1 < SYM_N;
                 for (size_t q = 0; q < it.items.size(); ++q) {
                     const uint32_t d = it.items[q];
-                    if (q >= it.groups) { lookup(rot_add(base2, d), rot_errors(d)); continue; }
-                    // a group: the word of the existence bitmap (built here from the table), in rotation space, masked; only J-mers that exist are looked up
-                    const uint32_t pre = rot_add(base2, d & ~63u);
+                    if (q >= it.low + it.mid) { lookup(rot_add(base2, d), rot_errors(d)); continue; }
+                    // a group: the word of its bitmap (built here by asking the index), in rotation space, masked; only patterns that pass are looked up
+                    const uint32_t shift = q < it.low ? 0u : 6u, own = (d >> shift) & 63u, kind = own >> 3, rotw = d & ~(63u << shift);
+                    const uint32_t pre = rot_add(base2, rotw);
                     uint64_t word = 0;
-                    for (uint32_t c = 0; c < 64u; ++c) { uint32_t f, r, w; table_entry<WPP>(ix, (pre & ~63u) | c, js.J, f, r, w); if (w) word |= 1ull << c; }
-                    uint64_t alive = word_to_rotations(word, base2 & 63u) & gmasks[d & 7u];
+                    for (uint32_t c = 0; c < 64u && (kind == 0u || extValid); ++c) {
+                        const uint64_t cand = (pre & ~(63u << shift)) | c << shift;
+                        uint32_t f, r, w;
+                        if (kind) table_entry<WPP>(ix, cand << 4 | e0 << 2 | e1, js.J + 2u, f, r, w); else table_entry<WPP>(ix, cand, js.J, f, r, w);
+                        if (w) word |= 1ull << c;
+                    }
+                    uint64_t alive = word_to_rotations(word, (base2 >> shift) & 63u) & gmasks[own & 7u];
                     while (alive) {
-                        const uint32_t rw = (d & ~63u) | (uint32_t)__builtin_ctzll(alive); alive &= alive - 1ull;
+                        const uint32_t rw = rotw | (uint32_t)__builtin_ctzll(alive) << shift; alive &= alive - 1ull;
                         lookup(rot_add(base2, rw), rot_errors(rw));
                     }
                 }
