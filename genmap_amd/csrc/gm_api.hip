@@ -348,7 +348,6 @@ void gm_index_free(gm_index* ix)
     hipFree(ix->d_saMark); hipFree(ix->d_saSamples);
     for (auto& kv : ix->qtables) hipFree(kv.second);
     for (auto& kv : ix->jbits) hipFree(kv.second);
-    for (auto& m : ix->jbits1) for (auto& kv : m) hipFree(kv.second);
     hipFree(ix->d_jinfo2); hipFree(ix->d_seqFile); hipFree(ix->d_bits);
     hipFree(ix->d_acc); hipFree(ix->d_stack); hipFree(ix->d_small); hipFree(ix->d_table); hipFree(ix->d_blocks); hipFree(ix->d_cumLocal);
     for (int i = 0; i < 4; ++i) if (ix->ev[i]) hipEventDestroy(ix->ev[i]);
@@ -539,7 +538,7 @@ template <typename T> static int grow(T** p, uint64_t* cap, uint64_t need)
 enum LeafMode { LEAF_COUNT = 0, LEAF_FILESET = 1, LEAF_OCC_COUNT = 2, LEAF_OCC_EMIT = 3, LEAF_STORE = 4, LEAF_STORE8 = 5, LEAF_COUNT_JUMP = 6, LEAF_SCATTER = 7 };
 
 // nu = 16-byte units per stored node / queue entry: 1, or 2 with 64-bit rows (gm_kernels.h: NodeIO)
-static inline size_t search_lds_bytes(const SearchArgs& A, uint32_t nu) { return (size_t)(4u * A.vqCap * nu + 4u * 64u * (A.ldsDepth * nu + A.winChunks)) * 16u + 4u * 128u * 4u + 320u + (A.lqCap ? 4u * (A.lqCap * 16u + 80u * 4u) : 0u); }
+static inline size_t search_lds_bytes(const SearchArgs& A, uint32_t nu) { return (size_t)(4u * A.vqCap * nu + 4u * 64u * (A.ldsDepth * nu + A.winChunks)) * 16u + 4u * 128u * 4u + 448u + (A.entrySlots ? 4096u : 0u) + (A.lqCap ? 4u * (A.lqCap * 16u + 80u * 4u) : 0u); }
 
 template <int WPP, class EnvT>
 static int launch_one(const SearchArgs& A, unsigned blocks, hipStream_t st)
@@ -641,58 +640,45 @@ static int get_qtable(gm_index* ix, uint32_t* qio, const uint4** out)
     return GM_OK;
 }
 
-// existence bitmap of the q-mers (cached; built from the table of all q-mers).  *out stays null when the device is short of memory:
-// the call then keeps plain pattern lists.
-static int get_jbits(gm_index* ix, uint32_t q, const uint4* tab, const unsigned long long** out)
+// The bitmaps of the groups of jump patterns (gm_oss.h), one array of (1 + 16 + 16) x 4^q / 64 words (cached per q):
+//   kind 0 "the q-mer occurs" (from the table of all q-mers) | kind 1 "... followed by letters x y", LOW layout, 16 pairs | the same, MID layout
+// (kind 1 from the sentinel text; q = 16: 0.5 + 8.6 + 8.6 GB).  *level: 0 = kind 0 only (device short of memory, or no sentinel text),
+// 1 = + LOW, 2 = + MID.  *out stays null when not even kind 0 fits: the call then keeps plain pattern lists.
+static int get_jbits(gm_index* ix, uint32_t q, const uint4* tab, const unsigned long long** out, int* level)
 {
-    *out = nullptr;
-    if (q < GROUP_SYMS || ix->wide || !tab) return GM_OK;
+    *out = nullptr; *level = 0;
+    if (q <= GROUP_SYMS || ix->wide || !tab) return GM_OK;
     auto it = ix->jbits.find(q);
-    if (it != ix->jbits.end()) { *out = it->second; return GM_OK; }
-    const uint64_t n = 1ull << (2 * q), bytes = n / 8;
-    size_t freeB = 0, totalB = 0;
-    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && bytes + (8ull << 30) > freeB && bytes > (1ull << 20)) return GM_OK;
+    if (it != ix->jbits.end()) { *out = it->second; *level = ix->jbitsLevel[q]; return GM_OK; }
+    const uint64_t n = 1ull << (2 * q), words = n / 64;
+    int lv = !ix->d_textS ? 0 : (q >= 2 * GROUP_SYMS ? 2 : 1);
     unsigned long long* d = nullptr;
-    if (hipMalloc(&d, bytes) != hipSuccess) { (void)hipGetLastError(); return GM_OK; }
+    for (;; --lv) {
+        if (lv < 0) return GM_OK;
+        const uint64_t bytes = (1 + 16 * (uint64_t)lv) * words * 8;
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && bytes + (8ull << 30) > freeB && bytes > (1ull << 24)) continue;
+        if (hipMalloc(&d, bytes) == hipSuccess) break;
+        (void)hipGetLastError();
+    }
     const uint64_t blocks = (n + 255) / 256;
     const dim3 grid((unsigned)std::min<uint64_t>(blocks, 1u << 22), (unsigned)((blocks + (1u << 22) - 1) >> 22));
     hipLaunchKernelGGL(jbits_kernel, grid, dim3(256), 0, 0, tab, n, d);
     hipError_t e = hipGetLastError();
+    if (e == hipSuccess && lv >= 1) {
+        e = hipMemset(d + words, 0, 16 * (uint64_t)lv * words * 8);
+        if (e == hipSuccess) {
+            const uint64_t threads = (ix->nRows + 63) / 64, tb = (threads + 255) / 256;
+            const dim3 g2((unsigned)std::min<uint64_t>(tb, 1u << 22), (unsigned)((tb + (1u << 22) - 1) >> 22));
+            hipLaunchKernelGGL(jbits1_kernel, g2, dim3(256), 0, 0, ix->d_textS, ix->nRows, q, d + words, lv >= 2 ? d + 17 * words : nullptr, words);
+            e = hipGetLastError();
+        }
+    }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) { hipFree(d); GM_HIP(e); }
-    ix->jbits[q] = d;
-    ix->qtableBytes += bytes;
-    *out = d;
-    return GM_OK;
-}
-
-// bitmaps of kind 1 (gm_oss.h), both layouts, built from the sentinel text (cached).  Null when the device is short of memory.
-static int get_jbits1(gm_index* ix, uint32_t q, const unsigned long long** low, const unsigned long long** mid)
-{
-    *low = *mid = nullptr;
-    if (q <= GROUP_SYMS || ix->wide || !ix->d_textS) return GM_OK;
-    auto it = ix->jbits1[0].find(q);
-    if (it != ix->jbits1[0].end()) { *low = it->second; auto im = ix->jbits1[1].find(q); *mid = im != ix->jbits1[1].end() ? im->second : nullptr; return GM_OK; }
-    const uint64_t words = (1ull << (2 * q)) / 64, bytes = 16 * words * 8;
-    const bool wantMid = q >= 2 * GROUP_SYMS;
-    size_t freeB = 0, totalB = 0;
-    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && bytes * (wantMid ? 2 : 1) + (8ull << 30) > freeB && bytes > (1ull << 24)) return GM_OK;
-    unsigned long long *dl = nullptr, *dm = nullptr;
-    if (hipMalloc(&dl, bytes) != hipSuccess) { (void)hipGetLastError(); return GM_OK; }
-    if (wantMid && hipMalloc(&dm, bytes) != hipSuccess) { (void)hipGetLastError(); hipFree(dl); return GM_OK; }
-    hipError_t e = hipMemset(dl, 0, bytes);
-    if (e == hipSuccess && dm) e = hipMemset(dm, 0, bytes);
-    if (e == hipSuccess) {
-        const uint64_t threads = (ix->nRows + 63) / 64, blocks = (threads + 255) / 256;
-        const dim3 grid((unsigned)std::min<uint64_t>(blocks, 1u << 22), (unsigned)((blocks + (1u << 22) - 1) >> 22));
-        hipLaunchKernelGGL(jbits1_kernel, grid, dim3(256), 0, 0, ix->d_textS, ix->nRows, q, dl, dm, words);
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipDeviceSynchronize();
-    }
-    if (e != hipSuccess) { hipFree(dl); hipFree(dm); GM_HIP(e); }
-    ix->jbits1[0][q] = dl; if (dm) ix->jbits1[1][q] = dm;
-    ix->qtableBytes += bytes * (dm ? 2 : 1);
-    *low = dl; *mid = dm;
+    ix->jbits[q] = d; ix->jbitsLevel[q] = lv;
+    ix->qtableBytes += (1 + 16 * (uint64_t)lv) * words * 8;
+    *out = d; *level = lv;
     return GM_OK;
 }
 
@@ -879,11 +865,14 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         verifyTExt = (uint32_t)std::max((int)verifyT, std::min(t, (int)VERIFY_TMAX));
     }
     const uint32_t depth = stack_bound(p->E, plan.stepSize) + STEAL_LEVELS;   // room for the levels work sharing may vacate at the bottom
-    const uint32_t vqCap = verifyT ? 64u + 64u * std::min(verifyTExt, VERIFY_ROWS) : 1u;   // a lane queues at most VERIFY_ROWS rows per iteration (search_body)
+    uint32_t verifyRows = std::min(verifyTExt, VERIFY_ROWS);   // rows of one node queued per iteration (search_body); one instead of two where that keeps a block per CU (below)
+    uint32_t vqCap = verifyT ? 64u + 64u * verifyRows : 1u;
     const uint32_t winChunks = (31u + p->K + plan.stepSize - 1u + 31u) / 32u;
     const uint32_t nu = ix->wide ? 2u : 1u;
     const int wantPerCU = std::max(1, ix->tune.blocksPerCU);   // default 4 = 4 waves/SIMD, what the kernel's VGPR count allows
-    auto lds_bytes_for = [&](uint32_t d) { return (size_t)(4u * vqCap * nu + 4u * 64u * (d * nu + winChunks)) * 16u + 4u * 128u * 4u + 320u + (lqCap ? 4u * (lqCap * 16u + 80u * 4u) : 0u); };   // == search_lds_bytes
+    // (calls that may jump keep their table entries in flight in LDS: one 16-byte slot per lane)
+    const bool mayJump = wantJump && p->E >= 1 && (ix->d_sa || ix->d_saMark) && ix->tune.jump != 0 && !ix->wide;
+    auto lds_bytes_for = [&](uint32_t d) { return (size_t)(4u * vqCap * nu + 4u * 64u * (d * nu + winChunks)) * 16u + 4u * 128u * 4u + 448u + (mayJump ? 4096u : 0u) + (lqCap ? 4u * (lqCap * 16u + 80u * 4u) : 0u); };   // == search_lds_bytes
     auto blocks_for = [&](uint32_t d, int* nb) {
         switch (ix->wpp) { case 1: return occupancy_blocks<1>(nb, lds_bytes_for(d)); case 2: return occupancy_blocks<2>(nb, lds_bytes_for(d)); case 3: return occupancy_blocks<3>(nb, lds_bytes_for(d)); default: return occupancy_blocks<9>(nb, lds_bytes_for(d)); }
     };
@@ -891,6 +880,12 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     // long windows (K >= ~60) trade levels for resident blocks -- a fourth block per CU is worth more than the levels
     // (3.09 Gbp e=1: K=100 676 -> 600 ms, K=150 819 -> 642 ms; at equal occupancy deeper is better; profiles/r02/sweep_grch38_ldsstack.txt)
     uint32_t ldsDepth = 0; int perCU = 0;
+    if (verifyRows > 1u && ix->tune.ldsStack < 0) {   // long windows (K >= ~64): a smaller verification queue where it buys the fourth block per CU (K=100 e=1: 220 -> 200 ms)
+        int nb2 = 0, nb1 = 0;
+        rc = blocks_for(1u, &nb2); if (rc) return rc;
+        vqCap = 64u + 64u; rc = blocks_for(1u, &nb1); if (rc) return rc;
+        if (std::min(nb1, wantPerCU) > std::min(nb2, wantPerCU)) verifyRows = 1u; else vqCap = 64u + 64u * verifyRows;
+    }
     if (ix->tune.ldsStack >= 0) {
         ldsDepth = std::min((uint32_t)ix->tune.ldsStack / nu, depth);   // the same LDS for the stack tops of wide nodes
         rc = blocks_for(ldsDepth, &perCU); if (rc) return rc;
@@ -913,9 +908,9 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     // ---- jump patterns (frequency calls with errors on an index that can locate): one J for every search ----
     std::vector<uint32_t> patHost; std::vector<uint4> jinfoHost; uint32_t jumpJ = 0, jumpAPacked[2] = {0, 0};
     const unsigned long long* jbitsCall = nullptr; unsigned long long gmaskCall[GROUP_MAX_MASKS] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned long long* jb1Call[2] = {nullptr, nullptr}; uint64_t jbitsWords = 0; std::vector<uint4> jinfo2Host(8, make_uint4(0, 0, 0, 0));
+    uint64_t jbitsWords = 0; std::vector<uint4> jinfo2Host(8, make_uint4(0, 0, 0, 0));
     const uint4* jtab = nullptr;
-    S->jump = wantJump && p->E >= 1 && (ix->d_sa || ix->d_saMark) && ix->tune.jump != 0 && !ix->wide;
+    S->jump = mayJump;
     if (S->jump) {
         const uint32_t L = plan.infix;
         uint32_t J = 1;   // longest tabulated string: as for the q-mer tables below
@@ -941,11 +936,8 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
             // Groups of patterns (gm_oss.h): patterns that differ in the last three characters only share one word of the existence bitmap.
             // A search is grouped when that saves table reads: groups + (share of J-mers that occur) x their patterns against one read
             // per pattern (3.09 Gbp, J = 16: 51 % occur; K = 30 e = 2, search 1: 211 reads -> 13 words + 54 + ~80 reads).
-            const unsigned long long *jbits = nullptr, *jb1Low = nullptr, *jb1Mid = nullptr;
-            if (ix->tune.jumpGroups != 0) {
-                rc = get_jbits(ix, J, jtab, &jbits); if (rc) return rc;
-                if (jbits) { rc = get_jbits1(ix, J, &jb1Low, &jb1Mid); if (rc) return rc; }
-            }
+            const unsigned long long* jbits = nullptr; int jbLevel = 0;
+            if (ix->tune.jumpGroups != 0) { rc = get_jbits(ix, J, jtab, &jbits, &jbLevel); if (rc) return rc; }
             const double occur = 1.0 - std::exp(-(double)ix->nRows / std::ldexp(1.0, 2 * (int)J));
             const double occur1 = 1.0 - std::exp(-(double)ix->nRows / std::ldexp(1.0, 2 * (int)J + 4));
             std::vector<uint64_t> masks;
@@ -953,10 +945,10 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
             jinfo2Host.assign(8, make_uint4(0, 0, 0, 0));
             for (uint32_t s2 = 0; s2 < plan.nSearches; ++s2) {
                 // kind 1 needs two more infix characters to the right of the J-mer (and, for MID groups, its second bitmap family)
-                const bool ext = jb1Low && (jb1Mid || J < 2 * GROUP_SYMS) && js[s2].regionA + J + 2u <= L;
+                const bool ext = jbLevel >= (J >= 2 * GROUP_SYMS ? 2 : 1) && js[s2].regionA + J + 2u <= L;
                 oss_make_items(js[s2], p->E, jbits ? (ix->tune.jumpGroups < 0 ? 2 : 1) : 0, ext, occur, occur1, &masks, &items[s2]);
             }
-            jbitsCall = masks.empty() ? nullptr : jbits; jb1Call[0] = jb1Low; jb1Call[1] = jb1Mid; jbitsWords = (1ull << (2 * J)) / 64;
+            jbitsCall = masks.empty() ? nullptr : jbits; jbitsWords = (1ull << (2 * J)) / 64;
             for (size_t k = 0; k < masks.size(); ++k) gmaskCall[k] = masks[k];
             for (uint32_t s2 = 0; s2 < plan.nSearches; ++s2) {
                 // neighbour filter (gm_kernels.h): how many infix characters right / left of the J-mer a one-row table entry is compared with
@@ -1044,7 +1036,8 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         }
         ix->lastQ = std::max(qA, qB) | jumpJ << 8;
     }
-    A.text4 = ix->d_text4; A.textBegin = text_begin; A.vqCap = vqCap; A.ldsDepth = ldsDepth; A.winChunks = winChunks; A.lqCap = lqCap;
+    A.entrySlots = mayJump ? 1u : 0u;
+    A.text4 = ix->d_text4; A.textBegin = text_begin; A.vqCap = vqCap; A.verifyRows = verifyRows ? verifyRows : 1u; A.ldsDepth = ldsDepth; A.winChunks = winChunks; A.lqCap = lqCap;
     A.workCounter = reinterpret_cast<unsigned long long*>(ix->d_small);
     A.errorFlag = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ix->d_small) + SMALL_ERR_OFF);
     A.counters = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ix->d_small) + 16);
@@ -1087,7 +1080,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     A.coop = ix->tune.coop >= 0 ? (uint32_t)(ix->tune.coop != 0) : (ix->wpp == 1 ? 1u : 0u);
     if (ix->wide) A.coop = 0u;
     A.jumpJ = jumpJ; A.jumpAPacked[0] = jumpAPacked[0]; A.jumpAPacked[1] = jumpAPacked[1];
-    A.patterns = ix->d_patterns; A.jinfo = ix->d_jinfo; A.jinfo2 = ix->d_jinfo2; A.jtab = jtab; A.jbits = jbitsCall; A.jbits1[0] = jb1Call[0]; A.jbits1[1] = jb1Call[1]; A.jbitsWords = jbitsWords;
+    A.patterns = ix->d_patterns; A.jinfo = ix->d_jinfo; A.jinfo2 = ix->d_jinfo2; A.jtab = jtab; A.jbits = jbitsCall; A.jbitsWords = jbitsWords;
     for (uint32_t k = 0; k < GROUP_MAX_MASKS; ++k) A.gmask[k] = gmaskCall[k];
     A.sliceBegin = text_begin; A.sliceLen = text_len; A.ownBegin = 0; A.ownEnd = text_len; A.ownChunkLen = 0; A.selBlocks = nullptr; A.nSelBlocks = 0;
     *Aout = A;
@@ -1188,6 +1181,7 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
         C.selBlocks = S.plan.useList ? ix->d_blocks : nullptr; C.nSelBlocks = (uint32_t)S.plan.blocks.size();
         C.steal = C.numRoots < 64ull * 4ull * 1024ull ? 1u : C.steal;
         C.lqCap = 128u;   // leaves are located by the whole wavefront (gm_kernels.h: LeafQueueEnv)
+        C.entrySlots = 0u;
         GM_HIP(hipMemsetAsync(ix->d_small, 0, 16, st));   // the work counter; statistics keep adding up
         GM_HIP(hipEventRecord(ix->ev[1], st));
         const uint64_t useful = (C.numRoots + 255) / 256;

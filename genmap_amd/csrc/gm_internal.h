@@ -53,7 +53,7 @@ struct gm_index {
     uint4* d_ctx = nullptr;           // verification records {SA[row], 56 symbols around it}, 32 B per row, when HBM allows (gm_kernels.h: CTX_*)
     std::map<uint32_t, uint4*> qtables;   // q -> device table of 4^q entries (built on first use)
     std::map<uint32_t, unsigned long long*> jbits;   // q -> existence bitmap of the q-mers, 4^q bits (groups of jump patterns, gm_oss.h)
-    std::map<uint32_t, unsigned long long*> jbits1[2];   // q -> "q-mer followed by two given letters occurs", 16 x 4^q bits; [1]: MID layout
+    std::map<uint32_t, int> jbitsLevel;              // q -> 0: "the q-mer occurs" only, 1: + "... followed by two given letters" (16 x 4^q bits), 2: + the same in the MID layout
     uint4* d_jinfo2 = nullptr;
     uint64_t sig = 0; bool sigValid = false;   // signature of the call whose tables are on the device
     uint32_t lastQ = 0;                   // longest q-mer table of the last call | jump length << 8 (statistics)

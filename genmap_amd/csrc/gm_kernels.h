@@ -70,8 +70,10 @@ struct SearchArgs {
     const uint4* text4;             // whole text, 4 bits per symbol (32 symbols per 16-byte chunk), sentinel-free
     uint64_t textBegin;             // slice offset inside the text (symbols)
     uint32_t vqCap;                 // queue entries per wavefront
+    uint32_t verifyRows;            // rows of one node queued per iteration (1 or 2)
     uint32_t ldsDepth;              // stack entries per lane kept in LDS (deeper ones spill to `stack`)
     uint32_t winChunks;             // 16-byte chunks per lane for the needle window
+    uint32_t entrySlots;            // != 0: 4 KB of LDS per block hold the table entries in flight of the jump patterns (one slot per lane)
     uint32_t lqCap;                 // leaf queue entries per wavefront (locating leaf policies: FileSetEnv, OccEmitEnv; 0 elsewhere)
     // ---- q-mer range tables: the first (always exact) OSS block of a root starts from a lookup instead of q steps ----
     const uint4* qtabA;             // {fwd lo, rev lo, width, 0} of every ACGT string of length q (two tables at most per call)
@@ -88,8 +90,7 @@ struct SearchArgs {
     const uint32_t* patterns;       // descriptors of every search, back to back
     const uint4* jinfo;             // per search {first pattern | patterns << 16, meta at depth J relative to n - 1, first descriptor, 0}
     const uint4* jtab;              // table of all J-mers
-    const unsigned long long* jbits;   // one bit per J-mer: does it occur (word = the 64 J-mers sharing their first J - 3 characters); groups of patterns
-    const unsigned long long* jbits1[2];   // per pair of following letters (16 x jbitsWords words): does the J-mer occur followed by them; [1]: MID layout
+    const unsigned long long* jbits;   // bitmaps of the groups of patterns, (1 + 16 + 16) x jbitsWords words: "the J-mer occurs" | "... followed by letters x y" (16 pairs) | the same in the MID layout
     uint64_t jbitsWords;            // 4^J / 64
     const uint4* jinfo2;            // per search {first item behind the LOW groups, first item behind the MID groups, groups of kind 1?, 0}
     unsigned long long gmask[8];    // masks of the groups (gm_oss.h: GROUP_MAX_MASKS)
@@ -223,7 +224,7 @@ constexpr uint32_t STEAL_LEVELS = 16;  // a lane gives away at most this many bo
 constexpr uint32_t JF_ENTRY = 4u, JF_WORD = 8u, JF_ITEM = 16u, JF_GROUP = 32u, JF_MID = 64u, JF_CURMID = 128u, JF_EXT_SHIFT = 8u, JF_EXTOK = 1u << 12;
 constexpr uint32_t WORK_CHUNK = 256;   // roots taken from the global counter per atomic
 constexpr uint32_t VERIFY_TMAX = 16;   // widest range resolved by verification
-constexpr uint32_t VERIFY_ROWS = 2;    // rows of one node queued per iteration (the rest waits on the lane's stack)
+constexpr uint32_t VERIFY_ROWS = 2;    // rows of one node queued per iteration at most (SearchArgs::verifyRows; the rest waits on the lane's stack)
 
 template <int WPP> struct EnvBase {
     static constexpr bool EXACT_ONLY = false;   // StoreEnv: the kernel only ever runs with E = 0
@@ -841,8 +842,10 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     // that lane's needle window (wlane) and the owner may not stage a new window while users[owner] != 0
     uint32_t* const users = reinterpret_cast<uint32_t*>(smem + 4u * A.vqCap * NU + 4u * 64u * (A.ldsDepth * NU + A.winChunks)) + wv * 128u;   // [64] users | [64] pairing
     uint32_t* const pairing = users + 64;
-    // the searches' jump records (Env::JUMPS), 8 x 16 bytes (+ 64 bytes of group masks + 8 x 16 bytes of group counts) per block behind the work-sharing bookkeeping
+    // the searches' jump records (Env::JUMPS), 8 x 16 bytes (+ 64 bytes of group masks + 8 x 16 bytes of group counts + 8 x 16 bytes of OSS records) per block behind the work-sharing bookkeeping
     uint4* const jl = smem + 4u * A.vqCap * NU + 4u * 64u * (A.ldsDepth * NU + A.winChunks) + (4u * 128u * 4u) / 16u;
+    if (threadIdx.x < 8u) jl[20u + threadIdx.x] = A.table[(size_t)(A.stepSize - 1u) * 8u + threadIdx.x];   // OSS records of the regular block shape (stage 2)
+    if constexpr (!EnvT::JUMPS) __syncthreads();
     if constexpr (EnvT::JUMPS) {
         if (threadIdx.x < 8u) jl[threadIdx.x] = A.jumpJ ? A.jinfo[threadIdx.x] : make_uint4(0, 0, 0, 0);
         // ... and the masks of its groups of patterns (gm_oss.h), 8 x 8 bytes behind them
@@ -850,8 +853,11 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
         if (threadIdx.x < 8u) jl[12u + threadIdx.x] = A.jumpJ ? A.jinfo2[threadIdx.x] : make_uint4(0, 0, 0, 0);   // ... and where its groups end
         __syncthreads();
     }
+    // jump patterns: the table entry in flight lives in LDS, one 16-byte slot per lane (global_load_lds: no destination registers, hence
+    // no wait behind the load to move them, and 4 VGPRs less) -- 4 KB per block behind the jump records
+    uint4* const ebufW = jl + 28 + wv * 64u;
     if constexpr (EnvT::LEAFQ) {   // leaf queue behind everything else: [4 x lqCap entries] [4 x 80 control words]
-        uint4* const lqBase = jl + 20;
+        uint4* const lqBase = jl + 28;
         env.lq = lqBase + wv * A.lqCap;
         env.lqCtl = reinterpret_cast<uint32_t*>(lqBase + 4u * A.lqCap) + wv * 80u;
         if (lane == 0u) env.lqCtl[0] = 0u;
@@ -901,6 +907,10 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
 #define GM_LAP(acc) do { } while (0)
 #define GM_LAP2(acc) do { } while (0)
 #endif
+    // (opaque scalar copies: the compiler otherwise turns "select one of two argument words" into a vector load from the argument segment,
+    //  which is then waited for behind the pattern reads issued in front of the root draw)
+    uint32_t jap0 = A.jumpAPacked[0], jap1 = A.jumpAPacked[1];
+    asm volatile("" : "+s"(jap0), "+s"(jap1));
     for (;;) {
 #ifndef GM_POP_LOOP
         if (!have && env.sp > 0) {   // one pop per iteration: a node dropped as saturated costs the lane one idle turn
@@ -975,23 +985,29 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
             if ((fs & (3u | JF_ENTRY)) == (2u | JF_ENTRY) && !have && env.sp == 0u) {
                 env.note_wave(3);
                 fs &= ~JF_ENTRY;
+                row_t eFlo, eRlo, eW; uint32_t eNb;
+                if constexpr (sizeof(row_t) == 4) {   // the entry went from HBM straight into this lane's LDS slot (part B): awaited explicitly
+                    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+                    const uint4 ft = ebufW[lane];
+                    eFlo = ft.x; eRlo = ft.y; eW = ft.z; eNb = ft.w;
+                } else { eFlo = ftFlo; eRlo = ftRlo; eW = ftW; eNb = ftNb; }
                 // every k-mer of the block at MAX: nothing a further pattern finds can change the result
                 const bool sat = env.root_hits() >= A.maxVal && env.saturated(rt, 0u, rt.n - 1u);
-                bool take = ftW != 0u && !sat;
-                if (take && ftW == 1u && (jn & ftNb & 0x8000u) != 0u) {
+                bool take = eW != 0u && !sat;
+                if (take && eW == 1u && (jn & eNb & 0x8000u) != 0u) {
                     // The substituted J-mer occurs once.  Whatever this node could still find lies at that one place and contains the whole
                     // infix, so the infix characters next to the J-mer must agree with the text there up to the errors the pattern has
                     // left; a text N or a sequence end within them ends it too (N-less pass).  No memory request is spent on the rest.
                     const uint32_t h = jl[rt.search].w;     // bits 2i / 16 + 2i: neighbour i counts; bits 12..14 / 28..30: how many do
-                    const uint32_t x = ftNb ^ jn;
+                    const uint32_t x = eNb ^ jn;
                     const uint32_t differ = (x | x >> 1) & h & 0x05550555u;
-                    take = ((ftNb >> 12) & 7u) >= ((h >> 12) & 7u) && ((ftNb >> 28) & 7u) >= ((h >> 28) & 7u) && meta_errs(jm) + (uint32_t)__popc(differ) <= A.E;
+                    take = ((eNb >> 12) & 7u) >= ((h >> 12) & 7u) && ((eNb >> 28) & 7u) >= ((h >> 28) & 7u) && meta_errs(jm) + (uint32_t)__popc(differ) <= A.E;
 #ifdef GM_COUNTERS
                     env.jumpDrops += take ? 0u : 1u;
 #endif
                 }
                 bool rowsOnly = false;
-                if (take && ftW == 2u && (jn & 0x8000u) != 0u && A.nbFilter == 1u) {
+                if (take && eW == 2u && (jn & 0x8000u) != 0u && A.nbFilter == 1u) {
                     // The substituted J-mer occurs TWICE: the same test with 3 + 3 neighbours for either row.  Neither passes: no node.  One
                     // passes: the node is that row alone, and a lone row of which only the forward position is known is never stepped --
                     // it goes to the verification queue (rows-only node, rlo = all ones).
@@ -1001,19 +1017,19 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                     bool pass[2];
 #pragma unroll
                     for (uint32_t r = 0; r < 2u; ++r) {
-                        const uint32_t x = (ftNb >> (16u * r)) & 0xFFFFu;
+                        const uint32_t x = (eNb >> (16u * r)) & 0xFFFFu;
                         const uint32_t dr = (x ^ jn) & 0x3Fu, dl = ((x >> 6) ^ (jn >> 16)) & 0x3Fu;
                         const uint32_t mism = (uint32_t)__popc((dr | dr >> 1) & mR) + (uint32_t)__popc((dl | dl >> 1) & mL);
                         pass[r] = ((x >> 12) & 3u) >= needR && (x >> 14) >= needL && mism <= budget;
                     }
                     take = pass[0] || pass[1];
-                    if (take && pass[0] != pass[1] && A.verifyT != 0u) { rowsOnly = true; ftFlo += pass[1] ? 1u : 0u; }
+                    if (take && pass[0] != pass[1] && A.verifyT != 0u) { rowsOnly = true; eFlo += pass[1] ? 1u : 0u; }
 #ifdef GM_COUNTERS
                     env.jumpDrops2 += take ? (rowsOnly ? 1u : 0u) : 2u;
 #endif
                 }
                 if (take) {
-                    nd.flo = ftFlo; nd.rlo = ftRlo; nd.w = ftW; nd.meta = jm;
+                    nd.flo = eFlo; nd.rlo = eRlo; nd.w = eW; nd.meta = jm;
                     if (rowsOnly) { nd.rlo = ~(row_t)0; nd.w = 1u; }
                     have = true; w1run = 0;
                 }
@@ -1043,6 +1059,11 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
         // stage 2: window chunks and record have arrived -> stage the window in LDS, look the first q characters up
         if (fs == 1u) {
             env.note_wave(4);
+            {   // the OSS record of the root's search: from LDS for the regular block shape, from the table for the odd ones (ends of the text / of an interval)
+                uint4 q;
+                if (frt.n == A.stepSize) q = jl[20u + frt.search]; else q = A.table[(size_t)(frt.n - 1u) * 8u + frt.search];
+                frt.rec.x = q.x; frt.rec.y = q.y; frt.rec.z = q.z; frt.rec.w = q.w;
+            }
             if (fql == 0u) { rt = frt; env.on_root(); nd = root_node(rt, (row_t)A.nRows); have = true; fs = 0u; w1run = 0; }
             else {
                 // 16 symbols starting at the lowest text position of the q-mer, 4 bits each: from the window this lane staged in
@@ -1108,74 +1129,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                 }
             }
         }
-        if constexpr (EnvT::JUMPS) {
-            // (B) the next table read of the lane's root, as soon as the previous entry has been consumed.  Items (gm_oss.h) are plain
-            // patterns -- substituted J-mer -> ONE 16-byte read of the table of all J-mers -- or GROUPS of patterns that differ in the last
-            // three characters only: one 8-byte word of the existence bitmap tells which of up to 64 such J-mers occur at all, and only
-            // those are looked up (on a genome half of the substituted 16-mers do not exist).  A group's word is requested as soon as its
-            // item is known, i.e. while the lane still works through the group before it.
-            if ((fs & 3u) == 2u) {
-                env.note_wave(16);
-                // the next item of the lane's root into jd (not looked at before the next iteration: nothing waits for that load)
-                bool fresh = false;
-                auto next_item = [&]() {
-                    const uint32_t jp = jpp & 0xFFFFu;
-                    if (jp < (jpp >> 16)) {
-                        jd = A.patterns[jp]; jpp += 1u; fresh = true;
-                        const uint4 lim = jl[12u + rt.search];
-                        fs |= JF_ITEM | (jp < lim.x ? JF_GROUP : jp < lim.y ? (JF_GROUP | JF_MID) : 0u);
-                    }
-                };
-                if ((fs & (JF_ITEM | JF_WORD | JF_GROUP)) == (JF_ITEM | JF_GROUP)) {   // a group item: request its word now
-                    const uint32_t sh = (fs & JF_MID) ? 6u : 0u, kind = (jd >> (sh + 3u)) & 1u;
-                    if (kind && !(fs & JF_EXTOK)) {   // a needle N behind the J-mer: no pattern without budget can match
-                        fs &= ~(JF_ITEM | JF_GROUP | JF_MID);
-                        next_item();
-                    } else {
-                        const uint32_t idxp = rot_add(jb, jd & ~(63u << sh));
-                        const uint32_t widx = ((fs & JF_MID) ? jump_swap_mid(idxp) : idxp) >> 6;
-                        const unsigned long long* base = A.jbits;
-                        if (kind) base = ((fs & JF_MID) ? A.jbits1[1] : A.jbits1[0]) + (size_t)((fs >> JF_EXT_SHIFT) & 15u) * A.jbitsWords;
-                        pw = base[widx];
-                        fs |= JF_WORD;
-                        fresh = true;
-#ifdef GM_COUNTERS
-                        env.jumpWords++;
-#endif
-                    }
-                }
-                if (galive == 0ull && (fs & JF_WORD) && !fresh) {   // the word of group jd has arrived: its patterns that pass
-                    const uint32_t sh = (fs & JF_MID) ? 6u : 0u;
-                    const uint2 mk = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint32_t*>(jl + 8) + 2u * ((jd >> sh) & 7u));
-                    galive = word_to_rotations(pw, (jb >> sh) & 63u) & ((unsigned long long)mk.y << 32 | mk.x);
-                    gcur = jd & ~(63u << sh);
-                    fs = (fs & ~(JF_WORD | JF_ITEM | JF_GROUP | JF_MID | JF_CURMID)) | ((fs & JF_MID) ? JF_CURMID : 0u);
-                    next_item();
-                }
-                if (!(fs & JF_ENTRY)) {
-                    uint32_t rw = 0u; bool go = false;
-                    if (galive != 0ull) {   // the next pattern of the current group that passed
-                        rw = gcur | ctz64(galive) << ((fs & JF_CURMID) ? 6u : 0u);
-                        galive &= galive - 1ull;
-                        go = true;
-                    } else if ((fs & (JF_ITEM | JF_WORD | JF_GROUP)) == JF_ITEM && !fresh) {   // a plain pattern
-                        rw = jd; go = true;
-                        fs &= ~JF_ITEM;
-                        next_item();
-                    }
-                    if (go) {
-                        IO::load_qentry(A.jtab, rot_add(jb, rw), ftFlo, ftRlo, ftW, ftNb);
-                        jm = (jm & ~(7u << META_ERRS_SHIFT)) | rot_errors(rw) << META_ERRS_SHIFT;
-                        fs |= JF_ENTRY;
-#ifdef GM_COUNTERS
-                        env.jumps++;
-#endif
-                    } else if (!(fs & (JF_ENTRY | JF_WORD | JF_ITEM))) fs = 0u;   // no entry in flight, no item, no word, nothing alive: the root's patterns are done
-                }
-            }
-        }
-        GM_LAP2(tSt32);
-        // ---- self hits, BEFORE the draw below: a lane whose root ends here (most roots of a large e = 0 call: the table leaves them one
+        // ---- self hits, BEFORE the draw below (and before part B issues its loads: the window reads here wait for every load in flight): a lane whose root ends here (most roots of a large e = 0 call: the table leaves them one
         // row) takes its next root in this very iteration (3.09 Gbp K=30 e=0: 51.6 against 54.1 ms) ----
         if constexpr (EnvT::SELF_HIT) {
             // Forward strand, no error spent, ONE row left: it is the window's own location (a string always matches itself), so every
@@ -1204,10 +1158,171 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                 }
             }
         }
+        GM_LAP2(tSt32);
+        // ---- defer narrow nodes: one queue entry per SA row ----
+        if (A.verifyT) {
+            const uint32_t md0 = meta_mode(nd.meta);
+            // (extension-phase nodes have the whole infix behind them: one row there costs a record read and two short scans, while the
+            //  walk still has ~n log n steps to go -- they may be wider than the nodes verified inside the infix)
+            bool narrow = have && nd.w <= (md0 == M_OSS ? A.verifyT : A.verifyTExt);
+            if (narrow && nd.rlo != ~(row_t)0) {   // is the subtree below worth one SA read + one text comparison per row?
+                const uint32_t m = nd.meta, a = meta_a(m), bx = meta_bx(m), t = meta_t(m), md = md0;
+                const uint32_t covered = md == M_OSS ? rt.n : md == M_EXT_R ? a + A.K - t + 1u : md == M_EXT_L ? t + A.K - bx + 1u : a + A.K - bx + 1u;
+                const uint32_t est = (A.K - (bx - a)) + covered - 1u;   // lower bound of the steps still needed
+                narrow = nd.w * A.verifyCost <= est;
+                // A lone row that may not mismatch any more is, more often than not, a chance hit that the next one or
+                // two characters kill with ONE rank line each (lo and hi share a block); verification costs an SA read
+                // plus a text read.  Step it a little first, verify only the survivors.
+                if (nd.w == 1u && meta_errs(m) == A.E && w1run < A.probation) narrow = false;
+                // e = 0: the table leaves one infix character; taking it first costs one rank line and spares the
+                // reverse-strand chance hits their SA + text reads (5.31 vs 5.46 ms, profiles/r01e_infix_sweeps.txt)
+                if (A.E == 0u && md == M_OSS) narrow = false;
+            }
+            // At most VERIFY_ROWS rows of a node are queued per iteration (SearchArgs::verifyRows; the queue holds 64 + 64 * verifyRows entries); the rows left
+            // over go back onto the lane's stack as a rows-only node (rlo = all ones: never stepped, queued the moment it is popped).
+#pragma unroll 1
+            for (uint32_t r = 0; r < A.verifyRows; ++r) {
+                const bool e = narrow && r < nd.w;
+                const unsigned long long m = __ballot(e);
+                if (m == 0ull) break;
+                env.note_wave(6);
+                if (e) {
+                    const uint32_t slot = qsize + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    IO::store_item(vq + (size_t)slot * NU, nd.flo + r, nd.meta, rt.win, rt.n | rt.strand << 8 | rt.search << 9);
+                }
+                qsize += (uint32_t)__popcll(m);
+            }
+            if (narrow) {
+                have = false;
+                if (nd.w > A.verifyRows) { nd.flo += A.verifyRows; nd.w -= A.verifyRows; nd.rlo = ~(row_t)0; env.push(nd); }
+            }
+            // a partial round only when the wavefront has nothing else left to do
+            const bool finishing = (__ballot(have || fs != 0u || env.sp != 0u) == 0ull) && (__ballot(!exhausted) == 0ull);
+            while (qsize >= 64u || (finishing && qsize > 0u)) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef GM_COUNTERS
+                wvRounds += 1;
+#endif
+                const uint32_t take = qsize < 64u ? qsize : 64u;
+                if (lane < take) {
+                    row_t irow, iwin; uint32_t imeta, inss;
+                    IO::load_item(vq + (size_t)(qsize - 1u - lane) * NU, irow, imeta, iwin, inss);
+                    Root vr; vr.win = iwin; vr.n = inss & 0xFFu; vr.strand = (inss >> 8) & 1u; vr.search = inss >> 9;
+                    const uint4 q = A.table[(size_t)(vr.n - 1u) * 8u + vr.search];
+                    vr.rec.x = q.x; vr.rec.y = q.y; vr.rec.z = q.z; vr.rec.w = q.w;
+                    verify_item(irow, imeta, vr, A.K, A.E, env);
+                }
+                qsize -= take;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        GM_LAP(tVerify);
+        env.drain(false);   // locating policies: queued leaves, once enough have gathered
+        // a wavefront without a single node (and nothing queued) skips the step, but still draws roots and reads patterns below
+        const bool stepWave = __ballot(have) != 0ull || qsize != 0u;
+        if (!stepWave && __ballot(!exhausted || fs != 0u || env.sp != 0u) == 0ull) { env.drain(true); break; }   // nothing in flight, nothing queued or stacked, nothing left to draw
+
+#ifdef GM_COUNTERS
+        if (stepWave) { wvIter += 1; wvActive += (uint32_t)__popcll(__ballot(have)); }
+#endif
+        if (have && meta_mode(nd.meta) == M_SPLIT) {
+            env.note_wave(7);
+            Node left; split_node(nd, left, A.K);
+            bool leftDone = false, rightDone = false;
+            if (nd.w >= A.satMinW) {   // (both halves have the parent's width)
+                uint32_t smin, smax;
+                covered_kmers(left.meta, rt.n, A.K, smin, smax);
+                leftDone = env.saturated(rt, smin, smax);
+                covered_kmers(nd.meta, rt.n, A.K, smin, smax);
+                rightDone = env.saturated(rt, smin, smax);
+            }
+            if (rightDone) { if (leftDone) have = false; else nd = left; }
+            else if (!leftDone) env.push(left);
+        }
+        GM_LAP(tStep);
+        // ---- every load of the iteration is issued from here on, back to back: the windows of new roots (LDS DMA), the pattern reads
+        // (an LDS DMA too), then the rank blocks of the step.  Any LDS access behind an LDS DMA waits for ALL loads in flight (the compiler
+        // cannot tell the addresses apart), so nothing else may stand between them: one memory round trip per iteration, not three ----
+        // (nobody else reads this lane's window: checked here, in front of the loads -- see above)
+        bool windowFree = !A.steal || __hip_atomic_load(&users[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == 0u;
+        if constexpr (EnvT::JUMPS) {
+            // (B) the next table read of the lane's root, as soon as the previous entry has been consumed.  Items (gm_oss.h) are plain
+            // patterns -- substituted J-mer -> ONE 16-byte read of the table of all J-mers -- or GROUPS of 64 patterns that differ in three
+            // adjacent characters only: one 8-byte word of a bitmap tells which of them can match at all, and only those are looked up.  A
+            // group's word is requested as soon as its item is known, i.e. while the lane still works through the group before it.
+            // ONE load site each for the next item, the word and the table entry: with a second site the compiler loads into temporaries
+            // and waits for the load right behind it to move the value over.  The LDS reads come first, the loads last (see above).
+            if ((fs & 3u) == 2u) {
+                env.note_wave(16);
+                const uint4 lim = jl[12u + rt.search];   // where the search's LOW / MID groups end
+                bool want = false, asked = false, go = false;   // the item in jd has been used up / its word is to be requested / a table entry is to be read
+                uint32_t widx = 0u, wsel = 0u, rw = 0u;
+                if ((fs & (JF_ITEM | JF_WORD | JF_GROUP)) == (JF_ITEM | JF_GROUP)) {   // a group item: request its word now
+                    const uint32_t sh = (fs & JF_MID) ? 6u : 0u, kind = (jd >> (sh + 3u)) & 1u;
+                    if (kind && !(fs & JF_EXTOK)) {   // a needle N behind the J-mer: no pattern without budget can match
+                        fs &= ~(JF_ITEM | JF_GROUP | JF_MID);
+                        want = true;
+                    } else {
+                        const uint32_t idxp = rot_add(jb, jd & ~(63u << sh));
+                        widx = ((fs & JF_MID) ? jump_swap_mid(idxp) : idxp) >> 6;
+                        // the bitmaps are one array: kind 0 | kind 1 LOW, 16 letter pairs | kind 1 MID, 16 letter pairs
+                        wsel = kind ? 1u + ((fs & JF_MID) ? 16u : 0u) + ((fs >> JF_EXT_SHIFT) & 15u) : 0u;
+                        asked = true;
+                    }
+                } else if (galive == 0ull && (fs & JF_WORD)) {   // the word of group jd has arrived: its patterns that pass
+                    const uint32_t sh = (fs & JF_MID) ? 6u : 0u;
+                    const uint2 mk = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint32_t*>(jl + 8) + 2u * ((jd >> sh) & 7u));
+                    galive = word_to_rotations(pw, (jb >> sh) & 63u) & ((unsigned long long)mk.y << 32 | mk.x);
+                    gcur = jd & ~(63u << sh);
+                    fs = (fs & ~(JF_WORD | JF_ITEM | JF_GROUP | JF_MID | JF_CURMID)) | ((fs & JF_MID) ? JF_CURMID : 0u);
+                    want = true;
+                }
+                if (!(fs & JF_ENTRY)) {
+                    if (galive != 0ull) {   // the next pattern of the current group that passed
+                        rw = gcur | ctz64(galive) << ((fs & JF_CURMID) ? 6u : 0u);
+                        galive &= galive - 1ull;
+                        go = true;
+                    } else if ((fs & (JF_ITEM | JF_WORD | JF_GROUP)) == JF_ITEM && !want && !asked) {   // a plain pattern
+                        rw = jd; go = true;
+                        fs &= ~JF_ITEM;
+                        want = true;
+                    }
+                }
+                if (want) {   // the next item of the lane's root (not looked at before the next iteration: nothing waits for that load)
+                    const uint32_t jp = jpp & 0xFFFFu;
+                    if (jp < (jpp >> 16)) {
+                        jd = A.patterns[jp]; jpp += 1u;
+                        fs |= JF_ITEM | (jp < lim.x ? JF_GROUP : jp < lim.y ? (JF_GROUP | JF_MID) : 0u);
+                    }
+                }
+                if (asked) {
+                    pw = A.jbits[(size_t)wsel * A.jbitsWords + widx];
+                    fs |= JF_WORD;
+#ifdef GM_COUNTERS
+                    env.jumpWords++;
+#endif
+                }
+                if (go) {
+                    if constexpr (sizeof(row_t) == 4) __builtin_amdgcn_global_load_lds(A.jtab + rot_add(jb, rw), ebufW, 16, 0, 0);
+                    else IO::load_qentry(A.jtab, rot_add(jb, rw), ftFlo, ftRlo, ftW, ftNb);
+                    jm = (jm & ~(7u << META_ERRS_SHIFT)) | rot_errors(rw) << META_ERRS_SHIFT;
+                    fs |= JF_ENTRY;
+#ifdef GM_COUNTERS
+                    env.jumps++;
+#endif
+                }
+                if (!(fs & (JF_ENTRY | JF_WORD | JF_ITEM)) && galive == 0ull) fs = 0u;   // nothing in flight, no item, nothing alive: the root's patterns are done
+            }
+        }
+        GM_LAP2(tSt32);
         // stage 1: lanes without node, stack or fetch in flight draw a root (ballot rank) and issue its loads
 #pragma unroll 1
         for (int round = 0; round < 2; ++round) {
-            const bool need = !have && fs == 0u && env.sp == 0u && !exhausted && (!A.steal || __hip_atomic_load(&users[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == 0u);
+            if (round > 0 && A.steal) windowFree = __hip_atomic_load(&users[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == 0u;   // (rare: the pool ran dry in round 0)
+            const bool need = !have && fs == 0u && env.sp == 0u && !exhausted && windowFree;
             const unsigned long long m = __ballot(need);
             if (m == 0ull) break;
             // the whole wavefront walks through the fetch stages for whoever needs a root: wait until enough lanes do
@@ -1254,10 +1369,10 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                         // regular blocks jump over the first jumpJ characters of their search; odd shapes (end of the text or of an
                         // interval) walk the tree from its root
                         fql = (frt.n == A.stepSize) ? A.jumpJ : 0u;
-                        startPos = (A.jumpAPacked[frt.search >> 2] >> (8u * (frt.search & 3u))) & 0xFFu;
+                        startPos = ((frt.search < 4u ? jap0 : jap1) >> (8u * (frt.search & 3u))) & 0xFFu;   // (selects, not a load from the argument segment: a load here would be waited for behind the pattern reads above)
                     } else {
-                    fql = (A.qlenPacked[frt.search >> 2] >> (8u * (frt.search & 3u))) & 0xFFu;
-                    if (frt.n == A.stepSize) startPos = (A.startPacked[frt.search >> 2] >> (8u * (frt.search & 3u))) & 0xFFu;
+                    fql = ((frt.search < 4u ? A.qlenPacked[0] : A.qlenPacked[1]) >> (8u * (frt.search & 3u))) & 0xFFu;
+                    if (frt.n == A.stepSize) startPos = ((frt.search < 4u ? A.startPacked[0] : A.startPacked[1]) >> (8u * (frt.search & 3u))) & 0xFFu;
                     else { const uint4 q = *recp; startPos = (q.y >> 16) & 0xFFu; }   // odd block shape (end of text / interval): rare
                     }
                     fa0 = frt.n - 1u + startPos;
@@ -1266,7 +1381,8 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                     env.woff = (uint32_t)(g & 31u);   // (an idle lane: nothing reads its window offset before the new root's node exists)
                     fsrc = A.text4 + (g >> 5);
                     fnch = (env.woff + W + 31u) >> 5;
-                    { const uint4 q = *recp; frt.rec.x = q.x; frt.rec.y = q.y; frt.rec.z = q.z; frt.rec.w = q.w; }
+                    // (the search's OSS record is installed in stage 2, from LDS: a load into the root context here would have to be
+                    //  awaited by the step below -- behind every other load of the iteration)
                     // the window goes from HBM straight into this lane's LDS slots (global_load_lds_dwordx4: chunk c of
                     // lane l lands at wbase + c * 1 KiB + l * 16 B -- exactly the [chunk][lane] layout text_char reads);
                     // the text has 20 chunks of padding behind it
@@ -1283,98 +1399,12 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
             poolCur += want < avail ? want : avail;
         }
         GM_LAP2(tSt1);
-        // ---- defer narrow nodes: one queue entry per SA row ----
-        if (A.verifyT) {
-            const uint32_t md0 = meta_mode(nd.meta);
-            // (extension-phase nodes have the whole infix behind them: one row there costs a record read and two short scans, while the
-            //  walk still has ~n log n steps to go -- they may be wider than the nodes verified inside the infix)
-            bool narrow = have && nd.w <= (md0 == M_OSS ? A.verifyT : A.verifyTExt);
-            if (narrow && nd.rlo != ~(row_t)0) {   // is the subtree below worth one SA read + one text comparison per row?
-                const uint32_t m = nd.meta, a = meta_a(m), bx = meta_bx(m), t = meta_t(m), md = md0;
-                const uint32_t covered = md == M_OSS ? rt.n : md == M_EXT_R ? a + A.K - t + 1u : md == M_EXT_L ? t + A.K - bx + 1u : a + A.K - bx + 1u;
-                const uint32_t est = (A.K - (bx - a)) + covered - 1u;   // lower bound of the steps still needed
-                narrow = nd.w * A.verifyCost <= est;
-                // A lone row that may not mismatch any more is, more often than not, a chance hit that the next one or
-                // two characters kill with ONE rank line each (lo and hi share a block); verification costs an SA read
-                // plus a text read.  Step it a little first, verify only the survivors.
-                if (nd.w == 1u && meta_errs(m) == A.E && w1run < A.probation) narrow = false;
-                // e = 0: the table leaves one infix character; taking it first costs one rank line and spares the
-                // reverse-strand chance hits their SA + text reads (5.31 vs 5.46 ms, profiles/r01e_infix_sweeps.txt)
-                if (A.E == 0u && md == M_OSS) narrow = false;
-            }
-            // At most VERIFY_ROWS rows of a node are queued per iteration (the queue holds 64 + 64 * VERIFY_ROWS entries); the rows left
-            // over go back onto the lane's stack as a rows-only node (rlo = all ones: never stepped, queued the moment it is popped).
-#pragma unroll 1
-            for (uint32_t r = 0; r < VERIFY_ROWS; ++r) {
-                const bool e = narrow && r < nd.w;
-                const unsigned long long m = __ballot(e);
-                if (m == 0ull) break;
-                env.note_wave(6);
-                if (e) {
-                    const uint32_t slot = qsize + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    IO::store_item(vq + (size_t)slot * NU, nd.flo + r, nd.meta, rt.win, rt.n | rt.strand << 8 | rt.search << 9);
-                }
-                qsize += (uint32_t)__popcll(m);
-            }
-            if (narrow) {
-                have = false;
-                if (nd.w > VERIFY_ROWS) { nd.flo += VERIFY_ROWS; nd.w -= VERIFY_ROWS; nd.rlo = ~(row_t)0; env.push(nd); }
-            }
-            // a partial round only when the wavefront has nothing else left to do
-            const bool finishing = (__ballot(have || fs != 0u || env.sp != 0u) == 0ull) && (__ballot(!exhausted) == 0ull);
-            while (qsize >= 64u || (finishing && qsize > 0u)) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#ifdef GM_COUNTERS
-                wvRounds += 1;
-#endif
-                const uint32_t take = qsize < 64u ? qsize : 64u;
-                if (lane < take) {
-                    row_t irow, iwin; uint32_t imeta, inss;
-                    IO::load_item(vq + (size_t)(qsize - 1u - lane) * NU, irow, imeta, iwin, inss);
-                    Root vr; vr.win = iwin; vr.n = inss & 0xFFu; vr.strand = (inss >> 8) & 1u; vr.search = inss >> 9;
-                    const uint4 q = A.table[(size_t)(vr.n - 1u) * 8u + vr.search];
-                    vr.rec.x = q.x; vr.rec.y = q.y; vr.rec.z = q.z; vr.rec.w = q.w;
-                    verify_item(irow, imeta, vr, A.K, A.E, env);
-                }
-                qsize -= take;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
+        if constexpr (!COOP) if (have) {
+            const bool lone = nd.w == 1u;
+            lane_step(nd, have, rt, A.K, A.E, env);
+            w1run = (lone && have && nd.w == 1u) ? w1run + 1u : 0u;
         }
-        GM_LAP(tVerify);
-        env.drain(false);   // locating policies: queued leaves, once enough have gathered
-        if (__ballot(have) == 0ull && qsize == 0u) {
-            if (__ballot(!exhausted || fs != 0u || env.sp != 0u) == 0ull) { env.drain(true); break; }   // nothing in flight, nothing queued or stacked, nothing left to draw
-            continue;
-        }
-
-#ifdef GM_COUNTERS
-        wvIter += 1; wvActive += (uint32_t)__popcll(__ballot(have));
-#endif
-        if (have) {
-            if (meta_mode(nd.meta) == M_SPLIT) {
-                env.note_wave(7);
-                Node left; split_node(nd, left, A.K);
-                bool leftDone = false, rightDone = false;
-                if (nd.w >= A.satMinW) {   // (both halves have the parent's width)
-                    uint32_t smin, smax;
-                    covered_kmers(left.meta, rt.n, A.K, smin, smax);
-                    leftDone = env.saturated(rt, smin, smax);
-                    covered_kmers(nd.meta, rt.n, A.K, smin, smax);
-                    rightDone = env.saturated(rt, smin, smax);
-                }
-                if (rightDone) { if (leftDone) have = false; else nd = left; }
-                else if (!leftDone) env.push(left);
-            }
-            if constexpr (!COOP) if (have) {
-                const bool lone = nd.w == 1u;
-                lane_step(nd, have, rt, A.K, A.E, env);
-                w1run = (lone && have && nd.w == 1u) ? w1run + 1u : 0u;
-            }
-        }
-        if constexpr (COOP) {   // the rank blocks are read by groups of lanes: every lane walks through the reads
+        if constexpr (COOP) if (stepWave) {   // the rank blocks are read by groups of lanes: every lane walks through the reads
             Plan pl; pl.right = pl.exact = pl.minErr = pl.charsLeft = pl.pos = 0;
             row_t plo = 0, phi = 0;
             if (have) {
