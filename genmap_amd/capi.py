@@ -217,6 +217,21 @@ def push_pieces(device, dst, src, first_byte, pitch_bytes, piece_bytes, n_rows, 
     _check(lib, lib.gm_push_pieces(device, C.c_void_p(dst), C.c_void_p(src), first_byte, pitch_bytes, piece_bytes, n_rows, last_piece_bytes, C.c_void_p(stream or 0)))
 
 
+class _OwnedArray(np.ndarray):
+    """ndarray view of memory owned by the library; `_owner` (carried by views of views through .base) frees it"""
+    _owner = None
+
+
+class _LocationsOwner:
+    def __init__(self, lib, L):
+        self._lib, self._L = lib, L
+
+    def __del__(self):
+        if self._L is not None:
+            self._lib.gm_locations_free(self._L)
+            self._L = None
+
+
 class Index:
     """gm_index handle: the bidirectional FM index resident in one GPU's HBM."""
 
@@ -379,17 +394,20 @@ class Index:
         iv = None if not intervals else np.ascontiguousarray(np.asarray(intervals, dtype=np.uint64).reshape(-1))
         L = C.POINTER(Locations)()
         _check(self._lib, self._lib.gm_locate(self._h, tb, tl, first_seq, n_seq, C.byref(p), _ptr(iv), 0 if iv is None else len(iv) // 2, C.byref(L)))
-        try:
-            c = L.contents
-            n = int(c.n_positions)
-            po = np.ctypeslib.as_array(c.plus_off, shape=(n + 1,)).copy()
-            mo = np.ctypeslib.as_array(c.minus_off, shape=(n + 1,)).copy()
-            # empty windows / shards carry NULL payload pointers
-            pl = np.ctypeslib.as_array(c.plus, shape=(int(po[-1]),)).copy() if int(po[-1]) > 0 and c.plus else np.zeros(0, np.uint64)
-            mi = np.ctypeslib.as_array(c.minus, shape=(int(mo[-1]),)).copy() if int(mo[-1]) > 0 and c.minus else np.zeros(0, np.uint64)
-            return int(c.pos_begin), po, pl, mo, mi
-        finally:
-            self._lib.gm_locations_free(L)
+        # The arrays are VIEWS of the library's host arrays (no copy: a csv window of config C5 holds 2 GB of locations and copying them
+        # here cost more than computing them); they keep the result alive, gm_locations_free runs when the last of them is collected.
+        owner = _LocationsOwner(self._lib, L)
+        c = L.contents
+        n = int(c.n_positions)
+
+        def view(ptr, count):
+            if count <= 0 or not ptr:
+                return np.zeros(0, np.uint64)      # empty windows / shards carry NULL payload pointers
+            a = np.ctypeslib.as_array(ptr, shape=(count,)).view(_OwnedArray)
+            a._owner = owner
+            return a
+        po, mo = view(c.plus_off, n + 1), view(c.minus_off, n + 1)
+        return int(c.pos_begin), po, view(c.plus, int(po[-1])), mo, view(c.minus, int(mo[-1]))
 
     def set_tuning(self, **knobs):
         """gm_index_set_tuning: scheduling knobs (verify_t, fetch_batch, ...); results never depend on them."""

@@ -348,7 +348,7 @@ void gm_index_free(gm_index* ix)
     hipFree(ix->d_saMark); hipFree(ix->d_saSamples);
     for (auto& kv : ix->qtables) hipFree(kv.second);
     for (auto& kv : ix->jbits) hipFree(kv.second);
-    hipFree(ix->d_jinfo2); hipFree(ix->d_seqFile); hipFree(ix->d_bits);
+    hipFree(ix->d_jinfo2); hipFree(ix->d_seqFile); hipFree(ix->d_rowFile); hipFree(ix->d_bits);
     hipFree(ix->d_acc); hipFree(ix->d_stack); hipFree(ix->d_small); hipFree(ix->d_table); hipFree(ix->d_blocks); hipFree(ix->d_cumLocal);
     for (int i = 0; i < 4; ++i) if (ix->ev[i]) hipEventDestroy(ix->ev[i]);
     for (uint32_t i = 0; i < gm_index::EV_RING; ++i) for (int j = 0; j < 2; ++j) if (ix->evRing[i][j]) hipEventDestroy(ix->evRing[i][j]);
@@ -544,19 +544,23 @@ template <int WPP, class EnvT>
 static int launch_one(const SearchArgs& A, unsigned blocks, hipStream_t st)
 {
     const size_t lds = search_lds_bytes(A, NodeIO<typename BlockGeom<WPP>::row_t>::NU);
-    constexpr bool CAN_COOP = WPP == 1 || WPP == 3;
     // 32- and 64-byte blocks with 32-bit rows are compiled for 4 waves per SIMD (at most 128 VGPRs: the kernels sit within a
-    // register or two of that limit); the 128-byte and the wide geometries take what they need
+    // register or two of that limit); the 128-byte and the wide geometries take what they need.  Cooperative reads of the rank
+    // blocks (groups of 2 / 4 lanes) exist for the 32- and 64-byte blocks and for the wide geometry's 64-byte blocks.
     constexpr bool W4 = WPP == 1 || WPP == 3;
+    constexpr bool CAN_COOP = W4 || WPP == 2;
     const void* fn;
-    if constexpr (CAN_COOP) fn = A.coop ? reinterpret_cast<const void*>(&search_kernel_w4<WPP, EnvT, true>) : reinterpret_cast<const void*>(&search_kernel_w4<WPP, EnvT, false>);
+    if constexpr (W4) fn = A.coop ? reinterpret_cast<const void*>(&search_kernel_w4<WPP, EnvT, true>) : reinterpret_cast<const void*>(&search_kernel_w4<WPP, EnvT, false>);
+    else if constexpr (CAN_COOP) fn = A.coop ? reinterpret_cast<const void*>(&search_kernel<WPP, EnvT, true>) : reinterpret_cast<const void*>(&search_kernel<WPP, EnvT, false>);
     else fn = reinterpret_cast<const void*>(&search_kernel<WPP, EnvT, false>);
     if (lds > 65536)   // long needle windows (K + n - 1 up to 509 symbols per lane): ask for more than the default 64 KB of LDS
         GM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if constexpr (CAN_COOP) {
-        static_assert(W4, "");
+    if constexpr (W4) {
         if (A.coop) hipLaunchKernelGGL((search_kernel_w4<WPP, EnvT, true>), dim3(blocks), dim3(256), lds, st, A);
         else hipLaunchKernelGGL((search_kernel_w4<WPP, EnvT, false>), dim3(blocks), dim3(256), lds, st, A);
+    } else if constexpr (CAN_COOP) {
+        if (A.coop) hipLaunchKernelGGL((search_kernel<WPP, EnvT, true>), dim3(blocks), dim3(256), lds, st, A);
+        else hipLaunchKernelGGL((search_kernel<WPP, EnvT, false>), dim3(blocks), dim3(256), lds, st, A);
     } else hipLaunchKernelGGL((search_kernel<WPP, EnvT, false>), dim3(blocks), dim3(256), lds, st, A);
     GM_HIP(hipGetLastError());
     return GM_OK;
@@ -1077,8 +1081,8 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     // quarter of the wavefront is idle gains 2-6 % on 3.09 Gbp (profiles/r04/sweep_k100_knobs.txt, sweep_verify_t_ext.txt)
     else if (p->E == 1 && p->K >= 64) stealDefault = 16u;
     A.steal = ix->tune.steal >= 0 ? (uint32_t)std::min(ix->tune.steal, 64) : stealDefault;
-    A.coop = ix->tune.coop >= 0 ? (uint32_t)(ix->tune.coop != 0) : (ix->wpp == 1 ? 1u : 0u);
-    if (ix->wide) A.coop = 0u;
+    A.coop = ix->tune.coop >= 0 ? (uint32_t)(ix->tune.coop != 0) : ((ix->wpp == 1 || ix->wide) ? 1u : 0u);   // (wide: groups of four lanes per 64-byte block, r04)
+    if (ix->wpp == 9) A.coop = 0u;
     A.jumpJ = jumpJ; A.jumpAPacked[0] = jumpAPacked[0]; A.jumpAPacked[1] = jumpAPacked[1];
     A.patterns = ix->d_patterns; A.jinfo = ix->d_jinfo; A.jinfo2 = ix->d_jinfo2; A.jtab = jtab; A.jbits = jbitsCall; A.jbitsWords = jbitsWords;
     for (uint32_t k = 0; k < GROUP_MAX_MASKS; ++k) A.gmask[k] = gmaskCall[k];
@@ -1117,6 +1121,20 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
         GM_HIP(hipMemcpyAsync(ix->d_seqFile, seq_file_id, (size_t)ix->nSeq * 4, hipMemcpyHostToDevice, st));
         rc = grow(&ix->d_bits, &ix->bitsCap, (text_len + 1) * wordsPerKmer); if (rc) return rc;
         GM_HIP(hipStreamSynchronize(st));
+        // fasta id per suffix-array row (full array, 32-bit rows, at most 256 files): built once per file assignment, one byte per row
+        if (ix->d_sa && !ix->wide && nFiles <= 256u) {
+            uint64_t h = 1469598103934665603ull;
+            for (uint32_t s = 0; s < ix->nSeq; ++s) h = (h ^ seq_file_id[s]) * 1099511628211ull;
+            if (!ix->rowFileValid || ix->rowFileSig != h) {
+                ix->rowFileValid = false;
+                if (!ix->d_rowFile && hipMalloc(&ix->d_rowFile, ix->nRows) != hipSuccess) { (void)hipGetLastError(); ix->d_rowFile = nullptr; }
+                if (ix->d_rowFile) {
+                    hipLaunchKernelGGL(row_file_kernel, dim3(grid_for(ix->nRows)), dim3(256), 0, st, (const uint32_t*)ix->d_sa, ix->nRows, ix->d_cum, ix->nSeq, ix->d_seqFile, ix->d_rowFile);
+                    GM_HIP(hipGetLastError());
+                    ix->rowFileSig = h; ix->rowFileValid = true;
+                }
+            }
+        } else ix->rowFileValid = false;
     } else {
         rc = grow(&ix->d_acc, &ix->accCap, 2 * (text_len + 4) + 16); if (rc) return rc;
     }
@@ -1166,7 +1184,7 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
     A.diff = useDiff ? ix->d_acc + diffOff : nullptr;
     // self hits of the counting kernels pay only with the difference plane (one atomic per block instead of one per k-mer)
     if (!store && !useDiff) A.selfHit = 0u;
-    A.maxVal = ix->tune.noSaturate ? 0xFFFFFFFFu : (p->value_bits == 8 ? 255u : 65535u); A.wordsPerKmer = wordsPerKmer; A.seqFile = ix->d_seqFile;
+    A.maxVal = ix->tune.noSaturate ? 0xFFFFFFFFu : (p->value_bits == 8 ? 255u : 65535u); A.wordsPerKmer = wordsPerKmer; A.seqFile = ix->d_seqFile; A.rowFile = (ep && ix->rowFileValid) ? ix->d_rowFile : nullptr;
 
     const uint32_t slot = (uint32_t)(ix->evCount % gm_index::EV_RING);
     GM_HIP(hipEventRecord(ix->evRing[slot][0], st));

@@ -61,6 +61,7 @@ struct gm_index {
     uint64_t qtableBytes = 0;
     uint64_t* d_C = nullptr;
     uint32_t* d_seqFile = nullptr; uint64_t seqFileCap = 0;
+    uint8_t* d_rowFile = nullptr; uint64_t rowFileSig = 0; bool rowFileValid = false;   // fasta id per suffix-array row for the file assignment with this signature
     uint32_t* d_bits = nullptr; uint64_t bitsCap = 0;
     int numCU = 0;
     // ---- workspace of gm_map*, grown on demand, reused across calls ----

@@ -48,6 +48,8 @@ struct SearchArgs {
     const uint64_t* cumGlobal;      // sentinel-free cumulative sequence lengths of the WHOLE index, nSeqGlobal + 1
     uint32_t nSeqGlobal;
     const uint32_t* seqFile;        // fasta id per global sequence (mappingSeqIdFile, src/mappability.hpp:230-248)
+    const uint8_t* rowFile;         // optional: fasta id of the sequence that suffix-array row r lies in (built once per index and file assignment): --exclude-pseudo
+                                    // reads ONE byte per located row instead of suffix array entry -> sequence lookup -> seqFile
     uint32_t* fileBits;             // [pos * wordsPerKmer + w]: set of fasta ids seen for the k-mer at pos
     uint32_t wordsPerKmer;
     uint64_t posBase;               // window origin of cnt2 / offs / emit arrays (slice position)
@@ -385,6 +387,52 @@ template <int WPP> struct EnvBase {
         if (lo | hi) { steps += 1; lines += 1 + (bl != bh); }
 #endif
     }
+    // the same for 64-bit rows (wide geometry): 64-byte blocks read by groups of FOUR lanes; block numbers take two registers (the
+    // direction travels in bit 31 of the upper one: a block number stays below 2^34)
+    template <int R> __device__ __forceinline__ void coop_round_wide(uint32_t blLo, uint32_t blHi, uint32_t bhLo, uint32_t bhHiX, uint32_t j, uint4& L, uint4& H, uint32_t& dup, uint32_t z)
+    {
+        constexpr int BC = R * 0x55;   // quad_perm [R,R,R,R]
+        const uint32_t oblLo = dpp<BC>(blLo), oblHi = dpp<BC>(blHi), obhLo = dpp<BC>(bhLo), obhHiX = dpp<BC>(bhHiX);
+        const uint64_t obl = (uint64_t)oblHi << 32 | oblLo, obh = (uint64_t)(obhHiX & 0x7FFFFFFFu) << 32 | obhLo;
+        const uint4* pb = reinterpret_cast<const uint4*>((obhHiX >> 31) ? A.blk[1] : A.blk[0]);
+        L = pb[obl * 4u + j];
+        H = make_uint4(z, z, z, z);
+        if (obl != obh) H = pb[obh * 4u + j];
+        uint32_t d = obl == obh ? 1u : 0u;
+        asm volatile("" : "+v"(d));
+        dup |= d << R;
+    }
+    __device__ __forceinline__ void rank2_coop(uint32_t right, uint64_t lo, uint64_t hi, uint64_t rl[NLET], uint64_t rh[NLET])   // 64-bit rows
+    {
+        constexpr uint32_t SPB = BlockGeom<WPP>::SPB;
+        constexpr int G = 4;
+        static_assert(BlockGeom<WPP>::BYTES == 64u, "four lanes per 64-byte block");
+        const uint32_t j = threadIdx.x & 3u;
+        const uint64_t bl = lo / SPB, bh = hi / SPB;
+        const uint32_t blLo = (uint32_t)bl, blHi = (uint32_t)(bl >> 32), bhLo = (uint32_t)bh, bhHiX = (uint32_t)(bh >> 32) | right << 31;
+        uint4 L[G], H[G];
+        uint32_t dup = 0;
+        const uint32_t z = opaque_zero();
+        coop_round_wide<0>(blLo, blHi, bhLo, bhHiX, j, L[0], H[0], dup, z);
+        coop_round_wide<1>(blLo, blHi, bhLo, bhHiX, j, L[1], H[1], dup, z);
+        coop_round_wide<2>(blLo, blHi, bhLo, bhHiX, j, L[2], H[2], dup, z);
+        coop_round_wide<3>(blLo, blHi, bhLo, bhHiX, j, L[3], H[3], dup, z);
+#pragma unroll
+        for (int r = 0; r < G; ++r) H[r] = sel4(((dup >> r) & 1u) != 0u, L[r], H[r]);
+        transpose<G>(j, L);
+        transpose<G>(j, H);
+        uint32_t wl[G * 4], wh[G * 4];
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            wl[4 * k] = L[k].x; wl[4 * k + 1] = L[k].y; wl[4 * k + 2] = L[k].z; wl[4 * k + 3] = L[k].w;
+            wh[4 * k] = H[k].x; wh[4 * k + 1] = H[k].y; wh[4 * k + 2] = H[k].z; wh[4 * k + 3] = H[k].w;
+        }
+        block_rank<WPP>(wl, (uint32_t)(lo - bl * SPB), rl);
+        block_rank<WPP>(wh, (uint32_t)(hi - bh * SPB), rh);
+#ifdef GM_COUNTERS
+        if (lo | hi) { steps += 1; lines += 1 + (bl != bh); }
+#endif
+    }
     __device__ __forceinline__ uint32_t text_char(const Root& rt, uint32_t pos) const
     {
         const uint32_t W = K + rt.n - 1u;
@@ -609,6 +657,11 @@ template <int WPP, class Derived> struct LeafQueueEnv : EnvBase<WPP> {
     uint4* lq = nullptr;          // LDS: entries {row lo, rows, target lo, target hi (56 bits) | row bits 32..39 << 24}
     uint32_t* lqCtl = nullptr;    // LDS: [0] entries pushed, [1..64] scratch of the expansion (exclusive prefix sums)
     __device__ __forceinline__ LeafQueueEnv(const SearchArgs& a, uint4* s, uint32_t k) : EnvBase<WPP>(a, s, k) {}
+    // one row of a queued leaf: by default "locate it, then Derived::row_action(target, index inside the leaf, (seqNo, seqPos))"
+    __device__ __forceinline__ void row_located(uint64_t target, uint32_t r, row_t row)
+    {
+        static_cast<Derived*>(this)->row_action(target, r, locate_position(A.cumGlobal, A.nSeqGlobal, this->locate(row)));
+    }
     // called by one lane (any control flow): returns false when the queue is full -- the caller then walks the leaf itself
     __device__ __forceinline__ bool enqueue(row_t flo, uint32_t w, uint64_t target)
     {
@@ -649,8 +702,7 @@ template <int WPP, class Derived> struct LeafQueueEnv : EnvBase<WPP> {
                     const uint4 e = lq[base + i];
                     const uint32_t r = g - lqCtl[1 + i];
                     const row_t row = (row_t)(((uint64_t)(e.w >> 24) << 32 | e.x) + r);
-                    const uint2 sp = locate_position(A.cumGlobal, A.nSeqGlobal, this->locate(row));
-                    static_cast<Derived*>(this)->row_action((uint64_t)(e.w & 0xFFFFFFu) << 32 | e.z, r, sp);
+                    static_cast<Derived*>(this)->row_located((uint64_t)(e.w & 0xFFFFFFu) << 32 | e.z, r, row);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -667,6 +719,21 @@ template <int WPP> struct FileSetEnv : LeafQueueEnv<WPP, FileSetEnv<WPP>> {
     typedef typename EnvBase<WPP>::row_t row_t;
     typedef typename EnvBase<WPP>::Root Root;
     __device__ __forceinline__ FileSetEnv(const SearchArgs& a, uint4* s, uint32_t k) : LeafQueueEnv<WPP, FileSetEnv<WPP>>(a, s, k) {}
+    // with the per-row file ids the set needs no position at all: one byte per row (rows of a leaf are consecutive: coalesced)
+    __device__ __forceinline__ void row_located(uint64_t pos, uint32_t r, row_t row)
+    {
+        if (A.rowFile) {   // wave-uniform
+#ifdef GM_COUNTERS
+            this->locRows++;
+#endif
+            add_file(pos, A.rowFile[row]);
+        } else row_action(pos, r, locate_position(A.cumGlobal, A.nSeqGlobal, this->locate(row)));
+    }
+    __device__ __forceinline__ void add_file(uint64_t pos, uint32_t f)
+    {
+        uint32_t* word = &A.fileBits[(size_t)pos * A.wordsPerKmer + (f >> 5)];
+        if (!((__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (f & 31u)) & 1u)) atomicOr(word, 1u << (f & 31u));   // mostly set already
+    }
     // target = the k-mer's slice position
     __device__ __forceinline__ void row_action(uint64_t pos, uint32_t, uint2 sp)
     {
@@ -680,7 +747,7 @@ template <int WPP> struct FileSetEnv : LeafQueueEnv<WPP, FileSetEnv<WPP>> {
         while (w > 0) {
             const uint32_t piece = w < (row_t)LQ_PIECE ? (uint32_t)w : LQ_PIECE;
             if (!this->enqueue(flo, piece, pos))   // queue full: this lane walks the piece itself
-                for (uint32_t r = 0; r < piece; ++r) row_action(pos, r, locate_position(A.cumGlobal, A.nSeqGlobal, this->locate(flo + r)));
+                for (uint32_t r = 0; r < piece; ++r) row_located(pos, r, flo + r);
             flo += piece; w -= piece;
         }
     }
@@ -1519,6 +1586,14 @@ __global__ __launch_bounds__(256) void qmer_table_kernel(const uint32_t* __restr
         }
     }
     NodeIO<row_t>::store_qentry(out, idx, flo, rlo, w, nb);
+}
+
+// fasta id of the sequence every suffix-array row lies in (--exclude-pseudo: FileSetEnv::row_located)
+__global__ __launch_bounds__(256) void row_file_kernel(const uint32_t* __restrict__ sa, uint64_t n, const uint64_t* __restrict__ cum, uint32_t nSeq,
+                                                       const uint32_t* __restrict__ seqFile, uint8_t* __restrict__ out)
+{
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x)
+        out[r] = (uint8_t)seqFile[locate_position(cum, nSeq, sa[r]).x];
 }
 
 // existence bitmap of the J-mers (groups of jump patterns, gm_oss.h): bit idx & 63 of word idx >> 6 = table entry idx holds a row.

@@ -151,3 +151,41 @@ def test_cli_sampled_suffix_array_with_64_bit_rows(case, tmp_path):
         out = tmp_path / f"out_{sub}"; out.mkdir()
         subprocess.check_call([str(GENMAP), "map", "-I", str(idx), "-O", str(out)] + flags + FORMAT_FLAGS[sub] + wide, stdout=subprocess.DEVNULL)
         _same_tree(out, d / sub)
+
+
+def test_cli_two_device_threads_k100_e1_at_0p77_gbp(tmp_path):
+    """The C++ host path of a multi-GPU run at a size where it matters (a quarter of the metric's text, 0.77 Gbp in 24 sequences):
+    `genmap index` writes the directory, `genmap map -K 100 -E 1 -r -fs -D 0,0` = config C4's (k, e) with one replica and one host thread
+    per listed device (the box has one: listed twice), interleaved chunks copied straight into the one pinned result vector -- the raw
+    file must equal the library's single-call result on an index built in this process."""
+    import numpy as np
+    import genmap_amd as g
+    from genmap_amd import synth
+    codes, lens, _ = synth.workload("grch38", 0.25)
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    fa = tmp_path / "genome.fa"
+    off = 0
+    with open(fa, "wb") as f:
+        for k, ln in enumerate(lens):
+            f.write(b">seq%d synthetic\n" % (k + 1))
+            seq = lut[codes[off:off + ln]]
+            off += ln
+            n = len(seq) // 60 * 60
+            if n:
+                rows = np.empty((n // 60, 61), dtype=np.uint8)
+                rows[:, :60] = seq[:n].reshape(-1, 60)
+                rows[:, 60] = 10
+                f.write(rows.tobytes())
+            if n < len(seq):
+                f.write(seq[n:].tobytes() + b"\n")
+    idx, out = tmp_path / "index", tmp_path / "out"
+    out.mkdir()
+    _run_checked([str(GENMAP), "index", "-F", str(fa), "-I", str(idx)])
+    _run_checked([str(GENMAP), "map", "-I", str(idx), "-O", str(out), "-K", "100", "-E", "1", "-r", "-fs", "-D", "0,0"])
+    got = np.fromfile(out / "genome.genmap.freq8", dtype=np.uint8)
+    shutil.rmtree(idx)
+    ix = g.Index.build(codes, lens, sampling=1)
+    try:
+        assert np.array_equal(got, ix.map(100, 1, value_bits=8))
+    finally:
+        ix.close()

@@ -74,6 +74,27 @@ if len(sys.argv) > 2:   # e.g. "14,15,16": forced lengths of the q-mer table (32
         same = bool(np.array_equal(dev[:len(out)].cpu().numpy(), out))
         ok &= same
         print(f"qtable={q}: search kernel {ix.kernel_times(1)[0]:.1f} ms, table_q {ix.last_stats()['detail']['table_q'] & 255}, same result: {same}", flush=True)
+# cooperative reads of the 64-byte blocks (groups of four lanes, the default since r04) against one lane per block, and an e = 1 figure
+import torch
+dev = torch.zeros(len(full) + 16, dtype=torch.uint8, device="cuda:0")
+st = torch.cuda.current_stream().cuda_stream
+for coop in (1, 0):
+    ix.set_tuning(qtable=-1, coop=coop)
+    for _ in range(2):
+        ix.map_device(dev.data_ptr(), K, 0, value_bits=8, stream=st)
+    same = bool(np.array_equal(dev[:len(out)].cpu().numpy(), out))
+    ok &= same
+    print(f"K=30 e=0 whole text, coop={coop}: search kernel {ix.kernel_times(1)[0]:.1f} ms = {(len(full) - K + 1) / ix.kernel_times(1)[0] / 1e6:.2f} G k-mers/s, same result: {same}", flush=True)
+    nk = len(full) - K + 1
+    rng = (nk // 2 // 8 * 8, nk // 2 // 8 * 8 + nk // 100 // 8 * 8)
+    ref = None
+    for _ in range(2):
+        ix.map_device(dev.data_ptr(), K, 1, value_bits=8, kmer_range=rng, stream=st)
+    e1 = dev[rng[0]:rng[1]].cpu().numpy()
+    if coop == 1: e1_first = e1
+    else: ok &= bool(np.array_equal(e1, e1_first))
+    print(f"K=30 e=1 on 1 % of the text, coop={coop}: search kernel {ix.kernel_times(1)[0]:.1f} ms = {(rng[1] - rng[0]) / ix.kernel_times(1)[0] / 1e6:.3f} G k-mers/s", flush=True)
+ix.set_tuning(coop=-1)
 print("WIDE_ROWS_OK" if ok else "WIDE_ROWS_FAILED", flush=True)
 ix.close()
 sys.exit(0 if ok else 1)
