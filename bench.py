@@ -581,13 +581,14 @@ def main():
         vi = d["verify_items"]
         ver = 32 * vi + 8 * d["verify_chunks"] if info["verify_records"] else 4 * vi + 16 * d["verify_chunks"]
         # (a root that jumps reads one 16-byte table entry per pattern instead of the single q-mer entry: counted as jump_lookups)
-        alg = bb * sp["rank_lines"] + 16 * (d.get("jump_lookups", 0) or sp["roots"]) + n + n + ver
+        # ... and one 8-byte bitmap word per group of patterns: jump_words)
+        alg = bb * sp["rank_lines"] + 16 * (d.get("jump_lookups", 0) or sp["roots"]) + 8 * d.get("jump_words", 0) + n + n + ver
         # N > 1: per GPU -- a rank's share of the bytes over the slowest rank's kernel time, against one GPU's peak
         ach = alg / world / (rec["kernel_ms"] * 1e-3) / 1e9
         # random requests the kernel issues (rank blocks, table entries, records) against the measured ceiling of the memory system
         # for random reads over a large footprint (48.3 G/s whatever the concurrency: profiles/r03/gather2_concurrency.txt); L2 hits
         # are included, so the figure can exceed the ceiling -- the lines actually fetched are in profiles/<round>/final/pmc_by_config.txt
-        issued = sp["rank_lines"] + (d.get("jump_lookups", 0) or sp["roots"]) + vi
+        issued = sp["rank_lines"] + (d.get("jump_lookups", 0) or sp["roots"]) + d.get("jump_words", 0) + vi
         tr = traffic.get((rec["K"], rec["E"]), {})
         tsum = (tr.get("FETCH_SIZE", 0.0) + tr.get("WRITE_SIZE", 0.0)) if len(tr) == 2 else None
         return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -598,7 +599,7 @@ def main():
                 "traffic_over_algorithmic": (tsum / alg) if tsum else None,
                 "per_gpu": True, "kernel": "search_kernel", "kernel_ms": rec["kernel_ms"], "algorithmic_bytes": alg, "rank_lines": sp["rank_lines"],
                 "roots": sp["roots"], "node_steps": sp["node_steps"], "node_steps_per_kmer": sp["node_steps"] / rec["num_kmers"],
-                "verify_items": d["verify_items"], "verify_chunks": d["verify_chunks"], "jump_lookups": d.get("jump_lookups", 0),
+                "verify_items": d["verify_items"], "verify_chunks": d["verify_chunks"], "jump_lookups": d.get("jump_lookups", 0), "jump_words": d.get("jump_words", 0),
                 "lanes_with_node_per_iteration": d["active_lane_sum"] / max(1, d["wave_iterations"])}
 
     def roofline_c5(rec):
