@@ -1055,14 +1055,16 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     // profiles/r01e_infix_sweeps.txt (r01h): 16 / 8 / 4 on the 249 Mbp index; beyond 2^30 rows the fetch loads are HBM
     // misses and larger batches pay (3.09 Gbp: e=0 82.6 vs 90.2 ms, K100 e=1 861 vs 900 ms with 32)
     const bool huge = ix->nRows >= (1ull << 30);
-    A.fetchBatch = p->E == 0 ? (huge ? 32u : 16u) : p->E == 1 ? (huge ? 32u : 8u) : 4u;
+    A.fetchBatch = p->E == 0 ? (huge ? 32u : 16u) : p->E == 1 ? (huge ? 32u : 8u) : (huge ? 8u : 4u);   // (e=2 on 3.09 Gbp: 8 -> -1.7 % over 4, 16 +3 %; profiles/r04/sweep_retune_e2.txt)
     if (ix->tune.fetchBatch > 0) A.fetchBatch = (uint32_t)std::min(ix->tune.fetchBatch, 64);
     // e = 0: a single row is almost always the k-mer's own location.  Beyond ~1 G rows a lone-row step is an HBM miss
     // like the verification reads it postpones, and no longer pays (3.09 Gbp e = 2: 90.7 vs 86.7 M k-mers/s without).
     // 3.09 Gbp: e=1 +8.5 %, e=2 +4 % over 0 (profiles/r02/sweep_grch38_retune.txt); K=100: no difference.  With the neighbour filter the
     // chance hits the two steps used to kill are mostly gone before they become nodes: e=2 one step 371-373 ms against 376-379 with
     // two, e=1 no difference (profiles/r03/sweep_neighbour_filter.txt, sweep_knobs_after_filter.txt)
-    A.probation = p->E == 0 ? 0u : p->E == 1 ? (p->K >= 64 ? 0u : 2u) : 1u;   // (K=100 e=1: 0 -> -1.3 % kernel time, r04)
+    // r04, with the two-row filter and the groups (chance hits are mostly gone before they become nodes): e=2 0 -> -3.2 % over 1, e=1 1 -> -1.2 %
+    // over 2 (profiles/r04/sweep_retune_e*.txt); K=100 e=1: 0 -> -1.3 %
+    A.probation = p->E == 1 && p->K < 64 ? 1u : 0u;
     if (ix->tune.probation >= 0) A.probation = (uint32_t)ix->tune.probation;
     A.verifyCost = (uint32_t)std::max(0, ix->tune.verifyCost);
     A.selfHit = ix->tune.selfHit != 0 ? 1u : 0u;

@@ -244,7 +244,8 @@ typedef struct gm_map_stats {
                                  the call | jump length << 8 (both set by the host in every build); [39] one-row table entries ended
                                  by the neighbour filter; [40] rows located (one suffix-array or mark-word read each: --exclude-pseudo, csv,
                                  correction pass), [41] LF steps of sampled suffix-array walks, [42] deepest lane stack of the call,
-                                 [43] self hits, [44] verified runs of k-mers; [45..47] spare */
+                                 [43] self hits, [44] verified runs of k-mers, [45] 8-byte bitmap words read for groups of jump patterns, [46] rows of two-row
+                                 table entries ended by the neighbour filter; [47] spare */
     double   search_ms;       /* HIP-event time of the search kernel alone */
     double   total_ms;        /* memset + search + finalize, HIP events on the call's stream */
 } gm_map_stats;
@@ -263,8 +264,10 @@ int gm_index_sync(gm_index *idx);
  * wavefront, n > 0: an exchange when at least n lanes are idle), part_bias (e = 1: characters moved from the second OSS block
  * to the first; every split gives the same result; may be negative, default 0), oss_weights (e >= 1: nibble i = relative length of
  * OSS block i, left to right; 0 = the reference's equal split); qtable / jump = 1..16 force the length of the q-mer table / of the jump
- * patterns (16: the 69 GB table of all 16-mers, the default beyond 2^30 rows), jump_filter = 0 switches the neighbour test of one-row
- * table entries off.  Results never depend on these.
+ * patterns (16: the 69 GB table of all 16-mers, the default beyond 2^30 rows), jump_filter = 0 switches the neighbour test of one- and
+ * two-row table entries off (2: one-row entries only), jump_groups = 0 / 1 forbids / forces the groups of jump patterns behind the
+ * bitmaps (default: where they are expected to save table reads), range_add = 0 adds verified runs k-mer by k-mer instead of through the
+ * difference plane, verify_t_ext = widest node verified in the extension phase.  Results never depend on these.
  * Two TEST-ONLY knobs do change the output: no_saturate = 1 counts without the min(total, MAX) clamp and stores the low bits,
  * no_store = 1 only switches e = 0 from plain stores to the atomic accumulators (same result).
  * value -1 restores the library default of any knob except part_bias; values outside a knob's range are GM_ERR_BAD_ARG.
