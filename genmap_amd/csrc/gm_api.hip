@@ -855,7 +855,8 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         int t = 1;
         // long k-mers with errors: a two-row node has a long way to go by rank steps; with the 32-byte row records two reads
         // settle it (K=100 e=1: +8 % on 3.09 Gbp, +12 % on 249 Mbp; K=30: -20 %, profiles/r02/sweep_*_steal_verify.txt)
-        if (p->K >= 64 && p->E >= 1 && ix->d_ctx && ix->tune.useCtx) t = 2;
+        // (only up to two errors: K=101 e=3 -5.5 %, e=4 -16 % kernel time with one row, profiles/r04/sweep_e3_e4.txt)
+        if (p->K >= 64 && p->E >= 1 && p->E <= 2 && ix->d_ctx && ix->tune.useCtx) t = 2;
         else if (plan.stepSize >= 32) t = 4;   // long blocks: a narrow node still covers many k-mers (profiles/r01c)
         if (ix->tune.verifyT >= 0) t = ix->tune.verifyT;
         verifyT = (uint32_t)std::max(0, std::min(t, (int)VERIFY_TMAX));
@@ -895,7 +896,9 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         rc = blocks_for(ldsDepth, &perCU); if (rc) return rc;
         perCU = std::max(1, std::min(perCU, wantPerCU));
     } else {
-        for (uint32_t d = std::min(4u / nu, depth); d >= 1u; --d) {
+        // (three and four errors stack deep: two levels in LDS are worth more than the block per CU they may cost -- K=101 e=4 -12 %, e=3 -1.6 %)
+        const uint32_t dmin = (p->E >= 3 && nu == 1u) ? std::min(2u, depth) : 1u;
+        for (uint32_t d = std::min(4u / nu, depth); d >= dmin; --d) {
             int nb = 0;
             rc = blocks_for(d, &nb); if (rc) return rc;
             nb = std::min(nb, wantPerCU);
@@ -1078,7 +1081,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     // the wavefront is idle gains 1.5 % (3.09 Gbp) to 5 % (249 Mbp) (profiles/r02/sweep_steal_e2.txt, sweep_chr1_steal_*.txt)
     uint32_t stealDefault = 0u;
     if ((p->E <= 1 && p->K < 64 && ix->nRows >= (1ull << 30)) || S->numRoots < 64ull * 4ull * 1024ull) stealDefault = 1u;
-    else if (p->E >= 2) stealDefault = p->K < 64 ? 16u : 8u;   // K=100 e=2: 8 -> +5.7 %, 16 -> 0 (sweep_steal_longk.txt)
+    else if (p->E >= 2) stealDefault = p->K < 64 ? 16u : (p->E >= 3 ? 4u : 8u);   // K=100 e=2: 8 -> +5.7 %, 16 -> 0 (sweep_steal_longk.txt); K=101 e=3 / e=4: 4 -> -2 / -7 % over 8 (r04)
     // e=1 at K >= 64: sharing used to lose 5..9 % (r02); with verified runs added in two atomics the balance turned: an exchange when a
     // quarter of the wavefront is idle gains 2-6 % on 3.09 Gbp (profiles/r04/sweep_k100_knobs.txt, sweep_verify_t_ext.txt)
     else if (p->E == 1 && p->K >= 64) stealDefault = 16u;
