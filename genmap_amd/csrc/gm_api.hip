@@ -348,7 +348,8 @@ void gm_index_free(gm_index* ix)
     hipFree(ix->d_saMark); hipFree(ix->d_saSamples);
     for (auto& kv : ix->qtables) hipFree(kv.second);
     for (auto& kv : ix->jbits) hipFree(kv.second);
-    hipFree(ix->d_jinfo2); hipFree(ix->d_seqFile); hipFree(ix->d_rowFile); hipFree(ix->d_bits);
+    hipFree(ix->d_jinfo2); hipFree(ix->d_seqFile); hipFree(ix->d_rowFile);
+    hipFree(ix->d_locCnt); hipFree(ix->d_locOffs); hipFree(ix->d_locEmit); hipFree(ix->d_locSorted); hipFree(ix->d_locTmp); hipFree(ix->d_locSeg); hipFree(ix->d_bits);
     hipFree(ix->d_acc); hipFree(ix->d_stack); hipFree(ix->d_small); hipFree(ix->d_table); hipFree(ix->d_blocks); hipFree(ix->d_cumLocal);
     for (int i = 0; i < 4; ++i) if (ix->ev[i]) hipEventDestroy(ix->ev[i]);
     for (uint32_t i = 0; i < gm_index::EV_RING; ++i) for (int j = 0; j < 2; ++j) if (ix->evRing[i][j]) hipEventDestroy(ix->evRing[i][j]);
@@ -1270,18 +1271,21 @@ static int locate_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uin
     if (!L->plus_off || !L->minus_off) return GM_ERR_OOM;
     if (W == 0 || S.numRoots == 0) return GM_OK;
 
-    uint32_t* d_cnt = nullptr; uint64_t* d_offs = nullptr; uint64_t *d_emit = nullptr, *d_sorted = nullptr; void* d_tmp = nullptr;
-    uint32_t *d_segB = nullptr, *d_segE = nullptr;
+    // the work buffers of the windows of one index are kept between calls (a csv pass over five FASTA files allocated and released
+    // 4.5 GB five times; gm_index_free releases them)
+    uint32_t*& d_cnt = ix->d_locCnt; uint64_t*& d_offs = ix->d_locOffs; uint64_t*& d_emit = ix->d_locEmit; uint64_t*& d_sorted = ix->d_locSorted; uint8_t*& d_tmp = ix->d_locTmp;
+    uint32_t*& d_segB = ix->d_locSeg; uint32_t* d_segE = nullptr;
     size_t tmpBytes = 0;
     const uint64_t slots = 2 * W;
 #define LC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); rc = (e_ == hipErrorOutOfMemory) ? GM_ERR_OOM : GM_ERR_HIP; goto done; } } while (0)
     {
-        LC(hipMalloc(&d_cnt, (slots + 1) * 4)); LC(hipMalloc(&d_offs, (slots + 1) * 8));
+        rc = grow(&d_cnt, &ix->locCntCap, slots + 1); if (rc) goto done;
+        rc = grow(&d_offs, &ix->locOffsCap, slots + 1); if (rc) goto done;
         LC(hipMemset(d_cnt, 0, (slots + 1) * 4)); LC(hipMemset(ix->d_small, 0, SMALL_ZEROED));
         A.cnt2 = d_cnt;
         rc = launch_search(ix, LEAF_OCC_COUNT, A, S.blocks, st); if (rc) goto done;
         LC(rocprim::exclusive_scan(nullptr, tmpBytes, d_cnt, d_offs, (uint64_t)0, slots + 1, rocprim::plus<uint64_t>()));
-        LC(hipMalloc(&d_tmp, tmpBytes ? tmpBytes : 16));
+        rc = grow(&d_tmp, &ix->locTmpCap, (uint64_t)(tmpBytes ? tmpBytes : 16)); if (rc) goto done;
         { size_t tb = tmpBytes; LC(rocprim::exclusive_scan(d_tmp, tb, d_cnt, d_offs, (uint64_t)0, slots + 1, rocprim::plus<uint64_t>())); }
         // (every device -> host transfer of this call goes through the page-locked ring: the plain hipMemcpy into pageable memory was
         //  most of the second that config C5's csv window took, profiles/r03/final/bench_c5_bacteria5.json)
@@ -1295,18 +1299,19 @@ static int locate_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uin
         L->plus = (uint64_t*)malloc((offs[W] + 1) * 8); L->minus = (uint64_t*)malloc((total - offs[W] + 1) * 8);
         if (!L->plus || !L->minus) { rc = GM_ERR_OOM; goto done; }
         if (total > 0) {
-            LC(hipMalloc(&d_emit, total * 8)); LC(hipMalloc(&d_sorted, total * 8));
+            rc = grow(&d_emit, &ix->locEmitCap, total); if (rc) goto done;
+            rc = grow(&d_sorted, &ix->locSortedCap, total); if (rc) goto done;
             LC(hipMemset(d_cnt, 0, (slots + 1) * 4)); LC(hipMemset(ix->d_small, 0, SMALL_ZEROED));
             A.offs = d_offs; A.emit = d_emit;
             rc = launch_search(ix, LEAF_OCC_EMIT, A, S.blocks, st); if (rc) goto done;
             // std::sort of every list (algo.hpp:336,348): segmented radix sort, segments = (position, strand) slots
-            LC(hipMalloc(&d_segB, (slots + 1) * 4));
+            rc = grow(&d_segB, &ix->locSegCap, slots + 1); if (rc) goto done;
             hipLaunchKernelGGL(narrow_offsets_kernel, dim3(grid_for(slots + 1)), dim3(256), 0, st, d_offs, slots + 1, d_segB);   // (total < 2^31)
             LC(hipGetLastError());
             d_segE = d_segB + 1;
             size_t sb = 0;
             LC(rocprim::segmented_radix_sort_keys(nullptr, sb, d_emit, d_sorted, (unsigned int)total, (unsigned int)slots, d_segB, d_segE, 0, 64));
-            if (sb > tmpBytes) { hipFree(d_tmp); d_tmp = nullptr; LC(hipMalloc(&d_tmp, sb)); tmpBytes = sb; }
+            if (sb > tmpBytes) { rc = grow(&d_tmp, &ix->locTmpCap, (uint64_t)sb); if (rc) goto done; tmpBytes = sb; }
             { size_t tb = tmpBytes; LC(rocprim::segmented_radix_sort_keys(d_tmp, tb, d_emit, d_sorted, (unsigned int)total, (unsigned int)slots, d_segB, d_segE, 0, 64)); }
             if (offs[W]) { rc = staged_copy_to_host(ix, (uint8_t*)L->plus, (const uint8_t*)d_sorted, offs[W] * 8, st); if (rc) goto done; }
             if (total > offs[W]) { rc = staged_copy_to_host(ix, (uint8_t*)L->minus, (const uint8_t*)(d_sorted + offs[W]), (total - offs[W]) * 8, st); if (rc) goto done; }
@@ -1315,7 +1320,6 @@ static int locate_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uin
     }
 done:
 #undef LC
-    hipFree(d_cnt); hipFree(d_offs); hipFree(d_emit); hipFree(d_sorted); hipFree(d_tmp); hipFree(d_segB);
     if (hipEventRecord(ix->evDone, st) == hipSuccess) ix->doneValid = true;
     if (!rc) rc = check_device_error(ix);
     return rc;

@@ -61,6 +61,9 @@ struct gm_index {
     uint64_t qtableBytes = 0;
     uint64_t* d_C = nullptr;
     uint32_t* d_seqFile = nullptr; uint64_t seqFileCap = 0;
+    // gm_locate: work buffers kept between calls
+    uint32_t* d_locCnt = nullptr; uint64_t* d_locOffs = nullptr; uint64_t* d_locEmit = nullptr; uint64_t* d_locSorted = nullptr; uint8_t* d_locTmp = nullptr; uint32_t* d_locSeg = nullptr;
+    uint64_t locCntCap = 0, locOffsCap = 0, locEmitCap = 0, locSortedCap = 0, locTmpCap = 0, locSegCap = 0;
     uint8_t* d_rowFile = nullptr; uint64_t rowFileSig = 0; bool rowFileValid = false;   // fasta id per suffix-array row for the file assignment with this signature
     uint32_t* d_bits = nullptr; uint64_t bitsCap = 0;
     int numCU = 0;
