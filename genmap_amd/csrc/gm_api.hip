@@ -548,7 +548,7 @@ static int launch_one(const SearchArgs& A, unsigned blocks, hipStream_t st)
     // 32- and 64-byte blocks with 32-bit rows are compiled for 4 waves per SIMD (at most 128 VGPRs: the kernels sit within a
     // register or two of that limit); the 128-byte and the wide geometries take what they need.  Cooperative reads of the rank
     // blocks (groups of 2 / 4 lanes) exist for the 32- and 64-byte blocks and for the wide geometry's 64-byte blocks.
-    constexpr bool W4 = WPP == 1 || WPP == 3;
+    constexpr bool W4 = WPP == 1 || WPP == 3 || (WPP == 2 && EnvT::EXACT_ONLY);   // (wide rows: the e = 0 kernels gain 5 % capped at 128 VGPRs, 3 spilled; the counting kernels lose 5 %: profiles/r04/final/wide_rows_smoke_w4.txt)
     constexpr bool CAN_COOP = W4 || WPP == 2;
     const void* fn;
     if constexpr (W4) fn = A.coop ? reinterpret_cast<const void*>(&search_kernel_w4<WPP, EnvT, true>) : reinterpret_cast<const void*>(&search_kernel_w4<WPP, EnvT, false>);
