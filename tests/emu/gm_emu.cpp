@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstring>
 #include <vector>
+#include <algorithm>
 #include "../../genmap_amd/csrc/gm_engine.h"
 #include "../../genmap_amd/csrc/gm_host.h"
 
@@ -324,6 +325,64 @@ static int run(const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nse
         for (uint64_t j = 1; j < lim; ++j) { if (valueBits == 8) ((uint8_t*)out)[seqCum[s] - j] = 0; else ((uint16_t*)out)[seqCum[s] - j] = 0; }
     }
     if (stats) { stats[0] = env.maxDepth; stats[1] = bound; stats[2] = env.steps; stats[3] = env.verified; stats[4] = nPatterns; stats[5] = corrRoots; stats[6] = env.selfHits; }
+    return 0;
+}
+
+
+// gm_oss.h self-check (no index involved): for every search of (K, E) under the library's block shape and jump length J, the items of
+// oss_make_items (plain / every possible group / groups by the occurrence rule) must expand to exactly the patterns of oss_jump_patterns --
+// same substituted J-mers with the same error counts -- for `reps` random needles; groups of kind 1 may only hold patterns that have spent
+// the whole budget; word_to_rotations / rot_add must agree with their definitions.  Returns 0, or a code that names the first failure.
+extern "C" int gm_emu_check_items(uint32_t K, uint32_t E, uint32_t J, uint32_t ossWeights, uint32_t reps, uint32_t seed, uint64_t* stats)
+{
+    uint64_t x = 88172645463325252ull ^ ((uint64_t)seed << 32 | seed);
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    for (int t = 0; t < 200; ++t) {
+        const uint64_t w = rnd(); const uint32_t low6 = (uint32_t)rnd() & 63u;
+        const uint64_t r = word_to_rotations(w, low6);
+        for (uint32_t rot = 0; rot < 64u; ++rot) {
+            const uint32_t c0 = ((low6 >> 4) + (rot >> 4)) & 3u, c1 = (((low6 >> 2) & 3u) + ((rot >> 2) & 3u)) & 3u, c2 = ((low6 & 3u) + (rot & 3u)) & 3u, b = c0 << 4 | c1 << 2 | c2;
+            if ((rot_add(low6, rot) & 63u) != b) return 1;
+            if (((r >> rot) & 1ull) != ((w >> b) & 1ull)) return 2;
+        }
+        const uint32_t idx = (uint32_t)rnd();
+        if (jump_swap_mid(jump_swap_mid(idx)) != idx || (jump_swap_mid(idx) & 63u) != ((idx >> 6) & 63u)) return 3;
+    }
+    const uint32_t infix = tuned_infix_length(K, E);
+    MapPlan plan;
+    if (infix == 0 || make_map_plan(K, E, infix, 1, 100000, nullptr, 0, &plan, 0, ossWeights)) return -1;
+    if (J >= plan.infix) return -2;
+    uint64_t nPat = 0, nItems = 0, nGroups = 0;
+    for (int mode = 0; mode < 3; ++mode) {
+        std::vector<uint64_t> masks;
+        for (uint32_t s = 0; s < plan.nSearches; ++s) {
+            JumpSearch js;
+            if (!oss_jump_patterns(E, plan.table[(size_t)(plan.stepSize - 1) * 8 + s], plan.infix, J, 4096, &js) || js.pat.empty()) continue;
+            SearchItems it;
+            oss_make_items(js, E, mode, js.regionA + J + 2u <= plan.infix, 0.51, 0.044, &masks, &it);
+            if (it.low + it.mid > it.items.size() || masks.size() > GROUP_MAX_MASKS) return 4;
+            if (mode == 2) { nPat += js.pat.size(); nItems += it.items.size(); nGroups += it.low + it.mid; }
+            for (uint32_t rep = 0; rep < reps; ++rep) {
+                const uint32_t base = J == 16u ? (uint32_t)rnd() : (uint32_t)rnd() & ((1u << (2u * J)) - 1u);
+                std::vector<uint64_t> A, B;   // (substituted J-mer, errors) of either form
+                for (uint32_t d : js.pat) A.push_back((uint64_t)jump_apply(base, d, J) << 8 | (d & 7u));
+                for (size_t q = 0; q < it.items.size(); ++q) {
+                    const uint32_t d = it.items[q];
+                    if (q >= it.low + it.mid) { B.push_back((uint64_t)rot_add(base, d) << 8 | rot_errors(d)); continue; }
+                    const uint32_t sh = q < it.low ? 0u : 6u, own = (d >> sh) & 63u, rotw = d & ~(63u << sh);
+                    if ((own & 7u) >= masks.size()) return 5;
+                    for (uint32_t rot = 0; rot < 64u; ++rot) if ((masks[own & 7u] >> rot) & 1ull) {
+                        const uint32_t rw = rotw | rot << sh;
+                        if ((own >> 3) && rot_errors(rw) != E) return 6;   // kind 1 is only valid without budget
+                        B.push_back((uint64_t)rot_add(base, rw) << 8 | rot_errors(rw));
+                    }
+                }
+                std::sort(A.begin(), A.end()); std::sort(B.begin(), B.end());
+                if (A != B) return 10 + mode;
+            }
+        }
+    }
+    if (stats) { stats[0] = nPat; stats[1] = nItems; stats[2] = nGroups; }
     return 0;
 }
 

@@ -362,3 +362,19 @@ def test_uneven_oss_block_lengths_give_the_same_counts(E, weights):
             assert np.array_equal(out, exp), (E, hex(weights), T, jump)
     finally:
         emu().gm_emu_set_oss_weights(0)
+
+
+@pytest.mark.parametrize("E", [1, 2, 3, 4])
+def test_items_of_a_search_expand_to_its_patterns(E):
+    """gm_oss.h without an index: rotation words, groups in both layouts and both kinds against the pattern descriptors, for the block shapes
+    the library schedules and the jump lengths the device uses (and short ones); the 3 Gbp case K=30 e=2 J=16 must form its 14 + 4 groups"""
+    e = emu()
+    e.gm_emu_check_items.restype = C.c_int
+    e.gm_emu_check_items.argtypes = [C.c_uint32] * 6 + [C.c_void_p]
+    st = np.zeros(3, dtype=np.uint64)
+    for K in (24, 30, 36, 50, 100, 150):
+        for J in (16, 15, 12, 9, 6, 5, 4):
+            rc = e.gm_emu_check_items(K, E, J, 0x8845 if E == 2 else 0, 3, K * 100 + J, H._ptr(st))
+            assert rc in (0, -1, -2), (K, E, J, rc)
+            if (K, E, J) == (30, 2, 16):
+                assert rc == 0 and tuple(int(v) for v in st) == (261, 80, 18), st
