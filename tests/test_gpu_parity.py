@@ -914,6 +914,20 @@ def test_gpu_full_size_grch38_e0_everywhere_e1_e2_k100_on_intervals():
     ix.set_tuning(**dflt)
     assert np.array_equal(d2, p2), np.flatnonzero(d2 != p2)[:10]
     assert (d2[r2[0] + 6:r2[1] - 6] >= d1[r2[0] + 6:r2[1] - 6]).all()
+    del d2, p2
+    # ... two more shares of 5 % for e=2 (the start of the text with its leading N block, the end of the text), and config C4's
+    # (K=100, e=1) at EVERY position: groups behind the bitmaps / difference plane / two-row verification against the plain walk
+    for r in ((0, int(0.05 * n)), (n - 29 - int(0.05 * n), n - 29)):
+        a = ix.map(30, 2, value_bits=8, kmer_range=r)
+        ix.set_tuning(**plain)
+        b = ix.map(30, 2, value_bits=8, kmer_range=r)
+        ix.set_tuning(**dflt)
+        assert np.array_equal(a, b), (r, np.flatnonzero(a != b)[:10])
+    a = ix.map(100, 1, value_bits=8)
+    ix.set_tuning(**plain)
+    b = ix.map(100, 1, value_bits=8)
+    ix.set_tuning(**dflt)
+    assert np.array_equal(a, b), np.flatnonzero(a != b)[:10]
     ix.close()
 
 
