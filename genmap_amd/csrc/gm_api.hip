@@ -539,7 +539,7 @@ template <typename T> static int grow(T** p, uint64_t* cap, uint64_t need)
 enum LeafMode { LEAF_COUNT = 0, LEAF_FILESET = 1, LEAF_OCC_COUNT = 2, LEAF_OCC_EMIT = 3, LEAF_STORE = 4, LEAF_STORE8 = 5, LEAF_COUNT_JUMP = 6, LEAF_SCATTER = 7 };
 
 // nu = 16-byte units per stored node / queue entry: 1, or 2 with 64-bit rows (gm_kernels.h: NodeIO)
-static inline size_t search_lds_bytes(const SearchArgs& A, uint32_t nu) { return (size_t)(4u * A.vqCap * nu + 4u * 64u * (A.ldsDepth * nu + A.winChunks)) * 16u + 4u * 128u * 4u + 448u + (A.entrySlots ? 4096u : 0u) + (A.lqCap ? 4u * (A.lqCap * 16u + 80u * 4u) : 0u); }
+static inline size_t search_lds_bytes(const SearchArgs& A, uint32_t nu) { return (size_t)(4u * A.vqCap * nu + 4u * 64u * (A.ldsDepth * nu + A.winChunks)) * 16u + 4u * 80u * 4u + 448u + (A.entrySlots ? 4096u : 0u) + (A.lqCap ? 4u * (A.lqCap * 16u + 80u * 4u) : 0u); }
 
 template <int WPP, class EnvT>
 static int launch_one(const SearchArgs& A, unsigned blocks, hipStream_t st)
@@ -872,13 +872,15 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     }
     const uint32_t depth = stack_bound(p->E, plan.stepSize) + STEAL_LEVELS;   // room for the levels work sharing may vacate at the bottom
     uint32_t verifyRows = std::min(verifyTExt, VERIFY_ROWS);   // rows of one node queued per iteration (search_body); one instead of two where that keeps a block per CU (below)
-    uint32_t vqCap = verifyT ? 64u + 64u * verifyRows : 1u;
+    // queue entries per wavefront: up to 63 left from the last iteration + one row of every lane + (two rows) 32 second rows; the rest waits (search_body)
+    auto vq_cap = [](uint32_t rows) { return rows >= 2u ? 160u : 128u; };
+    uint32_t vqCap = verifyT ? vq_cap(verifyRows) : 1u;
     const uint32_t winChunks = (31u + p->K + plan.stepSize - 1u + 31u) / 32u;
     const uint32_t nu = ix->wide ? 2u : 1u;
     const int wantPerCU = std::max(1, ix->tune.blocksPerCU);   // default 4 = 4 waves/SIMD, what the kernel's VGPR count allows
     // (calls that may jump keep their table entries in flight in LDS: one 16-byte slot per lane)
     const bool mayJump = wantJump && p->E >= 1 && (ix->d_sa || ix->d_saMark) && ix->tune.jump != 0 && !ix->wide;
-    auto lds_bytes_for = [&](uint32_t d) { return (size_t)(4u * vqCap * nu + 4u * 64u * (d * nu + winChunks)) * 16u + 4u * 128u * 4u + 448u + (mayJump ? 4096u : 0u) + (lqCap ? 4u * (lqCap * 16u + 80u * 4u) : 0u); };   // == search_lds_bytes
+    auto lds_bytes_for = [&](uint32_t d) { return (size_t)(4u * vqCap * nu + 4u * 64u * (d * nu + winChunks)) * 16u + 4u * 80u * 4u + 448u + (mayJump ? 4096u : 0u) + (lqCap ? 4u * (lqCap * 16u + 80u * 4u) : 0u); };   // == search_lds_bytes
     auto blocks_for = [&](uint32_t d, int* nb) {
         switch (ix->wpp) { case 1: return occupancy_blocks<1>(nb, lds_bytes_for(d)); case 2: return occupancy_blocks<2>(nb, lds_bytes_for(d)); case 3: return occupancy_blocks<3>(nb, lds_bytes_for(d)); default: return occupancy_blocks<9>(nb, lds_bytes_for(d)); }
     };
@@ -889,8 +891,8 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     if (verifyRows > 1u && ix->tune.ldsStack < 0) {   // long windows (K >= ~64): a smaller verification queue where it buys the fourth block per CU (K=100 e=1: 220 -> 200 ms)
         int nb2 = 0, nb1 = 0;
         rc = blocks_for(1u, &nb2); if (rc) return rc;
-        vqCap = 64u + 64u; rc = blocks_for(1u, &nb1); if (rc) return rc;
-        if (std::min(nb1, wantPerCU) > std::min(nb2, wantPerCU)) verifyRows = 1u; else vqCap = 64u + 64u * verifyRows;
+        vqCap = vq_cap(1u); rc = blocks_for(1u, &nb1); if (rc) return rc;
+        if (std::min(nb1, wantPerCU) > std::min(nb2, wantPerCU)) verifyRows = 1u; else vqCap = vq_cap(verifyRows);
     }
     if (ix->tune.ldsStack >= 0) {
         ldsDepth = std::min((uint32_t)ix->tune.ldsStack / nu, depth);   // the same LDS for the stack tops of wide nodes

@@ -907,10 +907,10 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     env.lwin = reinterpret_cast<const uint8_t*>(wbase + lane);
     // work sharing inside the wavefront: a lane may work on the root of another lane (stolen stack entries); it then reads
     // that lane's needle window (wlane) and the owner may not stage a new window while users[owner] != 0
-    uint32_t* const users = reinterpret_cast<uint32_t*>(smem + 4u * A.vqCap * NU + 4u * 64u * (A.ldsDepth * NU + A.winChunks)) + wv * 128u;   // [64] users | [64] pairing
-    uint32_t* const pairing = users + 64;
+    uint32_t* const users = reinterpret_cast<uint32_t*>(smem + 4u * A.vqCap * NU + 4u * 64u * (A.ldsDepth * NU + A.winChunks)) + wv * 80u;   // [64] users (words) | [64] pairing (bytes): 320 B per wavefront
+    uint8_t* const pairing = reinterpret_cast<uint8_t*>(users + 64);
     // the searches' jump records (Env::JUMPS), 8 x 16 bytes (+ 64 bytes of group masks + 8 x 16 bytes of group counts + 8 x 16 bytes of OSS records) per block behind the work-sharing bookkeeping
-    uint4* const jl = smem + 4u * A.vqCap * NU + 4u * 64u * (A.ldsDepth * NU + A.winChunks) + (4u * 128u * 4u) / 16u;
+    uint4* const jl = smem + 4u * A.vqCap * NU + 4u * 64u * (A.ldsDepth * NU + A.winChunks) + (4u * 80u * 4u) / 16u;
     if (threadIdx.x < 8u) jl[20u + threadIdx.x] = A.table[(size_t)(A.stepSize - 1u) * 8u + threadIdx.x];   // OSS records of the regular block shape (stage 2)
     if constexpr (!EnvT::JUMPS) __syncthreads();
     if constexpr (EnvT::JUMPS) {
@@ -1011,7 +1011,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                 const uint32_t ri = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
                 const uint32_t rv = __builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0u));
                 const bool robbed = rich && rv < np, thief = idle && ri < np;
-                if (robbed) pairing[rv] = lane;
+                if (robbed) pairing[rv] = (uint8_t)lane;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1247,11 +1247,16 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
             }
             // At most VERIFY_ROWS rows of a node are queued per iteration (SearchArgs::verifyRows; the queue holds 64 + 64 * verifyRows entries); the rows left
             // over go back onto the lane's stack as a rows-only node (rlo = all ones: never stepped, queued the moment it is popped).
+            // (the queue holds 64 + 96 entries with two rows per lane: a second row that would not fit -- more than 96 - qsize lanes with a
+            //  second row to queue -- waits on the stacks like the rows beyond the second; 2 KB of LDS per block are a stack level at K = 30)
+            uint32_t rowsDone = 0;   // wave-uniform
 #pragma unroll 1
             for (uint32_t r = 0; r < A.verifyRows; ++r) {
                 const bool e = narrow && r < nd.w;
                 const unsigned long long m = __ballot(e);
                 if (m == 0ull) break;
+                if (qsize + (uint32_t)__popcll(m) > A.vqCap) break;
+                rowsDone = r + 1u;
                 env.note_wave(6);
                 if (e) {
                     const uint32_t slot = qsize + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -1261,7 +1266,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
             }
             if (narrow) {
                 have = false;
-                if (nd.w > A.verifyRows) { nd.flo += A.verifyRows; nd.w -= A.verifyRows; nd.rlo = ~(row_t)0; env.push(nd); }
+                if (nd.w > rowsDone) { nd.flo += rowsDone; nd.w -= rowsDone; nd.rlo = ~(row_t)0; env.push(nd); }
             }
             // a partial round only when the wavefront has nothing else left to do
             const bool finishing = (__ballot(have || fs != 0u || env.sp != 0u) == 0ull) && (__ballot(!exhausted) == 0ull);
