@@ -218,8 +218,14 @@ def push_pieces(device, dst, src, first_byte, pitch_bytes, piece_bytes, n_rows, 
 
 
 class _OwnedArray(np.ndarray):
-    """ndarray view of memory owned by the library; `_owner` (carried by views of views through .base) frees it"""
+    """Read-only ndarray view of memory owned by the library.  `_owner` frees that memory when the last view is collected; it is
+    handed on explicitly to every view / slice / reshape (__array_finalize__), not left to the .base chain.  Whoever keeps a small part
+    of a large result for long should .copy() it: a view keeps the whole result alive; pickling or sending to another process copies."""
     _owner = None
+
+    def __array_finalize__(self, obj):
+        if obj is not None:
+            self._owner = getattr(obj, "_owner", None)
 
 
 class _LocationsOwner:
@@ -405,6 +411,7 @@ class Index:
                 return np.zeros(0, np.uint64)      # empty windows / shards carry NULL payload pointers
             a = np.ctypeslib.as_array(ptr, shape=(count,)).view(_OwnedArray)
             a._owner = owner
+            a.flags.writeable = False      # the library's memory: results are not scratch space
             return a
         po, mo = view(c.plus_off, n + 1), view(c.minus_off, n + 1)
         return int(c.pos_begin), po, view(c.plus, int(po[-1])), mo, view(c.minus, int(mo[-1]))

@@ -357,6 +357,9 @@ void gm_index_free(gm_index* ix)
     hipFree(ix->d_shardOut); hipFree(ix->d_patterns); hipFree(ix->d_jinfo); hipFree(ix->d_cblocks);
     if (ix->h_stage) hipHostFree(ix->h_stage);
     for (auto& e : ix->evStage) if (e) hipEventDestroy(e);
+    if (ix->stCorr) hipStreamDestroy(ix->stCorr);
+    if (ix->evCorrGo) hipEventDestroy(ix->evCorrGo);
+    if (ix->evCorrDone) hipEventDestroy(ix->evCorrDone);
     if (ix->stCompute) hipStreamDestroy(ix->stCompute);
     if (ix->stCopy) hipStreamDestroy(ix->stCopy);
     for (auto& e : ix->evShard) if (e) hipEventDestroy(e);
@@ -913,7 +916,8 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     const uint64_t useful = (S->numRoots + 255) / 256;
     if (blocks > useful) blocks = std::max<uint64_t>(useful, 1);
     S->blocks = (unsigned)blocks;
-    rc = grow(&ix->d_stack, &ix->stackCap, blocks * 256ull * std::max<uint32_t>(depth - ldsDepth, 1u) * nu); if (rc) return rc;
+    // (twice: the correction pass of an N-less call runs beside the main search with the same geometry and at most as many blocks: the upper half is its)
+    rc = grow(&ix->d_stack, &ix->stackCap, 2ull * blocks * 256ull * std::max<uint32_t>(depth - ldsDepth, 1u) * nu); if (rc) return rc;
 
     // ---- jump patterns (frequency calls with errors on an index that can locate): one J for every search ----
     std::vector<uint32_t> patHost; std::vector<uint4> jinfoHost; uint32_t jumpJ = 0, jumpAPacked[2] = {0, 0};
@@ -1050,12 +1054,23 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     A.text4 = ix->d_text4; A.textBegin = text_begin; A.vqCap = vqCap; A.verifyRows = verifyRows ? verifyRows : 1u; A.ldsDepth = ldsDepth; A.winChunks = winChunks; A.lqCap = lqCap;
     A.workCounter = reinterpret_cast<unsigned long long*>(ix->d_small);
     A.errorFlag = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ix->d_small) + SMALL_ERR_OFF);
+    // (a wavefront without a node for seconds on end is spinning: a root has a few hundred patterns at most.  iter_cap bounds ALL iterations: tests)
+    if (ix->tune.iterCap > 0) { A.guardCap = (uint32_t)ix->tune.iterCap; A.guardKeep = 0xFFFFFFFFu; }
+    else { A.guardCap = ix->tune.stallCap > 0 ? (uint32_t)ix->tune.stallCap : (1u << 22); A.guardKeep = 0u; }
     A.counters = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ix->d_small) + 16);
     A.sa = ix->d_sa; A.saMark = ix->d_saMark; A.saSamples = ix->d_saSamples; A.cumGlobal = ix->d_cum; A.nSeqGlobal = ix->nSeq;
     A.posBase = S->posBase; A.windowLen = S->posEnd - S->posBase;
     A.textS = ix->d_textS;
     A.ctx = ix->tune.useCtx ? ix->d_ctx : nullptr;
     A.verifyT = verifyT;
+    {   // fast verification (gm_engine.h: fv_masks): every text symbol an item may look at must lie inside its row's record, i.e. K <= 32
+        // symbols to the right of the anchor and at most CTX_LEFT to its left -- the anchor is the node's window coordinate `a`, which never
+        // exceeds the start of its search (n - 1 + startPos, any block shape of the call) -- and the window must fit the masks
+        uint32_t maxA0 = 0;
+        for (uint32_t n = 1; n <= plan.stepSize; ++n)
+            for (uint32_t s = 0; s < plan.nSearches; ++s) maxA0 = std::max(maxA0, n - 1u + oss_start(plan.table[(size_t)(n - 1) * 8 + s]));
+        A.fastVerify = (verifyT && A.ctx && !ix->wide && ix->tune.fastVerify != 0 && p->K <= 32u && p->K + plan.stepSize - 1u <= FV_MAXW && maxA0 <= (uint32_t)CTX_LEFT) ? 1u : 0u;
+    }
     A.verifyTExt = verifyTExt;   // (== verifyT at e = 0: the plain stores rely on one row per k-mer and strand)
     A.satMinW = (uint32_t)std::max(1, ix->tune.satMinW);   // default 256: narrow nodes finish sooner than the lookup takes (r01h sweep: 128-256 best)
     // profiles/r01e_infix_sweeps.txt (r01h): 16 / 8 / 4 on the 249 Mbp index; beyond 2^30 rows the fetch loads are HBM
@@ -1109,8 +1124,12 @@ static int launch_reset_limits(gm_index* ix, TValue* d_out, uint32_t n_seq, uint
 
 // wrote (optional): the slice positions [wrote[0], wrote[1]) this call has written into d_out (everything else is untouched,
 // except for the zeros of resetLimits at the sequence ends)
+// whole (optional): the k-mer range [whole[0], whole[1]) of the CALL this launch is one piece of (gm_map_shard delivers a share in up to four
+// launches so that the copy of one piece overlaps the search of the next).  The first piece (ix->pieceIndex == 0) then clears the
+// accumulators of the whole range and starts the call's ONE correction pass; the later pieces do neither.
 static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t first_seq, uint32_t n_seq, const gm_map_params* p,
-                    const uint64_t* intervals, uint64_t n_intervals, const uint32_t* seq_file_id, void* d_out, hipStream_t st, uint64_t* wrote = nullptr)
+                    const uint64_t* intervals, uint64_t n_intervals, const uint32_t* seq_file_id, void* d_out, hipStream_t st, uint64_t* wrote = nullptr,
+                    const uint64_t* whole = nullptr)
 {
     if (!d_out) { set_error("null output"); return GM_ERR_BAD_ARG; }
     SearchSetup S; SearchArgs A;
@@ -1150,7 +1169,9 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
     const bool store = !ep && p->E == 0 && A.verifyT <= 1 && !ix->tune.noStore;
     const uint64_t plane = (text_len + 4 + 15) & ~15ull;   // both planes aligned alike: finalize2 reads 16 bytes per lane
     // counting kernels on the regular partition: verified runs of k-mers go into a difference plane behind acc (gm_kernels.h: CountEnv::leaf_range)
-    const bool useDiff = !ep && !store && !S.plan.useList && ix->tune.rangeAdd != 0;
+    // (finalize_diff_kernel restarts its running sum at every multiple of stepSize from the range's first position and CountEnv::leaf_range
+    //  never lets a run leave its block: both hold because ranges and chunks are whole blocks of the regular partition -- checked, not assumed)
+    const bool useDiff = !ep && !store && !S.plan.useList && ix->tune.rangeAdd != 0 && S.posBase % S.plan.stepSize == 0 && S.sel.len % S.plan.stepSize == 0;
     const uint64_t diffOff = (text_len + 4 + 3) & ~3ull;
     // kernels over positions: blockIdx.y walks the shard's own chunk ranges (one range without chunks), blockIdx.x one range
     auto range_grid = [](const ChunkSel& c, uint64_t n, uint32_t perThread) {
@@ -1168,54 +1189,80 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
     if (wrote) { wrote[0] = r0; wrote[1] = r1; }
     if (ix->pieceIndex == 0) GM_HIP(hipEventRecord(ix->ev[0], st));
     const ChunkSel sel = S.sel;   // positions are relative to r0 == posBase (a multiple of the block length)
-    if (rn > 0) {
-        if (ep) GM_HIP(hipMemsetAsync(ix->d_bits + r0 * wordsPerKmer, 0, rn * wordsPerKmer * sizeof(uint32_t), st));
+    // the positions of the whole CALL, [c0, c1): what the first piece clears and what the call's one correction pass owns
+    const bool firstPiece = ix->pieceIndex == 0;
+    uint64_t c0 = r0, c1 = r1;
+    if (whole) {   // (regular partition: a selection is never delivered in pieces; pieces begin at multiples of the chunk row from whole[0])
+        const uint64_t step = S.plan.stepSize;
+        const uint64_t bb = std::min<uint64_t>((whole[0] + step - 1) / step, S.plan.numBlocks), be = std::min<uint64_t>((whole[1] + step - 1) / step, S.plan.numBlocks);
+        c0 = std::min<uint64_t>(bb * step, text_len);
+        c1 = std::min<uint64_t>(std::max<uint64_t>(std::min<uint64_t>(be * step, S.plan.numKmers), c0), text_len);
+        if (S.plan.useList || (rn > 0 && (r0 < c0 || r1 > c1))) { set_error("internal: a piece outside its call"); return GM_ERR_INTERNAL; }
+    }
+    const uint64_t cn = c1 - c0;
+    if (cn > 0 && (!whole || firstPiece)) {
+        if (ep) GM_HIP(hipMemsetAsync(ix->d_bits + c0 * wordsPerKmer, 0, cn * wordsPerKmer * sizeof(uint32_t), st));
         else if (store) {
             const size_t pb = p->value_bits == 8 ? 1 : 2;   // plane element: as wide as the result
             if (sel.len) {
-                hipLaunchKernelGGL(clear_chunks_kernel, range_grid(sel, rn, 16), dim3(256), 0, st, (uint8_t*)ix->d_acc + r0 * pb, (uint32_t)pb, rn, sel);
-                hipLaunchKernelGGL(clear_chunks_kernel, range_grid(sel, rn, 16), dim3(256), 0, st, (uint8_t*)ix->d_acc + (plane + r0) * pb, (uint32_t)pb, rn, sel);
+                hipLaunchKernelGGL(clear_chunks_kernel, range_grid(sel, cn, 16), dim3(256), 0, st, (uint8_t*)ix->d_acc + c0 * pb, (uint32_t)pb, cn, sel);
+                hipLaunchKernelGGL(clear_chunks_kernel, range_grid(sel, cn, 16), dim3(256), 0, st, (uint8_t*)ix->d_acc + (plane + c0) * pb, (uint32_t)pb, cn, sel);
             } else {
-                GM_HIP(hipMemsetAsync((uint8_t*)ix->d_acc + r0 * pb, 0, rn * pb, st));
-                GM_HIP(hipMemsetAsync((uint8_t*)ix->d_acc + (plane + r0) * pb, 0, rn * pb, st));
+                GM_HIP(hipMemsetAsync((uint8_t*)ix->d_acc + c0 * pb, 0, cn * pb, st));
+                GM_HIP(hipMemsetAsync((uint8_t*)ix->d_acc + (plane + c0) * pb, 0, cn * pb, st));
             }
         } else if (sel.len) {
-            hipLaunchKernelGGL(clear_chunks_kernel, range_grid(sel, rn, 4), dim3(256), 0, st, (uint8_t*)(ix->d_acc + r0), 4u, rn, sel);
-            if (useDiff) hipLaunchKernelGGL(clear_chunks_kernel, range_grid(sel, rn, 4), dim3(256), 0, st, (uint8_t*)(ix->d_acc + diffOff + r0), 4u, rn, sel);
+            hipLaunchKernelGGL(clear_chunks_kernel, range_grid(sel, cn, 4), dim3(256), 0, st, (uint8_t*)(ix->d_acc + c0), 4u, cn, sel);
+            if (useDiff) hipLaunchKernelGGL(clear_chunks_kernel, range_grid(sel, cn, 4), dim3(256), 0, st, (uint8_t*)(ix->d_acc + diffOff + c0), 4u, cn, sel);
         } else {
-            GM_HIP(hipMemsetAsync(ix->d_acc + r0, 0, rn * sizeof(uint32_t), st));
-            if (useDiff) GM_HIP(hipMemsetAsync(ix->d_acc + diffOff + r0, 0, rn * sizeof(uint32_t), st));
+            GM_HIP(hipMemsetAsync(ix->d_acc + c0, 0, cn * sizeof(uint32_t), st));
+            if (useDiff) GM_HIP(hipMemsetAsync(ix->d_acc + diffOff + c0, 0, cn * sizeof(uint32_t), st));
         }
     }
-    GM_HIP(hipMemsetAsync(ix->d_small, 0, ix->pieceIndex == 0 ? SMALL_ZEROED : 16, st));   // later pieces of one call keep adding to the statistics
+    // [0, 8) work counter of the main search, [8, 16) of the correction pass (which may still run beside a later piece), [16, 512) statistics
+    GM_HIP(hipMemsetAsync(ix->d_small, 0, firstPiece ? SMALL_ZEROED : 8, st));   // later pieces of one call keep adding to the statistics
     A.acc = ix->d_acc; A.accPlane = plane; A.fileBits = ix->d_bits;
     A.diff = useDiff ? ix->d_acc + diffOff : nullptr;
     // self hits of the counting kernels pay only with the difference plane (one atomic per block instead of one per k-mer)
     if (!store && !useDiff) A.selfHit = 0u;
     A.maxVal = ix->tune.noSaturate ? 0xFFFFFFFFu : (p->value_bits == 8 ? 255u : 65535u); A.wordsPerKmer = wordsPerKmer; A.seqFile = ix->d_seqFile; A.rowFile = (ep && ix->rowFileValid) ? ix->d_rowFile : nullptr;
 
-    const uint32_t slot = (uint32_t)(ix->evCount % gm_index::EV_RING);
-    GM_HIP(hipEventRecord(ix->evRing[slot][0], st));
-    if (S.numRoots > 0) { rc = launch_search(ix, ep ? LEAF_FILESET : store ? (p->value_bits == 8 ? LEAF_STORE8 : LEAF_STORE) : S.jump ? LEAF_COUNT_JUMP : LEAF_COUNT, A, S.blocks, st); if (rc) return rc; }
-    if (S.jump && ix->nCBlocks > 0 && rn > 0 && !(S.plan.useList && S.plan.blocks.empty())) {
-        // correction pass: the text windows that hold N, from the whole index, searched with the full rules; every occurrence
-        // inside this call's positions adds one at its own position (ScatterEnv)
+    if (S.jump && ix->nCBlocks > 0 && cn > 0 && !(S.plan.useList && S.plan.blocks.empty()) && (!whole || firstPiece)) {
+        // Correction pass: the text windows that hold N, from the whole index, searched with the full rules; every occurrence inside
+        // this CALL's positions adds one at its own position (ScatterEnv).  ONE launch per call, on a stream of its own and in front of
+        // the main search: it is a few thousand roots whose cost is the latency of their dependent steps (3.09 Gbp: 2.4 ms at K=100
+        // e=1, 12-19 ms at e=2), so it runs in a corner of the device while the main search fills the rest.  Round 4 ran it behind
+        // every launch of a share -- four times per gm_map_shard call: a fixed cost per rank that did not shrink with the number of ranks.
+        // Order does not matter for the result: both kernels only ever add to acc (gm_kernels.h: the invariant next to ScatterEnv::leaf).
+        if (!ix->stCorr) {
+            GM_HIP(hipStreamCreateWithFlags(&ix->stCorr, hipStreamNonBlocking));
+            GM_HIP(hipEventCreateWithFlags(&ix->evCorrGo, hipEventDisableTiming));
+            GM_HIP(hipEventCreateWithFlags(&ix->evCorrDone, hipEventDisableTiming));
+        }
         SearchArgs C = A;
         C.text = ix->d_text; C.textBegin = 0; C.numKmers = ix->textLen >= p->K ? ix->textLen - p->K + 1 : 0;
         C.blockList = ix->d_cblocks; C.blockBegin = 0; C.numRoots = ix->nCBlocks * C.rootsPerBlock; C.chunkBlocks = 0;
-        C.ownBegin = r0; C.ownEnd = r1; C.ownChunkLen = sel.len;
+        C.ownBegin = c0; C.ownEnd = c1; C.ownChunkLen = sel.len;
         C.selBlocks = S.plan.useList ? ix->d_blocks : nullptr; C.nSelBlocks = (uint32_t)S.plan.blocks.size();
         C.steal = C.numRoots < 64ull * 4ull * 1024ull ? 1u : C.steal;
         C.lqCap = 128u;   // leaves are located by the whole wavefront (gm_kernels.h: LeafQueueEnv)
         C.entrySlots = 0u;
-        GM_HIP(hipMemsetAsync(ix->d_small, 0, 16, st));   // the work counter; statistics keep adding up
-        GM_HIP(hipEventRecord(ix->ev[1], st));
+        C.workCounter = reinterpret_cast<unsigned long long*>(ix->d_small) + 1;   // its own counter: the two kernels run side by side
+        C.stack = ix->d_stack + ix->stackCap / 2;                                  // ... and its own half of the spill area (prepare_search)
         const uint64_t useful = (C.numRoots + 255) / 256;
         const unsigned cb = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ix->numCU * std::max(1, std::min(ix->tune.blocksPerCU, 4)), useful));
-        rc = launch_search(ix, LEAF_SCATTER, C, std::min(cb, std::max(1u, S.blocks)), st); if (rc) return rc;
-        GM_HIP(hipEventRecord(ix->ev[2], st));
-        ix->corrTimed = true;
-    } else ix->corrTimed = false;
+        GM_HIP(hipEventRecord(ix->evCorrGo, st));           // accumulators cleared, counters zeroed
+        GM_HIP(hipStreamWaitEvent(ix->stCorr, ix->evCorrGo, 0));
+        GM_HIP(hipEventRecord(ix->ev[1], ix->stCorr));
+        rc = launch_search(ix, LEAF_SCATTER, C, std::min(cb, std::max(1u, S.blocks)), ix->stCorr); if (rc) return rc;
+        GM_HIP(hipEventRecord(ix->ev[2], ix->stCorr));
+        GM_HIP(hipEventRecord(ix->evCorrDone, ix->stCorr));
+        ix->corrTimed = true; ix->corrPending = true;
+    } else if (!whole || firstPiece) ix->corrTimed = false;
+    const uint32_t slot = (uint32_t)(ix->evCount % gm_index::EV_RING);
+    GM_HIP(hipEventRecord(ix->evRing[slot][0], st));
+    if (S.numRoots > 0) { rc = launch_search(ix, ep ? LEAF_FILESET : store ? (p->value_bits == 8 ? LEAF_STORE8 : LEAF_STORE) : S.jump ? LEAF_COUNT_JUMP : LEAF_COUNT, A, S.blocks, st); if (rc) return rc; }
+    if (ix->corrPending) { GM_HIP(hipStreamWaitEvent(st, ix->evCorrDone, 0)); ix->corrPending = false; }   // finalize reads what the correction pass added
     GM_HIP(hipEventRecord(ix->evRing[slot][1], st));
     ix->evCount++;
     if (text_len > 0) {
@@ -1333,7 +1380,8 @@ static int check_device_error(gm_index* ix)
     GM_HIP(hipMemcpy(&flag, reinterpret_cast<char*>(ix->d_small) + SMALL_ERR_OFF, 4, hipMemcpyDeviceToHost));   // synchronises with the device
     if (flag) {
         GM_HIP(hipMemset(reinterpret_cast<char*>(ix->d_small) + SMALL_ERR_OFF, 0, 4));
-        set_error("device-side invariant violated (lane stack overflow) in this or an earlier call on the index");
+        set_error("device-side invariant violated in this or an earlier call on the index:%s%s", (flag & 1u) ? " lane stack overflow" : "",
+                  (flag & 2u) ? " a wavefront of the search kernel ran past its iteration bound (iter_cap / stall_cap) and gave up" : "");
         return GM_ERR_INTERNAL;
     }
     return GM_OK;
@@ -1517,7 +1565,8 @@ int gm_map_shard(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t 
                 if (pe <= pb) continue;
             }
             uint64_t wrote[2] = {0, 0};
-            int rc = map_impl(ix, text_begin, text_len, first_seq, n_seq, &q, intervals, n_intervals, seq_file_id, d_out, ix->stCompute, wrote);
+            const uint64_t whole[2] = {b, std::min<uint64_t>(e, ke)};   // (S > 1: the pieces of ONE call -- one clear, one correction pass)
+            int rc = map_impl(ix, text_begin, text_len, first_seq, n_seq, &q, intervals, n_intervals, seq_file_id, d_out, ix->stCompute, wrote, S > 1 ? whole : nullptr);
             ix->pieceIndex += 1;
             if (rc) { ix->pieceIndex = 0; return rc; }
             // A selection's blocks begin at interval starts, not at multiples of the block length: the share delivers exactly the
@@ -1553,7 +1602,8 @@ int gm_map_shard(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t 
         gm_map_params q = *p;
         q.flags |= GM_MAP_FLAG_RANGE;
         q.kmer_begin = base + r0 * rowLen; q.kmer_end = std::min<uint64_t>(base + r1 * rowLen, ke);   // rows start at multiples of the row length: chunk numbers keep their residue
-        int rc = map_impl(ix, text_begin, text_len, first_seq, n_seq, &q, nullptr, 0, seq_file_id, d_out, ix->stCompute);
+        const uint64_t whole[2] = {base, ke};
+        int rc = map_impl(ix, text_begin, text_len, first_seq, n_seq, &q, nullptr, 0, seq_file_id, d_out, ix->stCompute, nullptr, S > 1 ? whole : nullptr);
         ix->pieceIndex += 1;
         if (rc) { ix->pieceIndex = 0; return rc; }
         GM_HIP(hipEventRecord(ix->evShard[s], ix->stCompute));
@@ -1678,6 +1728,8 @@ int gm_index_set_tuning(gm_index* ix, const char* name, int64_t value)
         {"child_tables", &ix->tune.childTables, dflt.childTables, 0, 1}, {"oss_weights", &ix->tune.ossWeights, dflt.ossWeights, 0, 0xFFFFFF},   // (-1: 5,4,7,8 at e = 2, the even split elsewhere)
         {"jump", &ix->tune.jump, dflt.jump, 0, 16}, {"self_hit", &ix->tune.selfHit, dflt.selfHit, 0, 1}, {"jump_filter", &ix->tune.jumpFilter, dflt.jumpFilter, 0, 2},
         {"range_add", &ix->tune.rangeAdd, dflt.rangeAdd, 0, 1}, {"verify_t_ext", &ix->tune.verifyTExt, dflt.verifyTExt, 0, (int64_t)VERIFY_TMAX},
+        {"fast_verify", &ix->tune.fastVerify, dflt.fastVerify, 0, 1},
+        {"iter_cap", &ix->tune.iterCap, dflt.iterCap, 1, 0x7FFFFFFF}, {"stall_cap", &ix->tune.stallCap, dflt.stallCap, 1, 0x7FFFFFFF},   // bounds of a hung search loop (tests force them)
         {"jump_groups", &ix->tune.jumpGroups, dflt.jumpGroups, 0, 1},   // groups of jump patterns behind the existence bitmap: 0 never, 1 wherever possible, -1 where they save table reads
     };
     for (auto& t : tab) if (!strcmp(t.n, name)) {

@@ -306,6 +306,112 @@ GM_HD uint32_t scan_side(Env& env, const RootT<typename Env::row_t>& rt, const t
     return need;
 }
 
+// ---- fast verification: short windows compared in one go ---------------------------------------------------------------------
+// The scans above fetch needle and text eight symbols at a time, every fetch a dependent memory request: a verification round of 64
+// items lasts as long as its longest chain of them (record, then up to five needle reads at K = 30), with the whole wavefront waiting.
+// For windows of at most FV_MAXW symbols whose every needed text symbol lies inside the row's 56-symbol record (the host checks:
+// K <= 32 and every window coordinate a node can be verified at is <= CTX_LEFT), all reads of an item are issued at once -- the record
+// and two or three 16-byte chunks of the 4-bit text that hold the needle window -- and the comparison of the WHOLE window with the text
+// around the location becomes two 64-bit masks over window coordinates: `mm` (this position is an event: mismatch, needle N, or stop)
+// and `st` (the occurrence ends here: sentinel; a text N too in N-less passes).  The replay of the OSS blocks and the run logic of
+// verify_with stay what they are: scan_side has an overload that reads the masks instead of memory.
+constexpr uint32_t FV_MAXW = 48;
+constexpr int32_t CTX_LEFT = 24, CTX_SYMS = 56;   // the record of a suffix-array row holds textS[p0 - CTX_LEFT .. p0 - CTX_LEFT + 55], 4 bits per symbol (gm_kernels.h)
+template <typename R> struct MaskItemT { R p0; uint64_t mm, st; };
+
+GM_HD uint64_t bitrev64(uint64_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brevll(x);
+#else
+    x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    return __builtin_bswap64(x);
+#endif
+}
+GM_HD uint64_t nib_reverse16(uint64_t x)   // the 16 nibbles of x in reverse order
+{
+    x = __builtin_bswap64(x);
+    return ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+}
+GM_HD uint64_t nib_complement(uint64_t x)  // A<->T, C<->G, N stays N, per nibble (codes 0..4)
+{
+    const uint64_t n4 = x & 0x4444444444444444ull;
+    return (x ^ 0x3333333333333333ull) ^ ((n4 >> 1) | (n4 >> 2));
+}
+GM_HD uint64_t nib_flags_to_bits(uint64_t f)   // flags at bit 0 of each of the 16 nibbles -> bits 0..15
+{
+    uint64_t t = (f | (f >> 3)) & 0x0303030303030303ull;
+    t = (t | (t >> 6)) & 0x000F000F000F000Full;
+    t = (t | (t >> 12)) & 0x000000FF000000FFull;
+    return (t | (t >> 24)) & 0xFFFFull;
+}
+// 16 symbols starting `sh` nibbles (0..15) into the 32-nibble string hi:lo
+GM_HD uint64_t nib_funnel(uint64_t lo, uint64_t hi, uint32_t sh) { return sh ? (lo >> (4u * sh)) | (hi << (64u - 4u * sh)) : lo; }
+
+// c[0..11]: three 16-byte chunks of the 4-bit text, the first one holding the window's first symbol at nibble `woff` (0..31); W <= FV_MAXW
+// symbols; strand 1: the needle is the window read backwards and complemented.  r[0..6]: the row's record; a0 <= CTX_LEFT: the window
+// coordinate that the record's anchor p0 is aligned with.  NLESS: a text N ends the occurrence like a sentinel.
+template <bool NLESS>
+GM_HD void fv_masks(const uint32_t c[12], uint32_t woff, uint32_t W, uint32_t strand, const uint32_t r[7], uint32_t a0, uint64_t& mm, uint64_t& st)
+{
+    uint64_t s0 = (uint64_t)c[1] << 32 | c[0], s1 = (uint64_t)c[3] << 32 | c[2], s2 = (uint64_t)c[5] << 32 | c[4], s3 = (uint64_t)c[7] << 32 | c[6],
+             s4 = (uint64_t)c[9] << 32 | c[8], s5 = (uint64_t)c[11] << 32 | c[10];
+    if (woff & 16u) { s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = s5; }
+    const uint32_t wr = woff & 15u;
+    uint64_t q0 = nib_funnel(s0, s1, wr), q1 = nib_funnel(s1, s2, wr), q2 = nib_funnel(s2, s3, wr);   // window symbols 0..15, 16..31, 32..47
+    if (strand) {
+        // needle(pos) = complement(window(W - 1 - pos)): the 48-symbol string reversed, moved down by 48 - W symbols, complemented
+        uint64_t v0 = nib_reverse16(q2), v1 = nib_reverse16(q1), v2 = nib_reverse16(q0), v3 = 0ull;
+        const uint32_t d = FV_MAXW - W;
+        if (d & 32u) { v0 = v2; v1 = 0ull; v2 = 0ull; } else if (d & 16u) { v0 = v1; v1 = v2; v2 = 0ull; }
+        const uint32_t dr = d & 15u;
+        q0 = nib_complement(nib_funnel(v0, v1, dr)); q1 = nib_complement(nib_funnel(v1, v2, dr)); q2 = nib_complement(nib_funnel(v2, v3, dr));
+    }
+    // the text at window coordinates: window(i) <-> record symbol i + CTX_LEFT - a0; behind the record: sentinels (never looked at)
+    uint64_t t0 = (uint64_t)r[1] << 32 | r[0], t1 = (uint64_t)r[3] << 32 | r[2], t2 = (uint64_t)r[5] << 32 | r[4], t3 = 0x5555555500000000ull | r[6], t4 = 0x5555555555555555ull;
+    const uint32_t sh = (uint32_t)CTX_LEFT - a0;
+    if (sh & 16u) { t0 = t1; t1 = t2; t2 = t3; t3 = t4; }
+    const uint32_t tr = sh & 15u;
+    const uint64_t x0 = nib_funnel(t0, t1, tr), x1 = nib_funnel(t1, t2, tr), x2 = nib_funnel(t2, t3, tr);
+    constexpr uint64_t M1 = 0x1111111111111111ull;
+    auto flags = [&](uint64_t q, uint64_t x, uint64_t& fm, uint64_t& fs) {
+        const uint64_t d = q ^ x;
+        fs = NLESS ? (x >> 2) & M1 : (x >> 2) & x & M1;                      // sentinel (5); N-less: a text N (4) too
+        fm = ((d | (d >> 1) | (d >> 2)) & M1) | ((q >> 2) & M1) | fs;       // differs, or the needle holds N (N never matches: find2:250)
+    };
+    uint64_t m0, m1, m2, e0, e1, e2;
+    flags(q0, x0, m0, e0); flags(q1, x1, m1, e1); flags(q2, x2, m2, e2);
+    mm = nib_flags_to_bits(m0) | nib_flags_to_bits(m1) << 16 | nib_flags_to_bits(m2) << 32;
+    st = (e0 | e1 | e2) ? nib_flags_to_bits(e0) | nib_flags_to_bits(e1) << 16 | nib_flags_to_bits(e2) << 32 : 0ull;   // (stops are rare)
+}
+
+// scan_side over the masks of a MaskItem: same contract, no memory.  (q0 <= 47; going down, position q0 - i is bit i of the reversed mask)
+template <class Env, typename R>
+GM_HD uint32_t scan_side(Env& env, const RootT<R>&, const MaskItemT<R>& it, uint32_t, uint32_t q0, bool down, uint32_t need, uint32_t budget,
+                         uint32_t& cnt, uint32_t pos[4])
+{
+    cnt = 0;
+    if (need == 0u) return 0u;
+    env.note_chunk(); env.note_wave(12);
+    uint64_t e = down ? bitrev64(it.mm) >> (63u - q0) : it.mm >> q0;
+    uint64_t s = down ? bitrev64(it.st) >> (63u - q0) : it.st >> q0;
+    if (need < 64u) e &= (1ull << need) - 1ull;
+#pragma unroll
+    for (uint32_t k = 0; k <= MAX_ERRORS; ++k) {
+        if (!e) break;
+        const uint32_t bit = ctz64(e);
+        e &= e - 1ull;
+        if ((s >> bit) & 1ull) return bit;          // the occurrence ends here
+        if (cnt == budget) return bit;              // one mismatch too many
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if ((uint32_t)j == cnt) pos[j] = bit + 1u;
+        ++cnt;
+    }
+    return need;
+}
+
 // k-mers s0..s1 of the root's block all hit at the verified location (p0 is aligned with needle coordinate a0).  Leaf policies that
 // only count (Env::RANGE_ADD) take the run whole: void leaf_range(const Root&, uint32_t s0, uint32_t s1); the others get one
 // leaf_at per k-mer with its text position.
@@ -335,12 +441,13 @@ GM_HD bool self_hit_kmers(uint32_t meta, const RootT<R>& rt, uint32_t K, uint32_
     return true;
 }
 
-template <class Env>
-GM_HD void verify_item(typename Env::row_t row, uint32_t meta, const RootT<typename Env::row_t>& rt, uint32_t K, uint32_t E, Env& env)
+// `it`: the candidate location -- Env::Item (symbols are fetched by the scans, eight at a time), or a MaskItem (below: the whole
+// comparison is at hand as two 64-bit masks; scan_side has an overload for either)
+template <class Env, class ItemT>
+GM_HD void verify_with(const ItemT& it, uint32_t meta, const RootT<typename Env::row_t>& rt, uint32_t K, uint32_t E, Env& env)
 {
     typedef typename Env::row_t R;
     uint32_t a = meta_a(meta), bx = meta_bx(meta), t = meta_t(meta), errs = meta_errs(meta), mode = meta_mode(meta);
-    const typename Env::Item it = env.item(row);
     const R p0 = it.p0;   // aligned with needle coordinate a0 (a changes below, keep the anchor)
     env.note_item(mode);
     const uint32_t a0 = a;
@@ -397,6 +504,13 @@ GM_HD void verify_item(typename Env::row_t row, uint32_t meta, const RootT<typen
         curLo = lo; curHi = hi;
     }
     if (curLo <= curHi) emit_kmer_run(env, rt, (uint32_t)curLo, (uint32_t)curHi, p0, a0);
+}
+
+template <class Env>
+GM_HD void verify_item(typename Env::row_t row, uint32_t meta, const RootT<typename Env::row_t>& rt, uint32_t K, uint32_t E, Env& env)
+{
+    const typename Env::Item it = env.item(row);
+    verify_with(it, meta, rt, K, E, env);
 }
 
 // upper bound of simultaneously stacked nodes of one lane (DESIGN.md "stack bound")

@@ -39,7 +39,10 @@ struct SearchArgs {
     uint32_t stackDepth;            // total entries a lane may stack (LDS part + spill part)
     uint32_t spillDepth;            // entries per lane in `stack`
     unsigned long long* workCounter;
-    uint32_t* errorFlag;
+    uint32_t* errorFlag;            // sticky: bit 0 lane stack overflow, bit 1 a wavefront ran past guardCap (a hung search ends as GM_ERR_INTERNAL)
+    uint32_t guardCap;              // a wavefront gives up when its guard counter passes this: the counter counts loop iterations and falls back to
+    uint32_t guardKeep;             // (counter & guardKeep) whenever a lane held a node or something was verified -- 0: CONSECUTIVE idle iterations are
+                                    // bounded (knob "stall_cap", default 2^22), ~0: all iterations are (knob "iter_cap": tests force the bound)
     unsigned long long* counters;   // [0] node steps, [1] distinct rank lines (only with GM_COUNTERS)
     // ---- locate path (csv, --exclude-pseudo; /root/reference/src/algo.hpp:311-387) ----
     const void* sa;                 // forward suffix array (sentinel-text positions, row_t each), sampling rate 1; nullptr when sampled
@@ -66,6 +69,8 @@ struct SearchArgs {
     uint32_t satMinW;               // saturation is looked up (a global read per covered k-mer) only for nodes at least this wide
     uint32_t probation;             // a single-row node that has spent every error is stepped this many times before it is verified
     uint32_t verifyCost;            // ... when width * verifyCost <= estimated rank steps left below the node
+    uint32_t fastVerify;            // 1: every item of a verification round is settled from ONE round of reads (record + needle window, gm_engine.h: fv_masks);
+                                    //    the host sets it when K <= 32, the window fits FV_MAXW symbols and no node can be verified right of the record's anchor range
     uint32_t nbFilter;              // != 0: one-row table entries are compared with the needle's next characters before they become nodes; 1: two-row entries too
     uint32_t selfHit;               // 1: a single error-free row on the forward strand is the window's own location -- no lookup at all
     // ---- LDS staging (per wavefront): verification queue | top of the lane stacks | packed needle windows ----
@@ -215,7 +220,7 @@ __device__ __forceinline__ void covered_kmers(uint32_t meta, uint32_t n, uint32_
 // Verification record of a suffix-array row (built once per index when HBM allows, gm_api.hip: make_ctx): word 0 = SA[row] = p0,
 // words 1..7 = the 56 symbols textS[p0 - CTX_LEFT .. p0 - CTX_LEFT + 55], 4 bits each (symbol i in bits 4(i%8) of word 1 + i/8).
 // One aligned 32-byte read replaces the dependent pair "SA entry, then text around it" (two to three random requests).
-constexpr int32_t CTX_LEFT = 24, CTX_SYMS = 56;
+// (CTX_LEFT = 24, CTX_SYMS = 56: gm_engine.h, next to the fast verification that reads whole windows from a record)
 
 constexpr uint32_t NB_SYMS = 6;       // neighbour symbols per side carried by one-row q-mer table entries (qmer_table_kernel)
 constexpr uint32_t NB_SYMS2 = 3;      // ... and per side and row by two-row entries
@@ -235,6 +240,7 @@ template <int WPP> struct EnvBase {
     static constexpr bool LEAFQ = false;        // leaves are queued per wavefront and located 64 rows at a time (LeafQueueEnv)
     static constexpr bool SELF_HIT = false;     // frequency policies: a lone error-free row on the forward strand is the window itself
     static constexpr bool RANGE_ADD = false;    // the policy takes a run of hit k-mers whole (leaf_range) instead of one leaf_at per k-mer
+    static constexpr bool LEGACY_LOOP = false;  // the loop order of round 3 (root draw in front of the verification, staged root context): StoreEnv
     typedef typename BlockGeom<WPP>::row_t row_t;
     typedef NodeT<row_t> Node;
     typedef RootT<row_t> Root;
@@ -452,7 +458,7 @@ template <int WPP> struct EnvBase {
         note_wave(15);
         if (lv < A.ldsDepth) { IO::store(lstk + (size_t)lv * IO::NU * 64u, 64u, nd); ++sp; }
         else if (lv < A.stackDepth) { IO::store(stk + (size_t)(lv - A.ldsDepth) * IO::NU * 64u, 64u, nd); ++sp; }
-        else *A.errorFlag = 1u;   // never expected: depth = stack_bound(E, stepSize) (+ STEAL_LEVELS with work sharing)
+        else atomicOr(A.errorFlag, 1u);   // never expected: depth = stack_bound(E, stepSize) (+ STEAL_LEVELS with work sharing)
     }
     __device__ __forceinline__ void drain(bool) {}
     __device__ __forceinline__ void on_root() {}
@@ -506,6 +512,23 @@ template <int WPP> struct EnvBase {
 #pragma unroll
             for (int k = 0; k < 7; ++k) it.w[k] = 0u;
         }
+        return it;
+    }
+    // fast verification (gm_engine.h): the record and the chunks of the 4-bit text that hold the needle window, requested together
+    typedef MaskItemT<row_t> MaskItem;
+    template <bool NL> __device__ __forceinline__ MaskItem mask_item(row_t row, uint32_t meta, const Root& rt) const
+    {
+        const uint64_t g = A.textBegin + rt.win;
+        const uint32_t wo = (uint32_t)(g & 31u), W = K + rt.n - 1u;
+        const uint4* src = A.text4 + (g >> 5);
+        const uint4 c0 = A.ctx[(size_t)row * 2], c1 = A.ctx[(size_t)row * 2 + 1];
+        const uint4 n0 = src[0], n1 = src[1];
+        uint4 n2 = make_uint4(0u, 0u, 0u, 0u);
+        if (wo + W > 64u) n2 = src[2];              // (the text has 20 chunks of padding behind it)
+        const uint32_t c[12] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w};
+        const uint32_t r[7] = {c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        MaskItem it; it.p0 = (row_t)c0.x;
+        fv_masks<NL>(c, wo, W, rt.strand, r, meta_a(meta), it.mm, it.st);
         return it;
     }
     // 8 consecutive symbols of the record starting at symbol index s (0 <= s <= 48), one per byte
@@ -630,6 +653,16 @@ template <int WPP, typename TPlane> struct StoreEnv : EnvBase<WPP> {
     typedef typename EnvBase<WPP>::Root Root;
     static constexpr bool EXACT_ONLY = true;    // launched for E = 0 only (gm_api.hip: `store`)
     static constexpr bool SELF_HIT = true;
+    // Round 4 reordered the loop for the kernels with jump patterns (every load of an iteration issued back to back at its end, the root
+    // context fetched in place, the OSS record from LDS in stage 2, argument words picked by selects).  The e = 0 kernel has no pattern
+    // reads to line up with and lost 3.3 % to it on one box (51.0 -> 52.7 ms, profiles/r04/final/ab_round_start_vs_commits.txt): it keeps
+    // the order of round 3 -- draw in front of the verification, a staged root context, the record read with the draw, indexed argument
+    // words (whose vector load parks the wavefront until its window has landed: profiles/r03/README_experiments.txt, item 10).
+#ifdef GM_NO_LEGACY_LOOP   // (A/B builds)
+    static constexpr bool LEGACY_LOOP = false;
+#else
+    static constexpr bool LEGACY_LOOP = WPP != 2;
+#endif   // (the wide e = 0 kernels sit at the 128-VGPR cap: the staged context would spill)
     static constexpr uint32_t CAP = sizeof(TPlane) == 1 ? 0xFFu : 0xFFFFu;   // min(MAX, f + r) == min(MAX, min(MAX, f) + min(MAX, r))
     __device__ __forceinline__ StoreEnv(const SearchArgs& a, uint4* s, uint32_t k) : EnvBase<WPP>(a, s, k) {}
     __device__ __forceinline__ void leaf(const Root& rt, uint32_t kmer, row_t, row_t w)
@@ -948,7 +981,8 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     // The root a lane fetches IS its next root: a lane draws only when it has no node, no stack and no fetch in flight, nobody takes work
     // from such a lane (work sharing robs lanes that hold a node) and it cannot become a thief while its fetch is in flight -- so the
     // fetch writes the root context in place (8 VGPRs less than a staged copy).
-    Root& frt = rt;
+    Root frtOwn; frtOwn.win = 0; frtOwn.n = 1; frtOwn.strand = 0; frtOwn.search = 0; frtOwn.rec = OssRecord{0, 0, 0, 0};   // (LEGACY_LOOP: a staged copy)
+    Root& frt = *(EnvT::LEGACY_LOOP ? &frtOwn : &rt);
     row_t ftFlo = 0, ftRlo = 0, ftW = 0;
     const uint4* fsrc = A.text4;
     // jump patterns of the lane's current root (Env::JUMPS): 2-bit packed J-mer of the needle, cursor | end << 16 into A.patterns,
@@ -978,6 +1012,10 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     //  which is then waited for behind the pattern reads issued in front of the root draw)
     uint32_t jap0 = A.jumpAPacked[0], jap1 = A.jumpAPacked[1];
     asm volatile("" : "+s"(jap0), "+s"(jap1));
+    // bound of a hung loop (wave-uniform, scalar): consecutive iterations without a node or a verification round (tests: all iterations).
+    // The fetch state machine below (parts A / B) is the code that once spun forever on the device (round 4): a wavefront that spins
+    // gives up, raises the sticky error flag and the host reports GM_ERR_INTERNAL instead of waiting for ever.
+    uint32_t itGuard = 0;
     for (;;) {
 #ifndef GM_POP_LOOP
         if (!have && env.sp > 0) {   // one pop per iteration: a node dropped as saturated costs the lane one idle turn
@@ -1126,7 +1164,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
         // stage 2: window chunks and record have arrived -> stage the window in LDS, look the first q characters up
         if (fs == 1u) {
             env.note_wave(4);
-            {   // the OSS record of the root's search: from LDS for the regular block shape, from the table for the odd ones (ends of the text / of an interval)
+            if constexpr (!EnvT::LEGACY_LOOP) {   // the OSS record of the root's search: from LDS for the regular block shape, from the table for the odd ones (ends of the text / of an interval)
                 uint4 q;
                 if (frt.n == A.stepSize) q = jl[20u + frt.search]; else q = A.table[(size_t)(frt.n - 1u) * 8u + frt.search];
                 frt.rec.x = q.x; frt.rec.y = q.y; frt.rec.z = q.z; frt.rec.w = q.w;
@@ -1226,6 +1264,10 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
             }
         }
         GM_LAP2(tSt32);
+        if constexpr (EnvT::LEGACY_LOOP) {
+            bool windowFree = !A.steal || __hip_atomic_load(&users[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == 0u;
+#include "gm_stage1.inc"
+        }
         // ---- defer narrow nodes: one queue entry per SA row ----
         if (A.verifyT) {
             const uint32_t md0 = meta_mode(nd.meta);
@@ -1283,8 +1325,22 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                     IO::load_item(vq + (size_t)(qsize - 1u - lane) * NU, irow, imeta, iwin, inss);
                     Root vr; vr.win = iwin; vr.n = inss & 0xFFu; vr.strand = (inss >> 8) & 1u; vr.search = inss >> 9;
                     const uint4 q = A.table[(size_t)(vr.n - 1u) * 8u + vr.search];
+#ifdef GM_PREFETCH_NEEDLE   // experiment: the needle window's bytes requested together with the record (the scans' own loads then hit L1 / L2)
+                    {
+                        const uint4* nb = reinterpret_cast<const uint4*>(reinterpret_cast<uintptr_t>(A.text + (size_t)vr.win) & ~static_cast<uintptr_t>(15));
+                        const uint4 n0 = nb[0], n1 = nb[1], n2 = nb[2];
+                        const uint4 c0 = A.ctx ? A.ctx[(size_t)irow * 2] : make_uint4(0, 0, 0, 0);
+                        asm volatile("" :: "v"(n0.x), "v"(n1.x), "v"(n2.x), "v"(c0.x));
+                        if (A.K + vr.n > 48u) { const uint4 n3 = nb[3], n4 = nb[4], n5 = nb[5], n6 = nb[6], n7 = nb[7]; asm volatile("" :: "v"(n3.x), "v"(n4.x), "v"(n5.x), "v"(n6.x), "v"(n7.x)); }
+                    }
+#endif
                     vr.rec.x = q.x; vr.rec.y = q.y; vr.rec.z = q.z; vr.rec.w = q.w;
-                    verify_item(irow, imeta, vr, A.K, A.E, env);
+                    if constexpr (sizeof(row_t) == 4 && !EnvT::EXACT_ONLY) {   // (e = 0 verifies one row in a hundred k-mers: not worth its registers there)
+                        if (A.fastVerify) {   // wave-uniform
+                            const typename EnvT::MaskItem mi = env.template mask_item<EnvT::NLESS>(irow, imeta, vr);
+                            verify_with(mi, imeta, vr, A.K, A.E, env);
+                        } else verify_item(irow, imeta, vr, A.K, A.E, env);
+                    } else verify_item(irow, imeta, vr, A.K, A.E, env);
                 }
                 qsize -= take;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1296,6 +1352,9 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
         // a wavefront without a single node (and nothing queued) skips the step, but still draws roots and reads patterns below
         const bool stepWave = __ballot(have) != 0ull || qsize != 0u;
         if (!stepWave && __ballot(!exhausted || fs != 0u || env.sp != 0u) == 0ull) { env.drain(true); break; }   // nothing in flight, nothing queued or stacked, nothing left to draw
+        if (stepWave) itGuard &= A.guardKeep;
+        if (++itGuard > A.guardCap) { if (lane == 0u) atomicOr(A.errorFlag, 2u); break; }
+        if constexpr (EnvT::LEGACY_LOOP) if (!stepWave) continue;   // (the draw has run already)
 
 #ifdef GM_COUNTERS
         if (stepWave) { wvIter += 1; wvActive += (uint32_t)__popcll(__ballot(have)); }
@@ -1390,85 +1449,8 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
             }
         }
         GM_LAP2(tSt32);
-        // stage 1: lanes without node, stack or fetch in flight draw a root (ballot rank) and issue its loads
-#pragma unroll 1
-        for (int round = 0; round < 2; ++round) {
-            if (round > 0 && A.steal) windowFree = __hip_atomic_load(&users[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == 0u;   // (rare: the pool ran dry in round 0)
-            const bool need = !have && fs == 0u && env.sp == 0u && !exhausted && windowFree;
-            const unsigned long long m = __ballot(need);
-            if (m == 0ull) break;
-            // the whole wavefront walks through the fetch stages for whoever needs a root: wait until enough lanes do
-            if ((uint32_t)__popcll(m) < A.fetchBatch && __ballot(have || fs != 0u || env.sp != 0u) != 0ull) break;
-            if (poolCur == poolEnd && !globalDone) {
-                unsigned long long base = 0;
-                const int leader = __ffsll((long long)m) - 1;
-                if ((int)lane == leader) base = atomicAdd(A.workCounter, (unsigned long long)WORK_CHUNK);
-                base = __shfl(base, leader);
-                if (base >= A.numRoots) globalDone = true;
-                else {
-                    poolCur = base; poolEnd = base + WORK_CHUNK < A.numRoots ? base + WORK_CHUNK : A.numRoots;
-                    poolBlock = base / A.rootsPerBlock;                       // one 64-bit division per chunk, not per root
-                    poolRem = (uint32_t)(base - poolBlock * A.rootsPerBlock);
-                    poolBase = base;
-                }
-            }
-            env.note_wave(5);
-            const uint32_t avail = (uint32_t)(poolEnd - poolCur);
-            const uint32_t want = (uint32_t)__popcll(m);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (need) {
-                if (rank < avail) {
-                    const uint32_t off = (uint32_t)(poolCur - poolBase) + rank + poolRem;   // < WORK_CHUNK + rootsPerBlock
-                    const uint32_t db = off / A.rootsPerBlock;
-                    const uint32_t r = off - db * A.rootsPerBlock;
-                    unsigned long long gb = poolBlock + db;   // ordinal of the block among this call's blocks
-                    if (A.chunkBlocks) {                      // interleaved chunks: ordinal -> (own chunk number, block inside it)
-                        const uint32_t q = (uint32_t)gb / A.chunkBlocks;
-                        gb = (unsigned long long)(q * A.chunkStride + A.chunkIndex) * A.chunkBlocks + ((uint32_t)gb - q * A.chunkBlocks);
-                    }
-                    gb += A.blockBegin;
-                    if (A.blockList) { const uint2 e = A.blockList[gb]; frt.win = (row_t)((uint64_t)(e.y >> 8) << 32 | e.x); frt.n = e.y & 0xFFu; }
-                    else {
-                        frt.win = (row_t)gb * A.stepSize;
-                        const row_t left = (row_t)A.numKmers - frt.win;
-                        frt.n = left < A.stepSize ? (uint32_t)left : A.stepSize;
-                    }
-                    frt.strand = r >= A.nSearches ? 1u : 0u;
-                    frt.search = r - frt.strand * A.nSearches;
-                    const uint4* recp = A.table + ((size_t)(frt.n - 1u) * 8u + frt.search);
-                    uint32_t startPos;
-                    if constexpr (EnvT::JUMPS) {
-                        // regular blocks jump over the first jumpJ characters of their search; odd shapes (end of the text or of an
-                        // interval) walk the tree from its root
-                        fql = (frt.n == A.stepSize) ? A.jumpJ : 0u;
-                        startPos = ((frt.search < 4u ? jap0 : jap1) >> (8u * (frt.search & 3u))) & 0xFFu;   // (selects, not a load from the argument segment: a load here would be waited for behind the pattern reads above)
-                    } else {
-                    fql = ((frt.search < 4u ? A.qlenPacked[0] : A.qlenPacked[1]) >> (8u * (frt.search & 3u))) & 0xFFu;
-                    if (frt.n == A.stepSize) startPos = ((frt.search < 4u ? A.startPacked[0] : A.startPacked[1]) >> (8u * (frt.search & 3u))) & 0xFFu;
-                    else { const uint4 q = *recp; startPos = (q.y >> 16) & 0xFFu; }   // odd block shape (end of text / interval): rare
-                    }
-                    fa0 = frt.n - 1u + startPos;
-                    const uint32_t W = A.K + frt.n - 1u;
-                    const uint64_t g = A.textBegin + frt.win;
-                    env.woff = (uint32_t)(g & 31u);   // (an idle lane: nothing reads its window offset before the new root's node exists)
-                    fsrc = A.text4 + (g >> 5);
-                    fnch = (env.woff + W + 31u) >> 5;
-                    // (the search's OSS record is installed in stage 2, from LDS: a load into the root context here would have to be
-                    //  awaited by the step below -- behind every other load of the iteration)
-                    // the window goes from HBM straight into this lane's LDS slots (global_load_lds_dwordx4: chunk c of
-                    // lane l lands at wbase + c * 1 KiB + l * 16 B -- exactly the [chunk][lane] layout text_char reads);
-                    // the text has 20 chunks of padding behind it
-                    __builtin_amdgcn_global_load_lds(fsrc, wbase, 16, 0, 0);
-                    if (fnch > 1u) __builtin_amdgcn_global_load_lds(fsrc + 1, wbase + 64, 16, 0, 0);
-                    if (fnch > 2u) __builtin_amdgcn_global_load_lds(fsrc + 2, wbase + 128, 16, 0, 0);
-                    for (uint32_t c = 3u; c < A.winChunks; ++c)   // long windows (K > ~45): remaining chunks
-                        if (c < fnch) __builtin_amdgcn_global_load_lds(fsrc + c, wbase + c * 64u, 16, 0, 0);
-                    fs = 1u;
-                } else if (globalDone && avail == 0u) {
-                    exhausted = true;
-                }
-            }
-            poolCur += want < avail ? want : avail;
+        if constexpr (!EnvT::LEGACY_LOOP) {
+#include "gm_stage1.inc"
         }
         GM_LAP2(tSt1);
         if constexpr (!COOP) if (have) {

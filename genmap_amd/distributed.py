@@ -144,10 +144,17 @@ class PeerGather:
         if rank == 0:
             try:   # only the root's allocation and export may fail here; the broadcast below ALWAYS runs (a root that skipped it left
                    # the other ranks inside it while it went on to the all_reduce: mismatched collectives)
-                self.piece_ptr = [capi.device_alloc(device, n) for n in self.piece_len]
+                for n in self.piece_len:   # (appended one by one: a failure half way must not lose the pieces already allocated)
+                    self.piece_ptr.append(capi.device_alloc(device, n))
                 handles = [[capi.ipc_export(device, q) for q in self.piece_ptr]]
             except Exception as e:   # noqa: BLE001
                 mark(f"PeerGather: the root cannot allocate / export its pieces: {e}")
+                for q in self.piece_ptr:
+                    try:
+                        capi.device_free(device, q)
+                    except Exception:   # noqa: BLE001
+                        pass
+                self.piece_ptr = []
                 handles = [None]
                 good = 0
         dist.broadcast_object_list(handles, src=0)

@@ -19,6 +19,10 @@ static int g_jumpGroups = 0;        // 1: patterns that differ in their last thr
 extern "C" void gm_emu_set_jump_groups(int on) { g_jumpGroups = on; }
 static int g_selfHit = 1;           // self hits of the counting pass (gm_engine.h: self_hit_kmers)
 extern "C" void gm_emu_set_self_hit(int on) { g_selfHit = on; }
+static int g_fastVerify = 1;        // narrow nodes settled from the masks of gm_engine.h: fv_masks where the device would (K <= 32, short windows)
+extern "C" void gm_emu_set_fast_verify(int on) { g_fastVerify = on; }
+static uint64_t g_fastItems = 0;    // items verified that way since the last reset (tests make sure the path is exercised)
+extern "C" uint64_t gm_emu_fast_items(int reset) { const uint64_t v = g_fastItems; if (reset) g_fastItems = 0; return v; }
 
 template <int WPP> struct HostIndex {
     std::vector<uint32_t> blk[2];
@@ -82,6 +86,28 @@ template <int WPP, bool NL = false, bool RA = false> struct EmuEnv {
     uint64_t verified = 0;
     struct Item { uint32_t p0; };
     Item item(uint32_t row) const { return Item{saArr[row]}; }
+    // fast verification: the device's reads restated on the host -- three 16-byte chunks of the 4-bit text around the window (here the
+    // slice's own packing: any alignment occurs) and the row's 56-symbol record -- through the SAME mask builder (gm_engine.h: fv_masks)
+    typedef MaskItemT<uint32_t> MaskItem;
+    uint64_t textAvail = 0;   // bytes readable from `text`
+    MaskItem mask_item(uint32_t row, uint32_t meta, const Root& rt) const
+    {
+        uint32_t c[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, r[7] = {0, 0, 0, 0, 0, 0, 0};
+        const uint64_t g = rt.win, g0 = g & ~31ull;
+        const uint32_t wo = (uint32_t)(g & 31u), W = K + rt.n - 1;
+        const uint32_t chunks = wo + W > 64u ? 3u : 2u;           // (the device requests the third chunk only when the window reaches it)
+        for (uint32_t k = 0; k < 32u * chunks; ++k) { const uint64_t p = g0 + k; const uint32_t code = p < textAvail ? text[p] : 0u; c[k >> 3] |= (code & 15u) << (4u * (k & 7u)); }
+        const uint32_t p0 = saArr[row];
+        for (int32_t i = 0; i < CTX_SYMS; ++i) {
+            const int64_t idx = (int64_t)p0 - CTX_LEFT + i;
+            const uint32_t code = (idx < 0 || idx >= (int64_t)ix->n) ? (uint32_t)SYM_SENT : (*textSent)[idx];
+            r[i >> 3] |= code << (4u * (i & 7u));
+        }
+        MaskItem it; it.p0 = p0;
+        fv_masks<NL>(c, wo, W, rt.strand, r, meta_a(meta), it.mm, it.st);
+        ++g_fastItems;
+        return it;
+    }
     uint64_t needle8(const Root& rt, uint32_t q, bool down) const
     {
         uint64_t v = 0;
@@ -186,6 +212,10 @@ static void search_plan(const MapPlan& plan, const HostIndex<WPP>& ix, Env& env,
         if (jumps[s].J) oss_make_items(jumps[s], E, g_jumpGroups ? 1 : 0, jumps[s].regionA + jumps[s].J + 2u <= L, 0.5, 0.05, &gmasks, &items[s]);
     uint64_t roots = plan.numRoots();
     uint32_t rpb = plan.nSearches * plan.nStrands;
+    // the rule of gm_api.hip (prepare_search): every text symbol an item may look at lies inside its row's record
+    uint32_t maxA0 = 0;
+    for (uint32_t n = 1; n <= plan.stepSize; ++n) for (uint32_t s = 0; s < plan.nSearches; ++s) maxA0 = std::max(maxA0, n - 1u + oss_start(plan.table[(size_t)(n - 1) * 8 + s]));
+    const bool fastOK = g_fastVerify && K <= 32u && K + plan.stepSize - 1u <= FV_MAXW && maxA0 <= (uint32_t)CTX_LEFT;
     auto walk = [&](Node nd, const Root& rt) {
         bool have = true;
         for (;;) {
@@ -200,7 +230,10 @@ static void search_plan(const MapPlan& plan, const HostIndex<WPP>& ix, Env& env,
                 }
             }
             if (env.saArr && verifyT && nd.w <= verifyT) {   // the device defers these to a wave-wide verification round
-                for (uint32_t r2 = 0; r2 < nd.w; ++r2) verify_item(nd.flo + r2, nd.meta, rt, K, E, env);
+                for (uint32_t r2 = 0; r2 < nd.w; ++r2) {
+                    if (fastOK) { const typename Env::MaskItem mi = env.mask_item(nd.flo + r2, nd.meta, rt); verify_with(mi, nd.meta, rt, K, E, env); }
+                    else verify_item(nd.flo + r2, nd.meta, rt, K, E, env);
+                }
                 env.verified += nd.w; have = false; continue;
             }
             if (meta_mode(nd.meta) == M_SPLIT) { Node left; split_node(nd, left, K); env.push(left); }
@@ -284,6 +317,8 @@ static int run(const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nse
             textS[allCum[q + 1] + q] = (uint8_t)SYM_SENT;
         }
         env.saArr = sa; env.textSent = &textS;
+        // (the slice is either a view into the whole text -- what follows it is readable, as on the device -- or a copy of its own)
+        env.textAvail = (text >= allCodes && text < allCodes + allCum[nseqTotal]) ? allCum[nseqTotal] - (uint64_t)(text - allCodes) : textLen;
     }
     uint32_t bound = stack_bound(E, plan.stepSize);
     uint64_t nPatterns = 0;
@@ -303,7 +338,7 @@ static int run(const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nse
             rc = make_map_plan(K, E, infix, revcompl, allLen, iv.data(), iv.size() / 2, &cplan, 0, g_ossWeights);
             if (rc) return rc;
             EmuEnv<WPP, false> cenv; cenv.ix = &ix; cenv.text = allCodes; cenv.K = K; cenv.acc = &acc;
-            cenv.saArr = sa; cenv.textSent = &textS;
+            cenv.saArr = sa; cenv.textSent = &textS; cenv.textAvail = allLen;
             if (plan.useList) cenv.selBlocks = &plan.blocks;
             cenv.scatter = true; cenv.cumAll = allCum; cenv.nSeqAll = nseqTotal; cenv.sliceBegin = (uint64_t)(text - allCodes); cenv.sliceLen = textLen;
             search_plan<WPP>(cplan, ix, cenv, K, E, rows, verifyT, 0, nullptr);
@@ -383,6 +418,71 @@ extern "C" int gm_emu_check_items(uint32_t K, uint32_t E, uint32_t J, uint32_t o
         }
     }
     if (stats) { stats[0] = nPat; stats[1] = nItems; stats[2] = nGroups; }
+    return 0;
+}
+
+// gm_engine.h self-check (no index involved): fv_masks against the definition, symbol by symbol.  Random windows of W <= FV_MAXW symbols at
+// every alignment inside three 16-byte chunks, either strand, needles with N, records with N and sentinels, every anchor a0 <= CTX_LEFT;
+// positions whose text symbol lies behind the record are not compared (the host never enables the fast path where they could be needed).
+// Also scan_side over the masks against a plain loop.  Returns 0, or a code that names the first failure.
+extern "C" int gm_emu_check_fv_masks(uint32_t reps, uint32_t seed)
+{
+    uint64_t x = 0x9E3779B97F4A7C15ull ^ ((uint64_t)seed << 32 | seed);
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    struct NoteEnv { void note_chunk() {} void note_wave(int) {} } nenv;
+    for (uint32_t rep = 0; rep < reps; ++rep) {
+        uint8_t chunkSym[96], rec[CTX_SYMS];
+        for (auto& v : chunkSym) { const uint64_t t = rnd() % 40; v = t == 0 ? 4 : (uint8_t)(t & 3u); }
+        for (auto& v : rec) { const uint64_t t = rnd() % 50; v = t == 0 ? 4 : t == 1 ? 5 : (uint8_t)(t & 3u); }
+        const uint32_t W = 1u + (uint32_t)(rnd() % FV_MAXW), wo = (uint32_t)(rnd() & 31u), strand = (uint32_t)(rnd() & 1u), a0 = (uint32_t)(rnd() % (CTX_LEFT + 1));
+        if (rep & 1u) for (uint32_t i = 0; i < W && i + CTX_LEFT - a0 < (uint32_t)CTX_SYMS; ++i) {   // mostly-matching pairs: the interesting case
+            const uint8_t nd = strand ? chunkSym[wo + W - 1 - i] : chunkSym[wo + i];
+            const uint8_t want = strand ? (nd < 4 ? 3 - nd : nd) : nd;
+            if (rnd() % 8) rec[i + CTX_LEFT - a0] = want;
+        }
+        uint32_t c[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, r[7] = {0, 0, 0, 0, 0, 0, 0};
+        const uint32_t chunks = wo + W > 64u ? 3u : 2u;
+        for (uint32_t k = 0; k < 32u * chunks; ++k) c[k >> 3] |= (uint32_t)chunkSym[k] << (4u * (k & 7u));
+        for (uint32_t i = 0; i < (uint32_t)CTX_SYMS; ++i) r[i >> 3] |= (uint32_t)rec[i] << (4u * (i & 7u));
+        for (int nl = 0; nl < 2; ++nl) {
+            uint64_t mm = 0, st = 0;
+            if (nl) fv_masks<true>(c, wo, W, strand, r, a0, mm, st); else fv_masks<false>(c, wo, W, strand, r, a0, mm, st);
+            uint64_t emm = 0, est = 0, known = 0;
+            for (uint32_t i = 0; i < W; ++i) {
+                const uint32_t ri = i + CTX_LEFT - a0;
+                if (ri >= (uint32_t)CTX_SYMS) continue;
+                known |= 1ull << i;
+                const uint8_t raw = strand ? chunkSym[wo + W - 1 - i] : chunkSym[wo + i];
+                const uint8_t nd = strand ? (raw < 4 ? 3 - raw : raw) : raw, tx = rec[ri];
+                const bool stop = tx == 5 || (nl && tx == 4);
+                if (stop) est |= 1ull << i;
+                if (stop || nd != tx || nd == 4) emm |= 1ull << i;
+            }
+            if ((mm & known) != emm) return 1 + nl;
+            if ((st & known) != est) return 3 + nl;
+            if (st & ~mm) return 5;
+            // scans over the masks
+            MaskItemT<uint32_t> it; it.p0 = 0; it.mm = emm; it.st = est;
+            Root rt; rt.win = 0; rt.n = 1; rt.strand = 0; rt.search = 0; rt.rec = OssRecord{0, 0, 0, 0};
+            for (int t = 0; t < 4; ++t) {
+                const bool down = (rnd() & 1u) != 0;
+                const uint32_t q0 = (uint32_t)(rnd() % W), need = down ? (uint32_t)(rnd() % (q0 + 2)) : (uint32_t)(rnd() % (W - q0 + 1)), budget = (uint32_t)(rnd() % 5);
+                uint32_t cnt = 0, pos[4] = {9999, 9999, 9999, 9999};
+                const uint32_t got = scan_side(nenv, rt, it, 0u, q0, down, need, budget, cnt, pos);
+                uint32_t ecnt = 0, epos[4] = {9999, 9999, 9999, 9999}, egot = need;
+                for (uint32_t i = 0; i < need; ++i) {
+                    const uint32_t p = down ? q0 - i : q0 + i;
+                    if (!((emm >> p) & 1ull)) continue;
+                    if ((est >> p) & 1ull) { egot = i; break; }
+                    if (ecnt == budget) { egot = i; break; }
+                    if (ecnt < 4) epos[ecnt] = i + 1;
+                    ++ecnt;
+                }
+                if (got != egot || cnt != ecnt) return 6;
+                for (uint32_t j = 0; j < cnt && j < 4; ++j) if (pos[j] != epos[j]) return 7;
+            }
+        }
+    }
     return 0;
 }
 

@@ -84,3 +84,38 @@ def test_tuned_block_shape_at_one_error_follows_the_measured_rule():
         if K <= 112:
             assert K + n(K) - 1 <= 127, K
         assert 5 <= n(K) <= 48
+
+
+def test_every_test_runs_under_a_time_limit(tmp_path):
+    """tests/conftest.py bounds every test (SIGALRM + a faulthandler watchdog): a hung kernel fails ITS test within minutes instead of
+    burning the whole `pytest -x` step.  Checked on a throw-away test that sleeps past a 1-second limit."""
+    import shutil
+    import subprocess
+    import sys
+    shutil.copy(Path(__file__).resolve().parent / "conftest.py", tmp_path / "conftest.py")
+    (tmp_path / "test_sleepy.py").write_text(
+        "import time, pytest\n"
+        "@pytest.mark.time_limit(1)\n"
+        "def test_sleeps():\n"
+        "    time.sleep(30)\n"
+        "def test_fine():\n"
+        "    assert True\n")
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-p", "no:cacheprovider", str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert time.time() - t0 < 25, "the limit did not interrupt the sleeping test"
+    assert r.returncode != 0 and "exceeded its time limit of 1 s" in r.stdout + r.stderr, r.stdout[-2000:]
+    assert "1 failed, 1 passed" in r.stdout, r.stdout[-2000:]
+
+
+def test_genmap_program_reports_where_it_crashed():
+    """The `genmap` program writes the faulting thread's stack to stderr before a fatal signal ends it (genmap_main.cpp:
+    genmap_crash_handler), and still ends with that signal: a crash can be located, and nothing hides it (no retry in the CLI tests)."""
+    import subprocess
+    exe = Path(__file__).resolve().parent.parent / "genmap_amd" / "bin" / "genmap"
+    assert exe.exists(), "genmap binary not built (python -c 'import __graft_entry__ as g; g.build()')"
+    r = subprocess.run([str(exe), "selftest-crash"], capture_output=True, text=True)
+    assert r.returncode == -11, r.returncode                                   # died from SIGSEGV itself
+    assert "genmap: fatal signal 11" in r.stderr and "main" in r.stderr, r.stderr
+    src = (Path(__file__).resolve().parent / "test_gpu_cli_end_to_end.py").read_text()
+    assert "retried" not in src and "warnings.warn" not in src                 # the round-4 retry is gone

@@ -378,3 +378,51 @@ def test_items_of_a_search_expand_to_its_patterns(E):
             assert rc in (0, -1, -2), (K, E, J, rc)
             if (K, E, J) == (30, 2, 16):
                 assert rc == 0 and tuple(int(v) for v in st) == (261, 80, 18), st
+
+
+# ---- fast verification: the whole window compared in one go (gm_engine.h: fv_masks, scan_side over masks) ---------------------------
+def test_fast_verification_masks_match_their_definition():
+    """fv_masks (nibble funnels, reversal + complement of the reverse-strand needle, record alignment, flag compression) against a
+    symbol-by-symbol loop, and the mask form of scan_side against a plain scan: 200 000 random windows, every alignment and anchor."""
+    e = emu()
+    e.gm_emu_check_fv_masks.restype = C.c_int
+    e.gm_emu_check_fv_masks.argtypes = [C.c_uint32, C.c_uint32]
+    for seed in (1, 2, 3, 4):
+        assert e.gm_emu_check_fv_masks(50000, seed) == 0, seed
+
+
+@pytest.mark.parametrize("K,E,T", [(30, 2, 1), (30, 1, 4), (30, 2, 16), (24, 1, 2), (32, 1, 3), (20, 3, 2), (12, 1, 1), (30, 0, 1)])
+def test_fast_verification_gives_the_same_counts(K, E, T):
+    """Narrow nodes settled from the masks (K <= 32: one round of reads per item on the device) against the oracle and against the
+    scanning verification, on a text with repeat families, N runs and short sequences; plain walk and jump patterns + N-less pass."""
+    e = emu()
+    e.gm_emu_fast_items.restype = C.c_uint64
+    rng = np.random.default_rng(K * 100 + E * 10 + T)
+    lens = [1500, 700, K - 1, 900, 3, K, K + 1, 33]
+    n = sum(lens)
+    codes = rng.integers(0, 4, size=n, dtype=np.uint8)
+    fam = rng.integers(0, 4, size=200, dtype=np.uint8)
+    for s in (50, 400, 1600, 2300, 2900):
+        cp = fam.copy()
+        mut = rng.random(200) < 0.04
+        cp[mut] = rng.integers(0, 4, size=int(mut.sum()), dtype=np.uint8)
+        codes[s:s + 200] = cp
+    codes[700:760] = 4
+    for p in (1234, 1610, 2333, 2334, 60):
+        codes[p] = 4
+    codes[1000:1100] = 0
+    codes[n - 40:n - 10] = codes[10:40]
+    ix = H.OracleIndex(codes, lens, keep_sa=True)
+    exp = ix.mappability(K, E, value_bits=16, threads=4)
+    try:
+        for fast in (1, 0):
+            e.gm_emu_set_fast_verify(fast)
+            e.gm_emu_fast_items(1)
+            out, st = emu_map(ix, 1, K, E, value_bits=16, verify_t=T)
+            assert np.array_equal(out, exp), (K, E, T, fast, "plain walk")
+            if E >= 1:
+                out, st = emu_map2(ix, 1, K, E, value_bits=16, verify_t=T, jump=9)
+                assert np.array_equal(out, exp), (K, E, T, fast, "jumps + N-less + correction")
+            assert (e.gm_emu_fast_items(0) > 0) == bool(fast), (K, E, T, fast)
+    finally:
+        e.gm_emu_set_fast_verify(1)

@@ -319,6 +319,62 @@ def test_gpu_correction_pass_near_the_8_bit_maximum_under_chunks_and_selections(
         ix.close()
 
 
+def test_gpu_hung_search_ends_as_an_internal_error_not_as_a_hang():
+    """The search kernel is a persistent loop over a fetch state machine; a bug there once spun for ever on the device (round 4).  Every
+    wavefront now counts its iterations without a node (knob stall_cap, default 2^22) and gives up past the bound: the call returns
+    GM_ERR_INTERNAL instead of hanging.  Forced here with iter_cap (a bound on ALL iterations): the error is reported, it is sticky for
+    exactly one report, and the index computes correct results again afterwards."""
+    g = _gm()
+    rng = np.random.default_rng(99)
+    lens = [150000, 40000]
+    codes = _repeat_text(rng, sum(lens), True)
+    ix = g.Index.build(codes, lens, sampling=1)
+    try:
+        good = ix.map(30, 1, value_bits=8)
+        for K, E in ((30, 1), (30, 0), (100, 1)):
+            ix.set_tuning(iter_cap=3)
+            with pytest.raises(g.GenmapError) as ei:
+                ix.map(K, E, value_bits=8)
+            assert ei.value.status == -12 and "iteration bound" in str(ei.value), str(ei.value)     # GM_ERR_INTERNAL
+            ix.set_tuning(iter_cap=-1)
+            ix.sync()                                                                             # the flag was reported once: clean again
+        assert np.array_equal(ix.map(30, 1, value_bits=8), good)
+        ix.set_tuning(stall_cap=1 << 20)                                                          # a generous idle bound never fires
+        assert np.array_equal(ix.map(30, 1, value_bits=8), good)
+    finally:
+        ix.close()
+
+
+def test_gpu_one_correction_pass_per_call_beside_the_main_search():
+    """The correction pass of an N-less call (text windows that hold N, searched with the full rules) runs ONCE per call, on a stream
+    of its own beside the main search, whatever the number of launches the call is delivered in: shares of interleaved chunks (up to four
+    launches per gm_map_shard call) on a text with many runs of N, against the oracle and against the plain tree walk (jump=0)."""
+    g = _gm()
+    rng = np.random.default_rng(4242)
+    lens = [90000, 60000, 30000]
+    codes = _repeat_text(rng, sum(lens), True)
+    for p in rng.integers(100, sum(lens) - 100, 300):          # many short runs of N, some next to repeats
+        codes[p:p + int(rng.integers(1, 4))] = 4
+    n = len(codes)
+    ora = H.OracleIndex(codes, lens, keep_sa=False)
+    ix = g.Index.build(codes, lens, sampling=1)
+    try:
+        for K, E in ((30, 1), (30, 2), (100, 1)):
+            exp = ora.mappability(K, E, value_bits=8, threads=8)
+            for stride in (2, 3):
+                host = np.zeros(n, dtype=np.uint8)
+                for r in range(stride):
+                    ix.map_shard(host, K, E, value_bits=8, chunks=(7, r, stride))
+                    st = ix.last_stats()
+                    assert st["detail"]["correction_us"] > 0, (K, E, stride, r)       # the pass ran (and was timed) in this call
+                assert np.array_equal(host, exp), (K, E, stride)
+            ix.set_tuning(jump=0)
+            assert np.array_equal(ix.map(K, E, value_bits=8), exp), (K, E, "plain walk")
+            ix.set_tuning(jump=-1)
+    finally:
+        ix.close()
+
+
 def test_gpu_shards_and_device_output():
     """kmer_begin/kmer_end shards written into a torch device buffer add up to the unsharded result."""
     g = _gm()
