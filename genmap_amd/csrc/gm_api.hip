@@ -360,6 +360,7 @@ void gm_index_free(gm_index* ix)
     if (ix->stCorr) hipStreamDestroy(ix->stCorr);
     if (ix->evCorrGo) hipEventDestroy(ix->evCorrGo);
     if (ix->evCorrDone) hipEventDestroy(ix->evCorrDone);
+    if (ix->evCorrStart) hipEventDestroy(ix->evCorrStart);
     if (ix->stCompute) hipStreamDestroy(ix->stCompute);
     if (ix->stCopy) hipStreamDestroy(ix->stCopy);
     for (auto& e : ix->evShard) if (e) hipEventDestroy(e);
@@ -1114,6 +1115,23 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     return GM_OK;
 }
 
+// Can an accumulator (u32) of a counting call reach 2^32?  What is added to the accumulator of ONE (position, strand):
+//   * one clamped add (<= addCap) per leaf step, i.e. at most one per distinct string within Hamming distance E of the k-mer, the text
+//     letter N included as a substitute: L = sum_{e <= E} C(K, e) 4^e strings per strand (every error configuration is searched exactly
+//     once, src/find2_index_approx.hpp:67-134);
+//   * ones from verified rows and self hits when the call has no difference plane: at most VERIFY_TMAX rows per narrow node, and a narrow
+//     node is a prefix of one of those strings: <= VERIFY_TMAX * K * L;
+//   * ones from the correction pass: at most one per (text window with N, strand): 2 * corrKmers.
+// If their sum stays below 2^32 no wrap-around can happen and the adds need not return anything (gm_kernels.h: CountEnv::add_acc).
+static bool acc_cannot_wrap(uint32_t K, uint32_t E, uint32_t strands, uint32_t addCap, uint64_t corrKmers)
+{
+    long double L = 0, c = 1, p4 = 1;
+    for (uint32_t e = 0; e <= E; ++e) { L += c * p4; c = c * (long double)(K - e) / (long double)(e + 1); p4 *= 4; }
+    L *= strands;
+    const long double bound = L * addCap + (long double)VERIFY_TMAX * K * L + 2.0L * (long double)corrKmers;
+    return bound < 4.0e9L;
+}
+
 template <typename TValue>
 static int launch_reset_limits(gm_index* ix, TValue* d_out, uint32_t n_seq, uint32_t K, hipStream_t st)
 {
@@ -1225,7 +1243,10 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
     A.diff = useDiff ? ix->d_acc + diffOff : nullptr;
     // self hits of the counting kernels pay only with the difference plane (one atomic per block instead of one per k-mer)
     if (!store && !useDiff) A.selfHit = 0u;
-    A.maxVal = ix->tune.noSaturate ? 0xFFFFFFFFu : (p->value_bits == 8 ? 255u : 65535u); A.wordsPerKmer = wordsPerKmer; A.seqFile = ix->d_seqFile; A.rowFile = (ep && ix->rowFileValid) ? ix->d_rowFile : nullptr;
+    A.maxVal = ix->tune.noSaturate ? 0xFFFFFFFFu : (p->value_bits == 8 ? 255u : 65535u);
+    A.addCap = std::min<uint32_t>(A.maxVal, 0xFFFFu);
+    A.noWrap = (ix->tune.noWrap != 0 && acc_cannot_wrap(p->K, p->E, S.plan.nStrands, A.addCap, S.jump ? ix->nCBlocks * (uint64_t)S.plan.stepSize : 0)) ? 1u : 0u;
+    A.wordsPerKmer = wordsPerKmer; A.seqFile = ix->d_seqFile; A.rowFile = (ep && ix->rowFileValid) ? ix->d_rowFile : nullptr;
 
     if (S.jump && ix->nCBlocks > 0 && cn > 0 && !(S.plan.useList && S.plan.blocks.empty()) && (!whole || firstPiece)) {
         // Correction pass: the text windows that hold N, from the whole index, searched with the full rules; every occurrence inside
@@ -1238,6 +1259,7 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
             GM_HIP(hipStreamCreateWithFlags(&ix->stCorr, hipStreamNonBlocking));
             GM_HIP(hipEventCreateWithFlags(&ix->evCorrGo, hipEventDisableTiming));
             GM_HIP(hipEventCreateWithFlags(&ix->evCorrDone, hipEventDisableTiming));
+            GM_HIP(hipEventCreateWithFlags(&ix->evCorrStart, hipEventDisableTiming));
         }
         SearchArgs C = A;
         C.text = ix->d_text; C.textBegin = 0; C.numKmers = ix->textLen >= p->K ? ix->textLen - p->K + 1 : 0;
@@ -1253,6 +1275,11 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
         const unsigned cb = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)ix->numCU * std::max(1, std::min(ix->tune.blocksPerCU, 4)), useful));
         GM_HIP(hipEventRecord(ix->evCorrGo, st));           // accumulators cleared, counters zeroed
         GM_HIP(hipStreamWaitEvent(ix->stCorr, ix->evCorrGo, 0));
+        // The main search must not be dispatched first: it is persistent and takes every CU, the correction pass would then start when
+        // the main search ends (measured: 19 ms at the END of a K=30 e=2 call).  Its stream therefore waits for an event that the correction
+        // stream records right in front of its kernel -- the small kernel is in the device's queue when the large one becomes eligible.
+        GM_HIP(hipEventRecord(ix->evCorrStart, ix->stCorr));
+        GM_HIP(hipStreamWaitEvent(st, ix->evCorrStart, 0));
         GM_HIP(hipEventRecord(ix->ev[1], ix->stCorr));
         rc = launch_search(ix, LEAF_SCATTER, C, std::min(cb, std::max(1u, S.blocks)), ix->stCorr); if (rc) return rc;
         GM_HIP(hipEventRecord(ix->ev[2], ix->stCorr));
@@ -1729,6 +1756,7 @@ int gm_index_set_tuning(gm_index* ix, const char* name, int64_t value)
         {"jump", &ix->tune.jump, dflt.jump, 0, 16}, {"self_hit", &ix->tune.selfHit, dflt.selfHit, 0, 1}, {"jump_filter", &ix->tune.jumpFilter, dflt.jumpFilter, 0, 2},
         {"range_add", &ix->tune.rangeAdd, dflt.rangeAdd, 0, 1}, {"verify_t_ext", &ix->tune.verifyTExt, dflt.verifyTExt, 0, (int64_t)VERIFY_TMAX},
         {"fast_verify", &ix->tune.fastVerify, dflt.fastVerify, 0, 1},
+        {"no_wrap", &ix->tune.noWrap, dflt.noWrap, 0, 1},   // 0: every add into an accumulator returns the old value and checks for a wrap-around (-1 / 1: only where one is possible)
         {"iter_cap", &ix->tune.iterCap, dflt.iterCap, 1, 0x7FFFFFFF}, {"stall_cap", &ix->tune.stallCap, dflt.stallCap, 1, 0x7FFFFFFF},   // bounds of a hung search loop (tests force them)
         {"jump_groups", &ix->tune.jumpGroups, dflt.jumpGroups, 0, 1},   // groups of jump patterns behind the existence bitmap: 0 never, 1 wherever possible, -1 where they save table reads
     };

@@ -28,6 +28,7 @@ namespace gm {
 struct Tuning {
     int verifyT = -1, ldsStack = -1, blocksPerCU = 4, qtable = -1, satMinW = 256, fetchBatch = -1, probation = -1, verifyCost = 3;
     int noStore = 0, noSaturate = 0, skipDup = -1, coop = -1, useCtx = 1, steal = -1, partBias = 0, childTables = -1, ossWeights = -1, jump = -1, selfHit = 1, jumpFilter = 1, rangeAdd = 1, verifyTExt = -1, jumpGroups = -1;
+    int noWrap = -1;                   // 0: adds into the accumulators always return and check for a 2^32 wrap-around (gm_api.hip: acc_cannot_wrap)
     int fastVerify = -1;               // -1: whenever the call allows it (gm_api.hip: prepare_search), 0: never
     int iterCap = -1, stallCap = -1;   // bounds of a hung search loop (gm_kernels.h: SearchArgs::iterCap / stallCap); -1: never / 2^22 idle iterations
 };
@@ -91,7 +92,7 @@ struct gm_index {
     hipStream_t stCompute = nullptr, stCopy = nullptr;
     // correction pass of N-less calls: ONE launch per call (not per piece of a share), on a stream of its own beside the main search
     hipStream_t stCorr = nullptr;
-    hipEvent_t evCorrGo = nullptr, evCorrDone = nullptr;
+    hipEvent_t evCorrGo = nullptr, evCorrDone = nullptr, evCorrStart = nullptr;
     bool corrPending = false;       // evCorrDone of the running call has not been waited for by the call's stream yet
     hipEvent_t evShard[8] = {};
     // results that go to ordinary (pageable) host memory are staged: DMA into this page-locked ring, then host threads copy

@@ -28,6 +28,9 @@ struct SearchArgs {
                                 // finalize_diff_kernel sums the plane inside each block and adds it to acc.  Regular partition only.
     uint64_t accPlane;
     uint32_t maxVal;            // 255 or 65535: the result is min(total, maxVal), so saturated k-mers need no further hits
+    uint32_t addCap;            // a single add into acc is clamped to this (min(maxVal, 65535): the result is min(total, maxVal) either way)
+    uint32_t noWrap;            // 1: the host has shown that no accumulator of this call can reach 2^32 (gm_api.hip: acc_cannot_wrap) -- the adds
+                                // are fire-and-forget; 0: every add returns the old value and a (theoretical) wrap sets the sticky top bit
     uint32_t K, E;
     uint32_t stepSize, nSearches, rootsPerBlock;
     uint64_t numKmers;
@@ -620,14 +623,20 @@ template <int WPP, bool JUMP = false> struct CountEnv : EnvBase<WPP> {
         if (!count) return;
         rootHits = rootHits + count < rootHits ? 0xFFFFFFFFu : rootHits + count;
         const row_t pos = this->slice_pos(rt, kmer);
-        const uint32_t add = count < 0xFFFFu ? count : 0xFFFFu;   // every add is <= MAX of the widest value type
-        const uint32_t old = atomicAdd(&A.acc[pos], add);
-        if (old > 0xFFFFFFFFu - add) atomicOr(&A.acc[pos], 0x80000000u);   // sticky saturation on (theoretical) wrap
+        add_acc(&A.acc[pos], count < A.addCap ? count : A.addCap);
+    }
+    // One add into an accumulator.  A RETURNING device-scope atomic is a round trip through the fabric that the whole wavefront waits
+    // for (s_waitcnt vmcnt(0) right behind it) -- in the step of nearly every iteration at e >= 1, for the sake of a wrap-around that the
+    // host can rule out for all but absurd (K, E): then the add is fire-and-forget.
+    __device__ __forceinline__ void add_acc(uint32_t* p, uint32_t add)
+    {
+        if (A.noWrap) { __hip_atomic_fetch_add(p, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }   // wave-uniform
+        const uint32_t old = atomicAdd(p, add);
+        if (old > 0xFFFFFFFFu - add) atomicOr(p, 0x80000000u);   // sticky saturation on (theoretical) wrap
     }
     __device__ __forceinline__ void leaf_at(const Root& rt, uint32_t kmer, row_t)
     {
-        uint32_t* p = &A.acc[this->slice_pos(rt, kmer)];
-        if (atomicAdd(p, 1u) == 0xFFFFFFFFu) atomicOr(p, 0x80000000u);
+        add_acc(&A.acc[this->slice_pos(rt, kmer)], 1u);
         // (verified hits are not added to rootHits: the verifying lane is not the root's lane)
     }
     // k-mers s0..s1 of the block each gain one occurrence
@@ -639,7 +648,7 @@ template <int WPP, bool JUMP = false> struct CountEnv : EnvBase<WPP> {
             __hip_atomic_fetch_add(&A.diff[lo], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (hi + 1u < rt.win + rt.n) __hip_atomic_fetch_add(&A.diff[hi + 1u], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            for (row_t p = lo; p <= hi; ++p) if (atomicAdd(&A.acc[p], 1u) == 0xFFFFFFFFu) atomicOr(&A.acc[p], 0x80000000u);
+            for (row_t p = lo; p <= hi; ++p) add_acc(&A.acc[p], 1u);
         }
     }
 };
@@ -868,6 +877,7 @@ template <int WPP> struct ScatterEnv : LeafQueueEnv<WPP, ScatterEnv<WPP>> {
         const uint64_t q = own_position(sp);
         if (q == ~0ull) return;
         uint32_t* p = &A.acc[q];
+        if (A.noWrap) { __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }   // (CountEnv::add_acc)
         if (atomicAdd(p, 1u) == 0xFFFFFFFFu) atomicOr(p, 0x80000000u);
     }
     // INVARIANT the two shortcuts below rest on: the main pass computes a position's count as a pure function of the k-mer AT that
@@ -1243,7 +1253,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
             // phase the self hit belongs to the search whose remaining lower bounds are all zero (find2:389-392): the others drop the
             // node.  (k-mers that cross a sequence end are zeroed by resetLimits whatever is added here; a window with an N anywhere
             // takes the ordinary path, which knows which k-mers the N spoils.)
-            if (A.selfHit && have && nd.w == 1u && rt.strand == 0u && meta_errs(nd.meta) == 0u && nd.rlo != ~(row_t)0) {   // (not the left-over rows of a wider node)
+            if (A.selfHit && have && nd.w == 1u && rt.strand == 0u && (EnvT::EXACT_ONLY || (meta_errs(nd.meta) == 0u && nd.rlo != ~(row_t)0))) {   // (not the left-over rows of a wider node; e = 0 has neither errors nor such nodes)
                 const uint32_t W = A.K + rt.n - 1u, nch = (env.woff + W + 31u) >> 5;
                 uint32_t anyN = 0;
                 for (uint32_t c = 0; c < nch; ++c) {
@@ -1273,8 +1283,8 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
             const uint32_t md0 = meta_mode(nd.meta);
             // (extension-phase nodes have the whole infix behind them: one row there costs a record read and two short scans, while the
             //  walk still has ~n log n steps to go -- they may be wider than the nodes verified inside the infix)
-            bool narrow = have && nd.w <= (md0 == M_OSS ? A.verifyT : A.verifyTExt);
-            if (narrow && nd.rlo != ~(row_t)0) {   // is the subtree below worth one SA read + one text comparison per row?
+            bool narrow = have && nd.w <= ((EnvT::EXACT_ONLY || md0 == M_OSS) ? A.verifyT : A.verifyTExt);
+            if (narrow && (EnvT::EXACT_ONLY || nd.rlo != ~(row_t)0)) {   // is the subtree below worth one SA read + one text comparison per row?
                 const uint32_t m = nd.meta, a = meta_a(m), bx = meta_bx(m), t = meta_t(m), md = md0;
                 const uint32_t covered = md == M_OSS ? rt.n : md == M_EXT_R ? a + A.K - t + 1u : md == M_EXT_L ? t + A.K - bx + 1u : a + A.K - bx + 1u;
                 const uint32_t est = (A.K - (bx - a)) + covered - 1u;   // lower bound of the steps still needed
@@ -1282,10 +1292,10 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                 // A lone row that may not mismatch any more is, more often than not, a chance hit that the next one or
                 // two characters kill with ONE rank line each (lo and hi share a block); verification costs an SA read
                 // plus a text read.  Step it a little first, verify only the survivors.
-                if (nd.w == 1u && meta_errs(m) == A.E && w1run < A.probation) narrow = false;
+                if (!EnvT::EXACT_ONLY && nd.w == 1u && meta_errs(m) == A.E && w1run < A.probation) narrow = false;
                 // e = 0: the table leaves one infix character; taking it first costs one rank line and spares the
                 // reverse-strand chance hits their SA + text reads (5.31 vs 5.46 ms, profiles/r01e_infix_sweeps.txt)
-                if (A.E == 0u && md == M_OSS) narrow = false;
+                if ((EnvT::EXACT_ONLY || A.E == 0u) && md == M_OSS) narrow = false;
             }
             // At most VERIFY_ROWS rows of a node are queued per iteration (SearchArgs::verifyRows; the queue holds 64 + 64 * verifyRows entries); the rows left
             // over go back onto the lane's stack as a rows-only node (rlo = all ones: never stepped, queued the moment it is popped).
@@ -1293,7 +1303,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
             //  second row to queue -- waits on the stacks like the rows beyond the second; 2 KB of LDS per block are a stack level at K = 30)
             uint32_t rowsDone = 0;   // wave-uniform
 #pragma unroll 1
-            for (uint32_t r = 0; r < A.verifyRows; ++r) {
+            for (uint32_t r = 0; r < (EnvT::EXACT_ONLY ? 1u : A.verifyRows); ++r) {   // (e = 0 verifies single rows only: the plain stores rely on it)
                 const bool e = narrow && r < nd.w;
                 const unsigned long long m = __ballot(e);
                 if (m == 0ull) break;
@@ -1324,23 +1334,20 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                     row_t irow, iwin; uint32_t imeta, inss;
                     IO::load_item(vq + (size_t)(qsize - 1u - lane) * NU, irow, imeta, iwin, inss);
                     Root vr; vr.win = iwin; vr.n = inss & 0xFFu; vr.strand = (inss >> 8) & 1u; vr.search = inss >> 9;
-                    const uint4 q = A.table[(size_t)(vr.n - 1u) * 8u + vr.search];
-#ifdef GM_PREFETCH_NEEDLE   // experiment: the needle window's bytes requested together with the record (the scans' own loads then hit L1 / L2)
-                    {
-                        const uint4* nb = reinterpret_cast<const uint4*>(reinterpret_cast<uintptr_t>(A.text + (size_t)vr.win) & ~static_cast<uintptr_t>(15));
-                        const uint4 n0 = nb[0], n1 = nb[1], n2 = nb[2];
-                        const uint4 c0 = A.ctx ? A.ctx[(size_t)irow * 2] : make_uint4(0, 0, 0, 0);
-                        asm volatile("" :: "v"(n0.x), "v"(n1.x), "v"(n2.x), "v"(c0.x));
-                        if (A.K + vr.n > 48u) { const uint4 n3 = nb[3], n4 = nb[4], n5 = nb[5], n6 = nb[6], n7 = nb[7]; asm volatile("" :: "v"(n3.x), "v"(n4.x), "v"(n5.x), "v"(n6.x), "v"(n7.x)); }
-                    }
-#endif
-                    vr.rec.x = q.x; vr.rec.y = q.y; vr.rec.z = q.z; vr.rec.w = q.w;
+                    // the OSS record of the item's search: from LDS for the regular block shape (read AFTER the masks of a fast item are
+                    // built: four registers fewer while they are), from the table for the odd shapes
+                    auto load_rec = [&]() {
+                        uint4 q;
+                        if (vr.n == A.stepSize) q = jl[20u + vr.search]; else q = A.table[(size_t)(vr.n - 1u) * 8u + vr.search];
+                        vr.rec.x = q.x; vr.rec.y = q.y; vr.rec.z = q.z; vr.rec.w = q.w;
+                    };
                     if constexpr (sizeof(row_t) == 4 && !EnvT::EXACT_ONLY) {   // (e = 0 verifies one row in a hundred k-mers: not worth its registers there)
                         if (A.fastVerify) {   // wave-uniform
                             const typename EnvT::MaskItem mi = env.template mask_item<EnvT::NLESS>(irow, imeta, vr);
+                            load_rec();
                             verify_with(mi, imeta, vr, A.K, A.E, env);
-                        } else verify_item(irow, imeta, vr, A.K, A.E, env);
-                    } else verify_item(irow, imeta, vr, A.K, A.E, env);
+                        } else { load_rec(); verify_item(irow, imeta, vr, A.K, A.E, env); }
+                    } else { load_rec(); verify_item(irow, imeta, vr, A.K, A.E, env); }
                 }
                 qsize -= take;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
