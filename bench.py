@@ -63,41 +63,113 @@ def cpu_model():
 
 
 class CpuBaseline:
-    """The oracle (a port of the reference algorithm, kind="port") on this box's host cores, on a bounded sample: whole k-mer
-    blocks from the start of the text, sized so that the timed run takes roughly 10 s.  Built for THIS host with -O3 -march=native
-    (POPCNT, as the reference ships it: README.rst:60-62), 64-byte rank blocks (one cache line per query), rank arrays built and
-    first touched by the threads that use them; timed with every hardware thread and with ONE thread."""
+    """The oracle (a port of the reference algorithm, kind="port") on this box's host cores, on a bounded sample of the SAME positions the
+    GPU rate covers: seeded random intervals of 1,000 positions spread over every sequence of the text (repeat families, unique
+    sequence and N runs in the text's own proportions -- round 4 sampled a prefix behind the leading N block, which held none of the
+    repeats).  The all-thread figure takes as many of the intervals as make the timed run last about 10 s; the one-thread figure takes a
+    prefix of the same list.  The output vector is allocated and cleared outside the timed calls.  Built for THIS host with -O3
+    -march=native (POPCNT, as the reference ships it: README.rst:60-62), 64-byte rank blocks (one cache line per query), rank arrays built
+    and first touched by the threads that use them."""
 
-    def __init__(self, codes, lens, bwt, threads):
+    INTERVAL = 1000
+
+    def __init__(self, codes, lens, bwt, threads, seq_file_id=None, sa=None):
         sys.path.insert(0, str(ROOT / "tests"))
         import helpers as H
         t0 = time.time()
         so = H.build_oracle_native()
         self.build = "-O3 -march=native" if so else "-O3 -mpopcnt (portable build: the native build failed on this host)"
-        self.ora = H.OracleIndex(codes, lens, keep_sa=False, bwt=bwt, lib=H.oracle_lib(so))
+        self.ora = H.OracleIndex(codes, lens, keep_sa=False, bwt=bwt, sa=sa, lib=H.oracle_lib(so))
+        self.fid = seq_file_id
         self.n, self.threads, self.model = len(codes), threads, cpu_model()
+        self.lens = [int(x) for x in lens]
+        self.cum = np.concatenate([[0], np.cumsum(np.asarray(self.lens, dtype=np.int64))])
+        self.out = {8: np.zeros(self.n, np.uint8), 16: np.zeros(self.n, np.uint16)}
+        try:
+            self.ora.lib.gmo_set_skip_clear(1)
+            self.skip_clear = True
+        except AttributeError:
+            self.skip_clear = False
         log(f"cpu_baseline: oracle ({self.build}) adopted the GPU-built BWTs in {time.time() - t0:.1f} s on {self.model}, {threads} threads")
 
-    def _timed(self, K, E, first_guess, threads, target):
-        n = self.n
-        skip = min(n // 10, 20_000)               # stay clear of the leading N block
-        avail = n - skip - K
-        sample, dt = min(first_guess, avail), 0.0
-        while True:                                # grow the sample until the timed run takes >= target s (or covers the text)
-            t0 = time.time()
-            self.ora.mappability(K, E, value_bits=8, threads=threads, intervals=[(skip, skip + sample)])
-            dt = time.time() - t0
-            if dt >= target or sample >= avail:
-                break
-            sample = int(min(avail, max(sample * 2, sample * (target * 1.4) / max(dt, 1e-3))))
-        return sample, dt, skip
+    def intervals(self, K, count, seed=20260929):
+        """`count` seeded intervals of INTERVAL positions, dealt to the sequences in proportion to their lengths, in a random ORDER (a prefix
+        of the list is itself spread over the whole text)"""
+        rng = np.random.default_rng(seed)
+        total = int(self.cum[-1])
+        iv = []
+        for _ in range(count):
+            p = int(rng.integers(0, max(1, total - self.INTERVAL - K)))
+            q = int(np.searchsorted(self.cum, p, side="right")) - 1
+            b = min(p + self.INTERVAL, int(self.cum[q + 1]))
+            if b - p >= 64:
+                iv.append((p, b))
+        return iv
 
-    def run(self, K, E, first_guess):
-        sample, dt, skip = self._timed(K, E, first_guess, self.threads, 8.0)
-        s1, dt1, _ = self._timed(K, E, max(1000, first_guess // max(1, self.threads // 2)), 1, 4.0)
-        return {"value": sample / dt, "unit": "k-mers/s", "cores": self.threads, "kind": "port", "build": self.build, "cpu_model": self.model,
-                "threads_1": {"value": s1 / dt1, "unit": "k-mers/s", "sample": f"{s1} positions, {dt1:.1f} s"},
-                "sample": f"{sample} consecutive k-mer positions from offset {skip} of the same index, K={K} E={E}, both strands, {dt:.1f} s"}
+    def _timed(self, K, E, threads, target, first, **kw):
+        """grow the prefix of the interval list until the timed run takes >= target seconds"""
+        bits = kw.pop("value_bits", 8)
+        pool = self.intervals(K, 400_000)
+        m, dt, npos = max(1, first), 0.0, 0
+        while True:
+            iv = sorted(pool[:m])
+            merged = []
+            for a, b in iv:
+                if merged and a < merged[-1][1]:
+                    merged[-1] = (merged[-1][0], max(b, merged[-1][1]))
+                else:
+                    merged.append((a, b))
+            npos = sum(b - a for a, b in merged)
+            t0 = time.time()
+            self.ora.mappability(K, E, value_bits=bits, threads=threads, intervals=merged, out=self.out[bits], **kw)
+            dt = time.time() - t0
+            if self.skip_clear:
+                for a, b in merged:
+                    self.out[bits][a:b + K] = 0
+            if dt >= target or m >= len(pool):
+                break
+            m = int(min(len(pool), max(m * 2, m * (target * 1.3) / max(dt, 1e-3))))
+        return m, npos, dt
+
+    def run_c5(self, K, E, slices):
+        """config C5: the --exclude-pseudo pass (16-bit) of every FASTA file of the index on seeded random intervals of each file; the same
+        intervals for the all-thread figure and (a prefix per file) the one-thread figure"""
+        def timed(threads, target, per_file):
+            while True:
+                t_sum, npos = 0.0, 0
+                for q, (fs, ns, tl) in enumerate(slices):
+                    rng = np.random.default_rng(1000 + q)
+                    st = np.sort(rng.integers(0, max(1, tl - self.INTERVAL - K), per_file))
+                    iv = []
+                    for a in st:
+                        a = int(a) if not iv or int(a) >= iv[-1][1] else iv[-1][1]
+                        b = min(a + self.INTERVAL, tl - K + 1)
+                        if b > a:
+                            iv.append((a, b))
+                    npos += sum(b - a for a, b in iv)
+                    t0 = time.time()
+                    self.ora.mappability(K, E, first_seq=fs, n_seq=ns, text_begin=int(self.cum[fs]), text_len=tl, value_bits=16, exclude_pseudo=True, directory=True,
+                                         threads=threads, intervals=iv, seq_file_id=self.fid)
+                    t_sum += time.time() - t0
+                if t_sum >= target or per_file * self.INTERVAL >= max(tl for _, _, tl in slices):
+                    return per_file, npos, t_sum
+                per_file = int(max(per_file * 2, per_file * (target * 1.3) / max(t_sum, 1e-3)))
+        try:
+            self.ora.lib.gmo_set_skip_clear(0)
+        except AttributeError:
+            pass
+        m, npos, dt = timed(self.threads, 8.0, 50)
+        m1, npos1, dt1 = timed(1, 4.0, max(1, m // max(8, self.threads // 2)))
+        return {"value": npos / dt, "unit": "k-mers/s", "cores": self.threads, "kind": "port", "build": self.build, "cpu_model": self.model,
+                "threads_1": {"value": npos1 / dt1, "unit": "k-mers/s", "sample": f"{m1} intervals per file: {npos1} positions, {dt1:.1f} s"},
+                "sample": f"{npos} k-mer positions in {m} seeded random intervals of {self.INTERVAL} per FASTA file ({len(slices)} files) of the same index, K={K} E={E}, --exclude-pseudo, both strands, {dt:.1f} s"}
+
+    def run(self, K, E, first_guess, **kw):
+        m, npos, dt = self._timed(K, E, self.threads, 8.0, max(1, first_guess // self.INTERVAL), **kw)
+        m1, npos1, dt1 = self._timed(K, E, 1, 4.0, max(1, m // max(8, self.threads // 2)), **kw)
+        return {"value": npos / dt, "unit": "k-mers/s", "cores": self.threads, "kind": "port", "build": self.build, "cpu_model": self.model,
+                "threads_1": {"value": npos1 / dt1, "unit": "k-mers/s", "sample": f"the first {m1} of the same intervals: {npos1} positions, {dt1:.1f} s"},
+                "sample": f"{npos} k-mer positions in {m} seeded random intervals of {self.INTERVAL} spread over all {len(self.lens)} sequences of the same index, K={K} E={E}, both strands, {dt:.1f} s (output vector cleared outside the timed call)"}
 
 
 def read_fasta(path):
@@ -504,7 +576,7 @@ def main():
     want_twin = not args.no_counters and g.lib_path(True).exists()
     if rank == 0 and (not args.no_cpu_baseline or want_twin):
         bwt_host = ix.export_bwt()
-        if want_twin and args.sampling == 1:
+        if (want_twin or (c5 and not args.no_cpu_baseline)) and args.sampling == 1:
             sa_host = ix.export_sa()
         elif want_twin and args.sampling > 1:
             sa_host = ix.export_sa_sampled()   # (mark words, samples)
@@ -521,6 +593,7 @@ def main():
     # The timed indexes are released first: the twin needs the same HBM (verification records included) to run the same schedule.
     # N > 1: the twin walks the ranks' shards one after the other with the shard arguments the ranks used.
     counted = {}
+    sa_cpu = sa_host if (c5 and args.sampling == 1) else None
     if want_twin:
         try:
             bf, br = bwt_host
@@ -529,6 +602,7 @@ def main():
             else:
                 ixp = g.Index.from_bwt(bf, br, codes, lens, sa_fwd=sa_host, sampling=args.sampling,
                                        block_bytes=info["block_bytes"], device=local_rank, profiling=True)
+            sa_cpu = sa_host if (c5 and args.sampling == 1) else None   # (config C5's CPU baseline locates: the oracle adopts the suffix array)
             sa_host = None
             if ixp.info()["verify_records"] != info["verify_records"]:
                 log("warning: the instrumented twin did not get the same verification records as the timed index")
@@ -607,7 +681,10 @@ def main():
         sampled array an 8-byte mark word per visit, a 32-byte rank block per LF step and the 4-byte sample) + one 4-byte word of the file
         set per located row + the text once per strand + the 16-bit result"""
         sp = counted.get((rec["K"], rec["E"]))
-        base = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "kernel": "search_kernel (FileSetEnv), one launch per FASTA file",
+        tr = traffic.get((rec["K"], rec["E"]), {})
+        tsum = (tr.get("FETCH_SIZE", 0.0) + tr.get("WRITE_SIZE", 0.0)) if len(tr) == 2 else None
+        base = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": tsum, "traffic_fetch_bytes": tr.get("FETCH_SIZE"), "traffic_write_bytes": tr.get("WRITE_SIZE"),
+                "kernel": "search_kernel (FileSetEnv), one launch per FASTA file",
                 "kernel_ms": rec["kernel_ms"], "per_gpu": True}
         if not sp or not sp["rank_lines"]:
             return dict(base, achieved=None, frac=None)
@@ -647,7 +724,40 @@ def main():
             shutil.rmtree(d, ignore_errors=True)
         return res
 
+    def pmc_traffic_c5():
+        """FETCH_SIZE / WRITE_SIZE of the --exclude-pseudo pass over the five files: this program itself as a child process under rocprofv3
+        (one warm-up step and one step, no csv pass): the FileSetEnv dispatches of the last step, summed"""
+        import csv, glob, shutil, subprocess, tempfile
+        if world != 1 or args.no_traffic or not shutil.which("rocprofv3"):
+            return {}
+        res, nfiles = {}, len(head["slices"])
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="gm_pmc_", dir="/tmp")
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable, str(ROOT / "bench.py"),
+                   "--workload", "bacteria5", "--scale", str(args.scale), "--sampling", str(args.sampling), "--K", str(head["K"]), "--E", str(head["E"]),
+                   "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-counters", "--no-traffic", "--no-csv", "--no-host-rate"]
+            try:
+                subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, env=dict(os.environ, TMPDIR="/tmp"), cwd=str(ROOT))
+                acc = {}
+                for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
+                    for r in csv.DictReader(open(f)):
+                        if "search_kernel" in r["Kernel_Name"] and "FileSetEnv" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                            acc[int(r["Dispatch_Id"])] = acc.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
+                vals = [acc[k] for k in sorted(acc)]
+                if len(vals) >= 2 * nfiles:
+                    res[counter] = sum(vals[-nfiles:]) * 1024.0
+            except Exception as e:
+                log(f"roofline.traffic (C5): rocprofv3 --pmc {counter} failed: {e}")
+            shutil.rmtree(d, ignore_errors=True)
+        return res
+
     traffic = {}
+    if c5:
+        t0 = time.time()
+        tr5 = pmc_traffic_c5()
+        if len(tr5) == 2:
+            traffic[(head["K"], head["E"])] = tr5
+            log(f"roofline.traffic (C5): FETCH_SIZE / WRITE_SIZE passes under rocprofv3 took {time.time() - t0:.0f} s")
     if not c5:
         t0 = time.time()
         traffic = pmc_traffic([(r["K"], r["E"]) for r in [head] + subs])
@@ -657,7 +767,10 @@ def main():
     cpu = None
     if not args.no_cpu_baseline:
         try:
-            cpu = CpuBaseline(codes, lens, bwt_host, os.cpu_count() or 1)
+            if c5 and sa_cpu is None:
+                log("cpu_baseline: config C5 locates, the oracle needs the full suffix array (-S 1): skipped")
+            else:
+                cpu = CpuBaseline(codes, lens, bwt_host, os.cpu_count() or 1, seq_file_id=fid if c5 else None, sa=sa_cpu)
         except Exception as e:
             log("cpu baseline failed:", e)
 
@@ -666,6 +779,8 @@ def main():
             return None
         guess = {0: 100_000_000, 1: 10_000_000}.get(rec["E"], 1_000_000)
         try:
+            if c5:
+                return cpu.run_c5(rec["K"], rec["E"], rec["slices"])
             return cpu.run(rec["K"], rec["E"], guess)
         except Exception as e:
             log("cpu baseline failed:", e)
@@ -712,7 +827,7 @@ def main():
     else:
         result["roofline"] = roofline(head)
     rank_fields(result, head)
-    if not args.no_cpu_baseline and not c5:
+    if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_rec(head)
     if subs:
         result["sub"] = []

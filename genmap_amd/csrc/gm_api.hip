@@ -543,7 +543,7 @@ template <typename T> static int grow(T** p, uint64_t* cap, uint64_t need)
 enum LeafMode { LEAF_COUNT = 0, LEAF_FILESET = 1, LEAF_OCC_COUNT = 2, LEAF_OCC_EMIT = 3, LEAF_STORE = 4, LEAF_STORE8 = 5, LEAF_COUNT_JUMP = 6, LEAF_SCATTER = 7 };
 
 // nu = 16-byte units per stored node / queue entry: 1, or 2 with 64-bit rows (gm_kernels.h: NodeIO)
-static inline size_t search_lds_bytes(const SearchArgs& A, uint32_t nu) { return (size_t)(4u * A.vqCap * nu + 4u * 64u * (A.ldsDepth * nu + A.winChunks)) * 16u + 4u * 80u * 4u + 448u + (A.entrySlots ? 4096u : 0u) + (A.lqCap ? 4u * (A.lqCap * 16u + 80u * 4u) : 0u); }
+static inline size_t search_lds_bytes(const SearchArgs& A, uint32_t nu) { return (size_t)(4u * A.vqCap * nu + 4u * 64u * (A.ldsDepth * nu + A.winChunks)) * 16u + 4u * 80u * 4u + 544u + (A.entrySlots ? 4096u : 0u) + (A.lqCap ? 4u * (A.lqCap * 16u + 80u * 4u) : 0u); }
 
 template <int WPP, class EnvT>
 static int launch_one(const SearchArgs& A, unsigned blocks, hipStream_t st)
@@ -653,22 +653,37 @@ static int get_qtable(gm_index* ix, uint32_t* qio, const uint4** out)
 //   kind 0 "the q-mer occurs" (from the table of all q-mers) | kind 1 "... followed by letters x y", LOW layout, 16 pairs | the same, MID layout
 // (kind 1 from the sentinel text; q = 16: 0.5 + 8.6 + 8.6 GB).  *level: 0 = kind 0 only (device short of memory, or no sentinel text),
 // 1 = + LOW, 2 = + MID.  *out stays null when not even kind 0 fits: the call then keeps plain pattern lists.
-static int get_jbits(gm_index* ix, uint32_t q, const uint4* tab, const unsigned long long** out, int* level)
+// one thread per word of the kind-0 bitmap of the layout at bit offset sh: its 64 J-mers differ in the layout's three characters
+__global__ __launch_bounds__(256) void jbits_layout_kernel(const uint4* __restrict__ tab, uint64_t words, uint32_t sh, unsigned long long* __restrict__ bits)
 {
-    *out = nullptr; *level = 0;
+    const uint64_t w = ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+    if (w >= words) return;
+    const uint64_t idx0 = ((w >> sh) << (sh + 6u)) | (w & ((1ull << sh) - 1ull));
+    unsigned long long m = 0ull;
+    for (uint32_t v = 0; v < 64u; ++v) if (tab[idx0 | (uint64_t)v << sh].z != 0u) m |= 1ull << v;
+    bits[w] = m;
+}
+
+// *extra: kind-0 planes of the layouts 1, 2, .. (gm_oss.h: group_layout_shifts) behind the 1 + 16 x level planes; 0 when the device is short of memory
+static int get_jbits(gm_index* ix, uint32_t q, const uint4* tab, const unsigned long long** out, int* level, uint32_t* extra)
+{
+    *out = nullptr; *level = 0; *extra = 0;
     if (q <= GROUP_SYMS || ix->wide || !tab) return GM_OK;
     auto it = ix->jbits.find(q);
-    if (it != ix->jbits.end()) { *out = it->second; *level = ix->jbitsLevel[q]; return GM_OK; }
+    if (it != ix->jbits.end()) { *out = it->second; *level = ix->jbitsLevel[q]; *extra = ix->jbitsExtra[q]; return GM_OK; }
     const uint64_t n = 1ull << (2 * q), words = n / 64;
     int lv = !ix->d_textS ? 0 : (q >= 2 * GROUP_SYMS ? 2 : 1);
+    const std::vector<uint32_t> shifts = group_layout_shifts(q);
+    uint32_t ex = shifts.size() > 1 ? (uint32_t)shifts.size() - 1u : 0u;   // kind-0 planes of the layouts beyond LOW: the first thing to go when memory is short
     unsigned long long* d = nullptr;
-    for (;; --lv) {
+    for (;;) {
         if (lv < 0) return GM_OK;
-        const uint64_t bytes = (1 + 16 * (uint64_t)lv) * words * 8;
+        const uint64_t bytes = (1 + 16 * (uint64_t)lv + ex) * words * 8;
         size_t freeB = 0, totalB = 0;
-        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && bytes + (8ull << 30) > freeB && bytes > (1ull << 24)) continue;
-        if (hipMalloc(&d, bytes) == hipSuccess) break;
+        const bool fits = !(hipMemGetInfo(&freeB, &totalB) == hipSuccess && bytes + (8ull << 30) > freeB && bytes > (1ull << 24));
+        if (fits && hipMalloc(&d, bytes) == hipSuccess) break;
         (void)hipGetLastError();
+        if (ex) ex = 0; else --lv;
     }
     const uint64_t blocks = (n + 255) / 256;
     const dim3 grid((unsigned)std::min<uint64_t>(blocks, 1u << 22), (unsigned)((blocks + (1u << 22) - 1) >> 22));
@@ -683,11 +698,17 @@ static int get_jbits(gm_index* ix, uint32_t q, const uint4* tab, const unsigned 
             e = hipGetLastError();
         }
     }
+    for (uint32_t k = 0; k < ex && e == hipSuccess; ++k) {
+        const uint64_t tb = (words + 255) / 256;
+        const dim3 g3((unsigned)std::min<uint64_t>(tb, 1u << 22), (unsigned)((tb + (1u << 22) - 1) >> 22));
+        hipLaunchKernelGGL(jbits_layout_kernel, g3, dim3(256), 0, 0, tab, words, shifts[k + 1], d + (1 + 16 * (uint64_t)lv + k) * words);
+        e = hipGetLastError();
+    }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) { hipFree(d); GM_HIP(e); }
-    ix->jbits[q] = d; ix->jbitsLevel[q] = lv;
-    ix->qtableBytes += (1 + 16 * (uint64_t)lv) * words * 8;
-    *out = d; *level = lv;
+    ix->jbits[q] = d; ix->jbitsLevel[q] = lv; ix->jbitsExtra[q] = ex;
+    ix->qtableBytes += (1 + 16 * (uint64_t)lv + ex) * words * 8;
+    *out = d; *level = lv; *extra = ex;
     return GM_OK;
 }
 
@@ -884,7 +905,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     const int wantPerCU = std::max(1, ix->tune.blocksPerCU);   // default 4 = 4 waves/SIMD, what the kernel's VGPR count allows
     // (calls that may jump keep their table entries in flight in LDS: one 16-byte slot per lane)
     const bool mayJump = wantJump && p->E >= 1 && (ix->d_sa || ix->d_saMark) && ix->tune.jump != 0 && !ix->wide;
-    auto lds_bytes_for = [&](uint32_t d) { return (size_t)(4u * vqCap * nu + 4u * 64u * (d * nu + winChunks)) * 16u + 4u * 80u * 4u + 448u + (mayJump ? 4096u : 0u) + (lqCap ? 4u * (lqCap * 16u + 80u * 4u) : 0u); };   // == search_lds_bytes
+    auto lds_bytes_for = [&](uint32_t d) { return (size_t)(4u * vqCap * nu + 4u * 64u * (d * nu + winChunks)) * 16u + 4u * 80u * 4u + 544u + (mayJump ? 4096u : 0u) + (lqCap ? 4u * (lqCap * 16u + 80u * 4u) : 0u); };   // == search_lds_bytes
     auto blocks_for = [&](uint32_t d, int* nb) {
         switch (ix->wpp) { case 1: return occupancy_blocks<1>(nb, lds_bytes_for(d)); case 2: return occupancy_blocks<2>(nb, lds_bytes_for(d)); case 3: return occupancy_blocks<3>(nb, lds_bytes_for(d)); default: return occupancy_blocks<9>(nb, lds_bytes_for(d)); }
     };
@@ -922,6 +943,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
 
     // ---- jump patterns (frequency calls with errors on an index that can locate): one J for every search ----
     std::vector<uint32_t> patHost; std::vector<uint4> jinfoHost; uint32_t jumpJ = 0, jumpAPacked[2] = {0, 0};
+    uint32_t layShift[8] = {0, 0, 0, 0, 0, 0, 0, 0}, layPlane0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, layPlane1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long* jbitsCall = nullptr; unsigned long long gmaskCall[GROUP_MAX_MASKS] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t jbitsWords = 0; std::vector<uint4> jinfo2Host(8, make_uint4(0, 0, 0, 0));
     const uint4* jtab = nullptr;
@@ -951,8 +973,15 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
             // Groups of patterns (gm_oss.h): patterns that differ in the last three characters only share one word of the existence bitmap.
             // A search is grouped when that saves table reads: groups + (share of J-mers that occur) x their patterns against one read
             // per pattern (3.09 Gbp, J = 16: 51 % occur; K = 30 e = 2, search 1: 211 reads -> 13 words + 54 + ~80 reads).
-            const unsigned long long* jbits = nullptr; int jbLevel = 0;
-            if (ix->tune.jumpGroups != 0) { rc = get_jbits(ix, J, jtab, &jbits, &jbLevel); if (rc) return rc; }
+            const unsigned long long* jbits = nullptr; int jbLevel = 0; uint32_t jbExtra = 0;
+            if (ix->tune.jumpGroups != 0) { rc = get_jbits(ix, J, jtab, &jbits, &jbLevel, &jbExtra); if (rc) return rc; }
+            // the call's layouts: bit offsets, the plane of each layout's kind-0 bitmap, the first plane of its kind-1 bitmaps
+            const std::vector<uint32_t> shifts = group_layout_shifts(J);
+            uint32_t kind0Layouts = jbits ? 1u : 0u;
+            for (uint32_t L = 0; L < GROUP_MAX_LAYOUTS; ++L) { layShift[L] = L < shifts.size() ? shifts[L] : 0u; layPlane0[L] = 0u; layPlane1[L] = 0u; }
+            if (jbLevel >= 1) layPlane1[0] = 1u;
+            if (jbLevel >= 2) layPlane1[1] = 17u;
+            for (uint32_t L = 1; L < shifts.size() && L - 1u < jbExtra && ix->tune.jumpLayouts != 0; ++L) { layPlane0[L] = 1u + 16u * (uint32_t)jbLevel + (L - 1u); kind0Layouts |= 1u << L; }
             const double occur = 1.0 - std::exp(-(double)ix->nRows / std::ldexp(1.0, 2 * (int)J));
             const double occur1 = 1.0 - std::exp(-(double)ix->nRows / std::ldexp(1.0, 2 * (int)J + 4));
             std::vector<uint64_t> masks;
@@ -961,7 +990,11 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
             for (uint32_t s2 = 0; s2 < plan.nSearches; ++s2) {
                 // kind 1 needs two more infix characters to the right of the J-mer (and, for MID groups, its second bitmap family)
                 const bool ext = jbLevel >= (J >= 2 * GROUP_SYMS ? 2 : 1) && js[s2].regionA + J + 2u <= L;
-                oss_make_items(js[s2], p->E, jbits ? (ix->tune.jumpGroups < 0 ? 2 : 1) : 0, ext, occur, occur1, &masks, &items[s2]);
+                // which groups are formed: where the occurrence estimate expects fewer table reads (e <= 1), wherever two patterns share a word (e >= 2:
+                // a dead table read also costs its lane a turn of the loop -- 3.09 Gbp K=30 e=2: 254.6 ms against 273.0 with the estimate,
+                // e=1 287.8 / 288.8, K=100 e=1 226.9 / 224.9; profiles/r05/sweep_layouts.txt)
+                const int gmode = !jbits ? 0 : ix->tune.jumpGroups > 0 ? 1 : (p->E >= 2 ? 1 : 2);
+                oss_make_items(js[s2], p->E, gmode, ext, occur, occur1, &masks, &items[s2], kind0Layouts);
             }
             jbitsCall = masks.empty() ? nullptr : jbits; jbitsWords = (1ull << (2 * J)) / 64;
             for (size_t k = 0; k < masks.size(); ++k) gmaskCall[k] = masks[k];
@@ -975,7 +1008,11 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
                     nbWord |= nr << 12 | nl << 28 | 1u << 31;
                 }
                 jinfoHost[s2] = make_uint4((uint32_t)patHost.size() | (uint32_t)items[s2].items.size() << 16, js[s2].meta0, items[s2].items[0], nbWord);
-                jinfo2Host[s2] = make_uint4((uint32_t)patHost.size() + items[s2].low, (uint32_t)patHost.size() + items[s2].low + items[s2].mid, items[s2].ext ? 1u : 0u, 0u);
+                {   // where the groups of each layout end among the call's items (16 bits each)
+                    uint32_t e16[GROUP_MAX_LAYOUTS], run = (uint32_t)patHost.size();
+                    for (uint32_t L = 0; L < GROUP_MAX_LAYOUTS; ++L) { run += L < items[s2].seg.size() ? items[s2].seg[L] : 0u; e16[L] = run; }
+                    jinfo2Host[s2] = make_uint4(e16[0] | e16[1] << 16, e16[2] | e16[3] << 16, e16[4] | e16[5] << 16, items[s2].ext ? 1u : 0u);
+                }
                 jumpAPacked[s2 >> 2] |= js[s2].regionA << (8u * (s2 & 3u));
                 patHost.insert(patHost.end(), items[s2].items.begin(), items[s2].items.end());
             }
@@ -991,7 +1028,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         // host-device synchronisation
         uint64_t h = 1469598103934665603ull;
         auto mix = [&h](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
-        mix(p->K); mix(p->E); mix(plan.infix); mix((uint64_t)(int64_t)ix->tune.partBias); mix((uint64_t)(int64_t)ix->tune.ossWeights); mix(jumpJ); mix((uint64_t)ix->tune.jumpFilter); mix(patHost.size()); for (uint32_t v : patHost) mix(v); for (const uint4& v : jinfo2Host) { mix(v.x); mix(v.y); mix(v.z); } mix(text_begin); mix(text_len); mix(first_seq); mix(n_seq); mix(n_intervals);
+        mix(p->K); mix(p->E); mix(plan.infix); mix((uint64_t)(int64_t)ix->tune.partBias); mix((uint64_t)(int64_t)ix->tune.ossWeights); mix(jumpJ); mix((uint64_t)ix->tune.jumpFilter); mix(patHost.size()); for (uint32_t v : patHost) mix(v); for (const uint4& v : jinfo2Host) { mix(v.x); mix(v.y); mix(v.z); mix(v.w); } mix(text_begin); mix(text_len); mix(first_seq); mix(n_seq); mix(n_intervals);
         for (uint64_t k = 0; k < 2 * n_intervals; ++k) mix(intervals[k]);
         if (!ix->sigValid || ix->sig != h) {
             GM_HIP(hipMemcpyAsync(ix->d_table, plan.table.data(), plan.table.size() * sizeof(OssRecord), hipMemcpyHostToDevice, st));
@@ -1110,6 +1147,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     A.jumpJ = jumpJ; A.jumpAPacked[0] = jumpAPacked[0]; A.jumpAPacked[1] = jumpAPacked[1];
     A.patterns = ix->d_patterns; A.jinfo = ix->d_jinfo; A.jinfo2 = ix->d_jinfo2; A.jtab = jtab; A.jbits = jbitsCall; A.jbitsWords = jbitsWords;
     for (uint32_t k = 0; k < GROUP_MAX_MASKS; ++k) A.gmask[k] = gmaskCall[k];
+    for (uint32_t k = 0; k < 8u; ++k) { A.layShift[k] = layShift[k]; A.layPlane0[k] = layPlane0[k]; A.layPlane1[k] = layPlane1[k]; }
     A.sliceBegin = text_begin; A.sliceLen = text_len; A.ownBegin = 0; A.ownEnd = text_len; A.ownChunkLen = 0; A.selBlocks = nullptr; A.nSelBlocks = 0;
     *Aout = A;
     return GM_OK;
@@ -1756,6 +1794,7 @@ int gm_index_set_tuning(gm_index* ix, const char* name, int64_t value)
         {"jump", &ix->tune.jump, dflt.jump, 0, 16}, {"self_hit", &ix->tune.selfHit, dflt.selfHit, 0, 1}, {"jump_filter", &ix->tune.jumpFilter, dflt.jumpFilter, 0, 2},
         {"range_add", &ix->tune.rangeAdd, dflt.rangeAdd, 0, 1}, {"verify_t_ext", &ix->tune.verifyTExt, dflt.verifyTExt, 0, (int64_t)VERIFY_TMAX},
         {"fast_verify", &ix->tune.fastVerify, dflt.fastVerify, 0, 1},
+        {"jump_layouts", &ix->tune.jumpLayouts, dflt.jumpLayouts, 0, 1},   // 0: groups of jump patterns in the LOW / MID layouts only (round 4), -1 / 1: at any three adjacent characters
         {"no_wrap", &ix->tune.noWrap, dflt.noWrap, 0, 1},   // 0: every add into an accumulator returns the old value and checks for a wrap-around (-1 / 1: only where one is possible)
         {"iter_cap", &ix->tune.iterCap, dflt.iterCap, 1, 0x7FFFFFFF}, {"stall_cap", &ix->tune.stallCap, dflt.stallCap, 1, 0x7FFFFFFF},   // bounds of a hung search loop (tests force them)
         {"jump_groups", &ix->tune.jumpGroups, dflt.jumpGroups, 0, 1},   // groups of jump patterns behind the existence bitmap: 0 never, 1 wherever possible, -1 where they save table reads

@@ -29,6 +29,7 @@ struct Tuning {
     int verifyT = -1, ldsStack = -1, blocksPerCU = 4, qtable = -1, satMinW = 256, fetchBatch = -1, probation = -1, verifyCost = 3;
     int noStore = 0, noSaturate = 0, skipDup = -1, coop = -1, useCtx = 1, steal = -1, partBias = 0, childTables = -1, ossWeights = -1, jump = -1, selfHit = 1, jumpFilter = 1, rangeAdd = 1, verifyTExt = -1, jumpGroups = -1;
     int noWrap = -1;                   // 0: adds into the accumulators always return and check for a 2^32 wrap-around (gm_api.hip: acc_cannot_wrap)
+    int jumpLayouts = -1;              // 0: groups of jump patterns only in the two layouts of round 4
     int fastVerify = -1;               // -1: whenever the call allows it (gm_api.hip: prepare_search), 0: never
     int iterCap = -1, stallCap = -1;   // bounds of a hung search loop (gm_kernels.h: SearchArgs::iterCap / stallCap); -1: never / 2^22 idle iterations
 };
@@ -56,6 +57,7 @@ struct gm_index {
     uint4* d_ctx = nullptr;           // verification records {SA[row], 56 symbols around it}, 32 B per row, when HBM allows (gm_kernels.h: CTX_*)
     std::map<uint32_t, uint4*> qtables;   // q -> device table of 4^q entries (built on first use)
     std::map<uint32_t, unsigned long long*> jbits;   // q -> existence bitmap of the q-mers, 4^q bits (groups of jump patterns, gm_oss.h)
+    std::map<uint32_t, uint32_t> jbitsExtra;         // q -> kind-0 planes of the layouts beyond LOW that follow the planes of jbitsLevel
     std::map<uint32_t, int> jbitsLevel;              // q -> 0: "the q-mer occurs" only, 1: + "... followed by two given letters" (16 x 4^q bits), 2: + the same in the MID layout
     uint4* d_jinfo2 = nullptr;
     uint64_t sig = 0; bool sigValid = false;   // signature of the call whose tables are on the device

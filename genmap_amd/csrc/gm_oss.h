@@ -162,13 +162,31 @@ inline bool oss_jump_patterns(uint32_t E, const OssRecord& rec, uint32_t L, uint
 //               belongs to the search.
 // The lane reads the group's word, brings it into "rotation space" (word_to_rotations) and walks the set bits of word & mask: only those
 // patterns are looked up in the table.  A search's items are its LOW groups, then its MID groups, then its plain patterns.
+// Round 5: a group may sit at ANY three adjacent characters ("layout" = the bit offset `sh` of their 6 bits inside the J-mer index): the
+// one-substitution patterns of the searches that start on the RIGHT of the infix (e = 2: searches 2 and 3) touch the first eight
+// characters of their J-mer, which neither LOW (sh = 0) nor MID (sh = 6) covers -- they were 50 of the 62 plain table reads of a
+// K = 30 e = 2 block.  Word index and bit of a J-mer in the bitmap of layout sh: group_word / (idx >> sh) & 63 (sh = 0 and 6 are the LOW and
+// MID of round 4, bit for bit).  Kind 1 exists for LOW and MID only (16 bitmaps each); the other layouts have a kind-0 bitmap of their own.
+// A call uses at most GROUP_MAX_LAYOUTS layouts; a search's items come layout by layout (segments), then its plain patterns.
 constexpr uint32_t GROUP_SYMS = 3;
 constexpr uint32_t GROUP_MAX_MASKS = 8;
+constexpr uint32_t GROUP_MAX_LAYOUTS = 6;
+// the layouts a call with jumps of J characters may use, in the order of its segments: LOW, MID, then from the left end of the J-mer
+inline std::vector<uint32_t> group_layout_shifts(uint32_t J)
+{
+    std::vector<uint32_t> sh;
+    if (J <= GROUP_SYMS) return sh;
+    sh.push_back(0u);
+    if (J >= 2u * GROUP_SYMS) sh.push_back(6u);
+    for (int32_t v = 2 * (int32_t)J - 6; v > 6 && sh.size() < GROUP_MAX_LAYOUTS; v -= 6) sh.push_back((uint32_t)v);
+    return sh;
+}
 inline uint32_t rot_errors_host(uint32_t rw) { return (uint32_t)__builtin_popcount((rw | rw >> 1) & 0x55555555u); }
 
 struct SearchItems {
-    std::vector<uint32_t> items;   // LOW groups, MID groups, plain rotation words
-    uint32_t low = 0, mid = 0;     // groups of either layout
+    std::vector<uint32_t> items;   // the groups of layout 0, of layout 1, ..., then the plain rotation words
+    std::vector<uint32_t> seg;     // groups per layout (same order as group_layout_shifts)
+    uint32_t groups() const { uint32_t g = 0; for (uint32_t v : seg) g += v; return g; }
     uint32_t patterns = 0;         // patterns covered (== JumpSearch::pat.size())
     bool ext = false;              // some group is of kind 1: the lane needs the two letters behind the J-mer
 };
@@ -184,54 +202,51 @@ inline uint32_t oss_rotation_word(uint32_t d, uint32_t J)
 //   group:  0 plain patterns only, 1 groups wherever two patterns share a word, 2 groups where they are expected to save table reads
 //           (occur0 / occur1 = share of the J-mers / of the (J+2)-mers that occur in the text)
 //   ext:    kind 1 bitmaps are at hand and two more infix characters lie to the right of the J-mer
-// masks: the distinct masks of the call so far (shared by its searches).  Falls back to plain patterns when the masks run out.
-inline void oss_make_items(const JumpSearch& js, uint32_t E, int group, bool ext, double occur0, double occur1, std::vector<uint64_t>* masks, SearchItems* out)
+// masks: the distinct masks of the call so far (shared by its searches).  A group whose mask would be the ninth is not formed.
+inline void oss_make_items(const JumpSearch& js, uint32_t E, int group, bool ext, double occur0, double occur1, std::vector<uint64_t>* masks, SearchItems* out,
+                           uint32_t kind0Layouts = 1u)   // kind0Layouts: bit L set = layout L has a kind-0 bitmap at hand (LOW always has)
 {
-    out->items.clear(); out->patterns = (uint32_t)js.pat.size(); out->low = out->mid = 0; out->ext = false;
+    const std::vector<uint32_t> shifts = group_layout_shifts(js.J);
+    out->items.clear(); out->patterns = (uint32_t)js.pat.size(); out->seg.assign(shifts.size(), 0u); out->ext = false;
     std::vector<uint32_t> rws;
     for (uint32_t d : js.pat) rws.push_back(oss_rotation_word(d, js.J));
-    if (!group || js.J <= GROUP_SYMS || !masks) { out->items = rws; return; }
-    struct G { uint32_t key; uint64_t mask; uint32_t kind; uint32_t one; };
+    if (!group || shifts.empty() || !masks) { out->items = rws; return; }
+    struct G { uint32_t key; uint64_t mask; uint32_t kind; };
     std::vector<uint64_t> m2 = *masks;
     bool fail = false;
-    // members that may share a word: same rotations outside the layout's three characters, same kind
-    auto collect = [&](const std::vector<uint32_t>& in, uint32_t shift, std::vector<G>* gs) {
-        for (uint32_t rw : in) {
-            const uint32_t key = rw & ~(63u << shift), kind = (ext && rot_errors_host(rw) == E) ? 1u : 0u;
+    std::vector<uint32_t> rest = rws, grouped;
+    for (size_t L = 0; L < shifts.size(); ++L) {
+        const uint32_t shift = shifts[L];
+        const bool k0 = ((kind0Layouts >> L) & 1u) != 0u, k1 = ext && L < 2u;   // kind 1 (two more letters) exists for LOW and MID
+        if (!k0 && !k1) continue;
+        // members that may share a word: same rotations outside the layout's three characters, same kind
+        std::vector<G> gs;
+        for (uint32_t rw : rest) {
+            const uint32_t key = rw & ~(63u << shift), kind = (k1 && rot_errors_host(rw) == E) ? 1u : 0u;
             size_t g = 0;
-            while (g < gs->size() && !((*gs)[g].key == key && (*gs)[g].kind == kind)) ++g;
-            if (g == gs->size()) gs->push_back(G{key, 0, kind, rw});
-            (*gs)[g].mask |= 1ull << ((rw >> shift) & 63u);
+            while (g < gs.size() && !(gs[g].key == key && gs[g].kind == kind)) ++g;
+            if (g == gs.size()) gs.push_back(G{key, 0, kind});
+            gs[g].mask |= 1ull << ((rw >> shift) & 63u);
         }
-    };
-    auto worth = [&](const G& g) {
-        const int m = __builtin_popcountll(g.mask);
-        if (m < 2) return false;
-        if (group == 1) return true;
-        return m * (1.0 - (g.kind ? occur1 : occur0)) >= 1.5;   // one word + the members that pass it, against one table read per member
-    };
-    auto emit = [&](const G& g, uint32_t shift) {
-        size_t id = 0;
-        while (id < m2.size() && m2[id] != g.mask) ++id;
-        if (id == m2.size()) { if (m2.size() == GROUP_MAX_MASKS) { fail = true; return; } m2.push_back(g.mask); }
-        out->items.push_back(g.key | ((uint32_t)id | g.kind << 3) << shift);
-        out->ext = out->ext || g.kind != 0u;
-    };
-    std::vector<G> lowG, midG; std::vector<uint32_t> rest, plain;
-    collect(rws, 0u, &lowG);
-    for (const G& g : lowG) {
-        if (worth(g)) { emit(g, 0u); out->low++; }
-        else for (uint32_t r = 0; r < 64u; ++r) if ((g.mask >> r) & 1ull) rest.push_back(g.key | r);
+        std::vector<uint32_t> left;
+        for (const G& g : gs) {
+            const int m = __builtin_popcountll(g.mask);
+            bool take = m >= 2 && (g.kind ? k1 : k0);
+            // one word + the members that pass it, against one table read per member
+            if (take && group != 1) take = m * (1.0 - (g.kind ? occur1 : occur0)) >= 1.5;
+            if (take) {
+                size_t id = 0;
+                while (id < m2.size() && m2[id] != g.mask) ++id;
+                if (id == m2.size()) { if (m2.size() == GROUP_MAX_MASKS) take = false; else m2.push_back(g.mask); }   // (out of masks: its members stay single)
+                if (take) { grouped.push_back(g.key | ((uint32_t)id | g.kind << 3) << shift); out->seg[L]++; out->ext = out->ext || g.kind != 0u; }
+            }
+            if (!take) for (uint32_t r = 0; r < 64u; ++r) if ((g.mask >> r) & 1ull) left.push_back(g.key | r << shift);
+        }
+        rest = left;
     }
-    if (js.J >= 2u * GROUP_SYMS && ext) {   // what stayed alone: the same with the three characters in front (kind 1 only: one more bitmap family)
-        collect(rest, 6u, &midG);
-        for (const G& g : midG) {
-            if (g.kind == 1u && worth(g)) { emit(g, 6u); out->mid++; }
-            else for (uint32_t r = 0; r < 64u; ++r) if ((g.mask >> r) & 1ull) plain.push_back(g.key | r << 6);
-        }
-    } else plain = rest;
-    out->items.insert(out->items.end(), plain.begin(), plain.end());
-    if (fail || out->low > 255u || out->mid > 255u) { out->items = rws; out->low = out->mid = 0; out->ext = false; return; }
+    out->items = grouped;
+    out->items.insert(out->items.end(), rest.begin(), rest.end());
+    if (fail || out->items.size() > 0xFFFFu) { out->items = rws; out->seg.assign(shifts.size(), 0u); out->ext = false; return; }
     *masks = m2;
 }
 
@@ -261,6 +276,9 @@ GM_HD uint32_t rot_errors(uint32_t rw)   // substitutions of a rotation word
 
 // index of a MID group's bitmaps: the J-mer index with its two lowest 6-bit fields swapped (the group's characters become the bit number)
 GM_HD uint32_t jump_swap_mid(uint32_t idx) { return (idx & ~0xFFFu) | (idx & 63u) << 6 | ((idx >> 6) & 63u); }
+// word of a J-mer in the bitmap of the layout whose three characters sit at bit offset sh of the index (its bit: (idx >> sh) & 63): the
+// index with those six bits taken out.  sh = 0: idx >> 6 (LOW); sh = 6: jump_swap_mid(idx) >> 6 (MID).
+GM_HD uint32_t group_word(uint32_t idx, uint32_t sh) { return (uint32_t)(((uint64_t)idx >> (sh + 6u)) << sh) | (idx & ((1u << sh) - 1u)); }
 
 // Bitmap word of the 64 J-mers that share the first J - 3 characters: bit (c0 << 4 | c1 << 2 | c2) = the J-mer ending in letters c0 c1 c2
 // occurs.  Returns the same bits indexed by ROTATIONS relative to the needle's last three letters low6 = n0 << 4 | n1 << 2 | n2:

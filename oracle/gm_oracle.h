@@ -115,4 +115,7 @@ void gmo_set_line_symbols(uint32_t syms);
 #ifdef __cplusplus
 }
 #endif
+/* 1: gmo_compute_mappability does not clear `out` (the caller hands in zeros); measurement only */
+void gmo_set_skip_clear(int on);
+
 #endif

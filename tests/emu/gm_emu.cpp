@@ -16,7 +16,7 @@ using namespace gm;
 static uint32_t g_ossWeights = 0;   // relative OSS block lengths for the plans below (gm_host.h: make_map_plan), 0 = even split
 extern "C" void gm_emu_set_oss_weights(uint32_t w) { g_ossWeights = w; }
 static int g_jumpGroups = 0;        // 1: patterns that differ in their last three characters only are read through one word of an existence bitmap (gm_oss.h)
-extern "C" void gm_emu_set_jump_groups(int on) { g_jumpGroups = on; }
+extern "C" void gm_emu_set_jump_groups(int on) { g_jumpGroups = on; }   // 2: groups in every layout (any three adjacent characters), 1: LOW / MID only
 static int g_selfHit = 1;           // self hits of the counting pass (gm_engine.h: self_hit_kmers)
 extern "C" void gm_emu_set_self_hit(int on) { g_selfHit = on; }
 static int g_fastVerify = 1;        // narrow nodes settled from the masks of gm_engine.h: fv_masks where the device would (K <= 32, short windows)
@@ -209,7 +209,7 @@ static void search_plan(const MapPlan& plan, const HostIndex<WPP>& ix, Env& env,
     std::vector<uint64_t> gmasks;
     std::vector<SearchItems> items(plan.nSearches);
     for (uint32_t s = 0; s < plan.nSearches; ++s)
-        if (jumps[s].J) oss_make_items(jumps[s], E, g_jumpGroups ? 1 : 0, jumps[s].regionA + jumps[s].J + 2u <= L, 0.5, 0.05, &gmasks, &items[s]);
+        if (jumps[s].J) oss_make_items(jumps[s], E, g_jumpGroups ? 1 : 0, jumps[s].regionA + jumps[s].J + 2u <= L, 0.5, 0.05, &gmasks, &items[s], g_jumpGroups > 1 ? 0xFFu : 1u);
     uint64_t roots = plan.numRoots();
     uint32_t rpb = plan.nSearches * plan.nStrands;
     // the rule of gm_api.hip (prepare_search): every text symbol an item may look at lies inside its row's record
@@ -270,11 +270,14 @@ static void search_plan(const MapPlan& plan, const HostIndex<WPP>& ix, Env& env,
                 uint32_t e0 = SYM_N, e1 = SYM_N;
                 if (it.ext) { e0 = env.text_char(rt, a0 + js.J); e1 = env.text_char(rt, a0 + js.J + 1u); }
                 const bool extValid = e0 < SYM_N && e1 < SYM_N;
+                const std::vector<uint32_t> shifts = group_layout_shifts(js.J);
                 for (size_t q = 0; q < it.items.size(); ++q) {
                     const uint32_t d = it.items[q];
-                    if (q >= it.low + it.mid) { lookup(rot_add(base2, d), rot_errors(d)); continue; }
+                    if (q >= it.groups()) { lookup(rot_add(base2, d), rot_errors(d)); continue; }
                     // a group: the word of its bitmap (built here by asking the index), in rotation space, masked; only patterns that pass are looked up
-                    const uint32_t shift = q < it.low ? 0u : 6u, own = (d >> shift) & 63u, kind = own >> 3, rotw = d & ~(63u << shift);
+                    size_t lay = 0, cum = it.seg[0];
+                    while (q >= cum) cum += it.seg[++lay];
+                    const uint32_t shift = shifts[lay], own = (d >> shift) & 63u, kind = own >> 3, rotw = d & ~(63u << shift);
                     const uint32_t pre = rot_add(base2, rotw);
                     uint64_t word = 0;
                     for (uint32_t c = 0; c < 64u && (kind == 0u || extValid); ++c) {
@@ -368,7 +371,13 @@ static int run(const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nse
 // oss_make_items (plain / every possible group / groups by the occurrence rule) must expand to exactly the patterns of oss_jump_patterns --
 // same substituted J-mers with the same error counts -- for `reps` random needles; groups of kind 1 may only hold patterns that have spent
 // the whole budget; word_to_rotations / rot_add must agree with their definitions.  Returns 0, or a code that names the first failure.
+extern "C" int gm_emu_check_items2(uint32_t K, uint32_t E, uint32_t J, uint32_t ossWeights, uint32_t reps, uint32_t seed, uint64_t* stats, uint32_t layouts);
 extern "C" int gm_emu_check_items(uint32_t K, uint32_t E, uint32_t J, uint32_t ossWeights, uint32_t reps, uint32_t seed, uint64_t* stats)
+{
+    return gm_emu_check_items2(K, E, J, ossWeights, reps, seed, stats, 1u);
+}
+// layouts: bit L = groups of layout L may be of kind 0 (1: the LOW / MID rule of round 4; 0xFF: every layout)
+extern "C" int gm_emu_check_items2(uint32_t K, uint32_t E, uint32_t J, uint32_t ossWeights, uint32_t reps, uint32_t seed, uint64_t* stats, uint32_t layouts)
 {
     uint64_t x = 88172645463325252ull ^ ((uint64_t)seed << 32 | seed);
     auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
@@ -394,17 +403,28 @@ extern "C" int gm_emu_check_items(uint32_t K, uint32_t E, uint32_t J, uint32_t o
             JumpSearch js;
             if (!oss_jump_patterns(E, plan.table[(size_t)(plan.stepSize - 1) * 8 + s], plan.infix, J, 4096, &js) || js.pat.empty()) continue;
             SearchItems it;
-            oss_make_items(js, E, mode, js.regionA + J + 2u <= plan.infix, 0.51, 0.044, &masks, &it);
-            if (it.low + it.mid > it.items.size() || masks.size() > GROUP_MAX_MASKS) return 4;
-            if (mode == 2) { nPat += js.pat.size(); nItems += it.items.size(); nGroups += it.low + it.mid; }
+            oss_make_items(js, E, mode, js.regionA + J + 2u <= plan.infix, 0.51, 0.044, &masks, &it, layouts);
+            if (it.groups() > it.items.size() || masks.size() > GROUP_MAX_MASKS) return 4;
+            if (mode == 2) { nPat += js.pat.size(); nItems += it.items.size(); nGroups += it.groups(); }
+            const std::vector<uint32_t> shifts = group_layout_shifts(J);
             for (uint32_t rep = 0; rep < reps; ++rep) {
                 const uint32_t base = J == 16u ? (uint32_t)rnd() : (uint32_t)rnd() & ((1u << (2u * J)) - 1u);
                 std::vector<uint64_t> A, B;   // (substituted J-mer, errors) of either form
                 for (uint32_t d : js.pat) A.push_back((uint64_t)jump_apply(base, d, J) << 8 | (d & 7u));
                 for (size_t q = 0; q < it.items.size(); ++q) {
                     const uint32_t d = it.items[q];
-                    if (q >= it.low + it.mid) { B.push_back((uint64_t)rot_add(base, d) << 8 | rot_errors(d)); continue; }
-                    const uint32_t sh = q < it.low ? 0u : 6u, own = (d >> sh) & 63u, rotw = d & ~(63u << sh);
+                    if (q >= it.groups()) { B.push_back((uint64_t)rot_add(base, d) << 8 | rot_errors(d)); continue; }
+                    size_t lay = 0, cum = it.seg[0];
+                    while (q >= cum) cum += it.seg[++lay];
+                    const uint32_t sh = shifts[lay], own = (d >> sh) & 63u, rotw = d & ~(63u << sh);
+                    if ((own >> 3) && lay >= 2) return 7;   // kind 1 exists for LOW and MID only
+                    // word / bit of the layout's bitmap: all 64 members share the word, and their bits are their three characters
+                    for (uint32_t c = 0; c < 64u; ++c) {
+                        const uint32_t cand = (rot_add(base, rotw) & ~(63u << sh)) | c << sh;
+                        if (group_word(cand, sh) != group_word(rot_add(base, rotw), sh) || ((cand >> sh) & 63u) != c) return 8;
+                    }
+                    if (sh == 0u && group_word(base, 0u) != base >> 6) return 9;
+                    if (sh == 6u && group_word(base, 6u) != jump_swap_mid(base) >> 6) return 9;
                     if ((own & 7u) >= masks.size()) return 5;
                     for (uint32_t rot = 0; rot < 64u; ++rot) if ((masks[own & 7u] >> rot) & 1ull) {
                         const uint32_t rw = rotw | rot << sh;

@@ -258,14 +258,17 @@ class OracleIndex:
 
     def mappability(self, K, E, text_begin=0, text_len=None, first_seq=0, n_seq=None, overlap=None, revcompl=True,
                     value_bits=16, directory=False, exclude_pseudo=False, csv=False, threads=1, use_shortcut=False,
-                    intervals=None, seq_file_id=None, want_flag=False, infix=0):
+                    intervals=None, seq_file_id=None, want_flag=False, infix=0, out=None):
         if n_seq is None:
             n_seq = len(self.seq_len) - first_seq
         if text_len is None:
             text_len = int(self.cum[first_seq + n_seq] - self.cum[first_seq])
         p = _Params(K, E, -1 if overlap is None else overlap, int(revcompl), value_bits, int(directory),
                     int(exclude_pseudo), int(csv), threads, int(use_shortcut), int(infix))
-        out = np.zeros(text_len, dtype=np.uint8 if value_bits == 8 else np.uint16)
+        if out is None:
+            out = np.zeros(text_len, dtype=np.uint8 if value_bits == 8 else np.uint16)
+        else:   # (bench.py: a vector kept between calls; with gmo_set_skip_clear the caller keeps it zeroed)
+            assert out.size == text_len and out.dtype == (np.uint8 if value_bits == 8 else np.uint16) and out.flags.c_contiguous
         iv = None
         if intervals:
             iv = np.ascontiguousarray(np.asarray(intervals, dtype=np.uint64).reshape(-1))

@@ -301,6 +301,10 @@ def test_groups_of_jump_patterns_read_through_the_existence_bitmap(K, E):
             out, st1 = emu_map2(ix, 1, K, E, value_bits=16, verify_t=T, jump=jump)
             assert np.array_equal(plain, exp) and np.array_equal(out, exp), (K, E, T, jump, np.flatnonzero(out != exp)[:10])
             assert 0 < st1[4] <= st0[4]          # only J-mers that occur are looked up
+            e.gm_emu_set_jump_groups(2)          # round 5: groups at any three adjacent characters (the searches that start on the right)
+            out2, st2 = emu_map2(ix, 1, K, E, value_bits=16, verify_t=T, jump=jump)
+            assert np.array_equal(out2, exp), (K, E, T, jump, "all layouts", np.flatnonzero(out2 != exp)[:10])
+            assert 0 < st2[4] <= st1[4]
     finally:
         e.gm_emu_set_jump_groups(0)
 
@@ -378,6 +382,16 @@ def test_items_of_a_search_expand_to_its_patterns(E):
             assert rc in (0, -1, -2), (K, E, J, rc)
             if (K, E, J) == (30, 2, 16):
                 assert rc == 0 and tuple(int(v) for v in st) == (261, 80, 18), st
+    # round 5: every layout may hold kind-0 groups -- the one-substitution patterns of the searches that start on the right of the infix
+    e.gm_emu_check_items2.restype = C.c_int
+    e.gm_emu_check_items2.argtypes = [C.c_uint32] * 6 + [C.c_void_p, C.c_uint32]
+    for K in (24, 30, 36, 50, 100, 150):
+        for J in (16, 15, 12, 9, 6, 5, 4):
+            rc = e.gm_emu_check_items2(K, E, J, 0x8845 if E == 2 else 0, 3, K * 100 + J + 1, H._ptr(st), 0xFF)
+            assert rc in (0, -1, -2), (K, E, J, rc)
+            if (K, E, J) == (30, 2, 16):
+                assert rc == 0 and int(st[0]) == 261 and int(st[1]) < 80 and int(st[2]) > 18, st
+                print("K=30 e=2 J=16 with every layout: patterns, items, groups =", [int(v) for v in st])
 
 
 # ---- fast verification: the whole window compared in one go (gm_engine.h: fv_masks, scan_side over masks) ---------------------------

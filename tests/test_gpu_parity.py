@@ -951,6 +951,32 @@ def test_gpu_full_size_grch38_e0_everywhere_e1_e2_k100_on_intervals():
         assert (got[~sel] == 0).all()
         if (K, E) == (30, 2):
             assert (np.minimum(got[sel], 255) >= out0[sel]).all()      # monotone in e
+    # ... and, for the metric's own settings, 2 million positions in 2,112 seeded random intervals spread over all 24 sequences (88 per sequence,
+    # 950 positions each: whole k-mer blocks of either shape and their ragged ends) against the oracle: config C3 (K=30, e=2) and C4 (K=100, e=1).
+    # (the hand-picked intervals above aim at the edges; these sample the bulk: repeat families, unique sequence, both strands)
+    rng = np.random.default_rng(20260929)
+    cumv = np.concatenate([[0], np.cumsum(np.asarray(lens, dtype=np.int64))])
+    riv = []
+    for q in range(len(lens)):
+        span = max(1, int(lens[q]) - 1100)
+        for st in np.sort(rng.integers(0, span, 88)):
+            a = int(cumv[q]) + int(st)
+            if riv and a < riv[-1][1]:
+                a = riv[-1][1]
+            b = min(a + 950, int(cumv[q + 1]))
+            if b > a:
+                riv.append((a, b))
+    rsel = np.zeros(n, bool)
+    for a, b in riv:
+        rsel[a:b] = True
+    assert rsel.sum() >= 1_900_000 * min(1.0, scale) or scale < 1.0
+    for K, E in ((30, 2), (100, 1)):
+        rv = [(a, min(b, n - K + 1)) for a, b in riv if a < n - K + 1]
+        got = ix.map(K, E, value_bits=8, intervals=rv)
+        want = ora.mappability(K, E, value_bits=8, threads=os.cpu_count() or 8, intervals=rv)
+        assert np.array_equal(got, want), (K, E, "random intervals", np.flatnonzero(got != want)[:10])
+        assert (got[~rsel] == 0).all()
+    del rsel
     # "the same result under every schedule" (tests/tests.sh:47-60) at the metric's own size: the default schedule (jumps of 16 characters,
     # neighbour filter, N-less pass + correction pass, verification records, self hits, difference plane) against the plain tree walk
     # with N children (none of those) -- K=30 e=1 at EVERY position, e=2 on 5 % of the k-mer blocks across a sequence boundary
