@@ -382,8 +382,10 @@ def main():
                     gather_chunks(out, plan, rank, dist, stage_on_host=(args.backend != "nccl"))
                     comm["wait_s"] += time.perf_counter() - t1
                 return
-            for sub in plan.sub_ranges(pg.launches):      # the chunks of one launch travel while the next launch computes
-                ix.map_device(pg.local_ptr, K, E, infix=args.infix, value_bits=8, kmer_range=sub, chunks=plan.chunk_arg(rank), stream=stream)
+            pieces = plan.sub_ranges(pg.launches)
+            share = (pieces[0][0], pieces[-1][1])         # the rank's whole share: ONE clear and ONE correction pass for its launches (GM_MAP_FLAG_PIECE)
+            for sub in pieces:                            # the chunks of one launch travel while the next launch computes
+                ix.map_device(pg.local_ptr, K, E, infix=args.infix, value_bits=8, kmer_range=sub, chunks=plan.chunk_arg(rank), stream=stream, piece_of=share)
                 ev = torch.cuda.Event()
                 ev.record()
                 pg.push(sub, ev)
@@ -456,10 +458,11 @@ def main():
             pg.close()
         dt = max_over_ranks(dt)
         my_ms = float(np.mean(kms))
-        pr = per_rank_of([my_ms, (comm["wait_s"] - warm_wait) / max(1, steps) * 1e3])
+        corr_ms = ix.last_stats()["detail"].get("correction_us", 0) / 1e3 if E >= 1 else 0.0   # the step's one correction pass (beside the main search)
+        pr = per_rank_of([my_ms, (comm["wait_s"] - warm_wait) / max(1, steps) * 1e3, corr_ms])
         return {"K": K, "E": E, "infix": infix, "num_kmers": num_kmers, "steps": steps, "warmup": warmup, "dt": dt,
                 "kernel_ms": max(r[0] for r in pr) if pr else my_ms, "kernel_ms_min": float(np.min(kms)), "plan": plan,
-                "comm_mode": comm["mode"], "comm_note": comm["note"], "per_rank": pr, "verified": verified}
+                "comm_mode": comm["mode"], "comm_note": comm["note"], "per_rank": pr, "verified": verified, "correction_ms": corr_ms}
 
     def host_rate(K, E):
         """PCIe-inclusive rates of the drop-in call gm_map (host result vector), never `value`: into ordinary (pageable) memory,
@@ -796,6 +799,8 @@ def main():
         if pr:
             r["per_rank_search_ms"] = [x[0] for x in pr]          # search kernel per step, per rank
             r["per_rank_comm_wait_ms"] = [x[1] for x in pr]       # host time per step spent waiting for the gather / the copies
+            if len(pr[0]) > 2:
+                r["per_rank_correction_ms"] = [x[2] for x in pr]  # the step's ONE correction pass per rank (it runs beside the main search, not behind every launch)
             r["shard_imbalance"] = max(x[0] for x in pr) / max(1e-9, float(np.mean([x[0] for x in pr])))
             r["comm"] = rec.get("comm_mode")
             if rec.get("comm_note"):

@@ -24,7 +24,8 @@ class MapParams(C.Structure):
     _fields_ = [("K", C.c_uint32), ("E", C.c_uint32), ("overlap", C.c_int32), ("infix", C.c_int32),
                 ("revcompl", C.c_int32), ("value_bits", C.c_int32), ("exclude_pseudo", C.c_int32),
                 ("flags", C.c_int32), ("kmer_begin", C.c_uint64), ("kmer_end", C.c_uint64),
-                ("chunk_blocks", C.c_uint32), ("chunk_index", C.c_uint32), ("chunk_stride", C.c_uint32), ("reserved1", C.c_uint32)]
+                ("chunk_blocks", C.c_uint32), ("chunk_index", C.c_uint32), ("chunk_stride", C.c_uint32), ("reserved1", C.c_uint32),
+                ("whole_begin", C.c_uint64), ("whole_end", C.c_uint64)]
 
 
 class IndexInfo(C.Structure):
@@ -50,6 +51,7 @@ class Locations(C.Structure):
 
 
 MAP_FLAG_RANGE = 1
+MAP_FLAG_PIECE = 2    # GM_MAP_FLAG_PIECE: the call is one launch of the share (whole_begin, whole_end)
 WIDE_ROWS = 0x10000   # GM_BLOCK_WIDE_ROWS: OR into block_bytes to force 64-bit rows
 
 EXPORTS = ["gm_device_alloc", "gm_device_free", "gm_ipc_export", "gm_ipc_open", "gm_ipc_close", "gm_push_pieces", "gm_map_shard", "gm_host_pin", "gm_host_unpin", "gm_index_set_tuning", "gm_index_sync", "gm_map_kernel_times", "gm_map_runs", "gm_runs_free", "gm_tuned_infix_length", "gm_tuned_infix_length_locating", "gm_index_export_sa", "gm_locate", "gm_locations_free", "gm_status_string", "gm_last_error", "gm_device_count", "gm_index_build", "gm_index_import", "gm_index_import_sampled", "gm_index_export_sa_sampled",
@@ -326,11 +328,16 @@ class Index:
         _check(self._lib, self._lib.gm_index_export_sa_sampled(self._h, _ptr(mk), _ptr(sm), sm.itemsize, C.byref(n)))
         return mk, sm
 
-    def _params(self, K, E, overlap, infix, revcompl, value_bits, exclude_pseudo, kmer_range, chunks=None):
+    def _params(self, K, E, overlap, infix, revcompl, value_bits, exclude_pseudo, kmer_range, chunks=None, piece_of=None):
         kb, ke = kmer_range if kmer_range is not None else (0, 0)
         flags = MAP_FLAG_RANGE if kmer_range is not None else 0   # an explicit range is literal: (b, b) computes nothing
         cb, ci, cs = chunks if chunks is not None else (0, 0, 0)   # (chunk_blocks, chunk_index, chunk_stride): interleaved chunks
-        return MapParams(K, E, -1 if overlap is None else overlap, infix, int(revcompl), value_bits, int(exclude_pseudo), flags, kb, ke, cb, ci, cs, 0)
+        wb, we = (0, 0)
+        if piece_of is not None:                                    # one launch of the share piece_of = (whole_begin, whole_end)
+            assert kmer_range is not None
+            flags |= MAP_FLAG_PIECE
+            wb, we = piece_of
+        return MapParams(K, E, -1 if overlap is None else overlap, infix, int(revcompl), value_bits, int(exclude_pseudo), flags, kb, ke, cb, ci, cs, 0, wb, we)
 
     def _slice(self, first_seq, n_seq):
         if n_seq is None:
@@ -364,11 +371,12 @@ class Index:
         _check(self._lib, self._lib.gm_map_shard(self._h, tb, tl, first_seq, n_seq, C.byref(p), _ptr(iv), 0 if iv is None else len(iv) // 2, _ptr(sf), _ptr(out)))
 
     def map_device(self, out_ptr, K, E, first_seq=0, n_seq=None, overlap=None, infix=0, revcompl=True, value_bits=16,
-                   exclude_pseudo=False, intervals=None, seq_file_id=None, kmer_range=None, chunks=None, stream=None):
+                   exclude_pseudo=False, intervals=None, seq_file_id=None, kmer_range=None, chunks=None, stream=None, piece_of=None):
         """gm_map_device: result written to device memory at out_ptr (e.g. a torch tensor's data_ptr()).
-        chunks = (chunk_blocks, chunk_index, chunk_stride): only the interleaved chunks of this shard (ShardPlan.chunk_arg)."""
+        chunks = (chunk_blocks, chunk_index, chunk_stride): only the interleaved chunks of this shard (ShardPlan.chunk_arg).
+        piece_of = (whole_begin, whole_end): kmer_range is one launch of that share (GM_MAP_FLAG_PIECE): one clear, one correction pass per share."""
         n_seq, tb, tl = self._slice(first_seq, n_seq)
-        p = self._params(K, E, overlap, infix, revcompl, value_bits, exclude_pseudo, kmer_range, chunks)
+        p = self._params(K, E, overlap, infix, revcompl, value_bits, exclude_pseudo, kmer_range, chunks, piece_of)
         iv = None if not intervals else np.ascontiguousarray(np.asarray(intervals, dtype=np.uint64).reshape(-1))
         sf = None if seq_file_id is None else np.ascontiguousarray(seq_file_id, dtype=np.uint32)
         _check(self._lib, self._lib.gm_map_device(self._h, tb, tl, first_seq, n_seq, C.byref(p), _ptr(iv), 0 if iv is None else len(iv) // 2,

@@ -543,7 +543,8 @@ template <typename T> static int grow(T** p, uint64_t* cap, uint64_t need)
 enum LeafMode { LEAF_COUNT = 0, LEAF_FILESET = 1, LEAF_OCC_COUNT = 2, LEAF_OCC_EMIT = 3, LEAF_STORE = 4, LEAF_STORE8 = 5, LEAF_COUNT_JUMP = 6, LEAF_SCATTER = 7 };
 
 // nu = 16-byte units per stored node / queue entry: 1, or 2 with 64-bit rows (gm_kernels.h: NodeIO)
-static inline size_t search_lds_bytes(const SearchArgs& A, uint32_t nu) { return (size_t)(4u * A.vqCap * nu + 4u * 64u * (A.ldsDepth * nu + A.winChunks)) * 16u + 4u * 80u * 4u + 544u + (A.entrySlots ? 4096u : 0u) + (A.lqCap ? 4u * (A.lqCap * 16u + 80u * 4u) : 0u); }
+static uint32_t g_ldsPad = 0;   // (measurement: bytes of LDS requested on top of what a block uses -- where is the occupancy cliff?  knob "lds_pad")
+static inline size_t search_lds_bytes(const SearchArgs& A, uint32_t nu) { return (size_t)g_ldsPad + (size_t)(4u * A.vqCap * nu + 4u * 64u * (A.ldsDepth * nu + A.winChunks)) * 16u + 4u * 80u * 4u + 448u + (A.entrySlots ? 4096u : 0u) + (A.lqCap ? 4u * (A.lqCap * 16u + 80u * 4u) : 0u); }
 
 template <int WPP, class EnvT>
 static int launch_one(const SearchArgs& A, unsigned blocks, hipStream_t st)
@@ -823,7 +824,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
 
     // shard [kmer_begin, kmer_end): blocks whose first k-mer lies inside
     uint64_t blockBegin = 0, blockEnd = plan.numBlocks;
-    if ((p->flags & GM_MAP_FLAG_RANGE) || p->kmer_begin != 0 || p->kmer_end != 0) {
+    if ((p->flags & (GM_MAP_FLAG_RANGE | GM_MAP_FLAG_PIECE)) || p->kmer_begin != 0 || p->kmer_end != 0) {
         if (plan.useList) {
             auto lo = std::lower_bound(plan.blocks.begin(), plan.blocks.end(), p->kmer_begin, [](const std::pair<uint32_t, uint32_t>& b, uint64_t v) { return MapPlan::block_pos(b) < v; });
             auto hi = std::lower_bound(plan.blocks.begin(), plan.blocks.end(), p->kmer_end, [](const std::pair<uint32_t, uint32_t>& b, uint64_t v) { return MapPlan::block_pos(b) < v; });
@@ -905,9 +906,18 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     const int wantPerCU = std::max(1, ix->tune.blocksPerCU);   // default 4 = 4 waves/SIMD, what the kernel's VGPR count allows
     // (calls that may jump keep their table entries in flight in LDS: one 16-byte slot per lane)
     const bool mayJump = wantJump && p->E >= 1 && (ix->d_sa || ix->d_saMark) && ix->tune.jump != 0 && !ix->wide;
-    auto lds_bytes_for = [&](uint32_t d) { return (size_t)(4u * vqCap * nu + 4u * 64u * (d * nu + winChunks)) * 16u + 4u * 80u * 4u + 544u + (mayJump ? 4096u : 0u) + (lqCap ? 4u * (lqCap * 16u + 80u * 4u) : 0u); };   // == search_lds_bytes
+    g_ldsPad = (uint32_t)std::max(0, ix->tune.ldsPad);
+    auto lds_bytes_for = [&](uint32_t d) { return (size_t)g_ldsPad + (size_t)(4u * vqCap * nu + 4u * 64u * (d * nu + winChunks)) * 16u + 4u * 80u * 4u + 448u + (mayJump ? 4096u : 0u) + (lqCap ? 4u * (lqCap * 16u + 80u * 4u) : 0u); };   // == search_lds_bytes
+    // Blocks per CU that REALLY become resident: the occupancy query says four blocks of up to 40,960 B fit the 160 KB of a CU, the device
+    // runs three of them beyond ~38.6 KB per block (measured with padded launches, 3.09 Gbp: K=30 e=2 244 ms at 36,544 and 37,568 B per
+    // block, 250 at 38,592, 279 at 39,616 and 40,640 = the time of three blocks per CU; K=100 e=1 192 / 193 / 220 ms at 36,544 / 38,592 /
+    // 40,640 B; profiles/r05/sweep_lds_occupancy_cliff.txt).  Round 4's last change had put K=30 e>=1 and K=100 at 40,640 B.
+    constexpr size_t LDS_USABLE_PER_CU = 154624;   // 151 KB
     auto blocks_for = [&](uint32_t d, int* nb) {
-        switch (ix->wpp) { case 1: return occupancy_blocks<1>(nb, lds_bytes_for(d)); case 2: return occupancy_blocks<2>(nb, lds_bytes_for(d)); case 3: return occupancy_blocks<3>(nb, lds_bytes_for(d)); default: return occupancy_blocks<9>(nb, lds_bytes_for(d)); }
+        int rc2;
+        switch (ix->wpp) { case 1: rc2 = occupancy_blocks<1>(nb, lds_bytes_for(d)); break; case 2: rc2 = occupancy_blocks<2>(nb, lds_bytes_for(d)); break; case 3: rc2 = occupancy_blocks<3>(nb, lds_bytes_for(d)); break; default: rc2 = occupancy_blocks<9>(nb, lds_bytes_for(d)); break; }
+        if (!rc2) *nb = std::min<int>(*nb, (int)(LDS_USABLE_PER_CU / std::max<size_t>(lds_bytes_for(d), 1)));
+        return rc2;
     };
     // stack levels kept in LDS: four when they fit beside the needle windows and the verification queue at full occupancy;
     // long windows (K >= ~60) trade levels for resident blocks -- a fourth block per CU is worth more than the levels
@@ -915,8 +925,9 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     uint32_t ldsDepth = 0; int perCU = 0;
     if (verifyRows > 1u && ix->tune.ldsStack < 0) {   // long windows (K >= ~64): a smaller verification queue where it buys the fourth block per CU (K=100 e=1: 220 -> 200 ms)
         int nb2 = 0, nb1 = 0;
-        rc = blocks_for(1u, &nb2); if (rc) return rc;
-        vqCap = vq_cap(1u); rc = blocks_for(1u, &nb1); if (rc) return rc;
+        const uint32_t d0 = (p->E >= 3 && nu == 1u) ? std::min(2u, depth) : 0u;   // the fewest LDS stack levels the choice below may end at
+        rc = blocks_for(d0, &nb2); if (rc) return rc;
+        vqCap = vq_cap(1u); rc = blocks_for(d0, &nb1); if (rc) return rc;
         if (std::min(nb1, wantPerCU) > std::min(nb2, wantPerCU)) verifyRows = 1u; else vqCap = vq_cap(verifyRows);
     }
     if (ix->tune.ldsStack >= 0) {
@@ -925,12 +936,13 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         perCU = std::max(1, std::min(perCU, wantPerCU));
     } else {
         // (three and four errors stack deep: two levels in LDS are worth more than the block per CU they may cost -- K=101 e=4 -12 %, e=3 -1.6 %)
-        const uint32_t dmin = (p->E >= 3 && nu == 1u) ? std::min(2u, depth) : 1u;
-        for (uint32_t d = std::min(4u / nu, depth); d >= dmin; --d) {
+        // (no level at all where that is what keeps the fourth block: K=100 e=1 203 ms against 226 with one level and three blocks)
+        const uint32_t dmin = (p->E >= 3 && nu == 1u) ? std::min(2u, depth) : 0u;
+        for (int d = (int)std::min(4u / nu, depth); d >= (int)dmin; --d) {
             int nb = 0;
-            rc = blocks_for(d, &nb); if (rc) return rc;
+            rc = blocks_for((uint32_t)d, &nb); if (rc) return rc;
             nb = std::min(nb, wantPerCU);
-            if (nb > perCU) { perCU = nb; ldsDepth = d; }
+            if (nb > perCU) { perCU = nb; ldsDepth = (uint32_t)d; }
         }
         perCU = std::max(1, perCU);
     }
@@ -1114,7 +1126,8 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     // profiles/r01e_infix_sweeps.txt (r01h): 16 / 8 / 4 on the 249 Mbp index; beyond 2^30 rows the fetch loads are HBM
     // misses and larger batches pay (3.09 Gbp: e=0 82.6 vs 90.2 ms, K100 e=1 861 vs 900 ms with 32)
     const bool huge = ix->nRows >= (1ull << 30);
-    A.fetchBatch = p->E == 0 ? (huge ? 32u : 16u) : p->E == 1 ? (huge ? 32u : 8u) : (huge ? 8u : 4u);   // (e=2 on 3.09 Gbp: 8 -> -1.7 % over 4, 16 +3 %; profiles/r04/sweep_retune_e2.txt)
+    // (K=100 e=1 on 3.09 Gbp: 48 -> -6 % over 32, 64 the same, 16 +8 %; profiles/r05/sweep_k100_knobs.txt, sweep_k100_lds_fetch_batch_steal.txt)
+    A.fetchBatch = p->E == 0 ? (huge ? 32u : 16u) : p->E == 1 ? (huge ? (p->K >= 64 ? 48u : 32u) : 8u) : (huge ? 8u : 4u);   // (e=2 on 3.09 Gbp: 8 -> -1.7 % over 4, 16 +3 %; profiles/r04/sweep_retune_e2.txt)
     if (ix->tune.fetchBatch > 0) A.fetchBatch = (uint32_t)std::min(ix->tune.fetchBatch, 64);
     // e = 0: a single row is almost always the k-mer's own location.  Beyond ~1 G rows a lone-row step is an HBM miss
     // like the verification reads it postpones, and no longer pays (3.09 Gbp e = 2: 90.7 vs 86.7 M k-mers/s without).
@@ -1140,7 +1153,8 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     else if (p->E >= 2) stealDefault = p->K < 64 ? 16u : (p->E >= 3 ? 4u : 8u);   // K=100 e=2: 8 -> +5.7 %, 16 -> 0 (sweep_steal_longk.txt); K=101 e=3 / e=4: 4 -> -2 / -7 % over 8 (r04)
     // e=1 at K >= 64: sharing used to lose 5..9 % (r02); with verified runs added in two atomics the balance turned: an exchange when a
     // quarter of the wavefront is idle gains 2-6 % on 3.09 Gbp (profiles/r04/sweep_k100_knobs.txt, sweep_verify_t_ext.txt)
-    else if (p->E == 1 && p->K >= 64) stealDefault = 16u;
+    // (round 5, with four blocks per CU again: an exchange at half a wavefront idle, -3.4 % over a quarter)
+    else if (p->E == 1 && p->K >= 64) stealDefault = 32u;
     A.steal = ix->tune.steal >= 0 ? (uint32_t)std::min(ix->tune.steal, 64) : stealDefault;
     A.coop = ix->tune.coop >= 0 ? (uint32_t)(ix->tune.coop != 0) : ((ix->wpp == 1 || ix->wide) ? 1u : 0u);   // (wide: groups of four lanes per 64-byte block, r04)
     if (ix->wpp == 9) A.coop = 0u;
@@ -1185,7 +1199,7 @@ static int launch_reset_limits(gm_index* ix, TValue* d_out, uint32_t n_seq, uint
 // accumulators of the whole range and starts the call's ONE correction pass; the later pieces do neither.
 static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t first_seq, uint32_t n_seq, const gm_map_params* p,
                     const uint64_t* intervals, uint64_t n_intervals, const uint32_t* seq_file_id, void* d_out, hipStream_t st, uint64_t* wrote = nullptr,
-                    const uint64_t* whole = nullptr)
+                    const uint64_t* whole = nullptr, int firstOfWhole = -1)
 {
     if (!d_out) { set_error("null output"); return GM_ERR_BAD_ARG; }
     SearchSetup S; SearchArgs A;
@@ -1238,7 +1252,7 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
     };
 
     // a shard (kmer_begin/kmer_end) touches only its own positions [r0, r1) of the accumulators and of out
-    const bool sharded = (p->flags & GM_MAP_FLAG_RANGE) || p->kmer_begin != 0 || p->kmer_end != 0 || S.sel.len != 0;
+    const bool sharded = (p->flags & (GM_MAP_FLAG_RANGE | GM_MAP_FLAG_PIECE)) || p->kmer_begin != 0 || p->kmer_end != 0 || S.sel.len != 0;
     const uint64_t r0 = sharded ? std::min<uint64_t>(S.posBase, text_len) : 0;
     const uint64_t r1 = sharded ? std::min<uint64_t>(std::max<uint64_t>(S.posEnd, r0), text_len) : text_len;
     const uint64_t rn = r1 - r0;
@@ -1246,7 +1260,7 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
     if (ix->pieceIndex == 0) GM_HIP(hipEventRecord(ix->ev[0], st));
     const ChunkSel sel = S.sel;   // positions are relative to r0 == posBase (a multiple of the block length)
     // the positions of the whole CALL, [c0, c1): what the first piece clears and what the call's one correction pass owns
-    const bool firstPiece = ix->pieceIndex == 0;
+    const bool firstPiece = firstOfWhole >= 0 ? firstOfWhole != 0 : ix->pieceIndex == 0;
     uint64_t c0 = r0, c1 = r1;
     if (whole) {   // (regular partition: a selection is never delivered in pieces; pieces begin at multiples of the chunk row from whole[0])
         const uint64_t step = S.plan.stepSize;
@@ -1459,6 +1473,11 @@ extern "C" {
 int gm_map_device(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t first_seq, uint32_t n_seq, const gm_map_params* p,
                   const uint64_t* intervals, uint64_t n_intervals, const uint32_t* seq_file_id, void* out_device, void* stream)
 {
+    if (p && (p->flags & GM_MAP_FLAG_PIECE)) {   // one launch of a share the caller delivers in several calls (include/genmap_amd.h)
+        if (n_intervals > 0 || p->kmer_begin < p->whole_begin || p->kmer_end > p->whole_end) { set_error("GM_MAP_FLAG_PIECE: a piece lies inside its share, and a selection is not delivered in pieces"); return GM_ERR_BAD_ARG; }
+        const uint64_t whole[2] = {p->whole_begin, p->whole_end};
+        return map_impl(ix, text_begin, text_len, first_seq, n_seq, p, intervals, n_intervals, seq_file_id, out_device, (hipStream_t)stream, nullptr, whole, p->kmer_begin == p->whole_begin ? 1 : 0);
+    }
     return map_impl(ix, text_begin, text_len, first_seq, n_seq, p, intervals, n_intervals, seq_file_id, out_device, (hipStream_t)stream);
 }
 
@@ -1793,7 +1812,7 @@ int gm_index_set_tuning(gm_index* ix, const char* name, int64_t value)
         {"child_tables", &ix->tune.childTables, dflt.childTables, 0, 1}, {"oss_weights", &ix->tune.ossWeights, dflt.ossWeights, 0, 0xFFFFFF},   // (-1: 5,4,7,8 at e = 2, the even split elsewhere)
         {"jump", &ix->tune.jump, dflt.jump, 0, 16}, {"self_hit", &ix->tune.selfHit, dflt.selfHit, 0, 1}, {"jump_filter", &ix->tune.jumpFilter, dflt.jumpFilter, 0, 2},
         {"range_add", &ix->tune.rangeAdd, dflt.rangeAdd, 0, 1}, {"verify_t_ext", &ix->tune.verifyTExt, dflt.verifyTExt, 0, (int64_t)VERIFY_TMAX},
-        {"fast_verify", &ix->tune.fastVerify, dflt.fastVerify, 0, 1},
+        {"fast_verify", &ix->tune.fastVerify, dflt.fastVerify, 0, 1}, {"lds_pad", &ix->tune.ldsPad, dflt.ldsPad, 0, 65536},
         {"jump_layouts", &ix->tune.jumpLayouts, dflt.jumpLayouts, 0, 1},   // 0: groups of jump patterns in the LOW / MID layouts only (round 4), -1 / 1: at any three adjacent characters
         {"no_wrap", &ix->tune.noWrap, dflt.noWrap, 0, 1},   // 0: every add into an accumulator returns the old value and checks for a wrap-around (-1 / 1: only where one is possible)
         {"iter_cap", &ix->tune.iterCap, dflt.iterCap, 1, 0x7FFFFFFF}, {"stall_cap", &ix->tune.stallCap, dflt.stallCap, 1, 0x7FFFFFFF},   // bounds of a hung search loop (tests force them)

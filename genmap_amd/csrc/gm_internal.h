@@ -30,6 +30,7 @@ struct Tuning {
     int noStore = 0, noSaturate = 0, skipDup = -1, coop = -1, useCtx = 1, steal = -1, partBias = 0, childTables = -1, ossWeights = -1, jump = -1, selfHit = 1, jumpFilter = 1, rangeAdd = 1, verifyTExt = -1, jumpGroups = -1;
     int noWrap = -1;                   // 0: adds into the accumulators always return and check for a 2^32 wrap-around (gm_api.hip: acc_cannot_wrap)
     int jumpLayouts = -1;              // 0: groups of jump patterns only in the two layouts of round 4
+    int ldsPad = 0;                    // measurement: extra bytes of LDS per block
     int fastVerify = -1;               // -1: whenever the call allows it (gm_api.hip: prepare_search), 0: never
     int iterCap = -1, stallCap = -1;   // bounds of a hung search loop (gm_kernels.h: SearchArgs::iterCap / stallCap); -1: never / 2^22 idle iterations
 };

@@ -234,15 +234,7 @@ constexpr uint32_t STEAL_LEVELS = 16;  // a lane gives away at most this many bo
 
 // fetch state of a lane with jump patterns: fs = 2 | flags.  Table entry in flight, bitmap word in flight, jd holds an item, that item is a
 // group / a MID group, the current set of live rotations belongs to a MID group; bits 8..11 the two letters behind the J-mer, bit 12: both are letters
-constexpr uint32_t JF_ENTRY = 4u, JF_WORD = 8u, JF_ITEM = 16u, JF_GROUP = 32u;
-constexpr uint32_t JF_IL_SHIFT = 6u, JF_IL_MASK = 7u << 6;       // layout of the group item in jd
-constexpr uint32_t JF_CLS_SHIFT = 9u, JF_CLS_MASK = 15u << 9;    // half the bit offset of the layout the live rotations (galive) belong to
-constexpr uint32_t JF_EXT_SHIFT = 13u, JF_EXTOK = 1u << 17;      // the two letters behind the J-mer; both are letters
-// which segment of its search item number jp lies in: e = the ends of the layouts' groups (16 bits each); GROUP_MAX_LAYOUTS: a plain pattern
-__device__ __forceinline__ uint32_t item_layout(uint32_t jp, const uint4& e)
-{
-    return (jp >= (e.x & 0xFFFFu)) + (jp >= (e.x >> 16)) + (jp >= (e.y & 0xFFFFu)) + (jp >= (e.y >> 16)) + (jp >= (e.z & 0xFFFFu)) + (jp >= (e.z >> 16));
-}
+// (JF_* flags of the pattern-fetch state, item_layout, jump_decide: gm_oss.h -- shared with the CPU harness)
 constexpr uint32_t WORK_CHUNK = 256;   // roots taken from the global counter per atomic
 constexpr uint32_t VERIFY_TMAX = 16;   // widest range resolved by verification
 constexpr uint32_t VERIFY_ROWS = 2;    // rows of one node queued per iteration at most (SearchArgs::verifyRows; the rest waits on the lane's stack)
@@ -963,7 +955,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     // that lane's needle window (wlane) and the owner may not stage a new window while users[owner] != 0
     uint32_t* const users = reinterpret_cast<uint32_t*>(smem + 4u * A.vqCap * NU + 4u * 64u * (A.ldsDepth * NU + A.winChunks)) + wv * 80u;   // [64] users (words) | [64] pairing (bytes): 320 B per wavefront
     uint8_t* const pairing = reinterpret_cast<uint8_t*>(users + 64);
-    // the searches' jump records (Env::JUMPS), 8 x 16 bytes (+ 64 bytes of group masks + 8 x 16 bytes of group ends + 8 x 16 bytes of OSS records + 6 x 16 bytes of group layouts) per block behind the work-sharing bookkeeping
+    // the searches' jump records (Env::JUMPS), 8 x 16 bytes (+ 64 bytes of group masks + 8 x 16 bytes of group ends + 8 x 16 bytes of OSS records) per block behind the work-sharing bookkeeping
     uint4* const jl = smem + 4u * A.vqCap * NU + 4u * 64u * (A.ldsDepth * NU + A.winChunks) + (4u * 80u * 4u) / 16u;
     if (threadIdx.x < 8u) jl[20u + threadIdx.x] = A.table[(size_t)(A.stepSize - 1u) * 8u + threadIdx.x];   // OSS records of the regular block shape (stage 2)
     if constexpr (!EnvT::JUMPS) __syncthreads();
@@ -971,15 +963,20 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
         if (threadIdx.x < 8u) jl[threadIdx.x] = A.jumpJ ? A.jinfo[threadIdx.x] : make_uint4(0, 0, 0, 0);
         // ... and the masks of its groups of patterns (gm_oss.h), 8 x 8 bytes behind them
         if (threadIdx.x < GROUP_MAX_MASKS) reinterpret_cast<unsigned long long*>(jl + 8)[threadIdx.x] = A.gmask[threadIdx.x];
-        if (threadIdx.x < 8u) jl[12u + threadIdx.x] = A.jumpJ ? A.jinfo2[threadIdx.x] : make_uint4(0, 0, 0, 0);   // ... and where its groups end
-        if (threadIdx.x < GROUP_MAX_LAYOUTS) jl[28u + threadIdx.x] = make_uint4(A.layShift[threadIdx.x], A.layPlane0[threadIdx.x], A.layPlane1[threadIdx.x], 0u);   // ... and the layouts
+        // ... and where its groups end; entry L additionally carries layout L in the upper bits of its 4th word (bit offset of the group's
+        // characters: 5 bits, kind-0 plane: 8, first kind-1 plane: 8) -- a table of their own would have cost the block 96 bytes of LDS it does not have
+        if (threadIdx.x < 8u) {
+            uint4 v = A.jumpJ ? A.jinfo2[threadIdx.x] : make_uint4(0, 0, 0, 0);
+            v.w = (v.w & 0xFFu) | (A.layShift[threadIdx.x] | A.layPlane0[threadIdx.x] << 5 | A.layPlane1[threadIdx.x] << 13) << 8;
+            jl[12u + threadIdx.x] = v;
+        }
         __syncthreads();
     }
     // jump patterns: the table entry in flight lives in LDS, one 16-byte slot per lane (global_load_lds: no destination registers, hence
     // no wait behind the load to move them, and 4 VGPRs less) -- 4 KB per block behind the jump records
-    uint4* const ebufW = jl + 34 + wv * 64u;
+    uint4* const ebufW = jl + 28 + wv * 64u;
     if constexpr (EnvT::LEAFQ) {   // leaf queue behind everything else: [4 x lqCap entries] [4 x 80 control words]
-        uint4* const lqBase = jl + 34;
+        uint4* const lqBase = jl + 28;
         env.lq = lqBase + wv * A.lqCap;
         env.lqCtl = reinterpret_cast<uint32_t*>(lqBase + 4u * A.lqCap) + wv * 80u;
         if (lane == 0u) env.lqCtl[0] = 0u;
@@ -1242,9 +1239,8 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                         env.on_root();
                         {
                             const uint4 lim = jl[12u + frt.search];
-                            const uint32_t fl = item_layout(fji.x & 0xFFFFu, lim);
-                            fs = 2u | JF_ITEM | (fl < GROUP_MAX_LAYOUTS ? JF_GROUP | fl << JF_IL_SHIFT : 0u);
-                            if (lim.w) {   // groups of kind 1 ask whether the J-mer occurs followed by the needle's next two letters
+                            fs = 2u | jump_item_flags(fji.x & 0xFFFFu, lim.x, lim.y, lim.z);
+                            if (lim.w & 0xFFu) {   // groups of kind 1 ask whether the J-mer occurs followed by the needle's next two letters
                                 const uint32_t e0 = env.text_char(frt, fa0 + A.jumpJ), e1 = env.text_char(frt, fa0 + A.jumpJ + 1u);
                                 if ((e0 | e1) < SYM_N) fs |= JF_EXTOK | (e0 << 2 | e1) << JF_EXT_SHIFT;
                             }
@@ -1408,45 +1404,23 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
             if ((fs & 3u) == 2u) {
                 env.note_wave(16);
                 const uint4 lim = jl[12u + rt.search];   // where the groups of each layout end among the search's items
-                bool want = false, asked = false, go = false;   // the item in jd has been used up / its word is to be requested / a table entry is to be read
-                uint32_t widx = 0u, wsel = 0u, rw = 0u;
-                if ((fs & (JF_ITEM | JF_WORD | JF_GROUP)) == (JF_ITEM | JF_GROUP)) {   // a group item: request its word now
-                    const uint4 ly = jl[28u + ((fs >> JF_IL_SHIFT) & 7u)];            // {bit offset of the group's characters, kind-0 plane, first kind-1 plane}
-                    const uint32_t sh = ly.x, kind = (jd >> (sh + 3u)) & 1u;
-                    if (kind && !(fs & JF_EXTOK)) {   // a needle N behind the J-mer: no pattern without budget can match
-                        fs &= ~(JF_ITEM | JF_GROUP | JF_IL_MASK);
-                        want = true;
-                    } else {
-                        widx = group_word(rot_add(jb, jd & ~(63u << sh)), sh);
-                        // the bitmaps are one array of planes: kind 0 LOW | kind 1 LOW, 16 letter pairs | kind 1 MID, 16 letter pairs | kind 0 of the other layouts
-                        wsel = kind ? ly.z + ((fs >> JF_EXT_SHIFT) & 15u) : ly.y;
-                        asked = true;
+                struct LdsTab {   // the layouts ride in the 4th words of the searches' group ends, the masks sit behind the jump records
+                    const uint4* jl;
+                    __device__ __forceinline__ uint32_t layout(uint32_t il) const { return jl[12u + il].w >> 8; }
+                    __device__ __forceinline__ unsigned long long mask(uint32_t id) const
+                    {
+                        const uint2 mk = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint32_t*>(jl + 8) + 2u * id);
+                        return (unsigned long long)mk.y << 32 | mk.x;
                     }
-                } else if (galive == 0ull && (fs & JF_WORD)) {   // the word of group jd has arrived: its patterns that pass
-                    const uint32_t sh = jl[28u + ((fs >> JF_IL_SHIFT) & 7u)].x;
-                    const uint2 mk = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint32_t*>(jl + 8) + 2u * ((jd >> sh) & 7u));
-                    galive = word_to_rotations(pw, (jb >> sh) & 63u) & ((unsigned long long)mk.y << 32 | mk.x);
-                    gcur = jd & ~(63u << sh);
-                    fs = (fs & ~(JF_WORD | JF_ITEM | JF_GROUP | JF_IL_MASK | JF_CLS_MASK)) | (sh >> 1) << JF_CLS_SHIFT;
-                    want = true;
-                }
-                if (!(fs & JF_ENTRY)) {
-                    if (galive != 0ull) {   // the next pattern of the current group that passed
-                        rw = gcur | ctz64(galive) << (((fs >> JF_CLS_SHIFT) & 15u) * 2u);
-                        galive &= galive - 1ull;
-                        go = true;
-                    } else if ((fs & (JF_ITEM | JF_WORD | JF_GROUP)) == JF_ITEM && !want && !asked) {   // a plain pattern
-                        rw = jd; go = true;
-                        fs &= ~JF_ITEM;
-                        want = true;
-                    }
-                }
+                };
+                const JumpStep D = jump_decide(fs, jd, gcur, galive, pw, jb, LdsTab{jl});   // gm_oss.h: the decisions; the loads stay here, ONE site each
+                const bool want = D.want, asked = D.asked, go = D.go;
+                const uint32_t widx = D.widx, wsel = D.wsel, rw = D.rw;
                 if (want) {   // the next item of the lane's root (not looked at before the next iteration: nothing waits for that load)
                     const uint32_t jp = jpp & 0xFFFFu;
                     if (jp < (jpp >> 16)) {
                         jd = A.patterns[jp]; jpp += 1u;
-                        const uint32_t il = item_layout(jp, lim);
-                        fs |= JF_ITEM | (il < GROUP_MAX_LAYOUTS ? JF_GROUP | il << JF_IL_SHIFT : 0u);
+                        fs |= jump_item_flags(jp, lim.x, lim.y, lim.z);
                     }
                 }
                 if (asked) {
@@ -1465,7 +1439,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                     env.jumps++;
 #endif
                 }
-                if (!(fs & (JF_ENTRY | JF_WORD | JF_ITEM)) && galive == 0ull) fs = 0u;   // nothing in flight, no item, nothing alive: the root's patterns are done
+                if (jump_done(fs, galive)) fs = 0u;   // nothing in flight, no item, nothing alive: the root's patterns are done
             }
         }
         GM_LAP2(tSt32);

@@ -293,4 +293,76 @@ GM_HD uint64_t word_to_rotations(uint64_t w, uint32_t low6)
     w = ((w >> s2) & lo2) | ((w << (4u - s2)) & ~lo2);
     return w;
 }
+
+// ---- the pattern-fetch state machine of a lane (gm_kernels.h: search_body, part B; tests/emu runs the same functions) ---------------------
+// fs of a lane with pattern work = 2 | flags: table entry in flight, bitmap word in flight, jd holds an item, that item is a group; layout
+// of the group item in jd; half the bit offset of the layout the live rotations (galive) belong to; the two letters behind the J-mer and
+// whether both are letters.  The one GPU-only bug of round 4 lived in exactly this logic (a flag that outlived its group: the lane asked
+// for the same word for ever); it is header code now so that the CPU harness walks every root through it, with an iteration bound.
+constexpr uint32_t JF_ENTRY = 4u, JF_WORD = 8u, JF_ITEM = 16u, JF_GROUP = 32u;
+constexpr uint32_t JF_IL_SHIFT = 6u, JF_IL_MASK = 7u << 6;       // layout of the group item in jd
+constexpr uint32_t JF_CLS_SHIFT = 9u, JF_CLS_MASK = 15u << 9;    // half the bit offset of the layout the live rotations belong to
+constexpr uint32_t JF_EXT_SHIFT = 13u, JF_EXTOK = 1u << 17;      // the two letters behind the J-mer; both are letters
+// ends of the layouts' groups among a search's items: six 16-bit numbers in x, y, z (gm_api.hip: jinfo2); GROUP_MAX_LAYOUTS = a plain pattern
+GM_HD uint32_t item_layout(uint32_t jp, uint32_t ex, uint32_t ey, uint32_t ez)
+{
+    return (jp >= (ex & 0xFFFFu)) + (jp >= (ex >> 16)) + (jp >= (ey & 0xFFFFu)) + (jp >= (ey >> 16)) + (jp >= (ez & 0xFFFFu)) + (jp >= (ez >> 16));
+}
+// flags of a freshly loaded item number jp
+GM_HD uint32_t jump_item_flags(uint32_t jp, uint32_t ex, uint32_t ey, uint32_t ez)
+{
+    const uint32_t il = item_layout(jp, ex, ey, ez);
+    return JF_ITEM | (il < GROUP_MAX_LAYOUTS ? JF_GROUP | il << JF_IL_SHIFT : 0u);
+}
+struct JumpStep {          // what a lane does in this iteration
+    bool want;             // the item in jd has been used up: load the next one (if any) and set jump_item_flags
+    bool asked;            // request word `widx` of bitmap plane `wsel`; the caller sets JF_WORD
+    bool go;               // read the table entry of the J-mer rot_add(jb, rw); the caller sets JF_ENTRY (errors of the pattern: rot_errors(rw))
+    uint32_t widx, wsel, rw;
+};
+// Tab::layout(il) -> {bit offset: 5 bits, kind-0 plane: 8, first kind-1 plane: 8}; Tab::mask(id) -> the group mask
+template <class Tab>
+GM_HD JumpStep jump_decide(uint32_t& fs, uint32_t jd, uint32_t& gcur, unsigned long long& galive, unsigned long long pw, uint32_t jb, const Tab& tab)
+{
+    JumpStep D; D.want = D.asked = D.go = false; D.widx = D.wsel = D.rw = 0u;
+    if ((fs & (JF_ITEM | JF_WORD | JF_GROUP)) == (JF_ITEM | JF_GROUP)) {   // a group item: request its word now
+        const uint32_t ly = tab.layout((fs >> JF_IL_SHIFT) & 7u);
+        const uint32_t sh = ly & 31u, kind = (jd >> (sh + 3u)) & 1u;
+        if (kind && !(fs & JF_EXTOK)) {   // a needle N behind the J-mer: no pattern without budget can match
+            fs &= ~(JF_ITEM | JF_GROUP | JF_IL_MASK);
+            D.want = true;
+        } else {
+            D.widx = group_word(rot_add(jb, jd & ~(63u << sh)), sh);
+            // the bitmaps are one array of planes: kind 0 LOW | kind 1 LOW, 16 letter pairs | kind 1 MID, 16 letter pairs | kind 0 of the other layouts
+            D.wsel = kind ? ((ly >> 13) & 255u) + ((fs >> JF_EXT_SHIFT) & 15u) : (ly >> 5) & 255u;
+            D.asked = true;
+        }
+    } else if (galive == 0ull && (fs & JF_WORD)) {   // the word of group jd has arrived: its patterns that pass
+        const uint32_t sh = tab.layout((fs >> JF_IL_SHIFT) & 7u) & 31u;
+        galive = word_to_rotations(pw, (jb >> sh) & 63u) & tab.mask((jd >> sh) & 7u);
+        gcur = jd & ~(63u << sh);
+        fs = (fs & ~(JF_WORD | JF_ITEM | JF_GROUP | JF_IL_MASK | JF_CLS_MASK)) | (sh >> 1) << JF_CLS_SHIFT;
+        D.want = true;
+    }
+    if (!(fs & JF_ENTRY)) {
+        if (galive != 0ull) {   // the next pattern of the current group that passed
+#if defined(__HIP_DEVICE_COMPILE__)
+            const uint32_t bit = (uint32_t)__ffsll((long long)galive) - 1u;
+#else
+            const uint32_t bit = (uint32_t)__builtin_ctzll(galive);
+#endif
+            D.rw = gcur | bit << (((fs >> JF_CLS_SHIFT) & 15u) * 2u);
+            galive &= galive - 1ull;
+            D.go = true;
+        } else if ((fs & (JF_ITEM | JF_WORD | JF_GROUP)) == JF_ITEM && !D.want && !D.asked) {   // a plain pattern
+            D.rw = jd; D.go = true;
+            fs &= ~JF_ITEM;
+            D.want = true;
+        }
+    }
+    return D;
+}
+// after the caller has applied the step (item loaded, JF_WORD / JF_ENTRY set): is the root's pattern work over?
+GM_HD bool jump_done(uint32_t fs, unsigned long long galive) { return !(fs & (JF_ENTRY | JF_WORD | JF_ITEM)) && galive == 0ull; }
+
 }  // namespace gm

@@ -133,8 +133,15 @@ typedef struct gm_map_params {
      * computes the chunks whose number is congruent to chunk_index modulo chunk_stride.  gm_map_device touches only the
      * positions of those chunks.  Not supported by gm_locate. */
     uint32_t chunk_blocks, chunk_index, chunk_stride, reserved1;
+    /* GM_MAP_FLAG_PIECE: this call is one launch of a larger share [whole_begin, whole_end) of k-mer positions (same chunk arguments) that the
+     * caller delivers in several gm_map_device calls on ONE stream, first piece first -- so that the transfer of one piece overlaps the search
+     * of the next (what gm_map_shard does inside one call).  The piece that begins at whole_begin clears the accumulators of the whole share and
+     * runs the call's ONE correction pass (the text windows with N, searched beside the main kernel); the later pieces do neither.  Round 4
+     * ran that pass behind every launch: a fixed cost per rank that did not shrink with the number of GPUs. */
+    uint64_t whole_begin, whole_end;
 } gm_map_params;
 #define GM_MAP_FLAG_RANGE 1   /* [kmer_begin, kmer_end) is a shard even when it is empty or (0,0) */
+#define GM_MAP_FLAG_PIECE 2   /* [kmer_begin, kmer_end) is one launch of the share [whole_begin, whole_end) (implies GM_MAP_FLAG_RANGE) */
 
 /* Concurrency: an index owns ONE set of device workspaces (work counter, accumulators, lane stacks, per-call tables).
  * Calls on the same index may be issued from one host thread at a time, on any streams: every call makes its stream

@@ -19,6 +19,10 @@ static int g_jumpGroups = 0;        // 1: patterns that differ in their last thr
 extern "C" void gm_emu_set_jump_groups(int on) { g_jumpGroups = on; }   // 2: groups in every layout (any three adjacent characters), 1: LOW / MID only
 static int g_selfHit = 1;           // self hits of the counting pass (gm_engine.h: self_hit_kmers)
 extern "C" void gm_emu_set_self_hit(int on) { g_selfHit = on; }
+static int g_stateMachine = 1;      // roots with jump patterns go through the device's pattern-fetch state machine (gm_oss.h: jump_decide); 0: a plain loop over the items
+extern "C" void gm_emu_set_state_machine(int on) { g_stateMachine = on; }
+static uint64_t g_hangs = 0;        // roots whose state machine did not finish within its iteration bound (+ 10^6 per wrong word address)
+extern "C" uint64_t gm_emu_hangs(int reset) { const uint64_t v = g_hangs; if (reset) g_hangs = 0; return v; }
 static int g_fastVerify = 1;        // narrow nodes settled from the masks of gm_engine.h: fv_masks where the device would (K <= 32, short windows)
 extern "C" void gm_emu_set_fast_verify(int on) { g_fastVerify = on; }
 static uint64_t g_fastItems = 0;    // items verified that way since the last reset (tests make sure the path is exercised)
@@ -271,14 +275,8 @@ static void search_plan(const MapPlan& plan, const HostIndex<WPP>& ix, Env& env,
                 if (it.ext) { e0 = env.text_char(rt, a0 + js.J); e1 = env.text_char(rt, a0 + js.J + 1u); }
                 const bool extValid = e0 < SYM_N && e1 < SYM_N;
                 const std::vector<uint32_t> shifts = group_layout_shifts(js.J);
-                for (size_t q = 0; q < it.items.size(); ++q) {
-                    const uint32_t d = it.items[q];
-                    if (q >= it.groups()) { lookup(rot_add(base2, d), rot_errors(d)); continue; }
-                    // a group: the word of its bitmap (built here by asking the index), in rotation space, masked; only patterns that pass are looked up
-                    size_t lay = 0, cum = it.seg[0];
-                    while (q >= cum) cum += it.seg[++lay];
-                    const uint32_t shift = shifts[lay], own = (d >> shift) & 63u, kind = own >> 3, rotw = d & ~(63u << shift);
-                    const uint32_t pre = rot_add(base2, rotw);
+                // the word of a group's bitmap, built here by asking the index (the device reads it from its bitmaps)
+                auto group_bits = [&](uint32_t pre, uint32_t shift, uint32_t kind) {
                     uint64_t word = 0;
                     for (uint32_t c = 0; c < 64u && (kind == 0u || extValid); ++c) {
                         const uint64_t cand = (pre & ~(63u << shift)) | c << shift;
@@ -286,7 +284,56 @@ static void search_plan(const MapPlan& plan, const HostIndex<WPP>& ix, Env& env,
                         if (kind) table_entry<WPP>(ix, cand << 4 | e0 << 2 | e1, js.J + 2u, f, r, w); else table_entry<WPP>(ix, cand, js.J, f, r, w);
                         if (w) word |= 1ull << c;
                     }
-                    uint64_t alive = word_to_rotations(word, (base2 >> shift) & 63u) & gmasks[own & 7u];
+                    return word;
+                };
+                if (g_stateMachine) {
+                    // The lane's pattern-fetch state machine itself (gm_oss.h: jump_decide -- the code part B of the kernel's loop runs), one
+                    // "iteration" at a time with the device's timing: a word asked for in one iteration is looked at in the next, a table
+                    // entry read in one iteration becomes a node in the next.  A root that has not finished its items after a generous
+                    // number of iterations is a hang of exactly the kind that reached the GPU in round 4: reported, not waited for.
+                    struct HostTab {
+                        const std::vector<uint32_t>* shifts; const std::vector<uint64_t>* masks;
+                        uint32_t layout(uint32_t il) const { return il < shifts->size() ? ((*shifts)[il] | il << 5 | (1u + 16u * il) << 13) : 0u; }   // (planes: any distinct numbers)
+                        uint64_t mask(uint32_t id) const { return id < masks->size() ? (*masks)[id] : 0ull; }
+                    } tab{&shifts, &gmasks};
+                    uint32_t e16[GROUP_MAX_LAYOUTS], run = 0;
+                    for (uint32_t L2 = 0; L2 < GROUP_MAX_LAYOUTS; ++L2) { run += L2 < it.seg.size() ? it.seg[L2] : 0u; e16[L2] = run; }
+                    const uint32_t ex = e16[0] | e16[1] << 16, ey = e16[2] | e16[3] << 16, ez = e16[4] | e16[5] << 16;
+                    uint32_t fs = 2u | jump_item_flags(0u, ex, ey, ez), jd = it.items[0], jpp = 1u | (uint32_t)it.items.size() << 16, gcur = 0;
+                    if (it.ext && extValid) fs |= JF_EXTOK | (e0 << 2 | e1) << JF_EXT_SHIFT;
+                    unsigned long long galive = 0, pw = 0;
+                    uint32_t entryIdx = 0, entryErrs = 0;
+                    const size_t cap = 8 * it.items.size() + 64 * 70 * it.items.size() + 16;
+                    size_t iter = 0;
+                    for (;; ++iter) {
+                        if (iter > cap) { g_hangs++; break; }
+                        if (fs & JF_ENTRY) { fs &= ~JF_ENTRY; lookup(entryIdx, entryErrs); }            // part A: the entry has arrived
+                        const uint32_t fsBefore = fs;
+                        const JumpStep D = jump_decide(fs, jd, gcur, galive, pw, base2, tab);
+                        if (D.want) { const uint32_t jp = jpp & 0xFFFFu; if (jp < (jpp >> 16)) { jd = it.items[jp]; jpp += 1u; fs |= jump_item_flags(jp, ex, ey, ez); } }
+                        if (D.asked) {
+                            // (an asked-for word leaves jd alone: it still holds the group item)
+                            const uint32_t il = (fsBefore >> JF_IL_SHIFT) & 7u, ly = tab.layout(il), sh = ly & 31u, kind = (jd >> (sh + 3u)) & 1u;
+                            // the word's address as the kernel would form it: plane of the kind (and of the two letters), word of the layout
+                            if (kind ? D.wsel != ((ly >> 13) & 255u) + (e0 << 2 | e1) : D.wsel != ((ly >> 5) & 255u)) g_hangs += 1000000;
+                            const uint32_t pre = rot_add(base2, jd & ~(63u << sh));
+                            if (group_word(pre, sh) != D.widx) g_hangs += 1000000;
+                            pw = group_bits(pre, sh, kind);
+                            fs |= JF_WORD;
+                        }
+                        if (D.go) { entryIdx = rot_add(base2, D.rw); entryErrs = rot_errors(D.rw); fs |= JF_ENTRY; }
+                        if (jump_done(fs, galive)) break;
+                    }
+                } else
+                for (size_t q = 0; q < it.items.size(); ++q) {
+                    const uint32_t d = it.items[q];
+                    if (q >= it.groups()) { lookup(rot_add(base2, d), rot_errors(d)); continue; }
+                    // a group: the word of its bitmap, in rotation space, masked; only patterns that pass are looked up
+                    size_t lay = 0, cum = it.seg[0];
+                    while (q >= cum) cum += it.seg[++lay];
+                    const uint32_t shift = shifts[lay], own = (d >> shift) & 63u, kind = own >> 3, rotw = d & ~(63u << shift);
+                    const uint32_t pre = rot_add(base2, rotw);
+                    uint64_t alive = word_to_rotations(group_bits(pre, shift, kind), (base2 >> shift) & 63u) & gmasks[own & 7u];
                     while (alive) {
                         const uint32_t rw = rotw | (uint32_t)__builtin_ctzll(alive) << shift; alive &= alive - 1ull;
                         lookup(rot_add(base2, rw), rot_errors(rw));

@@ -305,8 +305,18 @@ def test_groups_of_jump_patterns_read_through_the_existence_bitmap(K, E):
             out2, st2 = emu_map2(ix, 1, K, E, value_bits=16, verify_t=T, jump=jump)
             assert np.array_equal(out2, exp), (K, E, T, jump, "all layouts", np.flatnonzero(out2 != exp)[:10])
             assert 0 < st2[4] <= st1[4]
+            # every root above went through the lane's pattern-fetch state machine (gm_oss.h: jump_decide, the code of the kernel's part B)
+            # with an iteration bound: none may hang, none may ask for a word at another address than the kernel would; and a plain loop
+            # over the items looks up exactly the same patterns
+            e.gm_emu_hangs.restype = C.c_uint64
+            assert e.gm_emu_hangs(1) == 0
+            e.gm_emu_set_state_machine(0)
+            out3, st3 = emu_map2(ix, 1, K, E, value_bits=16, verify_t=T, jump=jump)
+            e.gm_emu_set_state_machine(1)
+            assert np.array_equal(out3, exp) and st3[4] == st2[4], (K, E, T, jump, st3[4], st2[4])
     finally:
         e.gm_emu_set_jump_groups(0)
+        e.gm_emu_set_state_machine(1)
 
 
 def test_n_window_intervals_list_exactly_the_windows_that_can_match():

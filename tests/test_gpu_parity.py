@@ -368,6 +368,25 @@ def test_gpu_one_correction_pass_per_call_beside_the_main_search():
                     st = ix.last_stats()
                     assert st["detail"]["correction_us"] > 0, (K, E, stride, r)       # the pass ran (and was timed) in this call
                 assert np.array_equal(host, exp), (K, E, stride)
+            # the same through gm_map_device calls flagged as pieces of one share (GM_MAP_FLAG_PIECE: what bench.py's ranks issue, one launch
+            # per piece so that its chunks travel while the next piece computes): the first piece clears and corrects the whole share
+            import torch
+            from genmap_amd.distributed import ShardPlan
+            step = K - g.tuned_infix_length(K, E) + 1
+            plan = ShardPlan(n - K + 1, step, 2)
+            acc = torch.zeros(plan.padded_len(n), dtype=torch.uint8, device="cuda:0")
+            for r in range(2):
+                buf = torch.zeros(plan.padded_len(n), dtype=torch.uint8, device="cuda:0")
+                pieces = plan.sub_ranges(3)
+                share = (pieces[0][0], pieces[-1][1])
+                for sub in pieces:
+                    ix.map_device(buf.data_ptr(), K, E, value_bits=8, kmer_range=sub, chunks=plan.chunk_arg(r), piece_of=share,
+                                  stream=torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                ix.sync()
+                assert ix.last_stats()["detail"]["correction_us"] > 0
+                acc |= buf
+            assert np.array_equal(acc[:n].cpu().numpy(), exp), (K, E, "pieces of a share")
             ix.set_tuning(jump=0)
             assert np.array_equal(ix.map(K, E, value_bits=8), exp), (K, E, "plain walk")
             ix.set_tuning(jump=-1)
@@ -1126,8 +1145,10 @@ def test_gpu_bench_two_ranks_on_one_device_at_0p77_gbp():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29611",
-           os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "grch38", "--scale", "0.25", "--sampling", "0", "--same-device", "--backend", "gloo",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "grch38", "--scale", "0.25", "--sampling", "1", "--same-device", "--backend", "gloo",
            "--comm", "p2p", "--watchdog", "400", "--E", "0", "--steps", "2", "--warmup", "1", "--verify", "--sub", "100,1:1", "--no-cpu-baseline"]
+    # (--sampling 1 since round 5: the DEFAULT index on both ranks -- suffix array, verification records, the table of all 15-mers, bitmaps:
+    #  jump patterns, N-less pass and ONE correction pass per rank and step, all of them inside the verified vector)
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     for K, E in ((30, 0), (100, 1)):
@@ -1136,6 +1157,9 @@ def test_gpu_bench_two_ranks_on_one_device_at_0p77_gbp():
     assert line["n_gpus"] == 2 and line["comm"] == "peer DMA copies overlapping compute" and len(line["per_rank_search_ms"]) == 2
     sub = [s for s in line["sub"] if (s["K"], s["E"]) == (100, 1)]
     assert sub and sub[0]["roofline"]["frac"] and sub[0]["roofline"]["rank_lines"] > 0 and line["roofline"]["frac"]
+    assert sub[0]["roofline"]["jump_lookups"] > 0                       # the ranks did jump: the default index, not the -S 0 one
+    corr = sub[0]["per_rank_correction_ms"]
+    assert len(corr) == 2 and all(0.0 < c < 100.0 for c in corr), corr    # one correction pass per rank and step, timed
 
 
 def test_gpu_index_of_more_than_2_to_32_rows():
