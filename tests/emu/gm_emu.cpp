@@ -204,7 +204,7 @@ static void search_plan(const MapPlan& plan, const HostIndex<WPP>& ix, Env& env,
     if (jumpCap && E >= 1) {
         for (uint32_t J = std::min(jumpCap, L - 1u); J >= 1; --J) {   // one J for every search: the largest whose pattern lists stay small
             bool ok = true;
-            for (uint32_t s = 0; s < plan.nSearches && ok; ++s) ok = oss_jump_patterns(E, plan.table[(size_t)(plan.stepSize - 1) * 8 + s], L, J, 4096, &jumps[s]);
+            for (uint32_t s = 0; s < plan.nSearches && ok; ++s) ok = oss_jump_patterns(E, plan.table[(size_t)(plan.stepSize - 1) * 8 + s], L, J, 4096, &jumps[s]) && !jumps[s].pat.empty();   // (the rule of gm_api.hip: prepare_search)
             if (ok) break;
             for (auto& j : jumps) j = JumpSearch();
         }
