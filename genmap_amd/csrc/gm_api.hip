@@ -15,6 +15,7 @@
 #include "gm_internal.h"
 #include "gm_host.h"
 #include "gm_kernels.h"
+#include "gm_longk.h"
 
 namespace gm {
 
@@ -317,7 +318,7 @@ const char* gm_status_string(int s)
         case GM_ERR_BAD_VALUE_BITS: return "value_bits must be 8 or 16";
         case GM_ERR_NEED_LOCATE: return "csv / --exclude-pseudo need an index with SA samples";
         case GM_ERR_BAD_OVERLAP: return "overlap cannot be larger than min(K - 1, K - E - 2)";
-        case GM_ERR_BAD_K: return "K out of range (1..255)";
+        case GM_ERR_BAD_K: return "K out of range (1..32768)";
         case GM_ERR_TOO_LONG: return "index too long for 32-bit positions";
         case GM_ERR_BAD_ARG: return "bad argument";
         case GM_ERR_HIP: return "HIP runtime error";
@@ -337,8 +338,8 @@ int gm_device_count(void)
 }
 
 uint32_t gm_default_infix_length(uint32_t K, uint32_t E, int32_t xo) { return default_infix_length(K, E, xo); }
-uint32_t gm_tuned_infix_length(uint32_t K, uint32_t E) { return (K < 1 || K > MAX_K || E > MAX_ERRORS) ? 0u : tuned_infix_length(K, E); }
-uint32_t gm_tuned_infix_length_locating(uint32_t K, uint32_t E) { return (K < 1 || K > MAX_K || E > MAX_ERRORS) ? 0u : tuned_infix_length(K, E, true); }
+uint32_t gm_tuned_infix_length(uint32_t K, uint32_t E) { return (K < 1 || K > MAX_K_LONG || E > MAX_ERRORS) ? 0u : long_k_infix(K, tuned_infix_length(K, E)); }
+uint32_t gm_tuned_infix_length_locating(uint32_t K, uint32_t E) { return (K < 1 || K > MAX_K_LONG || E > MAX_ERRORS) ? 0u : long_k_infix(K, tuned_infix_length(K, E, true)); }
 
 void gm_index_free(gm_index* ix)
 {
@@ -350,7 +351,7 @@ void gm_index_free(gm_index* ix)
     for (auto& kv : ix->jbits) hipFree(kv.second);
     hipFree(ix->d_jinfo2); hipFree(ix->d_seqFile); hipFree(ix->d_rowFile);
     hipFree(ix->d_locCnt); hipFree(ix->d_locOffs); hipFree(ix->d_locEmit); hipFree(ix->d_locSorted); hipFree(ix->d_locTmp); hipFree(ix->d_locSeg); hipFree(ix->d_bits);
-    hipFree(ix->d_acc); hipFree(ix->d_stack); hipFree(ix->d_small); hipFree(ix->d_table); hipFree(ix->d_blocks); hipFree(ix->d_cumLocal);
+    hipFree(ix->d_acc); hipFree(ix->d_stack); hipFree(ix->d_small); hipFree(ix->d_table); hipFree(ix->d_tableL); hipFree(ix->d_blocks); hipFree(ix->d_cumLocal);
     for (int i = 0; i < 4; ++i) if (ix->ev[i]) hipEventDestroy(ix->ev[i]);
     for (uint32_t i = 0; i < gm_index::EV_RING; ++i) for (int j = 0; j < 2; ++j) if (ix->evRing[i][j]) hipEventDestroy(ix->evRing[i][j]);
     if (ix->evDone) hipEventDestroy(ix->evDone);
@@ -585,8 +586,31 @@ static int launch_mode(int mode, const SearchArgs& A, unsigned blocks, hipStream
         default: return launch_one<WPP, OccEmitEnv<WPP>>(A, blocks, st);
     }
 }
+// k-mers longer than MAX_K: gm_longk.h (one leaf policy each for frequency, --exclude-pseudo and the two csv passes)
+template <int WPP>
+static int launch_long(int mode, const SearchArgs& A, unsigned blocks, hipStream_t st)
+{
+    constexpr size_t LDS = 4u * 80u * 4u + 64u;   // control words of the (empty) leaf queues
+    switch (mode) {
+        case LEAF_FILESET: hipLaunchKernelGGL((longk_kernel<WPP, FileSetEnv<WPP>>), dim3(blocks), dim3(256), LDS, st, A); break;
+        case LEAF_OCC_COUNT: hipLaunchKernelGGL((longk_kernel<WPP, OccCountEnv<WPP>>), dim3(blocks), dim3(256), LDS, st, A); break;
+        case LEAF_OCC_EMIT: hipLaunchKernelGGL((longk_kernel<WPP, OccEmitEnv<WPP>>), dim3(blocks), dim3(256), LDS, st, A); break;
+        case LEAF_COUNT: hipLaunchKernelGGL((longk_kernel<WPP, CountEnv<WPP>>), dim3(blocks), dim3(256), LDS, st, A); break;
+        default: set_error("internal: leaf policy %d has no long k-mer kernel", mode); return GM_ERR_INTERNAL;
+    }
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+}
 static int launch_search(const gm_index* ix, int mode, const SearchArgs& A, unsigned blocks, hipStream_t st)
 {
+    if (A.K > MAX_K) {
+        switch (ix->wpp) {
+            case 1: return launch_long<1>(mode, A, blocks, st);
+            case 2: return launch_long<2>(mode, A, blocks, st);
+            case 3: return launch_long<3>(mode, A, blocks, st);
+            default: return launch_long<9>(mode, A, blocks, st);
+        }
+    }
     switch (ix->wpp) {
         case 1: return launch_mode<1>(mode, A, blocks, st);
         case 2: return launch_mode<2>(mode, A, blocks, st);
@@ -814,9 +838,12 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     // issued on another stream than its predecessor waits for the predecessor's end-of-call event
     if (ix->doneValid) GM_HIP(hipStreamWaitEvent(st, ix->evDone, 0));
 
-    if (p->K < 1 || p->K > MAX_K) return GM_ERR_BAD_K;
+    if (p->K < 1 || p->K > MAX_K_LONG) return GM_ERR_BAD_K;
+    // k-mers longer than MAX_K: the plain tree walk of gm_longk.h (no tables, no verification, no jump patterns, no LDS staging)
+    const bool longK = p->K > MAX_K;
+    if (longK) wantJump = false;
     // (frequency calls ask for jump patterns; --exclude-pseudo and gm_locate do not: gm_tuned_infix_length_locating)
-    const uint32_t infix = p->infix > 0 ? (uint32_t)p->infix : (p->overlap >= 0 ? default_infix_length(p->K, p->E, p->overlap) : tuned_infix_length(p->K, p->E, !wantJump));
+    const uint32_t infix = long_k_infix(p->K, p->infix > 0 ? (uint32_t)p->infix : (p->overlap >= 0 ? default_infix_length(p->K, p->E, p->overlap) : tuned_infix_length(p->K, p->E, !wantJump)));
     if (infix == 0) return GM_ERR_BAD_OVERLAP;
     MapPlan& plan = S->plan;
     int rc = make_map_plan(p->K, p->E, infix, p->revcompl, text_len, intervals, n_intervals, &plan, ix->tune.partBias, oss_weights_for(ix, p->E));
@@ -872,13 +899,14 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     {
         const void *t0 = ix->d_table, *c0 = ix->d_cumLocal, *b0 = ix->d_blocks;
         rc = grow(&ix->d_table, &ix->tableCap, (uint64_t)plan.table.size()); if (rc) return rc;
+        if (longK) { const void* l0 = ix->d_tableL; rc = grow(&ix->d_tableL, &ix->tableLCap, (uint64_t)plan.tableL.size()); if (rc) return rc; if (l0 != ix->d_tableL) ix->sigValid = false; }
         rc = grow(&ix->d_cumLocal, &ix->cumLocalCap, (uint64_t)n_seq + 1); if (rc) return rc;
         if (plan.useList) { rc = grow(&ix->d_blocks, &ix->blocksCap, std::max<uint64_t>(plan.blocks.size(), 1)); if (rc) return rc; }
         if (t0 != ix->d_table || c0 != ix->d_cumLocal || b0 != ix->d_blocks) ix->sigValid = false;   // reallocated: contents are gone
     }
     // LDS staging per block of 4 wavefronts: verification queue, top of the lane stacks, packed needle windows
     uint32_t verifyT = 0;
-    if (ix->d_sa && ix->d_textS) {   // narrow nodes are resolved against the text when the SA is resident
+    if (ix->d_sa && ix->d_textS && !longK) {   // narrow nodes are resolved against the text when the SA is resident
         int t = 1;
         // long k-mers with errors: a two-row node has a long way to go by rank steps; with the 32-byte row records two reads
         // settle it (K=100 e=1: +8 % on 3.09 Gbp, +12 % on 249 Mbp; K=30: -20 %, profiles/r02/sweep_*_steal_verify.txt)
@@ -901,7 +929,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     // queue entries per wavefront: up to 63 left from the last iteration + one row of every lane + (two rows) 32 second rows; the rest waits (search_body)
     auto vq_cap = [](uint32_t rows) { return rows >= 2u ? 160u : 128u; };
     uint32_t vqCap = verifyT ? vq_cap(verifyRows) : 1u;
-    const uint32_t winChunks = (31u + p->K + plan.stepSize - 1u + 31u) / 32u;
+    const uint32_t winChunks = longK ? 1u : (31u + p->K + plan.stepSize - 1u + 31u) / 32u;   // (long k-mers read their needle from the text)
     const uint32_t nu = ix->wide ? 2u : 1u;
     const int wantPerCU = std::max(1, ix->tune.blocksPerCU);   // default 4 = 4 waves/SIMD, what the kernel's VGPR count allows
     // (calls that may jump keep their table entries in flight in LDS: one 16-byte slot per lane)
@@ -946,10 +974,11 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         }
         perCU = std::max(1, perCU);
     }
-    uint64_t blocks = (uint64_t)ix->numCU * perCU;
+    uint64_t blocks = (uint64_t)ix->numCU * (longK ? 8u : (uint32_t)perCU);   // (gm_longk.h: no LDS to speak of, eight blocks of 256 lanes per CU)
     const uint64_t useful = (S->numRoots + 255) / 256;
     if (blocks > useful) blocks = std::max<uint64_t>(useful, 1);
     S->blocks = (unsigned)blocks;
+    if (longK) { ldsDepth = 0; rc = grow(&ix->d_stack, &ix->stackCap, blocks * 256ull * depth * 2ull); if (rc) return rc; }   // LNodeT: at most 32 bytes per entry
     // (twice: the correction pass of an N-less call runs beside the main search with the same geometry and at most as many blocks: the upper half is its)
     rc = grow(&ix->d_stack, &ix->stackCap, 2ull * blocks * 256ull * std::max<uint32_t>(depth - ldsDepth, 1u) * nu); if (rc) return rc;
 
@@ -1044,6 +1073,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         for (uint64_t k = 0; k < 2 * n_intervals; ++k) mix(intervals[k]);
         if (!ix->sigValid || ix->sig != h) {
             GM_HIP(hipMemcpyAsync(ix->d_table, plan.table.data(), plan.table.size() * sizeof(OssRecord), hipMemcpyHostToDevice, st));
+            if (longK) GM_HIP(hipMemcpyAsync(ix->d_tableL, plan.tableL.data(), plan.tableL.size() * sizeof(OssRecordL), hipMemcpyHostToDevice, st));
             if (plan.useList && !plan.blocks.empty())
                 GM_HIP(hipMemcpyAsync(ix->d_blocks, plan.blocks.data(), plan.blocks.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
             if (jumpJ) {
@@ -1083,6 +1113,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         while (qmax < qcap && (1ull << (2 * qmax)) < 4ull * ix->nRows) ++qmax;
         if (ix->wide) qmax = std::min(qmax, 14u);   // 32-byte entries
         if (ix->tune.qtable >= 0) qmax = (uint32_t)std::min(ix->tune.qtable, 16);
+        if (longK) qmax = 0;
         A.qtabA = A.qtabB = nullptr; A.qlenPacked[0] = A.qlenPacked[1] = 0; A.qselMask = 0; A.startPacked[0] = A.startPacked[1] = 0;
         uint32_t qA = 0, qB = 0;
         for (uint32_t s = 0; s < plan.nSearches; ++s) {
@@ -1162,6 +1193,8 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     A.patterns = ix->d_patterns; A.jinfo = ix->d_jinfo; A.jinfo2 = ix->d_jinfo2; A.jtab = jtab; A.jbits = jbitsCall; A.jbitsWords = jbitsWords;
     for (uint32_t k = 0; k < GROUP_MAX_MASKS; ++k) A.gmask[k] = gmaskCall[k];
     for (uint32_t k = 0; k < 8u; ++k) { A.layShift[k] = layShift[k]; A.layPlane0[k] = layPlane0[k]; A.layPlane1[k] = layPlane1[k]; }
+    A.tableL = longK ? ix->d_tableL : nullptr;
+    if (longK) { A.lqCap = 0u; A.entrySlots = 0u; A.selfHit = 0u; A.spillDepth = depth; }
     A.sliceBegin = text_begin; A.sliceLen = text_len; A.ownBegin = 0; A.ownEnd = text_len; A.ownChunkLen = 0; A.selBlocks = nullptr; A.nSelBlocks = 0;
     *Aout = A;
     return GM_OK;
@@ -1236,12 +1269,13 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
         rc = grow(&ix->d_acc, &ix->accCap, 2 * (text_len + 4) + 16); if (rc) return rc;
     }
     // E = 0 with single-row verification: plain stores into one plane per strand instead of atomics
-    const bool store = !ep && p->E == 0 && A.verifyT <= 1 && !ix->tune.noStore;
+    const bool longK = p->K > MAX_K;   // gm_longk.h: counts go through the accumulators at any E
+    const bool store = !ep && p->E == 0 && A.verifyT <= 1 && !ix->tune.noStore && !longK;
     const uint64_t plane = (text_len + 4 + 15) & ~15ull;   // both planes aligned alike: finalize2 reads 16 bytes per lane
     // counting kernels on the regular partition: verified runs of k-mers go into a difference plane behind acc (gm_kernels.h: CountEnv::leaf_range)
     // (finalize_diff_kernel restarts its running sum at every multiple of stepSize from the range's first position and CountEnv::leaf_range
     //  never lets a run leave its block: both hold because ranges and chunks are whole blocks of the regular partition -- checked, not assumed)
-    const bool useDiff = !ep && !store && !S.plan.useList && ix->tune.rangeAdd != 0 && S.posBase % S.plan.stepSize == 0 && S.sel.len % S.plan.stepSize == 0;
+    const bool useDiff = !ep && !store && !longK && !S.plan.useList && ix->tune.rangeAdd != 0 && S.posBase % S.plan.stepSize == 0 && S.sel.len % S.plan.stepSize == 0;
     const uint64_t diffOff = (text_len + 4 + 3) & ~3ull;
     // kernels over positions: blockIdx.y walks the shard's own chunk ranges (one range without chunks), blockIdx.x one range
     auto range_grid = [](const ChunkSel& c, uint64_t n, uint32_t perThread) {
@@ -1609,7 +1643,7 @@ int gm_map_shard(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t 
 {
     if (!ix || !p || !out_host) { set_error("null argument"); return GM_ERR_BAD_ARG; }
     if (p->value_bits != 8 && p->value_bits != 16) return GM_ERR_BAD_VALUE_BITS;
-    if (p->K < 1 || p->K > MAX_K) return GM_ERR_BAD_K;
+    if (p->K < 1 || p->K > MAX_K_LONG) return GM_ERR_BAD_K;
     GM_HIP(hipSetDevice(ix->device));
     const size_t eb = p->value_bits / 8;
     if (!ix->stCompute) {
@@ -1630,7 +1664,7 @@ int gm_map_shard(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t 
     const bool chunked = p->chunk_blocks > 0 && p->chunk_stride > 1;
     if (n_intervals > 0 || !chunked) {
         // a selection, or a plain contiguous share (gm_map is the share "everything")
-        const uint32_t infix = p->infix > 0 ? (uint32_t)p->infix : (p->overlap >= 0 ? default_infix_length(p->K, p->E, p->overlap) : tuned_infix_length(p->K, p->E, p->exclude_pseudo != 0));
+        const uint32_t infix = long_k_infix(p->K, p->infix > 0 ? (uint32_t)p->infix : (p->overlap >= 0 ? default_infix_length(p->K, p->E, p->overlap) : tuned_infix_length(p->K, p->E, p->exclude_pseudo != 0 || p->K > MAX_K)));
         if (infix == 0 || infix > p->K) return GM_ERR_BAD_OVERLAP;
         const uint64_t step = p->K - infix + 1;
         // whole blocks: the share ends where the next one begins; the tail past the last k-mer is all zeros (resetLimits)
@@ -1672,7 +1706,7 @@ int gm_map_shard(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t 
         GM_HIP(hipStreamSynchronize(ix->stCompute));
         return check_device_error(ix);
     }
-    const uint32_t infix = p->infix > 0 ? (uint32_t)p->infix : (p->overlap >= 0 ? default_infix_length(p->K, p->E, p->overlap) : tuned_infix_length(p->K, p->E, p->exclude_pseudo != 0));
+    const uint32_t infix = long_k_infix(p->K, p->infix > 0 ? (uint32_t)p->infix : (p->overlap >= 0 ? default_infix_length(p->K, p->E, p->overlap) : tuned_infix_length(p->K, p->E, p->exclude_pseudo != 0 || p->K > MAX_K)));
     if (infix == 0 || infix > p->K) return GM_ERR_BAD_OVERLAP;
     const uint64_t step = p->K - infix + 1, chunkLen = (uint64_t)p->chunk_blocks * step, rowLen = chunkLen * p->chunk_stride;
     const uint64_t base = (kb + step - 1) / step * step;                       // first block of the range

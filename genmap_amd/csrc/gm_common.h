@@ -18,6 +18,7 @@ enum : uint32_t { SYM_A = 0, SYM_C = 1, SYM_G = 2, SYM_T = 3, SYM_N = 4, SYM_SEN
 
 constexpr uint32_t MAX_ERRORS = 4;   // "E > 4 not yet supported." src/mappability.hpp:187
 constexpr uint32_t MAX_K = 255;      // 16-byte node encoding: needle-window coordinates <= 2K-1 <= 509 fit 9 bits; OSS block lengths fit 8
+constexpr uint32_t MAX_K_LONG = 32768;   // longer k-mers run the plain tree walk of gm_longk.h (16-bit coordinates, blocks of at most 255 k-mers)
 
 GM_HD uint32_t complement(uint32_t c) { return c < 4u ? 3u - c : c; }   // N stays N (src/algo.hpp:5-8)
 

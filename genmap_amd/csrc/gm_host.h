@@ -49,6 +49,12 @@ inline uint32_t tuned_infix_length(uint32_t K, uint32_t E, bool locating = false
 {
     auto clampu = [](uint32_t v, uint32_t lo, uint32_t hi) { return v < lo ? lo : (v > hi ? hi : v); };
     uint32_t n;
+    if (K > MAX_K) {
+        // gm_longk.h walks the plain tree: the infix (K - n + 1 characters) is searched once per block, the extension costs ~n log2 n steps
+        // per surviving path -- long blocks pay at any E and for every leaf policy
+        n = clampu(K / 4, 48, 255);
+        return std::max(K - n + 1, std::min(K, std::max<uint32_t>(E + 2, oss_scheme(E > MAX_ERRORS ? 0 : E).s[0].nb)));
+    }
     if (locating) {   // (e = 0 alike: K=24 28 ms against 116 with blocks of 8, K=30 25 / 120, K=100 13.5 with n = 4 against 14.1 with 31 and 29 with 1)
         n = K < 64 ? 1 : 4;
         const uint32_t minInfixL = std::min(K, std::max<uint32_t>(E + 2, oss_scheme(E > MAX_ERRORS ? 0 : E).s[0].nb));
@@ -80,6 +86,9 @@ inline uint32_t tuned_infix_length(uint32_t K, uint32_t E, bool locating = false
     return std::max(infix, minInfix);
 }
 
+// K > MAX_K: the common infix is kept long enough that a block holds at most 255 k-mers (the result does not depend on it)
+inline uint32_t long_k_infix(uint32_t K, uint32_t infix) { return (K > MAX_K && infix >= 1 && infix <= K && K - infix + 1 > 255u) ? K - 254u : infix; }
+
 struct MapPlan {
     uint32_t K = 0, E = 0, infix = 0, stepSize = 0, nSearches = 0, nStrands = 0;
     uint64_t textLen = 0, numKmers = 0;
@@ -90,6 +99,7 @@ struct MapPlan {
     static uint32_t block_n(const std::pair<uint32_t, uint32_t>& b) { return b.second & 0xFFu; }
     uint64_t numBlocks = 0;
     std::vector<OssRecord> table;                        // [(n-1)*8 + s], n = 1..stepSize
+    std::vector<OssRecordL> tableL;                      // the same for K > MAX_K (gm_longk.h); `table` is then all zeros
     uint64_t numRoots() const { return numBlocks * nSearches * nStrands; }
 };
 
@@ -103,14 +113,18 @@ inline int make_map_plan(uint32_t K, uint32_t E, uint32_t infix, int revcompl, u
 {
     MapPlan& p = *out;
     if (E > MAX_ERRORS) return PLAN_BAD_E;
-    if (K < 1 || K > MAX_K) return PLAN_BAD_K;
+    if (K < 1 || K > MAX_K_LONG) return PLAN_BAD_K;
     if (infix < 1 || infix > K) return PLAN_BAD_OVERLAP;
+    const bool longK = K > MAX_K;
+    if (longK && K - infix + 1 > 255u) return PLAN_BAD_OVERLAP;   // (callers clamp: long_k_infix; block lists hold the k-mers of a block in 8 bits)
     if (textLen >= (1ull << 40)) return PLAN_TOO_LONG;
     p.K = K; p.E = E; p.infix = infix; p.stepSize = K - infix + 1;   // algo.hpp:416
     p.nSearches = oss_scheme(E).ns; p.nStrands = revcompl ? 2 : 1;
     p.textLen = textLen;
     p.numKmers = textLen >= K ? textLen - K + 1 : 0;                 // algo.hpp:414 underflows for textLen < K
     p.table.assign((size_t)p.stepSize * 8, OssRecord{0, 0, 0, 0});
+    p.tableL.clear();
+    if (longK) p.tableL.assign((size_t)p.stepSize * 8, OssRecordL{{0, 0, 0, 0, 0, 0}, 0, 0, 0, 0});
     for (uint32_t n = 1; n <= p.stepSize; ++n)
         for (uint32_t s = 0; s < p.nSearches; ++s)
         {
@@ -133,7 +147,8 @@ inline int make_map_plan(uint32_t K, uint32_t E, uint32_t infix, int revcompl, u
                 for (uint32_t i = nb; sum > L; ) { i = i ? i - 1 : nb - 1; if (lens[i] > 1) { lens[i]--; sum--; } }   // (minimum lengths pushed it over)
                 lp = lens;
             }
-            if (!oss_make_record(E, s, L, &p.table[(size_t)(n - 1) * 8 + s], lp)) return PLAN_BAD_OVERLAP;
+            if (longK) { if (!oss_make_record_long(E, s, L, &p.tableL[(size_t)(n - 1) * 8 + s], lp)) return PLAN_BAD_OVERLAP; }
+            else if (!oss_make_record(E, s, L, &p.table[(size_t)(n - 1) * 8 + s], lp)) return PLAN_BAD_OVERLAP;
         }
     p.blocks.clear();
     if (nIntervals == 0) {

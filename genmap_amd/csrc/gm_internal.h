@@ -8,6 +8,7 @@
 #include <thread>
 #include "../../include/genmap_amd.h"
 #include "gm_common.h"
+#include "gm_oss.h"
 
 namespace gm {
 
@@ -78,6 +79,7 @@ struct gm_index {
     uint4* d_stack = nullptr; uint64_t stackCap = 0;       // in uint4 units
     void* d_small = nullptr;                               // counter(8) | error(4) | pad | counters(16)
     uint4* d_table = nullptr; uint64_t tableCap = 0;
+    gm::OssRecordL* d_tableL = nullptr; uint64_t tableLCap = 0;   // K > MAX_K (gm_longk.h)
     uint2* d_blocks = nullptr; uint64_t blocksCap = 0;
     uint64_t* d_cumLocal = nullptr; uint64_t cumLocalCap = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};

@@ -115,6 +115,8 @@ struct SearchArgs {
     uint32_t ownChunkLen;           // positions per chunk (0: no chunks)
     const uint2* selBlocks;         // a selection's blocks, sorted by position (nullptr: every position is computed)
     uint32_t nSelBlocks;
+    // ---- k-mers longer than MAX_K (gm_longk.h) ----
+    const void* tableL;             // OssRecordL[(n-1)*8 + s]
 };
 
 // which positions of a range belong to the calling shard (interleaved chunks of `len` positions); len == 0: all of them

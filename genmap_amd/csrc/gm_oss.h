@@ -65,30 +65,55 @@ GM_HD uint32_t oss_right(const OssRecord& r, uint32_t bi) { return (r.z >> (18u 
 // blockLens (optional): lengths of blocks 1..nb in left-to-right order, summing to infixLen.  The scheme covers every
 // error distribution exactly once for ANY positive block lengths (l/u constrain errors per block, not per position);
 // the reference always uses equal lengths (:167-172).
-inline bool oss_make_record(uint32_t E, uint32_t s, uint32_t infixLen, OssRecord* out, const uint32_t* blockLens = nullptr)
+// layout of search s over an infix of infixLen characters: cumulative block lengths in search order, start position, packed bounds
+inline bool oss_layout(uint32_t E, uint32_t s, uint32_t infixLen, const uint32_t* blockLens, uint32_t bl[OSS_MAXB], uint32_t* startOut, uint32_t* zOut, uint32_t* wOut, uint32_t* blocksOut)
 {
     const OssSearch& S = oss_scheme(E).s[s];
     uint32_t blocks = S.nb;
-    if (infixLen < blocks || infixLen > 255u) return false;
+    if (infixLen < blocks) return false;
     uint32_t base = infixLen / blocks, rest = infixLen - blocks * base;   // :167-172
-    uint32_t bl[OSS_MAXB] = {0, 0, 0, 0, 0, 0}, cum = 0, start = 0;
+    uint32_t cum = 0, start = 0;
+    for (uint32_t i = 0; i < (uint32_t)OSS_MAXB; ++i) bl[i] = 0;
     for (uint32_t i = 0; i < blocks; ++i) {
         uint32_t len = blockLens ? blockLens[S.pi[i] - 1] : base + ((uint32_t)(S.pi[i] - 1) < rest ? 1u : 0u);   // :145 blocklength[pi[i]-1]
         cum += len;
         bl[i] = cum;
         if (S.pi[i] < S.pi[0]) start += len;                               // :158-160
     }
+    uint32_t z = 0, w = 0;
+    for (uint32_t i = 0; i < blocks; ++i) {
+        z |= (uint32_t)S.l[i] << (3u * i);
+        w |= (uint32_t)S.u[i] << (3u * i);
+        // direction of block i: the first block always goes right (:441); later ones by pi order (:274,:321)
+        uint32_t right = (i == 0) ? 1u : (S.pi[i] > S.pi[i - 1] ? 1u : 0u);
+        z |= right << (18u + i);
+    }
+    *startOut = start; *zOut = z; *wOut = w; *blocksOut = blocks;
+    return true;
+}
+
+inline bool oss_make_record(uint32_t E, uint32_t s, uint32_t infixLen, OssRecord* out, const uint32_t* blockLens = nullptr)
+{
+    uint32_t bl[OSS_MAXB], start, z, w, blocks;
+    if (infixLen > 255u || !oss_layout(E, s, infixLen, blockLens, bl, &start, &z, &w, &blocks)) return false;
     OssRecord r;
     r.x = bl[0] | bl[1] << 8 | bl[2] << 16 | bl[3] << 24;
     r.y = bl[4] | bl[5] << 8 | start << 16 | blocks << 24;
-    r.z = 0; r.w = 0;
-    for (uint32_t i = 0; i < blocks; ++i) {
-        r.z |= (uint32_t)S.l[i] << (3u * i);
-        r.w |= (uint32_t)S.u[i] << (3u * i);
-        // direction of block i: the first block always goes right (:441); later ones by pi order (:274,:321)
-        uint32_t right = (i == 0) ? 1u : (S.pi[i] > S.pi[i - 1] ? 1u : 0u);
-        r.z |= right << (18u + i);
-    }
+    r.z = z; r.w = w;
+    *out = r;
+    return true;
+}
+
+// The same search for k-mers longer than MAX_K (gm_longk.h): 16-bit lengths, 24 bytes, read from memory by the lane (not kept in registers).
+//   z, w as in OssRecord (l / goRight, u)
+struct OssRecordL { uint16_t bl[OSS_MAXB]; uint16_t start, nb; uint32_t z, w; };
+inline bool oss_make_record_long(uint32_t E, uint32_t s, uint32_t infixLen, OssRecordL* out, const uint32_t* blockLens = nullptr)
+{
+    uint32_t bl[OSS_MAXB], start, z, w, blocks;
+    if (infixLen > 0xFFFFu || !oss_layout(E, s, infixLen, blockLens, bl, &start, &z, &w, &blocks)) return false;
+    OssRecordL r;
+    for (int i = 0; i < OSS_MAXB; ++i) r.bl[i] = (uint16_t)bl[i];
+    r.start = (uint16_t)start; r.nb = (uint16_t)blocks; r.z = z; r.w = w;
     *out = r;
     return true;
 }

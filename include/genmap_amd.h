@@ -29,7 +29,7 @@ typedef enum gm_status {
     GM_ERR_BAD_VALUE_BITS = -3,/* value_bits must be 8 (-fs) or 16 (-fl, mappability) src/mappability.hpp:388-394 */
     GM_ERR_NEED_LOCATE = -4,   /* csv / --exclude-pseudo requested on an index without SA samples */
     GM_ERR_BAD_OVERLAP = -5,   /* -xo larger than min(K-1, K-E-2), src/mappability.hpp:528-540; or infix < #blocks */
-    GM_ERR_BAD_K = -6,         /* K < 1 or K > 255 (this build's node encoding) */
+    GM_ERR_BAD_K = -6,         /* K < 1 or K > 32768 (K <= 255: the persistent kernel with 16-byte nodes; longer k-mers: the plain tree walk, gm_longk.h) */
     GM_ERR_TOO_LONG = -7,      /* beyond the build's limits: 2^40 rows; a gm_locate window of 2^31 occurrences */
     GM_ERR_BAD_ARG = -8,
     GM_ERR_HIP = -9,           /* a HIP call failed; gm_last_error() has the text */

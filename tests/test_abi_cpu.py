@@ -66,7 +66,14 @@ def test_tuned_infix_is_always_schedulable():
             if K < nb[E]:
                 continue  # the call is rejected with GM_ERR_BAD_OVERLAP (infix shorter than the number of blocks)
             assert nb[E] <= t <= K, (K, E, t)
-    assert g.tuned_infix_length(256, 0) == 0 and g.tuned_infix_length(30, 5) == 0
+    assert g.tuned_infix_length(30, 5) == 0
+    # k-mers longer than 255 (gm_longk.h): blocks of 48 .. 255 k-mers, never more (a block list holds the count in 8 bits)
+    for K in (256, 300, 1000, 1021, 5000, 32768):
+        for E in range(5):
+            t = g.tuned_infix_length(K, E)
+            assert nb[E] <= t <= K and 48 <= K - t + 1 <= 255, (K, E, t)
+            assert g.tuned_infix_length(K, E, locating=True) == t
+    assert g.tuned_infix_length(32769, 0) == 0
 
 
 def test_tuned_block_shape_at_one_error_follows_the_measured_rule():

@@ -247,6 +247,66 @@ def test_gpu_baseline_settings_small(K, E):
         ix.close()
 
 
+@pytest.mark.parametrize("bb", [0, 64, WIDE])
+def test_gpu_long_kmers_beyond_255(bb):
+    """The reference takes any -K (src/mappability.hpp:425-426).  K > 255 runs the plain tree walk of gm_longk.h: frequencies at
+    8 and 16 bits, an explicit infix (also one that would make blocks of more than 255 k-mers: clamped), both strands or one,
+    a selection, a k-mer range and interleaved chunks, --exclude-pseudo and the located occurrences -- all against the oracle."""
+    g = _gm()
+    rng = np.random.default_rng(2550 + bb % 97)
+    lens = [60000, 1300, 299, 30000, 700, 12000]
+    codes = _repeat_text(rng, sum(lens), True)
+    # long exact and near-exact copies, so that long k-mers do have several occurrences (and pseudo copies in other "files")
+    fam = codes[2000:5000].copy()
+    for i, s0 in enumerate((70000, 92000, 95000)):
+        cp = fam.copy()
+        if i: cp[rng.integers(0, 3000, size=4)] ^= 1
+        codes[s0:s0 + 3000] = cp
+    ora = H.OracleIndex(codes, lens, keep_sa=True)
+    ix = g.Index.build(codes, lens, sampling=1, block_bytes=bb)
+    fid = np.array([0, 0, 1, 1, 2, 2], dtype=np.uint32)
+    try:
+        for K, E in ((256, 0), (300, 1), (300, 2), (1000, 0), (1000, 1), (513, 3)):
+            for bits in (8, 16):
+                exp = ora.mappability(K, E, value_bits=bits, threads=8)
+                assert np.array_equal(ix.map(K, E, value_bits=bits), exp), (K, E, bits, bb)
+            assert exp.max() >= 2
+            assert np.array_equal(ix.map(K, E, value_bits=16, infix=K - 6), exp), (K, E, "infix")
+            assert np.array_equal(ix.map(K, E, value_bits=16, infix=max(K // 3, 8)), exp), (K, E, "blocks of 255")
+            assert np.array_equal(ix.map(K, E, value_bits=16, revcompl=False), ora.mappability(K, E, value_bits=16, revcompl=False, threads=8)), (K, E, "one strand")
+            # shards: a k-mer range, then three interleaved chunk shares into one vector
+            step = K - g.tuned_infix_length(K, E) + 1
+            host = np.zeros(sum(lens), dtype=np.uint16)
+            for r in range(3):
+                ix.map_shard(host, K, E, value_bits=16, chunks=(2, r, 3))
+            assert np.array_equal(host, exp), (K, E, "chunks", step)
+        K, E = 300, 1
+        iv = [(100, 900), (59000, 60000), (61000, 61400), (95000, 99000)]
+        exp = ora.mappability(K, E, value_bits=16, intervals=iv, threads=8)
+        assert np.array_equal(ix.map(K, E, value_bits=16, intervals=iv), exp)
+        # --exclude-pseudo and csv on the fourth "file" (sequences 2..3) and on the whole index
+        for first, nseq in ((2, 2), (0, 6)):
+            tb, tl = int(ora.cum[first]), int(ora.cum[first + nseq] - ora.cum[first])
+            exp, _, locs = ora.mappability(K, E, first_seq=first, n_seq=nseq, text_begin=tb, text_len=tl, value_bits=16, directory=True,
+                                           exclude_pseudo=True, csv=True, seq_file_id=fid, threads=8)
+            out = ix.map(K, E, first_seq=first, n_seq=nseq, value_bits=16, exclude_pseudo=True, seq_file_id=fid)
+            assert np.array_equal(out, exp), (first, nseq)
+            gen = type("G", (), {"seq_len": np.asarray(lens), "cum": np.asarray(ora.cum)})()
+            ent = _csv_entries(gen, first, nseq, K, ix.locate(K, E, first_seq=first, n_seq=nseq))
+            assert ent == locs, (first, nseq)
+        with pytest.raises(g.GenmapError) as ei:
+            ix.map(32769, 0, value_bits=8)
+        assert ei.value.status == -6                                                               # GM_ERR_BAD_K
+        ix.set_tuning(iter_cap=3)                                                                  # the hang guard covers this kernel too
+        with pytest.raises(g.GenmapError) as ei:
+            ix.map(300, 1, value_bits=8)
+        assert ei.value.status == -12
+        ix.set_tuning(iter_cap=-1)
+        ix.sync()
+    finally:
+        ix.close()
+
+
 def test_gpu_sixteen_symbol_table_on_a_small_text():
     """Indexes beyond 2^30 rows start their searches from the table of all 16-mers (69 GB); forced here on a small text so that the
     oracle can check it: q-mer table at e = 0 (infix 17 and longer), jump patterns of 16 characters at e = 1 and 2."""
