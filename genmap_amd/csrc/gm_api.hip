@@ -590,7 +590,7 @@ static int launch_mode(int mode, const SearchArgs& A, unsigned blocks, hipStream
 template <int WPP>
 static int launch_long(int mode, const SearchArgs& A, unsigned blocks, hipStream_t st)
 {
-    constexpr size_t LDS = 4u * 80u * 4u + 64u;   // control words of the (empty) leaf queues
+    constexpr size_t LDS = 4u * 80u * 4u + 4u * 64u + 64u;   // control words of the (empty) leaf queues, pairing bytes of the work sharing
     switch (mode) {
         case LEAF_FILESET: hipLaunchKernelGGL((longk_kernel<WPP, FileSetEnv<WPP>>), dim3(blocks), dim3(256), LDS, st, A); break;
         case LEAF_OCC_COUNT: hipLaunchKernelGGL((longk_kernel<WPP, OccCountEnv<WPP>>), dim3(blocks), dim3(256), LDS, st, A); break;
@@ -906,6 +906,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     }
     // LDS staging per block of 4 wavefronts: verification queue, top of the lane stacks, packed needle windows
     uint32_t verifyT = 0;
+    if (ix->d_sa && ix->d_textS && longK) verifyT = (uint32_t)std::max(0, std::min(ix->tune.verifyT >= 0 ? ix->tune.verifyT : 1, (int)VERIFY_TMAX));   // gm_longk.h: a row costs one suffix-array read and a scan of the text by its lane alone (3.09 Gbp K=300: one row e=0 -53 %, e=1 -7 % over none; four rows +10 % / +28 % over one, profiles/r05/longk_scale.txt)
     if (ix->d_sa && ix->d_textS && !longK) {   // narrow nodes are resolved against the text when the SA is resident
         int t = 1;
         // long k-mers with errors: a two-row node has a long way to go by rank steps; with the 32-byte row records two reads
@@ -1194,7 +1195,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     for (uint32_t k = 0; k < GROUP_MAX_MASKS; ++k) A.gmask[k] = gmaskCall[k];
     for (uint32_t k = 0; k < 8u; ++k) { A.layShift[k] = layShift[k]; A.layPlane0[k] = layPlane0[k]; A.layPlane1[k] = layPlane1[k]; }
     A.tableL = longK ? ix->d_tableL : nullptr;
-    if (longK) { A.lqCap = 0u; A.entrySlots = 0u; A.selfHit = 0u; A.spillDepth = depth; }
+    if (longK) { A.lqCap = 0u; A.entrySlots = 0u; A.selfHit = 0u; A.spillDepth = depth; A.steal = ix->tune.steal >= 0 ? (uint32_t)(ix->tune.steal != 0) : 1u; }
     A.sliceBegin = text_begin; A.sliceLen = text_len; A.ownBegin = 0; A.ownEnd = text_len; A.ownChunkLen = 0; A.selBlocks = nullptr; A.nSelBlocks = 0;
     *Aout = A;
     return GM_OK;

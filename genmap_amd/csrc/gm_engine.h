@@ -443,20 +443,20 @@ GM_HD bool self_hit_kmers(uint32_t meta, const RootT<R>& rt, uint32_t K, uint32_
 
 // `it`: the candidate location -- Env::Item (symbols are fetched by the scans, eight at a time), or a MaskItem (below: the whole
 // comparison is at hand as two 64-bit masks; scan_side has an overload for either)
-template <class Env, class ItemT>
-GM_HD void verify_with(const ItemT& it, uint32_t meta, const RootT<typename Env::row_t>& rt, uint32_t K, uint32_t E, Env& env)
+// (the node's fields unpacked, the search's record as OssRecord or OssRecordL: gm_longk.h verifies with 16-bit coordinates)
+template <class Env, class ItemT, class RecT>
+GM_HD void verify_fields(const ItemT& it, uint32_t a, uint32_t bx, uint32_t t, uint32_t errs, uint32_t mode, const RecT& rec, const RootT<typename Env::row_t>& rt, uint32_t K, uint32_t E, Env& env)
 {
     typedef typename Env::row_t R;
-    uint32_t a = meta_a(meta), bx = meta_bx(meta), t = meta_t(meta), errs = meta_errs(meta), mode = meta_mode(meta);
     const R p0 = it.p0;   // aligned with needle coordinate a0 (a changes below, keep the anchor)
     env.note_item(mode);
     const uint32_t a0 = a;
     uint32_t scratch[4];
     if (mode == M_OSS) {
-        const uint32_t nb = oss_nb(rt.rec);
+        const uint32_t nb = oss_nb(rec);
         for (uint32_t bi = t; bi < nb; ++bi) {
             env.note_wave(11);
-            const uint32_t right = oss_right(rt.rec, bi), blen = oss_bl(rt.rec, bi), u = oss_u(rt.rec, bi), l = oss_l(rt.rec, bi);
+            const uint32_t right = oss_right(rec, bi), blen = oss_bl(rec, bi), u = oss_u(rec, bi), l = oss_l(rec, bi);
             const uint32_t need = blen - (bx - a);
             uint32_t c = 0;
             const uint32_t got = scan_side(env, rt, it, a0, right ? bx : a - 1u, !right, need, u - errs, c, scratch);
@@ -504,6 +504,12 @@ GM_HD void verify_with(const ItemT& it, uint32_t meta, const RootT<typename Env:
         curLo = lo; curHi = hi;
     }
     if (curLo <= curHi) emit_kmer_run(env, rt, (uint32_t)curLo, (uint32_t)curHi, p0, a0);
+}
+
+template <class Env, class ItemT>
+GM_HD void verify_with(const ItemT& it, uint32_t meta, const RootT<typename Env::row_t>& rt, uint32_t K, uint32_t E, Env& env)
+{
+    verify_fields(it, meta_a(meta), meta_bx(meta), meta_t(meta), meta_errs(meta), meta_mode(meta), rt.rec, rt, K, E, env);
 }
 
 template <class Env>

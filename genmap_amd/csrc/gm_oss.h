@@ -107,6 +107,12 @@ inline bool oss_make_record(uint32_t E, uint32_t s, uint32_t infixLen, OssRecord
 // The same search for k-mers longer than MAX_K (gm_longk.h): 16-bit lengths, 24 bytes, read from memory by the lane (not kept in registers).
 //   z, w as in OssRecord (l / goRight, u)
 struct OssRecordL { uint16_t bl[OSS_MAXB]; uint16_t start, nb; uint32_t z, w; };
+GM_HD uint32_t oss_bl(const OssRecordL& r, uint32_t bi) { return r.bl[bi]; }
+GM_HD uint32_t oss_start(const OssRecordL& r) { return r.start; }
+GM_HD uint32_t oss_nb(const OssRecordL& r) { return r.nb; }
+GM_HD uint32_t oss_l(const OssRecordL& r, uint32_t bi) { return (r.z >> (3u * bi)) & 7u; }
+GM_HD uint32_t oss_u(const OssRecordL& r, uint32_t bi) { return (r.w >> (3u * bi)) & 7u; }
+GM_HD uint32_t oss_right(const OssRecordL& r, uint32_t bi) { return (r.z >> (18u + bi)) & 1u; }
 inline bool oss_make_record_long(uint32_t E, uint32_t s, uint32_t infixLen, OssRecordL* out, const uint32_t* blockLens = nullptr)
 {
     uint32_t bl[OSS_MAXB], start, z, w, blocks;

@@ -272,6 +272,10 @@ def test_gpu_long_kmers_beyond_255(bb):
                 assert np.array_equal(ix.map(K, E, value_bits=bits), exp), (K, E, bits, bb)
             assert exp.max() >= 2
             assert np.array_equal(ix.map(K, E, value_bits=16, infix=K - 6), exp), (K, E, "infix")
+            for T in (0, 4, 16):   # the plain walk down to the leaves / up to 4 or 16 rows settled against the text (default: one row); work sharing off / on
+                ix.set_tuning(verify_t=T, steal=(T >> 2) & 1)
+                assert np.array_equal(ix.map(K, E, value_bits=16), exp), (K, E, "verify_t", T)
+            ix.set_tuning(verify_t=-1, steal=-1)
             assert np.array_equal(ix.map(K, E, value_bits=16, infix=max(K // 3, 8)), exp), (K, E, "blocks of 255")
             assert np.array_equal(ix.map(K, E, value_bits=16, revcompl=False), ora.mappability(K, E, value_bits=16, revcompl=False, threads=8)), (K, E, "one strand")
             # shards: a k-mer range, then three interleaved chunk shares into one vector
