@@ -380,14 +380,14 @@ int gm_index_build(const uint8_t* codes, const uint64_t* seq_len, uint32_t n_seq
     const size_t rb = ix->wide ? 8 : 4;   // bytes per suffix-array entry
     if (!rc && hipMalloc(&d_sa, ix->nRows * rb) != hipSuccess) rc = GM_ERR_OOM;
     if (!rc && hipMalloc(&d_bwt, ix->nRows) != hipSuccess) rc = GM_ERR_OOM;
-    for (int d = 0; d < 2 && !rc; ++d) {
+    // the reverse direction first: the forward suffix array, built last, is the one that stays -- no second array beside the sort's own six
+    // (4.32 G rows with 64-bit rows: 35 GB each; with the forward direction first a resident suffix array did not fit beside the second sort)
+    for (int k = 0; k < 2 && !rc; ++k) {
+        const int d = 1 - k;
         rc = ix->wide ? build_sa_bwt_wide(ix->d_text, ix->d_cum, n_seq, ix->textLen, d, (uint64_t*)d_sa, d_bwt, &ix->buildRounds[d])
                       : build_sa_bwt(ix->d_text, ix->d_cum, n_seq, ix->textLen, d, (uint32_t*)d_sa, d_bwt, &ix->buildRounds[d]);
         if (!rc) rc = pack_dispatch(ix, d, d_bwt);
-        if (!rc && d == 0 && sampling == 1) {   // the forward SA stays resident: 4 (8) B/row of 288 GB buys locate without LF walks
-            ix->d_sa = d_sa; d_sa = nullptr;
-            if (hipMalloc(&d_sa, ix->nRows * rb) != hipSuccess) rc = GM_ERR_OOM;
-        }
+        if (!rc && d == 0 && sampling == 1) { ix->d_sa = d_sa; d_sa = nullptr; }   // the forward SA stays resident: 4 (8) B/row of 288 GB buys locate without LF walks
         if (!rc && d == 0 && sampling > 1) rc = sample_sa(ix, d_sa);   // -S: keep 1/s of it, locate walks the LF mapping
     }
     hipFree(d_sa); hipFree(d_bwt);
@@ -643,7 +643,7 @@ static int get_qtable(gm_index* ix, uint32_t* qio, const uint4** out)
     for (;; --q) {   // shorter prefixes when the device is short of memory (the table is an accelerator, not a requirement)
         if (q == 0) { *qio = 0; *out = nullptr; return GM_OK; }
         size_t freeB = 0, totalB = 0;
-        const uint64_t bytes = (1ull << (2 * q)) * sizeof(uint4) * (ix->wide ? 2 : 1);
+        const uint64_t bytes = (1ull << (2 * q)) * sizeof(uint4);
         // (tables up to 4^15 entries leave half of the free memory alone; the 69 GB of 4^16 ask for 16 GiB of slack instead)
         if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && (q >= 16 ? bytes + (16ull << 30) > freeB : bytes > freeB / 2)) { ix->qtableCap = q - 1; continue; }
         if (hipMalloc(&d, bytes) == hipSuccess) break;
@@ -668,7 +668,7 @@ static int get_qtable(gm_index* ix, uint32_t* qio, const uint4** out)
         if (e != hipSuccess) { hipFree(d); GM_HIP(e); }
     }
     ix->qtables[q] = d;
-    ix->qtableBytes += n * sizeof(uint4) * (ix->wide ? 2 : 1);
+    ix->qtableBytes += n * sizeof(uint4);
     *qio = q;
     *out = d;
     return GM_OK;
@@ -934,9 +934,11 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     const uint32_t nu = ix->wide ? 2u : 1u;
     const int wantPerCU = std::max(1, ix->tune.blocksPerCU);   // default 4 = 4 waves/SIMD, what the kernel's VGPR count allows
     // (calls that may jump keep their table entries in flight in LDS: one 16-byte slot per lane)
-    const bool mayJump = wantJump && p->E >= 1 && (ix->d_sa || ix->d_saMark) && ix->tune.jump != 0 && !ix->wide;
+    // (64-bit rows jump too since round 5: plain pattern lists -- no bitmaps, no neighbour filter, the table entry travels in registers)
+    const bool mayJump = wantJump && p->E >= 1 && (ix->d_sa || ix->d_saMark) && ix->tune.jump != 0;
+    const bool entrySlots = mayJump && !ix->wide;
     g_ldsPad = (uint32_t)std::max(0, ix->tune.ldsPad);
-    auto lds_bytes_for = [&](uint32_t d) { return (size_t)g_ldsPad + (size_t)(4u * vqCap * nu + 4u * 64u * (d * nu + winChunks)) * 16u + 4u * 80u * 4u + 448u + (mayJump ? 4096u : 0u) + (lqCap ? 4u * (lqCap * 16u + 80u * 4u) : 0u); };   // == search_lds_bytes
+    auto lds_bytes_for = [&](uint32_t d) { return (size_t)g_ldsPad + (size_t)(4u * vqCap * nu + 4u * 64u * (d * nu + winChunks)) * 16u + 4u * 80u * 4u + 448u + (entrySlots ? 4096u : 0u) + (lqCap ? 4u * (lqCap * 16u + 80u * 4u) : 0u); };   // == search_lds_bytes
     // Blocks per CU that REALLY become resident: the occupancy query says four blocks of up to 40,960 B fit the 160 KB of a CU, the device
     // runs three of them beyond ~38.6 KB per block (measured with padded launches, 3.09 Gbp: K=30 e=2 244 ms at 36,544 and 37,568 B per
     // block, 250 at 38,592, 279 at 39,616 and 40,640 = the time of three blocks per CU; K=100 e=1 192 / 193 / 220 ms at 36,544 / 38,592 /
@@ -1112,7 +1114,6 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         uint32_t qmax = 1;
         const uint32_t qcap = ix->tune.qtable >= 0 ? (uint32_t)ix->tune.qtable : (ix->nRows > (1ull << 30) ? 16u : 15u);
         while (qmax < qcap && (1ull << (2 * qmax)) < 4ull * ix->nRows) ++qmax;
-        if (ix->wide) qmax = std::min(qmax, 14u);   // 32-byte entries
         if (ix->tune.qtable >= 0) qmax = (uint32_t)std::min(ix->tune.qtable, 16);
         if (longK) qmax = 0;
         A.qtabA = A.qtabB = nullptr; A.qlenPacked[0] = A.qlenPacked[1] = 0; A.qselMask = 0; A.startPacked[0] = A.startPacked[1] = 0;
@@ -1132,7 +1133,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         }
         ix->lastQ = std::max(qA, qB) | jumpJ << 8;
     }
-    A.entrySlots = mayJump ? 1u : 0u;
+    A.entrySlots = entrySlots ? 1u : 0u;
     A.text4 = ix->d_text4; A.textBegin = text_begin; A.vqCap = vqCap; A.verifyRows = verifyRows ? verifyRows : 1u; A.ldsDepth = ldsDepth; A.winChunks = winChunks; A.lqCap = lqCap;
     A.workCounter = reinterpret_cast<unsigned long long*>(ix->d_small);
     A.errorFlag = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ix->d_small) + SMALL_ERR_OFF);

@@ -203,15 +203,18 @@ template <> struct NodeIO<uint64_t> {
     {
         const uint4 a = p[0], b = p[1]; row = (uint64_t)a.y << 32 | a.x; meta = a.z; nss = a.w; win = (uint64_t)b.y << 32 | b.x;
     }
+    // q-mer table entry of the wide geometry: 16 bytes like the narrow one -- {fwd lo, rev lo, width} as 40-bit numbers (an index has fewer
+    // than 2^40 rows): x, y, z = their low words, w = their bits 32..39 in bytes 0, 1, 2.  (Round 4 kept three 64-bit numbers in 32 bytes: two
+    // loads per root, and a table of all 16-mers would have taken 137 GB -- the table stopped at 14 characters.)
     static __device__ __forceinline__ void load_qentry(const uint4* tab, uint32_t idx, uint64_t& flo, uint64_t& rlo, uint64_t& w)
     {
-        const uint4 a = tab[2 * (size_t)idx], b = tab[2 * (size_t)idx + 1]; flo = (uint64_t)a.y << 32 | a.x; rlo = (uint64_t)a.w << 32 | a.z; w = (uint64_t)b.y << 32 | b.x;
+        const uint4 a = tab[idx];
+        flo = (uint64_t)(a.w & 0xFFu) << 32 | a.x; rlo = (uint64_t)((a.w >> 8) & 0xFFu) << 32 | a.y; w = (uint64_t)((a.w >> 16) & 0xFFu) << 32 | a.z;
     }
     static __device__ __forceinline__ void load_qentry(const uint4* tab, uint32_t idx, uint64_t& flo, uint64_t& rlo, uint64_t& w, uint32_t& nb) { load_qentry(tab, idx, flo, rlo, w); nb = 0u; }
     static __device__ __forceinline__ void store_qentry(uint4* tab, uint32_t idx, uint64_t flo, uint64_t rlo, uint64_t w, uint32_t = 0u)
     {
-        tab[2 * (size_t)idx] = make_uint4((uint32_t)flo, (uint32_t)(flo >> 32), (uint32_t)rlo, (uint32_t)(rlo >> 32));
-        tab[2 * (size_t)idx + 1] = make_uint4((uint32_t)w, (uint32_t)(w >> 32), 0u, 0u);
+        tab[idx] = make_uint4((uint32_t)flo, (uint32_t)rlo, (uint32_t)w, ((uint32_t)(flo >> 32) & 0xFFu) | ((uint32_t)(rlo >> 32) & 0xFFu) << 8 | ((uint32_t)(w >> 32) & 0xFFu) << 16);
     }
 };
 

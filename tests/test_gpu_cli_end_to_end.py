@@ -184,3 +184,34 @@ def test_cli_two_device_threads_k100_e1_at_0p77_gbp(tmp_path):
         assert np.array_equal(got, ix.map(100, 1, value_bits=8))
     finally:
         ix.close()
+
+
+def test_cli_long_kmers_k300(tmp_path):
+    """`genmap map -K 300` (the reference takes any -K, src/mappability.hpp:425-426): the program goes through the long k-mer kernel
+    (gm_longk.h); raw 16-bit frequencies with the library's block shape and with an explicit -xo 290 (blocks of 291 k-mers in the reference:
+    clamped to 255 here, the result does not depend on it), against the oracle."""
+    import numpy as np
+    rng = np.random.default_rng(300)
+    lens = [30000, 500, 9000]
+    codes = rng.integers(0, 4, size=sum(lens), dtype=np.uint8)
+    codes[20000:22000] = codes[3000:5000]            # a long exact copy
+    codes[31000:32500] = codes[3200:4700]; codes[31700] ^= 1   # and one a substitution away, in another sequence
+    codes[8000:8040] = 4
+    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    fa = tmp_path / "genome.fa"
+    off = 0
+    with open(fa, "wb") as f:
+        for k, ln in enumerate(lens):
+            f.write(b">s%d\n" % k)
+            f.write(lut[codes[off:off + ln]].tobytes() + b"\n")
+            off += ln
+    idx = tmp_path / "index"
+    _run_checked([str(GENMAP), "index", "-F", str(fa), "-I", str(idx)])
+    ora = H.OracleIndex(codes, lens, keep_sa=False)
+    for E, extra in ((0, []), (1, []), (1, ["-xo", "290"])):
+        exp = ora.mappability(300, E, value_bits=16, threads=4)
+        assert exp.max() >= 2
+        out = tmp_path / f"out_{E}_{len(extra)}"; out.mkdir()
+        _run_checked([str(GENMAP), "map", "-I", str(idx), "-O", str(out), "-K", "300", "-E", str(E), "-r", "-fl"] + extra)
+        got = np.fromfile(out / "genome.genmap.freq16", dtype=np.uint16)
+        assert np.array_equal(got, exp), (E, extra)
