@@ -685,7 +685,7 @@ __global__ __launch_bounds__(256) void jbits_layout_kernel(const uint4* __restri
     if (w >= words) return;
     const uint64_t idx0 = ((w >> sh) << (sh + 6u)) | (w & ((1ull << sh) - 1ull));
     unsigned long long m = 0ull;
-    for (uint32_t v = 0; v < 64u; ++v) if (tab[idx0 | (uint64_t)v << sh].z != 0u) m |= 1ull << v;
+    for (uint32_t v = 0; v < 64u; ++v) { const uint4 t = tab[idx0 | (uint64_t)v << sh]; if ((t.z | (t.w & 0x00FF0000u)) != 0u) m |= 1ull << v; }   // (64-bit rows keep bits 32..39 of the width in byte 2 of .w; 32-bit rows: zero there whenever .z is)
     bits[w] = m;
 }
 
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(256) void jbits_layout_kernel(const uint4* __restri
 static int get_jbits(gm_index* ix, uint32_t q, const uint4* tab, const unsigned long long** out, int* level, uint32_t* extra)
 {
     *out = nullptr; *level = 0; *extra = 0;
-    if (q <= GROUP_SYMS || ix->wide || !tab) return GM_OK;
+    if (q <= GROUP_SYMS || !tab) return GM_OK;
     auto it = ix->jbits.find(q);
     if (it != ix->jbits.end()) { *out = it->second; *level = ix->jbitsLevel[q]; *extra = ix->jbitsExtra[q]; return GM_OK; }
     const uint64_t n = 1ull << (2 * q), words = n / 64;
@@ -1621,11 +1621,14 @@ static int staged_copy_to_host(gm_index* ix, uint8_t* h_dst, const uint8_t* d_sr
             const uint8_t* src = ix->h_stage + (j % NS) * SLOT;
             uint8_t* dst = h_dst + (uint64_t)j * SLOT;
             const uint64_t len = len_of(j);
-            constexpr int T = 4;
-            std::thread th[T - 1];
+            // (the destination is usually fresh pageable memory: the copy is bound by its first-touch page faults, which scale with the
+            //  threads that take them -- 2 GB of csv locations per pass of config C5: 16 threads instead of 4)
+            constexpr int TMAX = 16;
+            const int T = len >= (8ull << 20) ? (int)std::min<unsigned>(TMAX, std::max(4u, std::thread::hardware_concurrency() / 4u)) : 4;
+            std::thread th[TMAX - 1];
             for (int t = 1; t < T; ++t) th[t - 1] = std::thread([=] { memcpy(dst + len * t / T, src + len * t / T, len * (t + 1) / T - len * t / T); });
             memcpy(dst, src, len / T);
-            for (auto& x : th) x.join();
+            for (int t = 1; t < T; ++t) th[t - 1].join();
         }
     }
     return GM_OK;

@@ -1587,7 +1587,8 @@ __global__ __launch_bounds__(256) void row_file_kernel(const uint32_t* __restric
 __global__ __launch_bounds__(256) void jbits_kernel(const uint4* __restrict__ tab, uint64_t nEntries, unsigned long long* __restrict__ bits)
 {
     const uint64_t i = ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
-    const bool alive = i < nEntries && tab[i].z != 0u;
+    bool alive = false;
+    if (i < nEntries) { const uint4 t = tab[i]; alive = (t.z | (t.w & 0x00FF0000u)) != 0u; }   // (width bits 32..39 of a 64-bit-row entry: byte 2 of .w)
     const unsigned long long m = __ballot(alive);
     if ((threadIdx.x & 63u) == 0u && i < nEntries) bits[i >> 6] = m;
 }

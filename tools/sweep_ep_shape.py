@@ -9,6 +9,9 @@ import genmap_amd as g
 from genmap_amd import synth
 
 args = sys.argv[1:]
+shapes = (0, 1, 2, 3, 4, 6, 8)
+if "--shapes" in args:   # e.g. --shapes 0 : the library's block shape only (knob sweeps)
+    k = args.index("--shapes"); shapes = tuple(int(x) for x in args[k + 1].split(",")); args = args[:k] + args[k + 2:]
 sets = [""]
 if "--" in args:
     k = args.index("--"); sets = args[k + 1:] or [""]; args = args[:k]
@@ -22,11 +25,11 @@ out = torch.zeros(len(codes) + 16, dtype=torch.uint16, device="cuda:0")
 st = torch.cuda.current_stream().cuda_stream
 ref = None
 for setting in sets:
-    knobs = dict(verify_t=-1, steal=-1, fetch_batch=-1, probation=-1, lds_stack=-1)
+    knobs = dict(verify_t=-1, steal=-1, fetch_batch=-1, probation=-1, lds_stack=-1, blocks_per_cu=4, verify_t_ext=-1, sat_min_w=256, skip_dup=-1, qtable=-1)
     for kv in filter(None, setting.split(",")):
         a, b = kv.split("="); knobs[a] = int(b)
     ix.set_tuning(**knobs)
-    for n in (0, 1, 2, 3, 4, 6, 8):
+    for n in shapes:
         infix = 0 if n == 0 else K - n + 1
         tot = 0.0; res = []
         for rep in range(2):
