@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void longk_kernel(const SearchArgs A)
         // its root's whole subtree with a dependent memory round trip per step: a root inside a repeat family (thousands of near-identical
         // copies: ~1e5 nodes at e = 1) would otherwise hold the kernel for tenths of a second after every other lane has finished.
         if (A.steal) {
-            const bool idle = !have && sp == 0u && exhausted;
+            const bool idle = !have && sp == 0u && (exhausted || A.steal >= 2u);   // (steal >= 2: before a lane draws its next root, too)
             const bool rich = have && sp >= 1u && sbase < STEAL_LEVELS;
             const unsigned long long im = __ballot(idle), vm = __ballot(rich);
             if (im != 0ull && vm != 0ull) {

@@ -26,6 +26,14 @@ def _run_checked(cmd):
     handler (genmap_main.cpp: genmap_crash_handler) has written the faulting thread's stack to stderr, which the assertion shows;
     tools/crash_hunt.sh loops the suspected commands thousands of times (plain and under AddressSanitizer) to catch it in the act."""
     r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    if r.returncode != 0:   # the whole of what the process said (pytest -q cuts the assertion's tuple short): printed, and kept for the round's evidence
+        print(f"FAILED {cmd}: exit {r.returncode}\n{r.stderr}", flush=True)
+        try:
+            out = H.ROOT / "gpurun_out"; out.mkdir(exist_ok=True)
+            with open(out / "cli_failures.txt", "a") as f:
+                f.write(f"== {cmd}: exit {r.returncode}\n{r.stderr}\n")
+        except OSError:
+            pass
     assert r.returncode == 0, (cmd, r.returncode, r.stderr[-4000:])
 
 
