@@ -1196,7 +1196,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     for (uint32_t k = 0; k < GROUP_MAX_MASKS; ++k) A.gmask[k] = gmaskCall[k];
     for (uint32_t k = 0; k < 8u; ++k) { A.layShift[k] = layShift[k]; A.layPlane0[k] = layPlane0[k]; A.layPlane1[k] = layPlane1[k]; }
     A.tableL = longK ? ix->d_tableL : nullptr;
-    if (longK) { A.lqCap = 0u; A.entrySlots = 0u; A.selfHit = 0u; A.spillDepth = depth; A.steal = ix->tune.steal >= 0 ? (uint32_t)std::min(ix->tune.steal, 2) : 1u; }
+    if (longK) { A.lqCap = 0u; A.entrySlots = 0u; A.selfHit = 0u; A.spillDepth = depth; A.steal = ix->tune.steal >= 0 ? (uint32_t)std::min(ix->tune.steal, 2) : 2u; }   // (2: lanes share before every root draw, 3.09 Gbp K=300 e=1 +19 %, K=1000 e=1 +14 %, e=0 +4 % over sharing at the end only; profiles/r05/longk_scale.txt)
     A.sliceBegin = text_begin; A.sliceLen = text_len; A.ownBegin = 0; A.ownEnd = text_len; A.ownChunkLen = 0; A.selBlocks = nullptr; A.nSelBlocks = 0;
     *Aout = A;
     return GM_OK;
@@ -1453,14 +1453,22 @@ static int locate_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uin
         { size_t tb = tmpBytes; LC(rocprim::exclusive_scan(d_tmp, tb, d_cnt, d_offs, (uint64_t)0, slots + 1, rocprim::plus<uint64_t>())); }
         // (every device -> host transfer of this call goes through the page-locked ring: the plain hipMemcpy into pageable memory was
         //  most of the second that config C5's csv window took, profiles/r03/final/bench_c5_bacteria5.json)
-        std::vector<uint64_t> offs(slots + 1);
-        rc = staged_copy_to_host(ix, (uint8_t*)offs.data(), (const uint8_t*)d_offs, (slots + 1) * 8, st); if (rc) goto done;
-        const uint64_t total = offs[slots];
+        // the offsets land in the caller's two arrays directly (slot W, the end of the plus strand, is the start of the minus strand): no
+        // 16 x W bytes of temporary, no serial pass over it -- the first touch of the fresh arrays is taken by the copy's threads
+        rc = staged_copy_to_host(ix, (uint8_t*)L->plus_off, (const uint8_t*)d_offs, (W + 1) * 8, st); if (rc) goto done;
+        rc = staged_copy_to_host(ix, (uint8_t*)L->minus_off, (const uint8_t*)(d_offs + W), (W + 1) * 8, st); if (rc) goto done;
+        const uint64_t nPlus = L->plus_off[W], total = L->minus_off[W];
         if (total >= (1ull << 31)) { set_error("%llu occurrences in one gm_locate window; use a smaller k-mer range", (unsigned long long)total); rc = GM_ERR_TOO_LONG; goto done; }
-        for (uint64_t j = 0; j <= W; ++j) { L->plus_off[j] = offs[j]; L->minus_off[j] = offs[W + j] - offs[W]; }
-        // slot W (end of the plus strand) == start of the minus strand
-        L->plus_off[W] = offs[W];
-        L->plus = (uint64_t*)malloc((offs[W] + 1) * 8); L->minus = (uint64_t*)malloc((total - offs[W] + 1) * 8);
+        {
+            uint64_t* mo = L->minus_off;
+            const unsigned T = W >= (1ull << 20) ? 8u : 1u;
+            std::thread th[7];
+            auto part = [=](unsigned t) { for (uint64_t j = (W + 1) * t / T; j < (W + 1) * (t + 1) / T; ++j) mo[j] -= nPlus; };
+            for (unsigned t = 1; t < T; ++t) th[t - 1] = std::thread(part, t);
+            part(0);
+            for (unsigned t = 1; t < T; ++t) th[t - 1].join();
+        }
+        L->plus = (uint64_t*)malloc((nPlus + 1) * 8); L->minus = (uint64_t*)malloc((total - nPlus + 1) * 8);
         if (!L->plus || !L->minus) { rc = GM_ERR_OOM; goto done; }
         if (total > 0) {
             rc = grow(&d_emit, &ix->locEmitCap, total); if (rc) goto done;
@@ -1477,8 +1485,8 @@ static int locate_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uin
             LC(rocprim::segmented_radix_sort_keys(nullptr, sb, d_emit, d_sorted, (unsigned int)total, (unsigned int)slots, d_segB, d_segE, 0, 64));
             if (sb > tmpBytes) { rc = grow(&d_tmp, &ix->locTmpCap, (uint64_t)sb); if (rc) goto done; tmpBytes = sb; }
             { size_t tb = tmpBytes; LC(rocprim::segmented_radix_sort_keys(d_tmp, tb, d_emit, d_sorted, (unsigned int)total, (unsigned int)slots, d_segB, d_segE, 0, 64)); }
-            if (offs[W]) { rc = staged_copy_to_host(ix, (uint8_t*)L->plus, (const uint8_t*)d_sorted, offs[W] * 8, st); if (rc) goto done; }
-            if (total > offs[W]) { rc = staged_copy_to_host(ix, (uint8_t*)L->minus, (const uint8_t*)(d_sorted + offs[W]), (total - offs[W]) * 8, st); if (rc) goto done; }
+            if (nPlus) { rc = staged_copy_to_host(ix, (uint8_t*)L->plus, (const uint8_t*)d_sorted, nPlus * 8, st); if (rc) goto done; }
+            if (total > nPlus) { rc = staged_copy_to_host(ix, (uint8_t*)L->minus, (const uint8_t*)(d_sorted + nPlus), (total - nPlus) * 8, st); if (rc) goto done; }
         }
         LC(hipDeviceSynchronize());
     }
