@@ -134,7 +134,7 @@ def test_verification_shortcut_on_reference_fixtures(case, T):
 @pytest.mark.parametrize("E", [0, 1, 2, 3, 4])
 def test_verification_shortcut_gtest_matrix(E, dna5):
     rng = np.random.default_rng(4000 + 10 * E + dna5)
-    nseq, ln = 3, (600 if E < 3 else 250)
+    nseq, ln = 3, (400 if E < 3 else 250)
     codes = rng.integers(0, 5 if dna5 else 4, size=nseq * ln, dtype=np.uint8)
     ix = H.OracleIndex(codes, [ln] * nseq, keep_sa=True)
     minK = E + 1 + (E >= 2)
@@ -224,7 +224,7 @@ def test_jump_patterns_and_n_correction_on_reference_fixtures(case):
 def test_jump_patterns_and_n_correction_gtest_matrix(E, dna5):
     """random Dna5 text is 20 % N: nearly every window goes through the correction pass; Dna4: the patterns alone"""
     rng = np.random.default_rng(6000 + 10 * E + dna5)
-    nseq, ln = 3, (600 if E < 3 else 250)
+    nseq, ln = 3, (400 if E < 3 else 250)
     codes = rng.integers(0, 5 if dna5 else 4, size=nseq * ln, dtype=np.uint8)
     ix = H.OracleIndex(codes, [ln] * nseq, keep_sa=True)
     minK = E + 1 + (E >= 2)
