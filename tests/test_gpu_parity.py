@@ -1227,11 +1227,13 @@ def test_gpu_bench_two_ranks_on_one_device_at_0p77_gbp():
 
 
 def test_gpu_index_of_more_than_2_to_32_rows():
-    """tools/wide_rows_smoke.py: an index of 4.32 G rows (64-bit rows for real, not forced): two copies of a 2.16 Gbp genome, so
-    every frequency must be exactly twice (up to MAX) what the 32-bit path of this library -- pinned by the rest of the suite --
-    computes on one copy: K=30 e=0 (8- and 16-bit) and e=1 on intervals at the N-block edges, a sequence boundary, the copy
-    boundary and the end of the text, and the doubling property on the whole e=0 vector"""
+    """tools/wide_rows_first_class.py --quick: an index of 4.32 G rows (64-bit rows for real, not forced) WITH its suffix array: two copies
+    of a 2.16 Gbp genome, so every frequency must be exactly twice (up to MAX) what the 32-bit path of this library -- pinned by the rest
+    of the suite -- computes on one copy: K=30 e=0 (8- and 16-bit), e=1 and e=2 with jump patterns (16-byte table entries, groups behind
+    bitmaps, N-less pass + correction pass) and without, on intervals at the N-block edges, a sequence boundary, the copy boundary and the
+    end of the text; whole-text passes at e=0 and e=1 and the doubling property on the whole e=1 vector.  (tools/wide_rows_smoke.py, the
+    round-3/4 form of this test, builds the same text without a suffix array.)"""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "wide_rows_smoke.py")], capture_output=True, text=True, timeout=900, cwd=root)
-    assert r.returncode == 0 and "WIDE_ROWS_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "wide_rows_first_class.py"), "--quick"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0 and "WIDE_FIRST_CLASS_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

@@ -12,7 +12,9 @@ import torch
 import genmap_amd as g
 from genmap_amd import synth
 
-scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.7
+quick = "--quick" in sys.argv   # (the GPU suite: no jump = 0 whole-text pass, no e = 2 sample timing)
+args = [a for a in sys.argv[1:] if a != "--quick"]
+scale = float(args[0]) if args else 0.7
 lens_half = [max(1000, int(x * scale)) for x in synth.GRCH38_LENGTHS[:24]]
 t0 = time.time()
 half = np.concatenate([synth.make_sequence(ln, seed=900 + i) for i, ln in enumerate(lens_half)])
@@ -25,7 +27,7 @@ iv = [(0, 20000), (int(lens_half[0] * 0.49) - 5000, int(lens_half[0] * 0.49) + 5
 t0 = time.time()
 ixh = g.Index.build(half, lens_half, sampling=1)
 print(f"half index ({ixh.info()['n_rows']} rows, 32-bit rows) in {time.time() - t0:.0f} s", flush=True)
-want = {(E, bits): ixh.map(K, E, value_bits=bits, intervals=iv) for E, bits in ((0, 8), (1, 16), (2, 8))}
+want = {(E, bits): ixh.map(K, E, value_bits=bits, intervals=iv) for E, bits in ((0, 8), (0, 16), (1, 16), (2, 8))}
 dev = torch.zeros(2 * nh + 16, dtype=torch.uint8, device="cuda:0")
 st = torch.cuda.current_stream().cuda_stream
 for E, frac in ((0, 1.0), (1, 1.0)):
@@ -44,7 +46,7 @@ print(f"wide index: {info['n_rows']} rows, row_bits {info['row_bits']}, {info['d
 assert info["row_bits"] == 64 and info["n_rows"] >= 2**32 - 1
 iv2 = iv + [(a + nh, b + nh) for a, b in iv[:-1]] + [(nh - 20000, nh + 20000), (2 * nh - 20000 - K, 2 * nh - K + 1)]
 ok = True
-for (E, bits), jump in (((0, 8), -1), ((1, 16), -1), ((1, 16), 0), ((2, 8), -1), ((2, 8), 0)):
+for (E, bits), jump in (((0, 8), -1), ((0, 16), -1), ((1, 16), -1), ((1, 16), 0), ((2, 8), -1), ((2, 8), 0)):
     ix.set_tuning(jump=jump)
     t0 = time.time()
     got = ix.map(K, E, value_bits=bits, intervals=iv2)
@@ -66,7 +68,7 @@ for (E, bits), jump in (((0, 8), -1), ((1, 16), -1), ((1, 16), 0), ((2, 8), -1),
     print(f"K={K} E={E} bits={bits} jump={'default' if jump < 0 else jump}: {'ok' if good else 'FAILED'} ({dt:.1f} s for the interval call; table q {tq & 255}, jump J {tq >> 8})", flush=True)
 nk = 2 * nh - K + 1
 ref = {}
-for E, frac, settings in ((0, 1.0, (-1,)), (1, 1.0, (-1, 0)), (2, 0.01, (-1, 0))):
+for E, frac, settings in (((0, 1.0, (-1,)), (1, 1.0, (-1,))) if quick else ((0, 1.0, (-1,)), (1, 1.0, (-1, 0)), (2, 0.01, (-1, 0)))):
     span = int(nk * frac) // 48 * 48
     kb = ((nk - span) // 2) // 48 * 48
     rng = None if frac >= 1.0 else (kb, kb + span)
