@@ -1162,6 +1162,8 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     // (K=100 e=1 on 3.09 Gbp: 48 -> -6 % over 32, 64 the same, 16 +8 %; profiles/r05/sweep_k100_knobs.txt, sweep_k100_lds_fetch_batch_steal.txt)
     A.fetchBatch = p->E == 0 ? (huge ? 32u : 16u) : p->E == 1 ? (huge ? (p->K >= 64 ? 48u : 32u) : 8u) : (huge ? 8u : 4u);   // (e=2 on 3.09 Gbp: 8 -> -1.7 % over 4, 16 +3 %; profiles/r04/sweep_retune_e2.txt)
     if (ix->tune.fetchBatch > 0) A.fetchBatch = (uint32_t)std::min(ix->tune.fetchBatch, 64);
+    // (3.09 Gbp: 8 -> K=30 e=2 -2.0 %, e=1 -2.0 % over 1, 4 the same, 16 none; K=100 e=1 +1.3 % with any batch; profiles/r05/sweep_pat_batch.txt)
+    A.patBatch = ix->tune.patBatch > 0 ? (uint32_t)std::min(ix->tune.patBatch, 64) : (p->K < 64 ? 8u : 1u);
     // e = 0: a single row is almost always the k-mer's own location.  Beyond ~1 G rows a lone-row step is an HBM miss
     // like the verification reads it postpones, and no longer pays (3.09 Gbp e = 2: 90.7 vs 86.7 M k-mers/s without).
     // 3.09 Gbp: e=1 +8.5 %, e=2 +4 % over 0 (profiles/r02/sweep_grch38_retune.txt); K=100: no difference.  With the neighbour filter the
@@ -1863,6 +1865,7 @@ int gm_index_set_tuning(gm_index* ix, const char* name, int64_t value)
         {"jump_layouts", &ix->tune.jumpLayouts, dflt.jumpLayouts, 0, 1},   // 0: groups of jump patterns in the LOW / MID layouts only (round 4), -1 / 1: at any three adjacent characters
         {"no_wrap", &ix->tune.noWrap, dflt.noWrap, 0, 1},   // 0: every add into an accumulator returns the old value and checks for a wrap-around (-1 / 1: only where one is possible)
         {"iter_cap", &ix->tune.iterCap, dflt.iterCap, 1, 0x7FFFFFFF}, {"stall_cap", &ix->tune.stallCap, dflt.stallCap, 1, 0x7FFFFFFF},   // bounds of a hung search loop (tests force them)
+        {"pat_batch", &ix->tune.patBatch, dflt.patBatch, 1, 64},
         {"jump_groups", &ix->tune.jumpGroups, dflt.jumpGroups, 0, 1},   // groups of jump patterns behind the existence bitmap: 0 never, 1 wherever possible, -1 where they save table reads
     };
     for (auto& t : tab) if (!strcmp(t.n, name)) {

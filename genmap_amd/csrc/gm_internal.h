@@ -32,6 +32,7 @@ struct Tuning {
     int noWrap = -1;                   // 0: adds into the accumulators always return and check for a 2^32 wrap-around (gm_api.hip: acc_cannot_wrap)
     int jumpLayouts = -1;              // 0: groups of jump patterns only in the two layouts of round 4
     int ldsPad = 0;                    // measurement: extra bytes of LDS per block
+    int patBatch = -1;                 // jump patterns: idle lanes that must wait for their pattern turn before parts A / B of the loop run (-1: 1 = every iteration)
     int fastVerify = -1;               // -1: whenever the call allows it (gm_api.hip: prepare_search), 0: never
     int iterCap = -1, stallCap = -1;   // bounds of a hung search loop (gm_kernels.h: SearchArgs::iterCap / stallCap); -1: never / 2^22 idle iterations
 };

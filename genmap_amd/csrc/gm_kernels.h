@@ -68,6 +68,7 @@ struct SearchArgs {
     const uint4* ctx;               // optional: per forward SA row one 32-byte record {SA[row], 56 symbols around it} (CTX_* below)
     uint32_t verifyT;               // nodes with range width <= verifyT are resolved by verification (0 = off)
     uint32_t verifyTExt;            // ... and this wide once the infix is complete (extension phase)
+    uint32_t patBatch;              // jump patterns: parts A / B of the loop run when this many idle lanes wait for their pattern turn (or no lane holds a node); 1: every iteration
     uint32_t fetchBatch;            // roots are drawn when this many lanes are idle (or nothing else is left): the fetch code runs per batch
     uint32_t satMinW;               // saturation is looked up (a global read per covered k-mer) only for nodes at least this wide
     uint32_t probation;             // a single-row node that has spent every error is stepped this many times before it is verified
@@ -1109,9 +1110,19 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
         GM_LAP2(tShare);
         // ---- root fetch, pipelined over iterations so that the wavefront never waits for it ----
         // stage 3: the q-mer table entry has arrived -> the root becomes the lane's node (or turns out empty)
+        // Pattern turns in batches (knob pat_batch): parts A and B are ~190 VALU instructions that the whole wavefront walks through for the
+        // one or two lanes that need them; with a batch they run when enough idle lanes wait for their turn, or when nobody holds a node.
+        // The state is level-triggered (an arrived entry stays in its slot, an item in jd): a turn that comes later changes nothing else.
+        bool patTurn = true;
+        if constexpr (EnvT::JUMPS) {
+            if (A.patBatch > 1u) {
+                const unsigned long long pm = __ballot((fs & 3u) == 2u && !have && env.sp == 0u);
+                patTurn = (uint32_t)__popcll(pm) >= A.patBatch || __ballot(have) == 0ull;
+            }
+        }
         if constexpr (EnvT::JUMPS) {
             // (A) the table entry of the pattern in flight has arrived, and the lane has finished the subtree of the one before
-            if ((fs & (3u | JF_ENTRY)) == (2u | JF_ENTRY) && !have && env.sp == 0u) {
+            if (patTurn && (fs & (3u | JF_ENTRY)) == (2u | JF_ENTRY) && !have && env.sp == 0u) {
                 env.note_wave(3);
                 fs &= ~JF_ENTRY;
                 row_t eFlo, eRlo, eW; uint32_t eNb;
@@ -1406,7 +1417,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
             // group's word is requested as soon as its item is known, i.e. while the lane still works through the group before it.
             // ONE load site each for the next item, the word and the table entry: with a second site the compiler loads into temporaries
             // and waits for the load right behind it to move the value over.  The LDS reads come first, the loads last (see above).
-            if ((fs & 3u) == 2u) {
+            if (patTurn && (fs & 3u) == 2u) {
                 env.note_wave(16);
                 const uint4 lim = jl[12u + rt.search];   // where the groups of each layout end among the search's items
                 struct LdsTab {   // the layouts ride in the 4th words of the searches' group ends, the masks sit behind the jump records

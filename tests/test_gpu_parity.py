@@ -241,7 +241,7 @@ def test_gpu_baseline_settings_small(K, E):
                 # ... patterns that differ in their last three characters read through one word of the existence bitmap: wherever
                 # possible / never / where the library's rule expects fewer table reads
                 for coop, ctx, steal, jump, ra, text, grp in (((1, 1, 0, -1, 1, 16, 1), (0, 0, 0, 0, 0, -1, 0), (1, 0, 1, 7, 1, 3, 1), (0, 1, 1, -1, 1, -1, 0), (1, 1, 1, 5, 1, -1, -1)) if bb in (32, 64) else ((0, 1, 0, -1, 1, 5, 1), (0, 0, 1, 0, 0, -1, 0))):
-                    ix.set_tuning(verify_t=T, coop=coop, use_ctx=ctx, steal=steal, jump=jump, jump_filter=(1, 0, 2)[T % 3], range_add=ra, self_hit=1 if T else ra, verify_t_ext=text, jump_groups=grp)   # neighbour filter on / off
+                    ix.set_tuning(verify_t=T, coop=coop, use_ctx=ctx, steal=steal, jump=jump, jump_filter=(1, 0, 2)[T % 3], range_add=ra, self_hit=1 if T else ra, verify_t_ext=text, jump_groups=grp, pat_batch={0: 1, 1: -1, 4: 3}[T])   # neighbour filter on / off; pattern turns every iteration / in the library's batches / in batches of 3
                     out = ix.map(K, E, value_bits=bits)
                     assert np.array_equal(out, exp), (K, E, bits, bb, T, coop, ctx, steal, jump, ra, text, grp)
         ix.close()
