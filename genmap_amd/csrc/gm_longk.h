@@ -17,10 +17,10 @@
 // through the restatement of gm_engine.h (make_plan, make_post, lane_children, split_node), with unpacked coordinates.
 #pragma once
 #include "gm_kernels.h"
+#include "gm_longk_step.h"
 
 namespace gm {
 
-template <typename R> struct LNodeT { R flo, rlo, w; uint32_t ab, tem; };   // ab = a | bx << 16, tem = t | errs << 16 | mode << 24
 
 template <int WPP, class EnvT>
 __global__ __launch_bounds__(256) void longk_kernel(const SearchArgs A)
@@ -97,9 +97,8 @@ __global__ __launch_bounds__(256) void longk_kernel(const SearchArgs A)
                 --sp; nd = stk[(size_t)(sbase + sp) * nth]; have = true;
                 if (sp == 0u) sbase = 0u;
                 if (nd.w >= (R)A.satMinW) {   // pending work for k-mers that already reached MAX is dropped (gm_kernels.h: search_body, covered_kmers)
-                    const uint32_t pa = nd.ab & 0xFFFFu, pbx = nd.ab >> 16, pt = nd.tem & 0xFFFFu, pm = nd.tem >> 24;
                     uint32_t smin, smax;
-                    if (pm == M_OSS) { smin = 0u; smax = rt.n - 1u; } else if (pm == M_EXT_R) { smin = pt - K; smax = pa; } else if (pm == M_EXT_L) { smin = pbx - K; smax = pt; } else { smin = pbx - K; smax = pa; }
+                    long_covered(nd, rt.n, K, smin, smax);
                     if (env.saturated(rt, smin, smax)) { have = false; continue; }
                 }
             }
@@ -126,110 +125,15 @@ __global__ __launch_bounds__(256) void longk_kernel(const SearchArgs A)
                 W = K + rt.n - 1u;
                 env.on_root();
                 // _optimalSearchSchemeGM(..., s.startPos, s.startPos + 1, 0, s, 0, Rev()) find2_index_approx.hpp:441
-                const uint32_t a0 = rt.n - 1u + rec->start;
-                nd.flo = 0; nd.rlo = 0; nd.w = (R)A.nRows; nd.ab = a0 | a0 << 16; nd.tem = M_OSS << 24;
+                nd = long_root_node<R>(rt.n, *rec, (R)A.nRows);
                 have = true;
             }
             if (!have) continue;   // (nothing left for this lane: it waits for its wavefront, or for a share of a neighbour's work)
         }
         if (++guard > A.guardCap && A.guardKeep != 0u) { atomicOr(A.errorFlag, 2u); break; }   // (iter_cap: tests force the bound)
-        uint32_t a = nd.ab & 0xFFFFu, bx = nd.ab >> 16, t = nd.tem & 0xFFFFu, errs = (nd.tem >> 16) & 0xFFu, mode = nd.tem >> 24;
-        if (nd.w <= (R)A.verifyT) {
-            // Narrow node: every string below it lies at the one text location of each of its rows.  On a genome a long k-mer is down to
-            // a single row after its first ~20 characters; the remaining hundreds of rank steps become one suffix-array read and a scan of
-            // the text there (gm_engine.h: verify_fields -- the remaining OSS blocks replayed with their bounds, then the runs of k-mers
-            // that extend with at most E mismatches).
-            for (R r = 0; r < nd.w; ++r) {
-                const typename EnvT::Item it = env.item(nd.flo + r);
-                verify_fields(it, a, bx, t, errs, mode, *rec, rt, K, E, env);
-            }
-            have = false;
-            continue;
-        }
-        if (mode == M_SPLIT) {
-            // SPLIT -> EXT_R kept, EXT_L pushed: the halving targets of algo.hpp:53-56 and :68-71 (same in :196-211); gm_engine.h: split_node
-            const uint32_t alm = bx - K;
-            const uint32_t bxNew = bx + ((a + K - bx + 1u) >> 1);
-            const uint32_t aNew = alm + ((a - alm - 1u) >> 1);
-            LN left = nd;
-            left.tem = aNew | errs << 16 | M_EXT_L << 24;
-            bool leftDone = false, rightDone = false;
-            if (nd.w >= (R)A.satMinW) {   // (both halves have the parent's width)
-                leftDone = env.saturated(rt, bx - K, aNew);
-                rightDone = env.saturated(rt, bxNew - K, a);
-            }
-            if (rightDone) {
-                if (leftDone) { have = false; continue; }
-                mode = M_EXT_L; t = aNew;
-            } else {
-                if (!leftDone) push(left);
-                mode = M_EXT_R; t = bxNew;
-            }
-        }
-        // ---- gm_engine.h: make_plan ----
-        uint32_t right, exact, minErr = 0, charsLeft = 0;
-        if (mode == M_OSS) {
-            const uint32_t u = (rec->w >> (3u * t)) & 7u, l = (rec->z >> (3u * t)) & 7u;
-            right = (rec->z >> (18u + t)) & 1u;
-            exact = (u == errs);                                  // find2:388,397
-            minErr = l > errs ? l - errs : 0u;                    // find2:389
-            charsLeft = (uint32_t)rec->bl[t] - (bx - a);          // find2:247
-        } else {
-            right = (mode == M_EXT_R);
-            exact = (errs == E);                                  // algo.hpp:106,117,143,154,175
-        }
-        const uint32_t pos = right ? bx : a - 1u;
-        uint32_t tc = A.text[(size_t)rt.win + (rt.strand ? W - 1u - pos : pos)];
-        if (rt.strand) tc = complement(tc);
-        const R plo = right ? nd.rlo : nd.flo;
-        R rl[NLET], rh[NLET];
-        env.rank2(right, plo, plo + nd.w, rl, rh);
-        // ---- make_post ----
-        if (right) bx += 1u; else a -= 1u;
-        bool done;
-        if (mode == M_OSS) {
-            done = false;
-            if (bx - a == (uint32_t)rec->bl[t]) { t += 1u; done = (t == (uint32_t)rec->nb); }   // find2:263, :335-344, :358-367, :392-395
-        } else done = right ? (bx == t) : (a == t);               // algo.hpp:101-105,138-142
-        bool leaf = false;
-        if (done) { leaf = (bx - a == K); mode = M_SPLIT; t = 0; }   // algo.hpp:38,180
-        const uint32_t ab1 = a | bx << 16, tem0 = t | mode << 24;
-        // ---- lane_children ----
-        const R olo = right ? nd.flo : nd.rlo;
-        R cnt[NLET], sm[NLET], pn[NLET], tot = 0;
-#pragma unroll
-        for (int x = 0; x < (int)NLET; ++x) { cnt[x] = rh[x] - rl[x]; tot += cnt[x]; pn[x] = env.C((uint32_t)x) + rl[x]; }
-        R run = nd.w - tot;   // sentinels sort before every letter
-        uint32_t nonEmpty = 0;
-#pragma unroll
-        for (int x = 0; x < (int)NLET; ++x) { sm[x] = run; run += cnt[x]; nonEmpty |= (cnt[x] != 0u ? 1u : 0u) << x; }
-        const uint32_t matchBit = tc < SYM_N ? 1u << tc : 0u;     // a needle N mismatches everything (find2:250, algo.hpp:111-112,148-149)
-        const bool okMatch = !(minErr > 0u && charsLeft < minErr + 1u);   // find2:254-258
-        const bool okMiss = !exact && !(minErr > 0u && charsLeft < minErr);
-        const uint32_t valid = nonEmpty & ((okMatch ? matchBit : 0u) | (okMiss ? ((1u << NLET) - 1u) & ~matchBit : 0u));
-        LN keep; keep.flo = keep.rlo = keep.w = 0; keep.ab = ab1; keep.tem = 0;
-        bool haveKeep = false;
-        // the matching child first (deepest in the LIFO), then the mismatching ones in alphabet order; the lane continues with the last
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-            for (int x = 0; x < (int)NLET; ++x) {
-                const bool isMatch = (uint32_t)x == tc && tc < SYM_N;   // (needle N against text N is a mismatch)
-                if ((pass == 0) != isMatch) continue;
-                if (!((valid >> x) & 1u)) continue;
-                const R pnew = pn[x], onew = olo + sm[x];
-                const R cf = right ? onew : pnew, cr = right ? pnew : onew;
-                if (leaf) env.leaf(rt, a, cf, cnt[x]);
-                else {
-                    if (haveKeep) push(keep);
-                    keep.flo = cf; keep.rlo = cr; keep.w = cnt[x];
-                    keep.tem = tem0 | (errs + (isMatch ? 0u : 1u)) << 16;
-                    haveKeep = true;
-                }
-            }
-        }
-        if (leaf) env.leaf_flush(rt, a);
-        nd = keep; have = haveKeep;
+        // one node: settled against the text when it is narrow, else split / stepped (gm_longk_step.h: the same code the CPU harness runs)
+        long_node(nd, have, rt, *rec, K, E, (R)A.verifyT, (R)A.satMinW, env,
+                  [&](uint32_t pos) { const uint32_t c = A.text[(size_t)rt.win + (rt.strand ? W - 1u - pos : pos)]; return rt.strand ? complement(c) : c; }, push);
     }
 }
 

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include "../../genmap_amd/csrc/gm_engine.h"
 #include "../../genmap_amd/csrc/gm_host.h"
+#include "../../genmap_amd/csrc/gm_longk_step.h"
 
 using namespace gm;
 
@@ -157,6 +158,7 @@ template <int WPP, bool NL = false, bool RA = false> struct EmuEnv {
         return rt.strand ? complement(text[rt.win + (W - 1 - pos)]) : text[rt.win + pos];
     }
     void push(const Node& nd) { stack.push_back(nd); if (stack.size() > maxDepth) maxDepth = stack.size(); }
+    bool saturated(const Root&, uint32_t, uint32_t) const { return false; }   // (the device's shortcut for k-mers at MAX: never needed for the result)
     void note_step(uint32_t, uint32_t) {}
     bool any(bool b) const { return b; }
     void note_chunk() {}
@@ -345,6 +347,33 @@ static void search_plan(const MapPlan& plan, const HostIndex<WPP>& ix, Env& env,
     }
 }
 
+// K > MAX_K: the per-node code of the long k-mer kernel (gm_longk_step.h), every root through a plain LIFO
+template <int WPP, class Env>
+static void search_plan_long(const MapPlan& plan, Env& env, uint32_t K, uint32_t E, uint64_t rows, uint32_t verifyT)
+{
+    typedef LNodeT<uint32_t> LN;
+    const uint32_t rpb = plan.nSearches * plan.nStrands;
+    std::vector<LN> st;
+    for (uint64_t id = 0; id < plan.numRoots(); ++id) {
+        const uint64_t b = id / rpb; const uint32_t r = (uint32_t)(id % rpb);
+        Root rt;
+        if (plan.useList) { rt.win = (uint32_t)MapPlan::block_pos(plan.blocks[b]); rt.n = MapPlan::block_n(plan.blocks[b]); }
+        else { rt.win = (uint32_t)(b * plan.stepSize); rt.n = (uint32_t)std::min<uint64_t>(plan.stepSize, plan.numKmers - rt.win); }
+        rt.strand = r / plan.nSearches; rt.search = r % plan.nSearches; rt.rec = OssRecord{0, 0, 0, 0};
+        const OssRecordL& rec = plan.tableL[(size_t)(rt.n - 1) * 8 + rt.search];
+        LN nd = long_root_node<uint32_t>(rt.n, rec, (uint32_t)rows);
+        bool have = true;
+        for (;;) {
+            if (!have) { if (st.empty()) break; nd = st.back(); st.pop_back(); have = true; }
+            const uint32_t w0 = nd.w;
+            long_node(nd, have, rt, rec, K, E, env.saArr ? verifyT : 0u, 0xFFFFFFFFu, env,
+                      [&](uint32_t pos) { return env.text_char(rt, pos); },
+                      [&](const LN& x) { st.push_back(x); if (st.size() > env.maxDepth) env.maxDepth = st.size(); });
+            if (env.saArr && verifyT && w0 <= verifyT) env.verified += w0;
+        }
+    }
+}
+
 template <int WPP, bool NL>
 static int run(const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nseqTotal, const uint8_t* text, uint64_t textLen,
                const uint64_t* seqCum, uint32_t nseqLocal, uint32_t K, uint32_t E, uint32_t infix, int revcompl, int valueBits,
@@ -372,7 +401,8 @@ static int run(const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nse
     }
     uint32_t bound = stack_bound(E, plan.stepSize);
     uint64_t nPatterns = 0;
-    search_plan<WPP>(plan, ix, env, K, E, rows, verifyT, jumpCap, &nPatterns);
+    if (K > MAX_K) { env.diff = nullptr; search_plan_long<WPP>(plan, env, K, E, rows, verifyT); }   // (verified runs k-mer by k-mer, as the device does there)
+    else search_plan<WPP>(plan, ix, env, K, E, rows, verifyT, jumpCap, &nPatterns);
     uint64_t corrRoots = 0;
     if (NL && E >= 1) {
         // correction pass: the text windows with N as needles, full semantics (N children followed), every located occurrence

@@ -450,3 +450,37 @@ def test_fast_verification_gives_the_same_counts(K, E, T):
             assert (e.gm_emu_fast_items(0) > 0) == bool(fast), (K, E, T, fast)
     finally:
         e.gm_emu_set_fast_verify(1)
+
+
+# ---- k-mers longer than 255: the per-node code of the long k-mer kernel (genmap_amd/csrc/gm_longk_step.h) ---------------------------------
+@pytest.mark.parametrize("K,E", [(256, 0), (300, 1), (300, 2), (513, 3), (1000, 1)])
+def test_long_kmer_node_logic(K, E):
+    """gm_longk_step.h (long_root_node, long_node: split, plan, children in the kernel's order, verify_fields with OssRecordL) through a plain
+    LIFO on the host: plain walk down to the leaves, single rows / up to four rows settled against the text; both counter widths, one strand,
+    a selection, an explicit infix -- all equal to the oracle; the lane stack stays within stack_bound."""
+    rng = np.random.default_rng(K * 10 + E + 5)
+    lens = [5000, K + 40, K - 1, 2600, 3]
+    n = sum(lens)
+    codes = rng.integers(0, 4, size=n, dtype=np.uint8)
+    fam = codes[100:1500].copy()                       # long exact and near-exact copies: long k-mers with several occurrences
+    for i, s0 in enumerate((2600, n - 2550)):
+        cp = fam.copy()
+        if i: cp[rng.integers(0, 1400, size=3)] ^= 1
+        codes[s0:s0 + 1400] = cp
+    codes[4000:4030] = 4
+    codes[700] = 4
+    ix = H.OracleIndex(codes, lens, keep_sa=True)
+    for bits in (8, 16):
+        exp = ix.mappability(K, E, value_bits=bits, threads=4)
+        for T in (0, 1, 4):
+            out, st = emu_map(ix, 1, K, E, value_bits=bits, verify_t=T)
+            assert np.array_equal(out, exp), (K, E, bits, T)
+            assert st[0] <= st[1] and (T == 0 or st[3] > 0), (K, E, T, st.tolist())
+    assert exp.max() >= 2
+    out, _ = emu_map(ix, 1, K, E, value_bits=16, verify_t=1, infix=K - 5)
+    assert np.array_equal(out, exp)
+    out, _ = emu_map(ix, 1, K, E, value_bits=16, verify_t=1, revcompl=False)
+    assert np.array_equal(out, ix.mappability(K, E, value_bits=16, revcompl=False, threads=4))
+    iv = [(50, 900), (2500, 3100), (4900, 5000)]
+    out, _ = emu_map(ix, 1, K, E, value_bits=16, verify_t=1, intervals=iv)
+    assert np.array_equal(out, ix.mappability(K, E, value_bits=16, intervals=iv, threads=4))
