@@ -1115,14 +1115,14 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         const uint32_t qcap = ix->tune.qtable >= 0 ? (uint32_t)ix->tune.qtable : (ix->nRows > (1ull << 30) ? 16u : 15u);
         while (qmax < qcap && (1ull << (2 * qmax)) < 4ull * ix->nRows) ++qmax;
         if (ix->tune.qtable >= 0) qmax = (uint32_t)std::min(ix->tune.qtable, 16);
-        if (longK) qmax = 0;
         A.qtabA = A.qtabB = nullptr; A.qlenPacked[0] = A.qlenPacked[1] = 0; A.qselMask = 0; A.startPacked[0] = A.startPacked[1] = 0;
         uint32_t qA = 0, qB = 0;
         for (uint32_t s = 0; s < plan.nSearches; ++s) {
             const OssRecord& r = plan.table[(size_t)(plan.stepSize - 1) * 8 + s];
-            A.startPacked[s >> 2] |= oss_start(r) << (8u * (s & 3u));
+            if (!longK) A.startPacked[s >> 2] |= oss_start(r) << (8u * (s & 3u));
             if (qmax == 0) continue;
-            const uint32_t bl0 = oss_bl(r, 0);
+            // (long k-mers, gm_longk.h: the first block of the REGULAR shape bounds the prefix; shorter blocks at the end of the text have longer infixes)
+            const uint32_t bl0 = longK ? oss_bl(plan.tableL[(size_t)(plan.stepSize - 1) * 8 + s], 0) : oss_bl(r, 0);
             uint32_t q = std::min(qmax, bl0 > 0 ? bl0 - 1u : 0u);
             if (q == 0) continue;
             if (qA == 0 || qA == q) { if (qA == 0) { rc = get_qtable(ix, &q, &A.qtabA); if (rc) return rc; qA = q; } }

@@ -11,7 +11,7 @@
 //   * pending nodes live on a lane-private stack in HBM (level-major: a level of the 64 lanes is contiguous), bounded by stack_bound();
 //   * narrow nodes (at most verifyT rows; needs the resident suffix array) are settled against the text by verify_fields (gm_engine.h):
 //     on a genome a long k-mer has one row left after ~20 characters, the rest of the walk is one suffix-array read and a text scan;
-//   * no q-mer tables, no jump patterns, no cooperative block reads, the text letter N is followed like any other (no correction pass).
+//   * the q-mer table for the first characters of a root, but no jump patterns, no cooperative block reads, the text letter N is followed like any other (no correction pass).
 // What it follows: _optimalSearchSchemeGM / ...ChildrenGM / ...ExactGM   /root/reference/src/find2_index_approx.hpp:223-457
 //                  extend / approxSearch / extendExact                   /root/reference/src/algo.hpp:26-218
 // through the restatement of gm_engine.h (make_plan, make_post, lane_children, split_node), with unpacked coordinates.
@@ -127,8 +127,28 @@ __global__ __launch_bounds__(256) void longk_kernel(const SearchArgs A)
                 // _optimalSearchSchemeGM(..., s.startPos, s.startPos + 1, 0, s, 0, Rev()) find2_index_approx.hpp:441
                 nd = long_root_node<R>(rt.n, *rec, (R)A.nRows);
                 have = true;
+                // the first q characters of the search's first (always exact) block from the table of all q-mers: one read instead of the q
+                // widest steps (gm_kernels.h: stage 2 of search_body); an N among them ends an exact block before it starts
+                const uint32_t q = ((rt.search < 4u ? A.qlenPacked[0] : A.qlenPacked[1]) >> (8u * (rt.search & 3u))) & 0xFFu;
+                if (q != 0u) {
+                    const uint32_t a0 = nd.ab & 0xFFFFu;
+                    uint32_t idx = 0, bad = 0;
+                    for (uint32_t i = 0; i < q; ++i) {
+                        uint32_t c = A.text[(size_t)rt.win + (rt.strand ? W - 1u - (a0 + i) : a0 + i)];
+                        bad |= c >> 2;
+                        if (rt.strand) c = 3u - (c & 3u);
+                        idx = idx << 2 | (c & 3u);
+                    }
+                    if (bad) have = false;
+                    else {
+                        R eFlo, eRlo, eW;
+                        NodeIO<R>::load_qentry(((A.qselMask >> rt.search) & 1u) ? A.qtabB : A.qtabA, idx, eFlo, eRlo, eW);
+                        if (eW == 0) have = false;
+                        else { nd.flo = eFlo; nd.rlo = eRlo; nd.w = eW; nd.ab = a0 | (a0 + q) << 16; }
+                    }
+                }
             }
-            if (!have) continue;   // (nothing left for this lane: it waits for its wavefront, or for a share of a neighbour's work)
+            if (!have) continue;   // (nothing left for this lane, or a root that ended at its table entry)
         }
         if (++guard > A.guardCap && A.guardKeep != 0u) { atomicOr(A.errorFlag, 2u); break; }   // (iter_cap: tests force the bound)
         // one node: settled against the text when it is narrow, else split / stepped (gm_longk_step.h: the same code the CPU harness runs)
