@@ -11,6 +11,7 @@
 #include "../../genmap_amd/csrc/gm_engine.h"
 #include "../../genmap_amd/csrc/gm_host.h"
 #include "../../genmap_amd/csrc/gm_longk_step.h"
+#include "../../genmap_amd/csrc/gm_expand.h"
 
 using namespace gm;
 
@@ -28,6 +29,13 @@ static int g_fastVerify = 1;        // narrow nodes settled from the masks of gm
 extern "C" void gm_emu_set_fast_verify(int on) { g_fastVerify = on; }
 static uint64_t g_fastItems = 0;    // items verified that way since the last reset (tests make sure the path is exercised)
 extern "C" uint64_t gm_emu_fast_items(int reset) { const uint64_t v = g_fastItems; if (reset) g_fastItems = 0; return v; }
+
+static int g_expand = 0;            // 1: roots with jump patterns go through phase A of the split search (gm_expand.h: one work item per (root, item), node
+extern "C" void gm_emu_set_expand(int on) { g_expand = on; }   // packets in three lists) and the packets are walked list by list, from their own windows
+static int g_nbFilter = 1;          // the neighbour filters of one- and two-row table entries (needs the suffix array); 2: one-row entries only, 0: off
+extern "C" void gm_emu_set_nb_filter(int v) { g_nbFilter = v; }
+static uint64_t g_packets[4] = {0, 0, 0, 0};   // packets per list since the last reset, [3]: nodes ended by the neighbour filters
+extern "C" void gm_emu_packets(uint64_t* out, int reset) { for (int i = 0; i < 4; ++i) { out[i] = g_packets[i]; if (reset) g_packets[i] = 0; } }
 
 template <int WPP> struct HostIndex {
     std::vector<uint32_t> blk[2];
@@ -152,9 +160,16 @@ template <int WPP, bool NL = false, bool RA = false> struct EmuEnv {
         block_rank<WPP>(base + (size_t)(hi / SPB) * WPB, hi % SPB, rh);
         ++steps;
     }
+    const uint64_t* pwin = nullptr;   // != null: the needle window of the packet being walked (gm_expand.h), 4 bits per symbol from nibble 0
+    uint64_t textLenSlice = 0;
     uint32_t text_char(const Root& rt, uint32_t pos) const
     {
         uint32_t W = K + rt.n - 1;
+        if (pwin) {
+            const uint32_t nib = rt.strand ? W - 1 - pos : pos;
+            const uint32_t c = (uint32_t)(pwin[nib >> 4] >> (4u * (nib & 15u))) & 15u;
+            return rt.strand ? complement(c) : c;
+        }
         return rt.strand ? complement(text[rt.win + (W - 1 - pos)]) : text[rt.win + pos];
     }
     void push(const Node& nd) { stack.push_back(nd); if (stack.size() > maxDepth) maxDepth = stack.size(); }
@@ -226,7 +241,7 @@ static void search_plan(const MapPlan& plan, const HostIndex<WPP>& ix, Env& env,
         bool have = true;
         for (;;) {
             if (!have) { if (env.stack.empty()) break; nd = env.stack.back(); env.stack.pop_back(); have = true; }
-            if (Env::RANGE_ADD && g_selfHit && nd.w == 1u && rt.strand == 0u && meta_errs(nd.meta) == 0u) {   // gm_kernels.h: self hits
+            if (Env::RANGE_ADD && g_selfHit && nd.w == 1u && rt.strand == 0u && meta_errs(nd.meta) == 0u && nd.rlo != ~0u) {   // gm_kernels.h: self hits
                 bool anyN = false;
                 for (uint32_t i = 0; i < K + rt.n - 1u; ++i) anyN |= env.text_char(rt, i) >= SYM_N;
                 if (!anyN) {
@@ -246,6 +261,133 @@ static void search_plan(const MapPlan& plan, const HostIndex<WPP>& ix, Env& env,
             lane_step(nd, have, rt, K, E, env);
         }
     };
+    bool anyJump = false;
+    for (uint32_t s = 0; s < plan.nSearches; ++s) anyJump = anyJump || jumps[s].J != 0;
+    if (g_expand && anyJump) {
+        // ---- phase A / phase B (gm_expand.h): what expand_kernel and the walker do, in the device's order ----
+        const uint32_t J = jumps[0].J;
+        // the call's items back to back, the searches' records as gm_api.hip (prepare_search) lays them out
+        std::vector<uint32_t> pat, first(plan.nSearches), count(plan.nSearches), nbWord(plan.nSearches, 0u);
+        std::vector<uint32_t> ex(plan.nSearches), ey(plan.nSearches), ez(plan.nSearches);
+        const bool canFilter = g_nbFilter != 0 && env.saArr && env.textSent;
+        for (uint32_t s = 0; s < plan.nSearches; ++s) {
+            first[s] = (uint32_t)pat.size(); count[s] = (uint32_t)items[s].items.size();
+            uint32_t e16[GROUP_MAX_LAYOUTS], run = first[s];
+            for (uint32_t L2 = 0; L2 < GROUP_MAX_LAYOUTS; ++L2) { run += L2 < items[s].seg.size() ? items[s].seg[L2] : 0u; e16[L2] = run; }
+            ex[s] = e16[0] | e16[1] << 16; ey[s] = e16[2] | e16[3] << 16; ez[s] = e16[4] | e16[5] << 16;
+            if (canFilter) {
+                const uint32_t nr = std::min<uint32_t>(NB_SYMS, L - jumps[s].regionA - J), nl = std::min<uint32_t>(NB_SYMS, jumps[s].regionA);
+                for (uint32_t i = 0; i < nr; ++i) nbWord[s] |= 1u << (2u * i);
+                for (uint32_t i = 0; i < nl; ++i) nbWord[s] |= 1u << (16u + 2u * i);
+                nbWord[s] |= nr << 12 | nl << 28 | 1u << 31;
+            }
+            pat.insert(pat.end(), items[s].items.begin(), items[s].items.end());
+        }
+        const std::vector<uint32_t> wmap = make_wmap(plan.nStrands, plan.nSearches, first.data(), count.data());
+        const std::vector<uint32_t> shifts = group_layout_shifts(J);
+        struct HostTab {
+            const std::vector<uint32_t>* shifts; const std::vector<uint64_t>* masks;
+            uint32_t layout(uint32_t il) const { return il < shifts->size() ? ((*shifts)[il] | il << 5 | (1u + 16u * il) << 13) : 0u; }
+            uint64_t mask(uint32_t id) const { return id < masks->size() ? (*masks)[id] : 0ull; }
+        } tab{&shifts, &gmasks};
+        struct EmuMem {
+            const uint8_t* text; uint64_t avail;
+            uint64_t word(uint64_t i) const { uint64_t v = 0; for (uint32_t k = 0; k < 16u; ++k) { const uint64_t p = 16u * i + k; const uint64_t c = p < avail ? text[p] : 0u; v |= (c & 15u) << (4u * k); } return v; }
+            void pair(uint64_t i, uint64_t& lo, uint64_t& hi) const { lo = word(i); hi = word(i + 1); }
+        } mem{env.text, env.textAvail ? env.textAvail : env.textLenSlice};
+        // the 4th word of a table entry (gm_kernels.h: qmer_table_kernel): the text next to the occurrence(s) of a one- / two-row entry
+        auto sent = [&](int64_t p) -> uint32_t { return (p < 0 || p >= (int64_t)ix.n) ? (uint32_t)SYM_SENT : (uint32_t)(*env.textSent)[p]; };
+        auto entry_nb = [&](uint32_t flo, uint32_t w) -> uint32_t {
+            uint32_t nb = 0;
+            if (!canFilter) return 0u;
+            if (w == 1u) {
+                const int64_t t = env.saArr[flo];
+                uint32_t nr = 0, nl = 0;
+                while (nr < NB_SYMS && sent(t + J + nr) < SYM_N) { nb |= sent(t + J + nr) << (2u * nr); ++nr; }
+                while (nl < NB_SYMS && sent(t - 1 - (int64_t)nl) < SYM_N) { nb |= sent(t - 1 - (int64_t)nl) << (16u + 2u * nl); ++nl; }
+                nb |= nr << 12 | nl << 28 | 0x80008000u;
+            }
+            if (w == 2u) for (uint32_t r2 = 0; r2 < 2u; ++r2) {
+                const int64_t t = env.saArr[flo + r2];
+                uint32_t x = 0, nr = 0, nl = 0;
+                while (nr < NB_SYMS2 && sent(t + J + nr) < SYM_N) { x |= sent(t + J + nr) << (2u * nr); ++nr; }
+                while (nl < NB_SYMS2 && sent(t - 1 - (int64_t)nl) < SYM_N) { x |= sent(t - 1 - (int64_t)nl) << (6u + 2u * nl); ++nl; }
+                nb |= (x | nr << 12 | nl << 14) << (16u * r2);
+            }
+            return nb;
+        };
+        struct Pkt { Node nd; uint32_t win, nss; std::vector<uint64_t> w; };
+        std::vector<Pkt> lists[3];
+        const uint32_t ipb = (uint32_t)wmap.size();
+        const uint64_t nBlocks = plan.useList ? plan.blocks.size() : plan.numBlocks;
+        auto packet = [&](uint32_t cls, const Node& nd, const Root& rt) {
+            Pkt p; p.nd = nd; p.win = rt.win; p.nss = pkt_root_word(rt.n, rt.strand, rt.search);
+            const uint32_t words = 2u * pkt_chunks_for(K, plan.stepSize);
+            for (uint32_t j = 0; j < words; ++j) p.w.push_back(nib64(mem, (uint64_t)rt.win + 16u * j));
+            lists[cls].push_back(p); g_packets[cls]++;
+        };
+        for (uint64_t b = 0; b < nBlocks; ++b) for (uint32_t q = 0; q < ipb; ++q) {
+            const uint32_t wm = wmap[q], search = wm & 7u, strand = (wm >> 3) & 1u, jp = wm >> 8;
+            Root rt;
+            if (plan.useList) { rt.win = (uint32_t)MapPlan::block_pos(plan.blocks[b]); rt.n = MapPlan::block_n(plan.blocks[b]); }
+            else { rt.win = (uint32_t)(b * plan.stepSize); rt.n = (uint32_t)std::min<uint64_t>(plan.stepSize, plan.numKmers - rt.win); }
+            rt.strand = strand; rt.search = search; rt.rec = plan.table[(size_t)(rt.n - 1) * 8 + search];
+            const JumpSearch& js = jumps[search];
+            const uint32_t W = K + rt.n - 1u;
+            XRoot xr; xr.jb = xr.jn = xr.ext = 0u; xr.bad = 1u;
+            if (rt.n == plan.stepSize) xr = expand_root(mem, rt.win, W, strand, rt.n - 1u + js.regionA, J, nbWord[search], items[search].ext);
+            if (xr.bad) {   // an odd block shape, or an N inside the J-mer: the root walks the tree from its root (its first item's lane says so)
+                if (jp == first[search]) packet(0u, root_node(rt, (uint32_t)rows), rt);
+                continue;
+            }
+            const uint32_t jd = pat[jp];
+            XItem it = expand_item(jd, jump_item_flags(jp, ex[search], ey[search], ez[search]), xr, tab);
+            if (it.state == 2u) {
+                // the word of the group's bitmap, built here by asking the index (the device reads it from its bitmaps); kind from the plane
+                const uint32_t kind = (jd >> (it.sh + 3u)) & 1u, e0 = (xr.ext >> (JF_EXT_SHIFT + 2u)) & 3u, e1 = (xr.ext >> JF_EXT_SHIFT) & 3u;
+                const uint32_t pre = rot_add(xr.jb, it.gcur);
+                if (group_word(pre, it.sh) != it.widx) g_hangs += 1000000;
+                uint64_t word = 0;
+                for (uint32_t c = 0; c < 64u; ++c) {
+                    const uint64_t cand = (pre & ~(63u << it.sh)) | c << it.sh;
+                    uint32_t f, r2, w;
+                    if (kind) table_entry<WPP>(ix, cand << 4 | e0 << 2 | e1, J + 2u, f, r2, w); else table_entry<WPP>(ix, cand, J, f, r2, w);
+                    if (w) word |= 1ull << c;
+                }
+                expand_word(it, word, jd, xr, tab);
+            }
+            const uint32_t off = rt.n - 1u;
+            const uint32_t jm0 = meta_pack((js.meta0 & 0x1FFu) + off, ((js.meta0 >> 9) & 0x1FFu) + off, js.meta0 >> 18, 0u, M_OSS);
+            uint32_t rw;
+            while (expand_next(it, rw)) {
+                uint32_t flo, rlo, w;
+                table_entry<WPP>(ix, rot_add(xr.jb, rw), J, flo, rlo, w);
+                if (nPatterns) ++*nPatterns;
+                const XNode x = expand_filter(flo, rlo, w, entry_nb(flo, w), rw, jm0, xr.jn, nbWord[search], E, (uint32_t)g_nbFilter, env.saArr ? verifyT : 0u);
+                if (!x.take) { if (w) g_packets[3]++; continue; }
+                Node nd; nd.flo = x.flo; nd.rlo = x.rlo; nd.w = x.w; nd.meta = x.meta;
+                if (Env::RANGE_ADD && g_selfHit && x.w == 1u && strand == 0u && x.errs == 0u && x.rlo != ~0u) {   // self hits are settled by phase A
+                    uint64_t anyN = 0;
+                    for (uint32_t j = 0; j < 2u * pkt_chunks_for(K, plan.stepSize); ++j) anyN |= nib64(mem, (uint64_t)rt.win + 16u * j) & 0x4444444444444444ull;
+                    if (!anyN) {
+                        uint32_t smin, smax;
+                        if (self_hit_kmers(nd.meta, rt, K, smin, smax)) { if constexpr (Env::RANGE_ADD) env.leaf_range(rt, smin, smax); }
+                        env.selfHits++;
+                        continue;
+                    }
+                }
+                packet(expand_class(x.errs), nd, rt);
+            }
+        }
+        for (uint32_t cls = 0; cls < 3u; ++cls) for (const Pkt& p : lists[cls]) {
+            Root rt; rt.win = p.win; rt.n = p.nss & 0xFFu; rt.strand = (p.nss >> 8) & 1u; rt.search = (p.nss >> 9) & 7u;
+            rt.rec = plan.table[(size_t)(rt.n - 1) * 8 + rt.search];
+            env.pwin = p.w.data();
+            walk(p.nd, rt);
+        }
+        env.pwin = nullptr;
+        return;
+    }
     for (uint64_t id = 0; id < roots; ++id) {
         uint64_t b = id / rpb; uint32_t r = (uint32_t)(id % rpb);
         Root rt;
@@ -385,7 +527,7 @@ static int run(const uint8_t* bf, const uint8_t* br, uint64_t rows, uint32_t nse
     if (rc) return rc;
     HostIndex<WPP> ix; ix.build(bf, br, rows, nseqTotal);
     std::vector<uint32_t> acc(textLen ? textLen : 1, 0);
-    EmuEnv<WPP, NL, true> env; env.ix = &ix; env.text = text; env.K = K; env.acc = &acc;
+    EmuEnv<WPP, NL, true> env; env.ix = &ix; env.text = text; env.K = K; env.acc = &acc; env.textLenSlice = textLen;
     std::vector<uint32_t> diff(textLen + 1, 0);
     if (!plan.useList) env.diff = &diff;
     std::vector<uint8_t> textS;

@@ -199,8 +199,19 @@ def emu_map2(ix, wpp, K, E, first_seq=0, n_seq=None, xo=None, infix=0, revcompl=
     return out, stats
 
 
+@pytest.fixture(params=[0, 1], ids=["one_loop", "split"])
+def expand_mode(request):
+    """0: a root's jump patterns are consumed by the lane that walks their subtrees (the kernels of rounds 3-5); 1: phase A / phase B of
+    round 6 (gm_expand.h): one work item per (root, item), node packets in three lists, every packet walked from its own needle window,
+    self hits settled by phase A, the neighbour filters of one- and two-row table entries on"""
+    e = emu()
+    e.gm_emu_set_expand(request.param)
+    yield request.param
+    e.gm_emu_set_expand(0)
+
+
 @pytest.mark.parametrize("case", sorted(H.CASES))
-def test_jump_patterns_and_n_correction_on_reference_fixtures(case):
+def test_jump_patterns_and_n_correction_on_reference_fixtures(case, expand_mode):
     d = H.CASES_DIR / f"case_{case}"
     g, directory, fl, bed = H.load_case(case)
     if fl.get("ep"):
@@ -221,7 +232,7 @@ def test_jump_patterns_and_n_correction_on_reference_fixtures(case):
 
 @pytest.mark.parametrize("dna5", [False, True])
 @pytest.mark.parametrize("E", [1, 2, 3, 4])
-def test_jump_patterns_and_n_correction_gtest_matrix(E, dna5):
+def test_jump_patterns_and_n_correction_gtest_matrix(E, dna5, expand_mode):
     """random Dna5 text is 20 % N: nearly every window goes through the correction pass; Dna4: the patterns alone"""
     rng = np.random.default_rng(6000 + 10 * E + dna5)
     nseq, ln = 3, (400 if E < 3 else 250)
@@ -242,7 +253,7 @@ def test_jump_patterns_and_n_correction_gtest_matrix(E, dna5):
 
 
 @pytest.mark.parametrize("K,E", [(30, 1), (30, 2), (100, 1), (24, 1), (50, 3), (36, 4), (150, 2), (250, 1)])
-def test_jump_patterns_and_n_correction_baseline_settings(K, E):
+def test_jump_patterns_and_n_correction_baseline_settings(K, E, expand_mode):
     rng = np.random.default_rng(K * 10 + E + 11)
     lens = [1500, 700, K - 1, 900, 3, K, K + 1]
     n = sum(lens)
@@ -273,7 +284,7 @@ def test_jump_patterns_and_n_correction_baseline_settings(K, E):
 
 
 @pytest.mark.parametrize("K,E", [(30, 1), (30, 2), (24, 1), (24, 2), (50, 3), (36, 4), (100, 1)])
-def test_groups_of_jump_patterns_read_through_the_existence_bitmap(K, E):
+def test_groups_of_jump_patterns_read_through_the_existence_bitmap(K, E, expand_mode):
     """gm_oss.h: patterns that differ in their last three characters only form a group answered by one word of the bitmap "which J-mers
     occur" (word_to_rotations, rotations_to_low6, rotations_errors, oss_group_patterns): grouped == plain patterns == oracle, for the jump
     lengths the device uses (15, 16) and short ones, on a text with repeats and N"""
@@ -317,6 +328,58 @@ def test_groups_of_jump_patterns_read_through_the_existence_bitmap(K, E):
     finally:
         e.gm_emu_set_jump_groups(0)
         e.gm_emu_set_state_machine(1)
+
+
+@pytest.mark.parametrize("K,E", [(30, 1), (30, 2), (24, 2), (36, 3), (100, 1)])
+def test_phase_a_node_packets_and_neighbour_filters(K, E):
+    """gm_expand.h end to end on the CPU: expand_root (J-mer index, neighbours and the two letters behind the J-mer taken from the 4-bit text at
+    any alignment, both strands), expand_item / expand_word / expand_next (plain patterns and groups of every layout), expand_filter (one- and
+    two-row entries, rows-only nodes), self hits settled by phase A, the three lists -- equal to the oracle with the filters on, one-row only,
+    and off; the filters must end nodes and every list must be used."""
+    e = emu()
+    e.gm_emu_packets.argtypes = [C.c_void_p, C.c_int]
+    rng = np.random.default_rng(K * 7 + E)
+    lens = [2500, 37, K + 5, 1900, K - 1, 600]
+    n = sum(lens)
+    codes = rng.integers(0, 4, size=n, dtype=np.uint8)
+    fam = rng.integers(0, 4, size=260, dtype=np.uint8)
+    for s0 in (100, 700, 2700, 3300, 4200, 4600):
+        cp = fam.copy()
+        mut = rng.random(260) < 0.03
+        cp[mut] = rng.integers(0, 4, size=int(mut.sum()), dtype=np.uint8)
+        codes[s0:s0 + 260] = cp
+    codes[1500:1560] = 4
+    for p0 in (150, 2801, 2802, 4300):
+        codes[p0] = 4
+    codes[1700:1800] = 3
+    ix = H.OracleIndex(codes, lens, keep_sa=True)
+    exp = ix.mappability(K, E, value_bits=16, threads=4)
+    pk = np.zeros(4, dtype=np.uint64)
+    ended = {}
+    try:
+        e.gm_emu_set_expand(1)
+        for groups in (0, 2):
+            e.gm_emu_set_jump_groups(groups)
+            for nbf in (1, 2, 0):
+                e.gm_emu_set_nb_filter(nbf)
+                for T, jump in ((1, 16), (4, 9), (0, 12)):
+                    e.gm_emu_packets(H._ptr(pk), 1)
+                    out, st = emu_map2(ix, 1, K, E, value_bits=16, verify_t=T, jump=jump)
+                    assert np.array_equal(out, exp), (K, E, groups, nbf, T, jump, np.flatnonzero(out != exp)[:10])
+                    e.gm_emu_packets(H._ptr(pk), 1)
+                    assert pk[0] > 0 and (jump < 16 or K >= 64 or (pk[1] > 0 and (E < 2 or pk[2] > 0))), pk
+                    ended[(groups, nbf, T, jump)] = int(pk[3])
+                    assert st[6] > 0                       # self hits (settled by phase A)
+        assert ended[(0, 1, 1, 16)] > 0 and ended[(0, 0, 1, 16)] == 0 and ended[(0, 1, 1, 16)] >= ended[(0, 2, 1, 16)] > 0, ended
+        # slices and a selection go through the same code
+        e.gm_emu_set_nb_filter(1)
+        out2, _ = emu_map2(ix, 1, K, E, first_seq=0, n_seq=2, value_bits=16, verify_t=1, jump=15)
+        assert np.array_equal(out2, ix.mappability(K, E, first_seq=0, n_seq=2, value_bits=16, threads=4))
+        iv = [(40, 900), (2400, 2600), (4100, 4500)]
+        out3, _ = emu_map2(ix, 1, K, E, value_bits=16, verify_t=1, jump=15, intervals=iv)
+        assert np.array_equal(out3, ix.mappability(K, E, value_bits=16, intervals=iv, threads=4))
+    finally:
+        e.gm_emu_set_expand(0); e.gm_emu_set_jump_groups(0); e.gm_emu_set_nb_filter(1)
 
 
 def test_n_window_intervals_list_exactly_the_windows_that_can_match():
