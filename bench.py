@@ -85,11 +85,7 @@ class CpuBaseline:
         self.lens = [int(x) for x in lens]
         self.cum = np.concatenate([[0], np.cumsum(np.asarray(self.lens, dtype=np.int64))])
         self.out = {8: np.zeros(self.n, np.uint8), 16: np.zeros(self.n, np.uint16)}
-        try:
-            self.ora.lib.gmo_set_skip_clear(1)
-            self.skip_clear = True
-        except AttributeError:
-            self.skip_clear = False
+        self.skip_clear = hasattr(self.ora.lib, "gmo_set_skip_clear")   # (a process-wide switch of the oracle: set around the timed calls only)
         log(f"cpu_baseline: oracle ({self.build}) adopted the GPU-built BWTs in {time.time() - t0:.1f} s on {self.model}, {threads} threads")
 
     def intervals(self, K, count, seed=20260929):
@@ -120,9 +116,15 @@ class CpuBaseline:
                 else:
                     merged.append((a, b))
             npos = sum(b - a for a, b in merged)
-            t0 = time.time()
-            self.ora.mappability(K, E, value_bits=bits, threads=threads, intervals=merged, out=self.out[bits], **kw)
-            dt = time.time() - t0
+            try:
+                if self.skip_clear:
+                    self.ora.lib.gmo_set_skip_clear(1)
+                t0 = time.time()
+                self.ora.mappability(K, E, value_bits=bits, threads=threads, intervals=merged, out=self.out[bits], **kw)
+                dt = time.time() - t0
+            finally:
+                if self.skip_clear:
+                    self.ora.lib.gmo_set_skip_clear(0)
             if self.skip_clear:
                 for a, b in merged:
                     self.out[bits][a:b + K] = 0
@@ -154,10 +156,6 @@ class CpuBaseline:
                 if t_sum >= target or per_file * self.INTERVAL >= max(tl for _, _, tl in slices):
                     return per_file, npos, t_sum
                 per_file = int(max(per_file * 2, per_file * (target * 1.3) / max(t_sum, 1e-3)))
-        try:
-            self.ora.lib.gmo_set_skip_clear(0)
-        except AttributeError:
-            pass
         m, npos, dt = timed(self.threads, 8.0, 50)
         m1, npos1, dt1 = timed(1, 4.0, max(1, m // max(8, self.threads // 2)))
         return {"value": npos / dt, "unit": "k-mers/s", "cores": self.threads, "kind": "port", "build": self.build, "cpu_model": self.model,

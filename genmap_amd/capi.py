@@ -446,5 +446,7 @@ class Index:
         d = {k: getattr(s, k) for k, _ in MapStats._fields_}
         d["detail"] = dict(zip(("steps_oss", "steps_ext", "ext_w1", "ext_w2_4", "oss_w1", "pushes", "verify_items", "verify_items_oss", "verify_chunks", "wave_iterations", "active_lane_sum", "verify_rounds", "cyc_fetch", "cyc_verify", "cyc_step", "cyc_pop", "cyc_share", "cyc_stage32", "cyc_stage1", "stolen",
                                 "w_pop", "w_saturated", "w_share", "w_stage3", "w_stage2", "w_stage1", "w_defer", "w_split", "w_miss_round", "w_leaf", "w_leaf_flush",
-                                "w_v_block", "w_v_chunk", "w_v_event", "w_v_kmer", "w_push_hbm", "jump_lookups", "correction_us", "table_q", "jump_filtered", "located_rows", "lf_steps", "max_stack", "self_hits", "verified_runs", "jump_words", "jump_filtered_rows2"), list(s.detail)))
+                                "w_v_block", "w_v_chunk", "w_v_event", "w_v_kmer", "w_push_hbm", "jump_lookups", "correction_us", "table_q", "jump_filtered", "located_rows", "lf_steps", "max_stack", "self_hits", "verified_runs", "jump_words", "jump_filtered_rows2", "packets_slices"), list(s.detail)))
+        d["detail"]["packets"] = d["detail"]["packets_slices"] & ((1 << 48) - 1)      # node packets written by phase A of the split search (profiling build)
+        d["detail"]["slices"] = d["detail"].pop("packets_slices") >> 48                # slices the call's split search took (0: the one-loop kernel ran)
         return d

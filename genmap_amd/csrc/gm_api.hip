@@ -357,6 +357,9 @@ void gm_index_free(gm_index* ix)
     if (ix->evDone) hipEventDestroy(ix->evDone);
     hipFree(ix->d_shardOut); hipFree(ix->d_patterns); hipFree(ix->d_jinfo); hipFree(ix->d_cblocks);
     if (ix->h_stage) hipHostFree(ix->h_stage);
+    hipFree(ix->d_pktX); hipFree(ix->d_pktY); hipFree(ix->d_xctl); hipFree(ix->d_xprog); hipFree(ix->d_wmap);
+    if (ix->h_xprog) hipHostFree(ix->h_xprog);
+    for (auto& e : ix->evX) if (e) hipEventDestroy(e);
     for (auto& e : ix->evStage) if (e) hipEventDestroy(e);
     if (ix->stCorr) hipStreamDestroy(ix->stCorr);
     if (ix->evCorrGo) hipEventDestroy(ix->evCorrGo);
@@ -541,7 +544,7 @@ template <typename T> static int grow(T** p, uint64_t* cap, uint64_t need)
     return GM_OK;
 }
 
-enum LeafMode { LEAF_COUNT = 0, LEAF_FILESET = 1, LEAF_OCC_COUNT = 2, LEAF_OCC_EMIT = 3, LEAF_STORE = 4, LEAF_STORE8 = 5, LEAF_COUNT_JUMP = 6, LEAF_SCATTER = 7 };
+enum LeafMode { LEAF_COUNT = 0, LEAF_FILESET = 1, LEAF_OCC_COUNT = 2, LEAF_OCC_EMIT = 3, LEAF_STORE = 4, LEAF_STORE8 = 5, LEAF_COUNT_JUMP = 6, LEAF_SCATTER = 7, LEAF_COUNT_NODES = 8 };
 
 // nu = 16-byte units per stored node / queue entry: 1, or 2 with 64-bit rows (gm_kernels.h: NodeIO)
 static uint32_t g_ldsPad = 0;   // (measurement: bytes of LDS requested on top of what a block uses -- where is the occupancy cliff?  knob "lds_pad")
@@ -577,7 +580,10 @@ static int launch_mode(int mode, const SearchArgs& A, unsigned blocks, hipStream
 {
     switch (mode) {
         case LEAF_COUNT: return launch_one<WPP, CountEnv<WPP>>(A, blocks, st);
-        case LEAF_COUNT_JUMP: return launch_one<WPP, CountEnv<WPP, true>>(A, blocks, st);
+        case LEAF_COUNT_JUMP: return launch_one<WPP, CountEnv<WPP, 1>>(A, blocks, st);
+        case LEAF_COUNT_NODES:   // the walker of the split search (32-bit rows: a packet holds a 16-byte node)
+            if constexpr (WPP != 2) return launch_one<WPP, CountEnv<WPP, 2>>(A, blocks, st);
+            else { set_error("internal: the split search has no 64-bit-row walker"); return GM_ERR_INTERNAL; }
         case LEAF_SCATTER: return launch_one<WPP, ScatterEnv<WPP>>(A, blocks, st);
         case LEAF_FILESET: return launch_one<WPP, FileSetEnv<WPP>>(A, blocks, st);
         case LEAF_OCC_COUNT: return launch_one<WPP, OccCountEnv<WPP>>(A, blocks, st);
@@ -821,6 +827,10 @@ struct SearchSetup {
     unsigned blocks = 1;
     uint64_t posBase = 0, posEnd = 0;   // slice positions covered by the selected blocks: [posBase, posEnd)
     bool jump = false;                  // the call runs the N-less kernel (with jump patterns where they apply) + the correction pass
+    // the split search (gm_expand.h): phase A enumerates the jump patterns of the call's blocks into node packets, the walker draws packets
+    bool expand = false;
+    uint32_t itemsPerBlock = 0, expandBlocks = 0, pktChunks = 0;
+    uint64_t numBlocksCall = 0, totalChunks = 0;
 };
 
 // validation, planning, workspace, uploads; fills every SearchArgs field that does not depend on the leaf policy
@@ -904,93 +914,18 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         if (plan.useList) { rc = grow(&ix->d_blocks, &ix->blocksCap, std::max<uint64_t>(plan.blocks.size(), 1)); if (rc) return rc; }
         if (t0 != ix->d_table || c0 != ix->d_cumLocal || b0 != ix->d_blocks) ix->sigValid = false;   // reallocated: contents are gone
     }
-    // LDS staging per block of 4 wavefronts: verification queue, top of the lane stacks, packed needle windows
-    uint32_t verifyT = 0;
-    if (ix->d_sa && ix->d_textS && longK) verifyT = (uint32_t)std::max(0, std::min(ix->tune.verifyT >= 0 ? ix->tune.verifyT : 1, (int)VERIFY_TMAX));   // gm_longk.h: a row costs one suffix-array read and a scan of the text by its lane alone (3.09 Gbp K=300: one row e=0 -53 %, e=1 -7 % over none; four rows +10 % / +28 % over one, profiles/r05/longk_scale.txt)
-    if (ix->d_sa && ix->d_textS && !longK) {   // narrow nodes are resolved against the text when the SA is resident
-        int t = 1;
-        // long k-mers with errors: a two-row node has a long way to go by rank steps; with the 32-byte row records two reads
-        // settle it (K=100 e=1: +8 % on 3.09 Gbp, +12 % on 249 Mbp; K=30: -20 %, profiles/r02/sweep_*_steal_verify.txt)
-        // (only up to two errors: K=101 e=3 -5.5 %, e=4 -16 % kernel time with one row, profiles/r04/sweep_e3_e4.txt)
-        if (p->K >= 64 && p->E >= 1 && p->E <= 2 && ix->d_ctx && ix->tune.useCtx) t = 2;
-        else if (plan.stepSize >= 32) t = 4;   // long blocks: a narrow node still covers many k-mers (profiles/r01c)
-        if (ix->tune.verifyT >= 0) t = ix->tune.verifyT;
-        verifyT = (uint32_t)std::max(0, std::min(t, (int)VERIFY_TMAX));
-    }
-    // extension-phase nodes (infix complete) may be wider: each row costs one record and two short scans against ~n log n steps
-    // (3.09 Gbp K=100 e=1: 4 rows -11 % kernel time over 2, 8 and 16 the same; profiles/r04/sweep_verify_t_ext.txt)
-    uint32_t verifyTExt = verifyT;
-    if (verifyT && p->E >= 1) {
-        int t = 4;   // K=30: e=1 -2 %, e=2 -0.7 % kernel time over 1 (2 rows: no gain)
-        if (ix->tune.verifyTExt >= 0) t = ix->tune.verifyTExt;
-        verifyTExt = (uint32_t)std::max((int)verifyT, std::min(t, (int)VERIFY_TMAX));
-    }
-    const uint32_t depth = stack_bound(p->E, plan.stepSize) + STEAL_LEVELS;   // room for the levels work sharing may vacate at the bottom
-    uint32_t verifyRows = std::min(verifyTExt, VERIFY_ROWS);   // rows of one node queued per iteration (search_body); one instead of two where that keeps a block per CU (below)
-    // queue entries per wavefront: up to 63 left from the last iteration + one row of every lane + (two rows) 32 second rows; the rest waits (search_body)
-    auto vq_cap = [](uint32_t rows) { return rows >= 2u ? 160u : 128u; };
-    uint32_t vqCap = verifyT ? vq_cap(verifyRows) : 1u;
-    const uint32_t winChunks = longK ? 1u : (31u + p->K + plan.stepSize - 1u + 31u) / 32u;   // (long k-mers read their needle from the text)
-    const uint32_t nu = ix->wide ? 2u : 1u;
-    const int wantPerCU = std::max(1, ix->tune.blocksPerCU);   // default 4 = 4 waves/SIMD, what the kernel's VGPR count allows
     // (calls that may jump keep their table entries in flight in LDS: one 16-byte slot per lane)
     // (64-bit rows jump too since round 5: plain pattern lists -- no bitmaps, no neighbour filter, the table entry travels in registers)
     const bool mayJump = wantJump && p->E >= 1 && (ix->d_sa || ix->d_saMark) && ix->tune.jump != 0;
-    const bool entrySlots = mayJump && !ix->wide;
-    g_ldsPad = (uint32_t)std::max(0, ix->tune.ldsPad);
-    auto lds_bytes_for = [&](uint32_t d) { return (size_t)g_ldsPad + (size_t)(4u * vqCap * nu + 4u * 64u * (d * nu + winChunks)) * 16u + 4u * 80u * 4u + 448u + (entrySlots ? 4096u : 0u) + (lqCap ? 4u * (lqCap * 16u + 80u * 4u) : 0u); };   // == search_lds_bytes
-    // Blocks per CU that REALLY become resident: the occupancy query says four blocks of up to 40,960 B fit the 160 KB of a CU, the device
-    // runs three of them beyond ~38.6 KB per block (measured with padded launches, 3.09 Gbp: K=30 e=2 244 ms at 36,544 and 37,568 B per
-    // block, 250 at 38,592, 279 at 39,616 and 40,640 = the time of three blocks per CU; K=100 e=1 192 / 193 / 220 ms at 36,544 / 38,592 /
-    // 40,640 B; profiles/r05/sweep_lds_occupancy_cliff.txt).  Round 4's last change had put K=30 e>=1 and K=100 at 40,640 B.
-    constexpr size_t LDS_USABLE_PER_CU = 154624;   // 151 KB
-    auto blocks_for = [&](uint32_t d, int* nb) {
-        int rc2;
-        switch (ix->wpp) { case 1: rc2 = occupancy_blocks<1>(nb, lds_bytes_for(d)); break; case 2: rc2 = occupancy_blocks<2>(nb, lds_bytes_for(d)); break; case 3: rc2 = occupancy_blocks<3>(nb, lds_bytes_for(d)); break; default: rc2 = occupancy_blocks<9>(nb, lds_bytes_for(d)); break; }
-        if (!rc2) *nb = std::min<int>(*nb, (int)(LDS_USABLE_PER_CU / std::max<size_t>(lds_bytes_for(d), 1)));
-        return rc2;
-    };
-    // stack levels kept in LDS: four when they fit beside the needle windows and the verification queue at full occupancy;
-    // long windows (K >= ~60) trade levels for resident blocks -- a fourth block per CU is worth more than the levels
-    // (3.09 Gbp e=1: K=100 676 -> 600 ms, K=150 819 -> 642 ms; at equal occupancy deeper is better; profiles/r02/sweep_grch38_ldsstack.txt)
-    uint32_t ldsDepth = 0; int perCU = 0;
-    if (verifyRows > 1u && ix->tune.ldsStack < 0) {   // long windows (K >= ~64): a smaller verification queue where it buys the fourth block per CU (K=100 e=1: 220 -> 200 ms)
-        int nb2 = 0, nb1 = 0;
-        const uint32_t d0 = (p->E >= 3 && nu == 1u) ? std::min(2u, depth) : 0u;   // the fewest LDS stack levels the choice below may end at
-        rc = blocks_for(d0, &nb2); if (rc) return rc;
-        vqCap = vq_cap(1u); rc = blocks_for(d0, &nb1); if (rc) return rc;
-        if (std::min(nb1, wantPerCU) > std::min(nb2, wantPerCU)) verifyRows = 1u; else vqCap = vq_cap(verifyRows);
-    }
-    if (ix->tune.ldsStack >= 0) {
-        ldsDepth = std::min((uint32_t)ix->tune.ldsStack / nu, depth);   // the same LDS for the stack tops of wide nodes
-        rc = blocks_for(ldsDepth, &perCU); if (rc) return rc;
-        perCU = std::max(1, std::min(perCU, wantPerCU));
-    } else {
-        // (three and four errors stack deep: two levels in LDS are worth more than the block per CU they may cost -- K=101 e=4 -12 %, e=3 -1.6 %)
-        // (no level at all where that is what keeps the fourth block: K=100 e=1 203 ms against 226 with one level and three blocks)
-        const uint32_t dmin = (p->E >= 3 && nu == 1u) ? std::min(2u, depth) : 0u;
-        for (int d = (int)std::min(4u / nu, depth); d >= (int)dmin; --d) {
-            int nb = 0;
-            rc = blocks_for((uint32_t)d, &nb); if (rc) return rc;
-            nb = std::min(nb, wantPerCU);
-            if (nb > perCU) { perCU = nb; ldsDepth = (uint32_t)d; }
-        }
-        perCU = std::max(1, perCU);
-    }
-    uint64_t blocks = (uint64_t)ix->numCU * (longK ? 8u : (uint32_t)perCU);   // (gm_longk.h: no LDS to speak of, eight blocks of 256 lanes per CU)
-    const uint64_t useful = (S->numRoots + 255) / 256;
-    if (blocks > useful) blocks = std::max<uint64_t>(useful, 1);
-    S->blocks = (unsigned)blocks;
-    if (longK) { ldsDepth = 0; rc = grow(&ix->d_stack, &ix->stackCap, blocks * 256ull * depth * 2ull); if (rc) return rc; }   // LNodeT: at most 32 bytes per entry
-    // (twice: the correction pass of an N-less call runs beside the main search with the same geometry and at most as many blocks: the upper half is its)
-    rc = grow(&ix->d_stack, &ix->stackCap, 2ull * blocks * 256ull * std::max<uint32_t>(depth - ldsDepth, 1u) * nu); if (rc) return rc;
-
+    const uint32_t nu = ix->wide ? 2u : 1u;
     // ---- jump patterns (frequency calls with errors on an index that can locate): one J for every search ----
     std::vector<uint32_t> patHost; std::vector<uint4> jinfoHost; uint32_t jumpJ = 0, jumpAPacked[2] = {0, 0};
     uint32_t layShift[8] = {0, 0, 0, 0, 0, 0, 0, 0}, layPlane0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, layPlane1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long* jbitsCall = nullptr; unsigned long long gmaskCall[GROUP_MAX_MASKS] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t jbitsWords = 0; std::vector<uint4> jinfo2Host(8, make_uint4(0, 0, 0, 0));
     const uint4* jtab = nullptr;
+    uint32_t firstItem[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nItems[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<uint32_t> wmapHost;
     S->jump = mayJump;
     if (S->jump) {
         const uint32_t L = plan.infix;
@@ -1058,6 +993,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
                     jinfo2Host[s2] = make_uint4(e16[0] | e16[1] << 16, e16[2] | e16[3] << 16, e16[4] | e16[5] << 16, items[s2].ext ? 1u : 0u);
                 }
                 jumpAPacked[s2 >> 2] |= js[s2].regionA << (8u * (s2 & 3u));
+                firstItem[s2] = (uint32_t)patHost.size(); nItems[s2] = (uint32_t)items[s2].items.size();
                 patHost.insert(patHost.end(), items[s2].items.begin(), items[s2].items.end());
             }
             const void *p0 = ix->d_patterns, *j0 = ix->d_jinfo;
@@ -1067,12 +1003,110 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
             if (p0 != ix->d_patterns || j0 != ix->d_jinfo) ix->sigValid = false;   // reallocated: contents are gone
         }
     }
+    // ---- the split search (gm_expand.h): one lane per (root, item) enumerates the patterns into node packets, the walker draws packets.
+    // 32-bit rows (a packet holds a 16-byte node); calls large enough that the extra launches do not show.
+    S->expand = false;
+    S->numBlocksCall = rpb ? S->numRoots / rpb : 0;
+    if (jumpJ >= 1 && !ix->wide && !longK && S->numBlocksCall > 0 && patHost.size() < (1u << 24) &&
+        (ix->tune.expand > 0 || (ix->tune.expand < 0 && S->numRoots >= (1ull << 20)))) {
+        wmapHost = make_wmap(plan.nStrands, plan.nSearches, firstItem, nItems);
+        S->itemsPerBlock = (uint32_t)wmapHost.size();
+        S->expandBlocks = ix->tune.expandChunk > 0 ? (uint32_t)ix->tune.expandChunk : std::max<uint32_t>(1u, 1024u / std::max<uint32_t>(S->itemsPerBlock, 1u));
+        S->expandBlocks = std::min<uint32_t>(S->expandBlocks, (1u << 22) / std::max<uint32_t>(S->itemsPerBlock, 1u));   // (work items of a chunk are numbered in 32 bits)
+        S->totalChunks = (S->numBlocksCall + S->expandBlocks - 1) / S->expandBlocks;
+        S->pktChunks = pkt_chunks_for(p->K, plan.stepSize);
+        S->expand = S->itemsPerBlock > 0 && S->expandBlocks > 0 && S->totalChunks < 0xFFFFFFF0ull;
+        if (S->expand) {
+            const void* w0 = ix->d_wmap;
+            rc = grow(&ix->d_wmap, &ix->wmapCap, (uint64_t)wmapHost.size()); if (rc) return rc;
+            if (w0 != ix->d_wmap) ix->sigValid = false;
+        }
+    }
+    const bool expand = S->expand;
+    // LDS staging per block of 4 wavefronts: verification queue, top of the lane stacks, packed needle windows
+    uint32_t verifyT = 0;
+    if (ix->d_sa && ix->d_textS && longK) verifyT = (uint32_t)std::max(0, std::min(ix->tune.verifyT >= 0 ? ix->tune.verifyT : 1, (int)VERIFY_TMAX));   // gm_longk.h: a row costs one suffix-array read and a scan of the text by its lane alone (3.09 Gbp K=300: one row e=0 -53 %, e=1 -7 % over none; four rows +10 % / +28 % over one, profiles/r05/longk_scale.txt)
+    if (ix->d_sa && ix->d_textS && !longK) {   // narrow nodes are resolved against the text when the SA is resident
+        int t = 1;
+        // long k-mers with errors: a two-row node has a long way to go by rank steps; with the 32-byte row records two reads
+        // settle it (K=100 e=1: +8 % on 3.09 Gbp, +12 % on 249 Mbp; K=30: -20 %, profiles/r02/sweep_*_steal_verify.txt)
+        // (only up to two errors: K=101 e=3 -5.5 %, e=4 -16 % kernel time with one row, profiles/r04/sweep_e3_e4.txt)
+        if (p->K >= 64 && p->E >= 1 && p->E <= 2 && ix->d_ctx && ix->tune.useCtx) t = 2;
+        else if (plan.stepSize >= 32) t = 4;   // long blocks: a narrow node still covers many k-mers (profiles/r01c)
+        if (ix->tune.verifyT >= 0) t = ix->tune.verifyT;
+        verifyT = (uint32_t)std::max(0, std::min(t, (int)VERIFY_TMAX));
+    }
+    // extension-phase nodes (infix complete) may be wider: each row costs one record and two short scans against ~n log n steps
+    // (3.09 Gbp K=100 e=1: 4 rows -11 % kernel time over 2, 8 and 16 the same; profiles/r04/sweep_verify_t_ext.txt)
+    uint32_t verifyTExt = verifyT;
+    if (verifyT && p->E >= 1) {
+        int t = 4;   // K=30: e=1 -2 %, e=2 -0.7 % kernel time over 1 (2 rows: no gain)
+        if (ix->tune.verifyTExt >= 0) t = ix->tune.verifyTExt;
+        verifyTExt = (uint32_t)std::max((int)verifyT, std::min(t, (int)VERIFY_TMAX));
+    }
+    const uint32_t depth = stack_bound(p->E, plan.stepSize) + STEAL_LEVELS;   // room for the levels work sharing may vacate at the bottom
+    uint32_t verifyRows = std::min(verifyTExt, VERIFY_ROWS);   // rows of one node queued per iteration (search_body); one instead of two where that keeps a block per CU (below)
+    // queue entries per wavefront: up to 63 left from the last iteration + one row of every lane + (two rows) 32 second rows; the rest waits (search_body)
+    auto vq_cap = [](uint32_t rows) { return rows >= 2u ? 160u : 128u; };
+    uint32_t vqCap = verifyT ? vq_cap(verifyRows) : 1u;
+    // (long k-mers read their needle from the text; the walker of the split search stages the window of its packet, which starts at nibble 0)
+    const uint32_t winChunks = longK ? 1u : expand ? S->pktChunks : (31u + p->K + plan.stepSize - 1u + 31u) / 32u;
+    const int wantPerCU = std::max(1, ix->tune.blocksPerCU);   // default 4 = 4 waves/SIMD, what the kernel's VGPR count allows
+    const bool entrySlots = mayJump && !ix->wide && !expand;
+    g_ldsPad = (uint32_t)std::max(0, ix->tune.ldsPad);
+    auto lds_bytes_for = [&](uint32_t d) { return (size_t)g_ldsPad + (size_t)(4u * vqCap * nu + 4u * 64u * (d * nu + winChunks)) * 16u + 4u * 80u * 4u + 448u + (entrySlots ? 4096u : 0u) + (lqCap ? 4u * (lqCap * 16u + 80u * 4u) : 0u); };   // == search_lds_bytes
+    // Blocks per CU that REALLY become resident: the occupancy query says four blocks of up to 40,960 B fit the 160 KB of a CU, the device
+    // runs three of them beyond ~38.6 KB per block (measured with padded launches, 3.09 Gbp: K=30 e=2 244 ms at 36,544 and 37,568 B per
+    // block, 250 at 38,592, 279 at 39,616 and 40,640 = the time of three blocks per CU; K=100 e=1 192 / 193 / 220 ms at 36,544 / 38,592 /
+    // 40,640 B; profiles/r05/sweep_lds_occupancy_cliff.txt).  Round 4's last change had put K=30 e>=1 and K=100 at 40,640 B.
+    constexpr size_t LDS_USABLE_PER_CU = 154624;   // 151 KB
+    auto blocks_for = [&](uint32_t d, int* nb) {
+        int rc2;
+        switch (ix->wpp) { case 1: rc2 = occupancy_blocks<1>(nb, lds_bytes_for(d)); break; case 2: rc2 = occupancy_blocks<2>(nb, lds_bytes_for(d)); break; case 3: rc2 = occupancy_blocks<3>(nb, lds_bytes_for(d)); break; default: rc2 = occupancy_blocks<9>(nb, lds_bytes_for(d)); break; }
+        if (!rc2) *nb = std::min<int>(*nb, (int)(LDS_USABLE_PER_CU / std::max<size_t>(lds_bytes_for(d), 1)));
+        return rc2;
+    };
+    // stack levels kept in LDS: four when they fit beside the needle windows and the verification queue at full occupancy;
+    // long windows (K >= ~60) trade levels for resident blocks -- a fourth block per CU is worth more than the levels
+    // (3.09 Gbp e=1: K=100 676 -> 600 ms, K=150 819 -> 642 ms; at equal occupancy deeper is better; profiles/r02/sweep_grch38_ldsstack.txt)
+    uint32_t ldsDepth = 0; int perCU = 0;
+    if (verifyRows > 1u && ix->tune.ldsStack < 0) {   // long windows (K >= ~64): a smaller verification queue where it buys the fourth block per CU (K=100 e=1: 220 -> 200 ms)
+        int nb2 = 0, nb1 = 0;
+        const uint32_t d0 = (p->E >= 3 && nu == 1u) ? std::min(2u, depth) : 0u;   // the fewest LDS stack levels the choice below may end at
+        rc = blocks_for(d0, &nb2); if (rc) return rc;
+        vqCap = vq_cap(1u); rc = blocks_for(d0, &nb1); if (rc) return rc;
+        if (std::min(nb1, wantPerCU) > std::min(nb2, wantPerCU)) verifyRows = 1u; else vqCap = vq_cap(verifyRows);
+    }
+    if (ix->tune.ldsStack >= 0) {
+        ldsDepth = std::min((uint32_t)ix->tune.ldsStack / nu, depth);   // the same LDS for the stack tops of wide nodes
+        rc = blocks_for(ldsDepth, &perCU); if (rc) return rc;
+        perCU = std::max(1, std::min(perCU, wantPerCU));
+    } else {
+        // (three and four errors stack deep: two levels in LDS are worth more than the block per CU they may cost -- K=101 e=4 -12 %, e=3 -1.6 %)
+        // (no level at all where that is what keeps the fourth block: K=100 e=1 203 ms against 226 with one level and three blocks)
+        const uint32_t dmin = (p->E >= 3 && nu == 1u) ? std::min(2u, depth) : 0u;
+        for (int d = (int)std::min(4u / nu, depth); d >= (int)dmin; --d) {
+            int nb = 0;
+            rc = blocks_for((uint32_t)d, &nb); if (rc) return rc;
+            nb = std::min(nb, wantPerCU);
+            if (nb > perCU) { perCU = nb; ldsDepth = (uint32_t)d; }
+        }
+        perCU = std::max(1, perCU);
+    }
+    uint64_t blocks = (uint64_t)ix->numCU * (longK ? 8u : (uint32_t)perCU);   // (gm_longk.h: no LDS to speak of, eight blocks of 256 lanes per CU)
+    const uint64_t useful = (S->numRoots + 255) / 256;
+    if (blocks > useful) blocks = std::max<uint64_t>(useful, 1);
+    S->blocks = (unsigned)blocks;
+    if (longK) { ldsDepth = 0; rc = grow(&ix->d_stack, &ix->stackCap, blocks * 256ull * depth * 2ull); if (rc) return rc; }   // LNodeT: at most 32 bytes per entry
+    // (twice: the correction pass of an N-less call runs beside the main search with the same geometry and at most as many blocks: the upper half is its)
+    rc = grow(&ix->d_stack, &ix->stackCap, 2ull * blocks * 256ull * std::max<uint32_t>(depth - ldsDepth, 1u) * nu); if (rc) return rc;
+
     {   // the call's small device-side tables (OSS records, block list, local sequence limits) are uploaded only when the
         // call differs from the previous one on this index: a loop over shards or repeated passes launches without any
         // host-device synchronisation
         uint64_t h = 1469598103934665603ull;
         auto mix = [&h](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
-        mix(p->K); mix(p->E); mix(plan.infix); mix((uint64_t)(int64_t)ix->tune.partBias); mix((uint64_t)(int64_t)ix->tune.ossWeights); mix(jumpJ); mix((uint64_t)ix->tune.jumpFilter); mix(patHost.size()); for (uint32_t v : patHost) mix(v); for (const uint4& v : jinfo2Host) { mix(v.x); mix(v.y); mix(v.z); mix(v.w); } mix(text_begin); mix(text_len); mix(first_seq); mix(n_seq); mix(n_intervals);
+        mix(p->K); mix(p->E); mix(plan.infix); mix((uint64_t)(int64_t)ix->tune.partBias); mix((uint64_t)(int64_t)ix->tune.ossWeights); mix(jumpJ); mix((uint64_t)ix->tune.jumpFilter); mix(patHost.size()); for (uint32_t v : patHost) mix(v); mix(wmapHost.size()); for (uint32_t v : wmapHost) mix(v); for (const uint4& v : jinfo2Host) { mix(v.x); mix(v.y); mix(v.z); mix(v.w); } mix(text_begin); mix(text_len); mix(first_seq); mix(n_seq); mix(n_intervals);
         for (uint64_t k = 0; k < 2 * n_intervals; ++k) mix(intervals[k]);
         if (!ix->sigValid || ix->sig != h) {
             GM_HIP(hipMemcpyAsync(ix->d_table, plan.table.data(), plan.table.size() * sizeof(OssRecord), hipMemcpyHostToDevice, st));
@@ -1084,6 +1118,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
                 GM_HIP(hipMemcpyAsync(ix->d_jinfo, jinfoHost.data(), 8 * sizeof(uint4), hipMemcpyHostToDevice, st));
                 GM_HIP(hipMemcpyAsync(ix->d_jinfo2, jinfo2Host.data(), 8 * sizeof(uint4), hipMemcpyHostToDevice, st));
             }
+            if (expand) GM_HIP(hipMemcpyAsync(ix->d_wmap, wmapHost.data(), wmapHost.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
             std::vector<uint64_t> cumLocal((size_t)n_seq + 1);
             for (uint32_t s = 0; s <= n_seq; ++s) cumLocal[s] = ix->cum[first_seq + s] - text_begin;
             GM_HIP(hipMemcpyAsync(ix->d_cumLocal, cumLocal.data(), cumLocal.size() * 8, hipMemcpyHostToDevice, st));
@@ -1198,6 +1233,8 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     for (uint32_t k = 0; k < GROUP_MAX_MASKS; ++k) A.gmask[k] = gmaskCall[k];
     for (uint32_t k = 0; k < 8u; ++k) { A.layShift[k] = layShift[k]; A.layPlane0[k] = layPlane0[k]; A.layPlane1[k] = layPlane1[k]; }
     A.tableL = longK ? ix->d_tableL : nullptr;
+    A.pktChunks = S->pktChunks; A.wmap = ix->d_wmap; A.itemsPerBlock = S->itemsPerBlock; A.expandBlocks = S->expandBlocks; A.numBlocksCall = S->numBlocksCall;
+    A.satDrawW = (uint32_t)(ix->tune.satDrawW >= 0 ? ix->tune.satDrawW : 16);
     if (longK) { A.lqCap = 0u; A.entrySlots = 0u; A.selfHit = 0u; A.spillDepth = depth; A.steal = ix->tune.steal >= 0 ? (uint32_t)std::min(ix->tune.steal, 2) : 2u; }   // (2: lanes share before every root draw, 3.09 Gbp K=300 e=1 +19 %, K=1000 e=1 +14 %, e=0 +4 % over sharing at the end only; profiles/r05/longk_scale.txt)
     A.sliceBegin = text_begin; A.sliceLen = text_len; A.ownBegin = 0; A.ownEnd = text_len; A.ownChunkLen = 0; A.selBlocks = nullptr; A.nSelBlocks = 0;
     *Aout = A;
@@ -1226,6 +1263,91 @@ static int launch_reset_limits(gm_index* ix, TValue* d_out, uint32_t n_seq, uint
 {
     hipLaunchKernelGGL(reset_limits_kernel<TValue>, dim3(n_seq), dim3(64), 0, st, d_out, ix->d_cumLocal, n_seq, K);
     GM_HIP(hipGetLastError());
+    return GM_OK;
+}
+
+// ---- the split search (gm_expand.h): slices of "phase A writes node packets, the walker draws them" ------------------------------------------
+__global__ void expand_reset_kernel(ExpandProgress* prog, unsigned long long totalChunks)
+{
+    if (threadIdx.x != 0u || blockIdx.x != 0u) return;
+    prog->committed = 0ull; prog->totalChunks = totalChunks; prog->slices = 0u; prog->lastChunks = 0u; prog->lastX = prog->lastY = 0u;   // (the stamp counter runs on: packets of earlier calls stay stale)
+}
+
+// The main search of a call whose roots have jump patterns.  Everything is queued on the call's stream; the host only reads, two slices
+// behind, how far the call has got (a slice takes as many chunks as its packet buffers hold -- decided on the device from what the slice
+// before it produced), so the device always has the next slice in its queue.
+static int run_expand(gm_index* ix, const SearchSetup& S, SearchArgs A, const gm_map_params* p, hipStream_t st)
+{
+    const uint32_t U = PKT_HEADER_UNITS + S.pktChunks;            // 16-byte units per packet
+    if (!ix->d_xctl) {
+        GM_HIP(hipMalloc(&ix->d_xctl, sizeof(ExpandCtl)));
+        GM_HIP(hipMalloc(&ix->d_xprog, sizeof(ExpandProgress)));
+        GM_HIP(hipMemset(ix->d_xprog, 0, sizeof(ExpandProgress)));
+        GM_HIP(hipHostMalloc(&ix->h_xprog, 4 * sizeof(ExpandProgress)));
+        for (int i = 0; i < 4; ++i) GM_HIP(hipEventCreateWithFlags(&ix->evX[i], hipEventDisableTiming));
+    }
+    // packet buffers: X (patterns without / with one substitution, from its two ends) and Y (two or more); kept between calls, grown on demand
+    uint64_t budget;
+    if (ix->tune.expandMB > 0) budget = (uint64_t)ix->tune.expandMB << 20;
+    else {
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) freeB = 0;
+        const uint64_t have = (ix->pktXCap + ix->pktYCap) * 16ull;
+        budget = std::min<uint64_t>((freeB + have) / 3, 12ull << 30);
+        budget = std::max<uint64_t>(budget, have);                 // (never shrink below what is there)
+    }
+    // what the call can use at all: every (work item, rotation) a packet (64 per item at most), rounded up generously
+    const uint64_t worstPackets = std::min<uint64_t>(S.numBlocksCall * (uint64_t)S.itemsPerBlock * 64ull + (1u << 20), 1ull << 31);
+    const bool twoPlus = p->E >= 2;
+    uint64_t pkts = std::min<uint64_t>(budget / (16ull * U), worstPackets + (twoPlus ? worstPackets : 0));
+    pkts = std::min<uint64_t>(pkts, (1ull << 31) - 1);
+    uint64_t capY = twoPlus ? pkts * 3 / 5 : 4ull * XREGION, capX = twoPlus ? pkts - capY : pkts;
+    capX = std::max<uint64_t>(capX, 16ull * XREGION); capY = std::max<uint64_t>(capY, 4ull * XREGION);
+    {
+        const uint64_t needX = capX * U, needY = capY * U;
+        if (ix->pktXCap < needX) { uint4* d = nullptr; if (ix->d_pktX) { hipFree(ix->d_pktX); ix->d_pktX = nullptr; ix->pktXCap = 0; } if (hipMalloc(&d, needX * 16) != hipSuccess) { (void)hipGetLastError(); set_error("no device memory for %llu node packets", (unsigned long long)capX); return GM_ERR_OOM; } GM_HIP(hipMemsetAsync(d, 0, needX * 16, st)); ix->d_pktX = d; ix->pktXCap = needX; }
+        if (ix->pktYCap < needY) { uint4* d = nullptr; if (ix->d_pktY) { hipFree(ix->d_pktY); ix->d_pktY = nullptr; ix->pktYCap = 0; } if (hipMalloc(&d, needY * 16) != hipSuccess) { (void)hipGetLastError(); set_error("no device memory for %llu node packets", (unsigned long long)capY); return GM_ERR_OOM; } GM_HIP(hipMemsetAsync(d, 0, needY * 16, st)); ix->d_pktY = d; ix->pktYCap = needY; }
+    }
+    A.pktX = ix->d_pktX; A.pktY = ix->d_pktY; A.capX = (uint32_t)capX; A.capY = (uint32_t)capY;
+    A.xctl = reinterpret_cast<ExpandCtl*>(ix->d_xctl);
+    ExpandProgress* prog = reinterpret_cast<ExpandProgress*>(ix->d_xprog);
+    ExpandProgress* hprog = reinterpret_cast<ExpandProgress*>(ix->h_xprog);
+    // phase A: as many wavefronts as the device holds, but no more than leave three quarters of a buffer to packets (a wavefront keeps one
+    // open region per class)
+    int perCU = 0;
+    GM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, expand_kernel, 256, 0));
+    perCU = std::max(1, std::min(perCU, 8));
+    uint64_t blocksA = (uint64_t)ix->numCU * (uint64_t)perCU;
+    const uint64_t smaller = twoPlus ? std::min(capX, capY) : capX;
+    blocksA = std::max<uint64_t>(1, std::min<uint64_t>(blocksA, smaller / (4ull * 4ull * XREGION)));
+    blocksA = std::min<uint64_t>(blocksA, std::max<uint64_t>(1, (S.totalChunks + 3) / 4));
+    const uint64_t slack = blocksA * 4ull * XREGION;
+    const uint32_t usableX = (uint32_t)(capX - std::min<uint64_t>(slack, capX / 2)), usableY = (uint32_t)(capY - std::min<uint64_t>(twoPlus ? slack : 0, capY / 2));
+    // first slice: a guess at the packets a chunk makes (8 per k-mer); the slices behind it follow what their predecessor measured
+    const uint64_t guess = (uint64_t)S.expandBlocks * S.plan.stepSize * 8ull;
+    const uint32_t firstChunks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(usableX, twoPlus ? usableY : usableX) / std::max<uint64_t>(guess, 1), 0x7FFFFFFFull));
+    hipLaunchKernelGGL(expand_reset_kernel, dim3(1), dim3(1), 0, st, prog, (unsigned long long)S.totalChunks);
+    SearchArgs W = A;                                              // the walker's view
+    W.workCounter = &A.xctl->walkCounter;
+    unsigned long long lastSeen = 0; bool seen = false;
+    uint32_t i = 0;
+    for (;; ++i) {
+        hipLaunchKernelGGL(expand_slice_begin_kernel, dim3(1), dim3(1), 0, st, prog, A.xctl, usableX, usableY, firstChunks, 0x7FFFFFFFu);
+        hipLaunchKernelGGL(expand_kernel, dim3((unsigned)blocksA), dim3(256), 0, st, A);
+        hipLaunchKernelGGL(expand_slice_commit_kernel, dim3(1), dim3(1), 0, st, prog, A.xctl, A.errorFlag);
+        GM_HIP(hipGetLastError());
+        GM_HIP(hipMemcpyAsync(&hprog[i & 3u], prog, sizeof(ExpandProgress), hipMemcpyDeviceToHost, st));
+        GM_HIP(hipEventRecord(ix->evX[i & 3u], st));
+        int rc = launch_search(ix, LEAF_COUNT_NODES, W, S.blocks, st); if (rc) return rc;
+        if (i >= 2u) {
+            GM_HIP(hipEventSynchronize(ix->evX[(i - 2u) & 3u]));
+            const unsigned long long c = hprog[(i - 2u) & 3u].committed;
+            if (c >= S.totalChunks) break;
+            if (seen && c == lastSeen) { set_error("the split search made no progress (packet buffers of %llu + %llu packets)", (unsigned long long)capX, (unsigned long long)capY); return GM_ERR_INTERNAL; }
+            lastSeen = c; seen = true;
+        }
+    }
+    ix->lastSlices = i + 1u;
     return GM_OK;
 }
 
@@ -1378,7 +1500,8 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
     } else if (!whole || firstPiece) ix->corrTimed = false;
     const uint32_t slot = (uint32_t)(ix->evCount % gm_index::EV_RING);
     GM_HIP(hipEventRecord(ix->evRing[slot][0], st));
-    if (S.numRoots > 0) { rc = launch_search(ix, ep ? LEAF_FILESET : store ? (p->value_bits == 8 ? LEAF_STORE8 : LEAF_STORE) : S.jump ? LEAF_COUNT_JUMP : LEAF_COUNT, A, S.blocks, st); if (rc) return rc; }
+    if (S.numRoots > 0 && S.expand && !ep && !store) { rc = run_expand(ix, S, A, p, st); if (rc) return rc; }
+    else if (S.numRoots > 0) { rc = launch_search(ix, ep ? LEAF_FILESET : store ? (p->value_bits == 8 ? LEAF_STORE8 : LEAF_STORE) : S.jump ? LEAF_COUNT_JUMP : LEAF_COUNT, A, S.blocks, st); if (rc) return rc; }
     if (ix->corrPending) { GM_HIP(hipStreamWaitEvent(st, ix->evCorrDone, 0)); ix->corrPending = false; }   // finalize reads what the correction pass added
     GM_HIP(hipEventRecord(ix->evRing[slot][1], st));
     ix->evCount++;
@@ -1410,6 +1533,7 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
     ix->doneValid = true;
     ix->evValid = true;
     if (ix->pieceIndex == 0) { ix->stats = gm_map_stats{}; ix->statPieces = 0; }
+    if (!S.expand) ix->lastSlices = 0;
     ix->stats.kmers += S.kmers; ix->stats.roots += S.numRoots; ix->statPieces += 1;
     return GM_OK;
 }
@@ -1506,7 +1630,7 @@ static int check_device_error(gm_index* ix)
     if (flag) {
         GM_HIP(hipMemset(reinterpret_cast<char*>(ix->d_small) + SMALL_ERR_OFF, 0, 4));
         set_error("device-side invariant violated in this or an earlier call on the index:%s%s", (flag & 1u) ? " lane stack overflow" : "",
-                  (flag & 2u) ? " a wavefront of the search kernel ran past its iteration bound (iter_cap / stall_cap) and gave up" : "");
+                  (flag & 2u) ? " a wavefront of the search kernel ran past its iteration bound (iter_cap / stall_cap) and gave up" : (flag & 4u) ? " the split search could not fit one chunk of work into its packet buffers" : "");
         return GM_ERR_INTERNAL;
     }
     return GM_OK;
@@ -1866,6 +1990,8 @@ int gm_index_set_tuning(gm_index* ix, const char* name, int64_t value)
         {"no_wrap", &ix->tune.noWrap, dflt.noWrap, 0, 1},   // 0: every add into an accumulator returns the old value and checks for a wrap-around (-1 / 1: only where one is possible)
         {"iter_cap", &ix->tune.iterCap, dflt.iterCap, 1, 0x7FFFFFFF}, {"stall_cap", &ix->tune.stallCap, dflt.stallCap, 1, 0x7FFFFFFF},   // bounds of a hung search loop (tests force them)
         {"pat_batch", &ix->tune.patBatch, dflt.patBatch, 1, 64},
+        {"expand", &ix->tune.expand, dflt.expand, 0, 1}, {"expand_mb", &ix->tune.expandMB, dflt.expandMB, 1, 1 << 20},   // the split search (gm_expand.h)
+        {"expand_chunk", &ix->tune.expandChunk, dflt.expandChunk, 1, 1 << 16}, {"sat_draw_w", &ix->tune.satDrawW, dflt.satDrawW, 0, 0x7FFFFFFF},
         {"jump_groups", &ix->tune.jumpGroups, dflt.jumpGroups, 0, 1},   // groups of jump patterns behind the existence bitmap: 0 never, 1 wherever possible, -1 where they save table reads
     };
     for (auto& t : tab) if (!strcmp(t.n, name)) {
@@ -1924,6 +2050,7 @@ int gm_last_map_stats(const gm_index* cix, gm_map_stats* out)
     ix->stats.node_steps = cnt[0]; ix->stats.rank_lines = cnt[1];
     for (int i = 0; i < 48; ++i) ix->stats.detail[i] = cnt[2 + i];
     ix->stats.detail[38] = ix->lastQ;   // longest q-mer table of the call | jump length << 8
+    ix->stats.detail[47] = (ix->stats.detail[47] & 0xFFFFFFFFFFFFull) | (uint64_t)ix->lastSlices << 48;   // node packets of the split search (counters) | its slices (every build)
     if (ix->corrTimed) { float c = 0; GM_HIP(hipEventElapsedTime(&c, ix->ev[1], ix->ev[2])); ix->stats.detail[37] = (uint64_t)(c * 1000.0f); }   // correction pass, microseconds
     int rc = check_device_error(ix);
     *out = ix->stats;

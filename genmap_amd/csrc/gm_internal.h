@@ -35,6 +35,11 @@ struct Tuning {
     int patBatch = -1;                 // jump patterns: idle lanes that must wait for their pattern turn before parts A / B of the loop run (-1: 1 = every iteration)
     int fastVerify = -1;               // -1: whenever the call allows it (gm_api.hip: prepare_search), 0: never
     int iterCap = -1, stallCap = -1;   // bounds of a hung search loop (gm_kernels.h: SearchArgs::iterCap / stallCap); -1: never / 2^22 idle iterations
+    // the split search (gm_expand.h): phase A enumerates the jump patterns into node packets, the walker draws packets
+    int expand = -1;                   // -1: where it pays (gm_api.hip: prepare_search), 0: never (the one-loop kernel of rounds 3-5), 1: whenever the call has jump patterns
+    int expandMB = -1;                 // MiB of packet buffers (-1: a share of the free device memory); tests force small ones: many slices, overflowing chunks
+    int expandChunk = -1;              // k-mer blocks per chunk of phase A (-1: about a thousand work items)
+    int satDrawW = -1;                 // the walker drops a drawn node at least this wide when its block's k-mers are all at MAX (-1: 16)
 };
 }  // namespace gm
 
@@ -107,6 +112,12 @@ struct gm_index {
     gm::Tuning tune;
     gm_map_stats stats{};
     // ---- jump patterns and the correction pass of N-less frequency calls (gm_oss.h, gm_engine.h: Env::NLESS) ----
+    // ---- the split search (gm_expand.h): node packets, control blocks, progress readback ----
+    uint4* d_pktX = nullptr; uint4* d_pktY = nullptr; uint64_t pktXCap = 0, pktYCap = 0;   // in uint4 units
+    void* d_xctl = nullptr; void* d_xprog = nullptr; void* h_xprog = nullptr;              // ExpandCtl, ExpandProgress (gm_kernels.h); 4 page-locked copies
+    hipEvent_t evX[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t* d_wmap = nullptr; uint64_t wmapCap = 0;
+    uint32_t lastSlices = 0;           // slices of the last call that took the split search (statistics)
     uint32_t* d_patterns = nullptr; uint64_t patternsCap = 0;
     uint4* d_jinfo = nullptr; uint64_t jinfoCap = 0;
     bool nRunsValid = false;

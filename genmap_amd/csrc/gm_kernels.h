@@ -14,8 +14,32 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gm_engine.h"
+#include "gm_expand.h"
 
 namespace gm {
+
+// ---- phase A / phase B of the split search (gm_expand.h): control block of one slice, device memory ------------------------------------
+// Phase A appends node packets to two buffers: X holds the packets of patterns without a substitution from its front and those with one
+// substitution from its back, Y those with two or more.  A wavefront reserves REGIONS of packets (one device-scope atomic per region and
+// class) and fills them privately; what it leaves unfilled keeps an older stamp and is skipped by the walker.  A reservation that does not
+// fit marks the wavefront's chunk of work as failed: the walker drops the packets of chunks >= failFrom, the next slice starts there.
+struct ExpandCtl {
+    unsigned long long nextChunk;        // work counter of phase A
+    unsigned long long tailsX;           // packets reserved in X: class 0 | class 1 << 32
+    unsigned long long walkCounter;      // work counter of the walker (phase B)
+    unsigned long long chunkBegin, chunkEnd;
+    uint32_t tailY, failFrom;
+    uint32_t valid[3];                   // per class: end of the last reservation that fitted (fit is monotone in the order of the atomics)
+    uint32_t stamp;
+    uint32_t t[3];                       // what the walker draws: valid[] at the end of phase A
+    uint32_t pad;
+};
+struct ExpandProgress {
+    unsigned long long committed;        // chunks of the call that are done (searched, or handed to a walker launch queued behind)
+    unsigned long long totalChunks;
+    uint32_t stampCounter, slices, lastChunks, lastX, lastY, pad;
+};
+constexpr uint32_t XREGION = 256;        // packets per reservation
 
 struct SearchArgs {
     const uint32_t* blk[2];     // rank blocks: [0] forward BWT (extend left), [1] reverse BWT (extend right)
@@ -118,6 +142,16 @@ struct SearchArgs {
     uint32_t nSelBlocks;
     // ---- k-mers longer than MAX_K (gm_longk.h) ----
     const void* tableL;             // OssRecordL[(n-1)*8 + s]
+    // ---- phase A / phase B of the split search (gm_expand.h; ExpandCtl above) ----
+    uint4* pktX; uint4* pktY;       // node packets, (2 + pktChunks) x 16 bytes each
+    uint32_t capX, capY;            // packets the buffers hold
+    uint32_t pktChunks;             // 16-byte chunks of needle window per packet
+    ExpandCtl* xctl;
+    const uint32_t* wmap;           // work item of a block -> search | strand << 3 | item << 8 (gm_expand.h: make_wmap)
+    uint32_t itemsPerBlock;         // work items per k-mer block
+    uint32_t expandBlocks;          // k-mer blocks per chunk of phase A
+    uint64_t numBlocksCall;         // k-mer blocks of the call (numRoots / rootsPerBlock)
+    uint32_t satDrawW;              // walker: a drawn node at least this wide is dropped when all k-mers of its block are at MAX already
 };
 
 // which positions of a range belong to the calling shard (interleaved chunks of `len` positions); len == 0: all of them
@@ -234,8 +268,7 @@ __device__ __forceinline__ void covered_kmers(uint32_t meta, uint32_t n, uint32_
 // One aligned 32-byte read replaces the dependent pair "SA entry, then text around it" (two to three random requests).
 // (CTX_LEFT = 24, CTX_SYMS = 56: gm_engine.h, next to the fast verification that reads whole windows from a record)
 
-constexpr uint32_t NB_SYMS = 6;       // neighbour symbols per side carried by one-row q-mer table entries (qmer_table_kernel)
-constexpr uint32_t NB_SYMS2 = 3;      // ... and per side and row by two-row entries
+// (NB_SYMS, NB_SYMS2: neighbour symbols per side carried by one- / two-row q-mer table entries -- gm_expand.h)
 constexpr uint32_t STEAL_LEVELS = 16;  // a lane gives away at most this many bottom entries before its stack has run empty once
 
 // fetch state of a lane with jump patterns: fs = 2 | flags.  Table entry in flight, bitmap word in flight, jd holds an item, that item is a
@@ -253,6 +286,7 @@ template <int WPP> struct EnvBase {
     static constexpr bool SELF_HIT = false;     // frequency policies: a lone error-free row on the forward strand is the window itself
     static constexpr bool RANGE_ADD = false;    // the policy takes a run of hit k-mers whole (leaf_range) instead of one leaf_at per k-mer
     static constexpr bool LEGACY_LOOP = false;  // the loop order of round 3 (root draw in front of the verification, staged root context): StoreEnv
+    static constexpr bool NODES = false;        // the walker of the split search: lanes draw node packets written by phase A (gm_expand.h) instead of roots
     typedef typename BlockGeom<WPP>::row_t row_t;
     typedef NodeT<row_t> Node;
     typedef RootT<row_t> Root;
@@ -599,11 +633,13 @@ template <int WPP> struct EnvBase {
 };
 
 // leaf policy 1: frequency only -- hits[a-ab] = min(countOccurrences(it) + hits[a-ab], max) (algo.hpp:48,191)
-template <int WPP, bool JUMP = false> struct CountEnv : EnvBase<WPP> {
+// MODE 0: the plain tree walk; 1: roots start from their jump patterns (N-less pass); 2: the walker of the split search (N-less pass too: its
+// packets come from the jump patterns, enumerated by phase A)
+template <int WPP, int MODE = 0> struct CountEnv : EnvBase<WPP> {
     using EnvBase<WPP>::A;
     typedef typename EnvBase<WPP>::row_t row_t;
     typedef typename EnvBase<WPP>::Root Root;
-    static constexpr bool NLESS = JUMP, JUMPS = JUMP;   // the tables of the jump hold A,C,G,T strings only
+    static constexpr bool NLESS = MODE != 0, JUMPS = MODE == 1, NODES = MODE == 2;   // the tables of the jump hold A,C,G,T strings only
     // Verified hits come as RUNS of k-mers of one block (gm_engine.h: verify_item): with the difference plane a run costs two
     // fire-and-forget atomics whatever its length instead of one returning device-scope atomic per k-mer (3.09 Gbp K=100 e=1: a third
     // of all memory requests of the pass were those atomics, WRITE_SIZE 98x the result, profiles/r03/final/pmc_by_config.txt).
@@ -619,7 +655,9 @@ template <int WPP, bool JUMP = false> struct CountEnv : EnvBase<WPP> {
     // node can change the result.  Checked only after this lane alone has produced MAX hits for the root (repeats).
     __device__ __forceinline__ bool saturated(const Root& rt, uint32_t smin, uint32_t smax) const
     {
-        if (rootHits < A.maxVal) return false;
+        // (the walker of the split search sees the nodes of a root one by one, in any lane: what the root has found so far is in acc, not in
+        //  this lane's count -- it looks whenever the caller asks, and the callers ask for wide nodes only)
+        if (!NODES && rootHits < A.maxVal) return false;
         const row_t lo = rt.win + (rt.strand ? rt.n - 1u - smax : smin);
         const uint32_t cnt = smax - smin + 1u;
         for (uint32_t i = 0; i < cnt; ++i) if (__hip_atomic_load(&A.acc[lo + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < A.maxVal) return false;
@@ -929,6 +967,31 @@ template <int WPP> struct ScatterEnv : LeafQueueEnv<WPP, ScatterEnv<WPP>> {
     __device__ __forceinline__ void leaf_at(const Root&, uint32_t, row_t textPos) { row_action(0ull, 0u, locate_position(A.cumGlobal, A.nSeqGlobal, textPos)); }
 };
 
+// the per-call records of the jump patterns as a block keeps them in LDS (search_body, expand_kernel): the layouts ride in the 4th words of
+// the searches' group ends, the masks sit behind the jump records
+struct LdsTab {
+    const uint4* jl;
+    __device__ __forceinline__ uint32_t layout(uint32_t il) const { return jl[12u + il].w >> 8; }
+    __device__ __forceinline__ unsigned long long mask(uint32_t id) const
+    {
+        const uint2 mk = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint32_t*>(jl + 8) + 2u * id);
+        return (unsigned long long)mk.y << 32 | mk.x;
+    }
+};
+// jl[0..8): jump records of the searches, jl[8..12): masks of the groups, jl[12..20): group ends + layouts, jl[20..28): OSS records of the regular block shape
+__device__ __forceinline__ void load_jump_records(uint4* jl, const SearchArgs& A)
+{
+    if (threadIdx.x < 8u) jl[threadIdx.x] = A.jumpJ ? A.jinfo[threadIdx.x] : make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < GROUP_MAX_MASKS) reinterpret_cast<unsigned long long*>(jl + 8)[threadIdx.x] = A.gmask[threadIdx.x];
+    // entry L additionally carries layout L in the upper bits of its 4th word (bit offset of the group's characters: 5 bits, kind-0 plane: 8,
+    // first kind-1 plane: 8) -- a table of their own would have cost the block 96 bytes of LDS it does not have
+    if (threadIdx.x < 8u) {
+        uint4 v = A.jumpJ ? A.jinfo2[threadIdx.x] : make_uint4(0, 0, 0, 0);
+        v.w = (v.w & 0xFFu) | (A.layShift[threadIdx.x] | A.layPlane0[threadIdx.x] << 5 | A.layPlane1[threadIdx.x] << 13) << 8;
+        jl[12u + threadIdx.x] = v;
+    }
+}
+
 #ifdef GM_WAVES
 #define GM_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(GM_WAVES, GM_WAVES)))
 #else
@@ -966,16 +1029,7 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     if (threadIdx.x < 8u) jl[20u + threadIdx.x] = A.table[(size_t)(A.stepSize - 1u) * 8u + threadIdx.x];   // OSS records of the regular block shape (stage 2)
     if constexpr (!EnvT::JUMPS) __syncthreads();
     if constexpr (EnvT::JUMPS) {
-        if (threadIdx.x < 8u) jl[threadIdx.x] = A.jumpJ ? A.jinfo[threadIdx.x] : make_uint4(0, 0, 0, 0);
-        // ... and the masks of its groups of patterns (gm_oss.h), 8 x 8 bytes behind them
-        if (threadIdx.x < GROUP_MAX_MASKS) reinterpret_cast<unsigned long long*>(jl + 8)[threadIdx.x] = A.gmask[threadIdx.x];
-        // ... and where its groups end; entry L additionally carries layout L in the upper bits of its 4th word (bit offset of the group's
-        // characters: 5 bits, kind-0 plane: 8, first kind-1 plane: 8) -- a table of their own would have cost the block 96 bytes of LDS it does not have
-        if (threadIdx.x < 8u) {
-            uint4 v = A.jumpJ ? A.jinfo2[threadIdx.x] : make_uint4(0, 0, 0, 0);
-            v.w = (v.w & 0xFFu) | (A.layShift[threadIdx.x] | A.layPlane0[threadIdx.x] << 5 | A.layPlane1[threadIdx.x] << 13) << 8;
-            jl[12u + threadIdx.x] = v;
-        }
+        load_jump_records(jl, A);   // ... the masks of its groups of patterns (gm_oss.h), and where its groups end + the layouts
         __syncthreads();
     }
     // jump patterns: the table entry in flight lives in LDS, one 16-byte slot per lane (global_load_lds: no destination registers, hence
@@ -1037,6 +1091,13 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     //  which is then waited for behind the pattern reads issued in front of the root draw)
     uint32_t jap0 = A.jumpAPacked[0], jap1 = A.jumpAPacked[1];
     asm volatile("" : "+s"(jap0), "+s"(jap1));
+    // the walker of the split search (Env::NODES): what phase A left for this slice (wave-uniform), and the header of the packet in flight
+    uint32_t xt0 = 0, xt1 = 0, xwork = 0, xfail = 0, xstamp = 0;
+    uint4 ph0 = make_uint4(0, 0, 0, 0), ph1 = make_uint4(0, 0, 0, 0);
+    if constexpr (EnvT::NODES) {
+        const ExpandCtl* xc = A.xctl;
+        xt0 = xc->t[0]; xt1 = xc->t[1]; xwork = xt0 + xt1 + xc->t[2]; xfail = xc->failFrom; xstamp = xc->stamp;
+    }
     // bound of a hung loop (wave-uniform, scalar): consecutive iterations without a node or a verification round (tests: all iterations).
     // The fetch state machine below (parts A / B) is the code that once spun forever on the device (round 4): a wavefront that spins
     // gives up, raises the sticky error flag and the host reports GM_ERR_INTERNAL instead of waiting for ever.
@@ -1196,8 +1257,29 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                 have = true; w1run = 0;
             }
         }
+        // the walker of the split search: the packet drawn in the last iteration has arrived -> the lane holds its node
+        if constexpr (EnvT::NODES) {
+            if (fs == 1u) {
+                env.note_wave(4);
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): header registers and the window's LDS slots (nothing else orders the LDS DMA)
+                fs = 0u;
+                // a slot phase A did not fill in this slice carries an older stamp; the packets of work that did not fit are redone by the next slice
+                if (ph1.w == xstamp && ph1.z < xfail) {
+                    nd.flo = ph0.x; nd.rlo = ph0.y; nd.w = ph0.z; nd.meta = ph0.w;
+                    rt.win = ph1.x; rt.n = ph1.y & 0xFFu; rt.strand = (ph1.y >> 8) & 1u; rt.search = (ph1.y >> 9) & 7u;
+                    uint4 q;
+                    if (rt.n == A.stepSize) q = jl[20u + rt.search]; else q = A.table[(size_t)(rt.n - 1u) * 8u + rt.search];
+                    rt.rec.x = q.x; rt.rec.y = q.y; rt.rec.z = q.z; rt.rec.w = q.w;
+                    env.woff = 0u; env.on_root();
+                    have = true; w1run = 0;
+                    // every k-mer of the block at MAX already (the lists come in the order of the patterns' substitutions: by the time a pattern
+                    // with errors is drawn, what the exact pattern of its root has found is in the accumulators): nothing below can change the result
+                    if (nd.w >= A.satDrawW) have = !env.saturated(rt, 0u, rt.n - 1u);
+                }
+            }
+        }
         // stage 2: window chunks and record have arrived -> stage the window in LDS, look the first q characters up
-        if (fs == 1u) {
+        if (!EnvT::NODES && fs == 1u) {
             env.note_wave(4);
             if constexpr (!EnvT::LEGACY_LOOP) {   // the OSS record of the root's search: from LDS for the regular block shape, from the table for the odd ones (ends of the text / of an interval)
                 uint4 q;
@@ -1420,15 +1502,6 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
             if (patTurn && (fs & 3u) == 2u) {
                 env.note_wave(16);
                 const uint4 lim = jl[12u + rt.search];   // where the groups of each layout end among the search's items
-                struct LdsTab {   // the layouts ride in the 4th words of the searches' group ends, the masks sit behind the jump records
-                    const uint4* jl;
-                    __device__ __forceinline__ uint32_t layout(uint32_t il) const { return jl[12u + il].w >> 8; }
-                    __device__ __forceinline__ unsigned long long mask(uint32_t id) const
-                    {
-                        const uint2 mk = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint32_t*>(jl + 8) + 2u * id);
-                        return (unsigned long long)mk.y << 32 | mk.x;
-                    }
-                };
                 const JumpStep D = jump_decide(fs, jd, gcur, galive, pw, jb, LdsTab{jl});   // gm_oss.h: the decisions; the loads stay here, ONE site each
                 const bool want = D.want, asked = D.asked, go = D.go;
                 const uint32_t widx = D.widx, wsel = D.wsel, rw = D.rw;
@@ -1459,7 +1532,9 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
             }
         }
         GM_LAP2(tSt32);
-        if constexpr (!EnvT::LEGACY_LOOP) {
+        if constexpr (EnvT::NODES) {
+#include "gm_stage1n.inc"
+        } else if constexpr (!EnvT::LEGACY_LOOP) {
 #include "gm_stage1.inc"
         }
         GM_LAP2(tSt1);
@@ -1533,6 +1608,216 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 template <int WPP, class EnvT, bool COOP>
 __global__ __launch_bounds__(256) void search_kernel_w4(const SearchArgs A) { search_body<WPP, EnvT, COOP>(A); }
 #endif
+
+// ---- phase A of the split search (gm_expand.h) ------------------------------------------------------------------------------------------
+// slice_begin: which chunks of the call this slice takes.  The number adapts to what the last slice produced (packets per chunk, X and Y
+// separately), aiming at three quarters of the buffers: a slice that overflows loses nothing (its failed chunks are redone), but it has
+// walked a shorter list than it could have.
+__global__ void expand_slice_begin_kernel(ExpandProgress* prog, ExpandCtl* ctl, uint32_t usableX, uint32_t usableY, uint32_t firstChunks, uint32_t maxChunks)
+{
+    if (threadIdx.x != 0u || blockIdx.x != 0u) return;
+    const unsigned long long begin = prog->committed, total = prog->totalChunks;
+    unsigned long long r = firstChunks;
+    if (prog->lastChunks) {
+        const unsigned long long rx = (unsigned long long)usableX * prog->lastChunks / (prog->lastX ? prog->lastX : 1u);
+        const unsigned long long ry = (unsigned long long)usableY * prog->lastChunks / (prog->lastY ? prog->lastY : 1u);
+        r = (rx < ry ? rx : ry) * 3ull / 4ull;
+    }
+    if (r < 1ull) r = 1ull;
+    if (r > maxChunks) r = maxChunks;
+    ctl->chunkBegin = begin; ctl->chunkEnd = begin + r < total ? begin + r : total;
+    ctl->nextChunk = begin; ctl->tailsX = 0ull; ctl->tailY = 0u; ctl->failFrom = 0xFFFFFFFFu; ctl->walkCounter = 0ull;
+    ctl->valid[0] = ctl->valid[1] = ctl->valid[2] = 0u; ctl->t[0] = ctl->t[1] = ctl->t[2] = 0u;
+    ctl->stamp = ++prog->stampCounter;
+}
+// slice_commit: phase A of the slice has ended -> what the walker draws, where the next slice starts
+__global__ void expand_slice_commit_kernel(ExpandProgress* prog, ExpandCtl* ctl, uint32_t* errorFlag)
+{
+    if (threadIdx.x != 0u || blockIdx.x != 0u) return;
+    const unsigned long long begin = ctl->chunkBegin, end = ctl->chunkEnd;
+    const unsigned long long done = (unsigned long long)ctl->failFrom < end ? (unsigned long long)ctl->failFrom : end;
+    ctl->t[0] = ctl->valid[0]; ctl->t[1] = ctl->valid[1]; ctl->t[2] = ctl->valid[2];
+    if (done <= begin && end > begin) atomicOr(errorFlag, 4u);   // not even one chunk fits the buffers: the host sized them (never expected)
+    prog->committed = done > begin ? done : begin;
+    prog->slices += 1u;
+    if (done > begin) { prog->lastChunks = (uint32_t)(done - begin); prog->lastX = ctl->valid[0] + ctl->valid[1]; prog->lastY = ctl->valid[2]; }
+}
+
+// One lane per (k-mer block, strand, search, item).  Blocks come in chunks of A.expandBlocks from a counter; a wavefront walks the work
+// items of its chunk 64 at a time: root context from the 4-bit text (expand_root), the item's bitmap word, then -- all lanes in step -- one
+// table entry per lane and turn until the items have run out of surviving rotations; what passes the neighbour filters is appended to the
+// class lists.  No stacks, no LDS windows, no loop-carried memory state: the kernel runs at whatever occupancy its registers allow.
+__global__ __launch_bounds__(256) void expand_kernel(const SearchArgs A)
+{
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2), aligned(8)));
+    struct DevMem {
+        const unsigned long long* t;
+        __device__ __forceinline__ void pair(uint64_t i, uint64_t& lo, uint64_t& hi) const { const u64x2 v = *reinterpret_cast<const u64x2*>(t + i); lo = v.x; hi = v.y; }
+    } mem{reinterpret_cast<const unsigned long long*>(A.text4)};
+    __shared__ uint4 jl[28];
+    load_jump_records(jl, A);
+    if (threadIdx.x < 8u) jl[20u + threadIdx.x] = A.table[(size_t)(A.stepSize - 1u) * 8u + threadIdx.x];
+    __syncthreads();
+    const LdsTab tab{jl};
+    const uint32_t lane = threadIdx.x & 63u;
+    ExpandCtl* const ctl = A.xctl;
+    const uint32_t U = PKT_HEADER_UNITS + A.pktChunks;
+    const uint32_t G = A.expandBlocks, IPB = A.itemsPerBlock;
+    const unsigned long long chunkEnd = ctl->chunkEnd;
+    const uint32_t stamp = ctl->stamp;
+    uint32_t rb[3] = {0u, 0u, 0u}, ru[3] = {XREGION, XREGION, XREGION};   // wave-uniform: the wavefront's open region per class, packets used in it
+    bool dead = false;                                                      // wave-uniform: a reservation did not fit
+#ifdef GM_COUNTERS
+    uint32_t cJumps = 0, cWords = 0, cDrops = 0, cDrops2 = 0, cSelf = 0, cPackets = 0;
+#endif
+    for (;;) {
+        unsigned long long cid = 0ull;
+        if (lane == 0u) cid = atomicAdd(&ctl->nextChunk, 1ull);
+        cid = __shfl(cid, 0);
+        if (cid >= chunkEnd || cid >= (unsigned long long)__hip_atomic_load(&ctl->failFrom, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        const unsigned long long blk0 = cid * G;
+        const uint32_t nblk = A.numBlocksCall - blk0 < G ? (uint32_t)(A.numBlocksCall - blk0) : G;
+        const uint32_t nwork = nblk * IPB;
+#pragma unroll 1
+        for (uint32_t base = 0; base < nwork && !dead; base += 64u) {
+            const uint32_t l = base + lane;
+            const bool on = l < nwork;
+            XRoot xr; xr.jb = xr.jn = xr.ext = 0u; xr.bad = 1u;
+            XItem it; it.alive = 0ull; it.gcur = it.sh = it.state = it.widx = it.wsel = 0u;
+            uint32_t win = 0, nss = 0, jm0 = 0, hword = 0, jd = 0;
+            bool pendRoot = false;
+            if (on) {
+                const uint32_t bi = l / IPB, q = l - bi * IPB;
+                const uint32_t wm = A.wmap[q], search = wm & 7u, strand = (wm >> 3) & 1u, jp = wm >> 8;
+                unsigned long long gb = blk0 + bi;        // ordinal of the block among this call's blocks (gm_stage1.inc)
+                if (A.chunkBlocks) {
+                    const uint32_t qq = (uint32_t)gb / A.chunkBlocks;
+                    gb = (unsigned long long)(qq * A.chunkStride + A.chunkIndex) * A.chunkBlocks + ((uint32_t)gb - qq * A.chunkBlocks);
+                }
+                gb += A.blockBegin;
+                uint32_t n;
+                if (A.blockList) { const uint2 e = A.blockList[gb]; win = e.x; n = e.y & 0xFFu; }   // (32-bit rows: slice positions fit 32 bits)
+                else { win = (uint32_t)gb * A.stepSize; const uint32_t left = (uint32_t)A.numKmers - win; n = left < A.stepSize ? left : A.stepSize; }
+                nss = pkt_root_word(n, strand, search);
+                const uint4 fji = jl[search];   // {first item | items << 16, meta at depth J relative to n - 1, first item, neighbour-filter mask}
+                hword = fji.w;
+                if (n == A.stepSize) {
+                    const uint32_t a0 = n - 1u + (((search < 4u ? A.jumpAPacked[0] : A.jumpAPacked[1]) >> (8u * (search & 3u))) & 0xFFu);
+                    xr = expand_root(mem, A.textBegin + win, A.K + n - 1u, strand, a0, A.jumpJ, fji.w, (jl[12u + search].w & 0xFFu) != 0u);
+                }
+                if (xr.bad) pendRoot = jp == (fji.x & 0xFFFFu);   // an odd block shape or an N inside the J-mer: the root walks the tree from its root
+                else {
+                    jm0 = meta_pack((fji.y & 0x1FFu) + n - 1u, ((fji.y >> 9) & 0x1FFu) + n - 1u, fji.y >> 18, 0u, M_OSS);
+                    jd = A.patterns[jp];
+                    const uint4 lim = jl[12u + search];
+                    it = expand_item(jd, jump_item_flags(jp, lim.x, lim.y, lim.z), xr, tab);
+                    if (it.state == 2u) {
+                        const unsigned long long pw = A.jbits[(size_t)it.wsel * A.jbitsWords + it.widx];
+                        expand_word(it, pw, jd, xr, tab);
+#ifdef GM_COUNTERS
+                        cWords++;
+#endif
+                    }
+                }
+            }
+#pragma unroll 1
+            for (;;) {
+                const bool more = on && !xr.bad && (it.state == 1u || (it.state == 3u && it.alive != 0ull));
+                if (__ballot(more || pendRoot) == 0ull) break;
+                bool take = false;
+                uint32_t cls = 0;
+                uint4 h0 = make_uint4(0, 0, 0, 0);
+                if (more) {
+                    uint32_t rw = 0;
+                    expand_next(it, rw);
+                    const uint4 e = A.jtab[rot_add(xr.jb, rw)];
+                    const XNode x = expand_filter(e.x, e.y, e.z, e.w, rw, jm0, xr.jn, hword, A.E, A.nbFilter, A.verifyT);
+#ifdef GM_COUNTERS
+                    cJumps++;
+                    if (!x.take && e.z == 1u) cDrops++;
+                    if (e.z == 2u && (xr.jn & 0x8000u) && A.nbFilter == 1u) cDrops2 += x.take ? (x.rlo == ~0u ? 1u : 0u) : 2u;
+#endif
+                    take = x.take != 0u;
+                    h0 = make_uint4(x.flo, x.rlo, x.w, x.meta); cls = expand_class(x.errs);
+                    if (take && A.selfHit && x.w == 1u && ((nss >> 8) & 1u) == 0u && x.errs == 0u && x.rlo != ~0u) {
+                        // Forward strand, no error spent, ONE row: the window's own location (search_body: self hits) -- settled here, no packet.
+                        // (windows holding an N take the ordinary path; the symbols behind the window in its last chunk count too: harmless)
+                        unsigned long long anyN = 0ull;
+                        for (uint32_t j = 0; j < 2u * A.pktChunks; ++j) anyN |= nib64(mem, A.textBegin + win + 16u * j) & 0x4444444444444444ull;
+                        if (anyN == 0ull) {
+                            take = false;
+                            RootT<uint32_t> rt; rt.win = win; rt.n = nss & 0xFFu; rt.strand = 0u; rt.search = (nss >> 9) & 7u;
+                            const uint4 q = jl[20u + rt.search];   // (a regular block: it has jump patterns)
+                            rt.rec.x = q.x; rt.rec.y = q.y; rt.rec.z = q.z; rt.rec.w = q.w;
+                            uint32_t smin, smax;
+                            if (self_hit_kmers(x.meta, rt, A.K, smin, smax)) {   // CountEnv::leaf_range with the difference plane (the host clears selfHit without one)
+                                const uint32_t lo = win + smin, hi = win + smax;
+                                __hip_atomic_fetch_add(&A.diff[lo], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (hi + 1u < win + rt.n) __hip_atomic_fetch_add(&A.diff[hi + 1u], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+#ifdef GM_COUNTERS
+                            cSelf++;
+#endif
+                        }
+                    }
+                } else if (pendRoot) {
+                    pendRoot = false; take = true; cls = 0u;
+                    const uint32_t n = nss & 0xFFu, search = (nss >> 9) & 7u;
+                    const uint32_t a = n - 1u + ((A.table[(size_t)(n - 1u) * 8u + search].y >> 16) & 0xFFu);   // root_node (gm_engine.h)
+                    h0 = make_uint4(0u, 0u, (uint32_t)A.nRows, meta_pack(a, a, 0u, 0u, M_OSS));
+                }
+                // ---- append: every class in turn, all lanes in step ----
+#pragma unroll
+                for (uint32_t c = 0; c < 3u; ++c) {
+                    const bool mine = take && cls == c;
+                    const unsigned long long m = __ballot(mine);
+                    if (m == 0ull) continue;
+                    const uint32_t cnt = (uint32_t)__popcll(m), room = XREGION - ru[c];
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    uint32_t nbase = 0xFFFFFFFFu;
+                    if (cnt > room) {   // a new region for this class: ONE atomic per XREGION packets
+                        if (lane == 0u) {
+                            if (c == 2u) {
+                                const uint32_t b = atomicAdd(&ctl->tailY, XREGION);
+                                if (b <= A.capY - XREGION) { nbase = b; atomicMax(&ctl->valid[2], b + XREGION); }
+                            } else {
+                                const unsigned long long old = atomicAdd(&ctl->tailsX, c == 0u ? (unsigned long long)XREGION : (unsigned long long)XREGION << 32);
+                                const uint32_t b0 = (uint32_t)old, b1 = (uint32_t)(old >> 32);
+                                if ((unsigned long long)b0 + b1 + XREGION <= A.capX) { nbase = c == 0u ? b0 : b1; atomicMax(&ctl->valid[c], nbase + XREGION); }
+                            }
+                        }
+                        nbase = (uint32_t)__shfl((int)nbase, 0);
+                        if (nbase == 0xFFFFFFFFu) dead = true;
+                    }
+                    if (mine && (rank < room || !dead)) {
+                        const uint32_t slot = rank < room ? rb[c] + ru[c] + rank : nbase + (rank - room);
+                        uint4* pk = (c == 2u ? A.pktY : A.pktX) + (size_t)(c == 1u ? A.capX - 1u - slot : slot) * U;
+                        pk[0] = h0;
+                        pk[1] = make_uint4(win, nss, (uint32_t)cid, stamp);
+                        for (uint32_t j = 0; j < A.pktChunks; ++j) {
+                            const unsigned long long w0 = nib64(mem, A.textBegin + win + 32u * j), w1 = nib64(mem, A.textBegin + win + 32u * j + 16u);
+                            pk[2u + j] = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
+                        }
+#ifdef GM_COUNTERS
+                        cPackets++;
+#endif
+                    }
+                    if (cnt > room) { rb[c] = nbase; ru[c] = cnt - room; } else ru[c] += cnt;
+                }
+                if (dead) break;
+            }
+        }
+        if (dead) { if (lane == 0u) atomicMin(&ctl->failFrom, (uint32_t)cid); break; }   // this chunk (and every later one) is redone by the next slice
+    }
+#ifdef GM_COUNTERS
+    atomicAdd(&A.counters[38], (unsigned long long)cJumps);
+    atomicAdd(&A.counters[41], (unsigned long long)cDrops);
+    atomicAdd(&A.counters[45], (unsigned long long)cSelf);
+    atomicAdd(&A.counters[47], (unsigned long long)cWords);
+    atomicAdd(&A.counters[48], (unsigned long long)cDrops2);
+    atomicAdd(&A.counters[49], (unsigned long long)cPackets);   // detail[47]: node packets written by phase A
+#endif
+}
 
 // SA ranges of every ACGT string of length q in both indexes (right extensions from the root): the top of the search
 // tree, tabulated once per index and q.

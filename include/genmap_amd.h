@@ -252,7 +252,8 @@ typedef struct gm_map_stats {
                                  by the neighbour filter; [40] rows located (one suffix-array or mark-word read each: --exclude-pseudo, csv,
                                  correction pass), [41] LF steps of sampled suffix-array walks, [42] deepest lane stack of the call,
                                  [43] self hits, [44] verified runs of k-mers, [45] 8-byte bitmap words read for groups of jump patterns, [46] rows of two-row
-                                 table entries ended by the neighbour filter; [47] spare */
+                                 table entries ended by the neighbour filter; [47] bits 0..47: node packets written by phase A of the split search
+                                 (gm_expand.h), bits 48..63: slices the call's split search took (set by the host in every build; 0: the one-loop kernel ran) */
     double   search_ms;       /* HIP-event time of the search kernel alone */
     double   total_ms;        /* memset + search + finalize, HIP events on the call's stream */
 } gm_map_stats;

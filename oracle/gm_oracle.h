@@ -112,10 +112,12 @@ void gmo_last_counters(uint64_t *node_visits, uint64_t *rank_lines);
 /* symbols per rank line of the layout being priced (default 96 = the product's 64-B block). */
 void gmo_set_line_symbols(uint32_t syms);
 
+/* 1: gmo_compute_mappability does not clear `out` (the caller hands in zeros); measurement only.  Process-wide and not
+ * thread-safe: set it, time, and reset it (bench.py does so in a try / finally). */
+void gmo_set_skip_clear(int on);
+
 #ifdef __cplusplus
 }
 #endif
-/* 1: gmo_compute_mappability does not clear `out` (the caller hands in zeros); measurement only */
-void gmo_set_skip_clear(int on);
 
 #endif

@@ -247,6 +247,58 @@ def test_gpu_baseline_settings_small(K, E):
         ix.close()
 
 
+@pytest.mark.parametrize("K,E", [(30, 1), (30, 2), (24, 1), (24, 2), (100, 1), (50, 3), (36, 4), (150, 2), (250, 1)])
+def test_gpu_split_search_phase_a_and_walker(K, E):
+    """Round 6: the jump patterns enumerated by lanes of their own (expand_kernel: one work item per (root, item), node packets in three
+    lists) and a walker that draws packets (search_kernel with Env::NODES) -- forced on small texts, against the oracle: default buffers
+    (one slice) and buffers of 1-2 MiB (many slices, chunks that do not fit and are redone), chunk sizes, both counter widths, work
+    sharing / cooperative reads / record verification on and off, neighbour filters, groups, the saturation test at the draw, shares
+    (k-mer ranges, interleaved chunks) and a selection.  The one-loop kernel must give the same."""
+    g = _gm()
+    rng = np.random.default_rng(K * 10 + E + 606)
+    lens = [70000, 700, K - 1, 40000, 3, K]
+    codes = _repeat_text(rng, sum(lens), True)
+    # a family of ~300 near-identical copies: the 8-bit counters saturate, the walker drops packets at the draw
+    fam = rng.integers(0, 4, size=120, dtype=np.uint8)
+    for s0 in range(2000, 2000 + 300 * 130, 130):
+        cp = fam.copy()
+        if s0 % 3 == 0: cp[rng.integers(0, 120)] ^= 2
+        codes[s0:s0 + 120] = cp
+    ora = H.OracleIndex(codes, lens, keep_sa=False)
+    exp = {bits: ora.mappability(K, E, value_bits=bits, threads=8) for bits in (8, 16)}
+    for bb in (32, 64):
+        ix = g.Index.build(codes, lens, block_bytes=bb, sampling=1)
+        try:
+            slices_seen = set()
+            for mb, chunk, T, coop, ctx, steal, flt, grp, satw in ((-1, -1, -1, -1, 1, -1, 1, -1, -1), (1, 1, 1, 1, 1, 0, 2, 1, 0), (2, 7, 4, 0, 0, 1, 0, 0, 1 << 20),
+                                                                    (1, -1, 0, 1, 1, 16, 1, 1, -1), (3, 50, -1, -1, 1, -1, 1, -1, 4)):
+                ix.set_tuning(expand=1, expand_mb=mb, expand_chunk=chunk, verify_t=T, coop=coop, use_ctx=ctx, steal=steal, jump_filter=flt, jump_groups=grp, sat_draw_w=satw)
+                for bits in (8, 16):
+                    out = ix.map(K, E, value_bits=bits)
+                    assert np.array_equal(out, exp[bits]), (K, E, bb, bits, mb, chunk, T, coop, ctx, steal, flt, grp, satw, np.flatnonzero(out != exp[bits])[:10])
+                    slices_seen.add(ix.last_stats()["detail"]["slices"])
+            assert min(slices_seen) >= 1 and max(slices_seen) > 3, slices_seen     # the small buffers forced many slices
+            ix.set_tuning(expand=0, expand_mb=-1, expand_chunk=-1, verify_t=-1, coop=-1, use_ctx=1, steal=-1, jump_filter=1, jump_groups=-1, sat_draw_w=-1)
+            assert np.array_equal(ix.map(K, E, value_bits=8), exp[8]) and ix.last_stats()["detail"]["slices"] == 0
+            # shares of one vector: k-mer ranges, interleaved chunks, a selection -- each through the split search with small buffers
+            ix.set_tuning(expand=1, expand_mb=2)
+            n = int(sum(lens))
+            host = np.zeros(n, dtype=np.uint16)
+            step = g.tuned_infix_length(K, E)
+            for r in range(3):
+                ix.map_shard(host, K, E, value_bits=16, chunks=(5, r, 3))
+            assert np.array_equal(host, exp[16]), (K, E, bb, "interleaved chunks")
+            host[:] = 0
+            cut = [0, n // 3, n // 2 + 7, n]
+            for r in range(3):
+                ix.map_shard(host, K, E, value_bits=16, kmer_range=(cut[r], cut[r + 1]))
+            assert np.array_equal(host, exp[16]), (K, E, bb, "k-mer ranges")
+            iv = [(100, 9000), (60000, 75000), (100000, n)]
+            assert np.array_equal(ix.map(K, E, value_bits=16, intervals=iv), ora.mappability(K, E, value_bits=16, intervals=iv, threads=8)), (K, E, bb, "selection")
+        finally:
+            ix.close()
+
+
 @pytest.mark.parametrize("bb", [0, 64, WIDE])
 def test_gpu_long_kmers_beyond_255(bb):
     """The reference takes any -K (src/mappability.hpp:425-426).  K > 255 runs the plain tree walk of gm_longk.h: frequencies at
