@@ -830,6 +830,7 @@ struct SearchSetup {
     // the split search (gm_expand.h): phase A enumerates the jump patterns of the call's blocks into node packets, the walker draws packets
     bool expand = false;
     uint32_t itemsPerBlock = 0, expandBlocks = 0, pktChunks = 0;
+    uint32_t rootWinChunks = 0;         // LDS chunks per lane of a kernel that stages the windows of ROOTS (any alignment): the correction pass beside a walker
     uint64_t numBlocksCall = 0, totalChunks = 0;
 };
 
@@ -1050,7 +1051,8 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     auto vq_cap = [](uint32_t rows) { return rows >= 2u ? 160u : 128u; };
     uint32_t vqCap = verifyT ? vq_cap(verifyRows) : 1u;
     // (long k-mers read their needle from the text; the walker of the split search stages the window of its packet, which starts at nibble 0)
-    const uint32_t winChunks = longK ? 1u : expand ? S->pktChunks : (31u + p->K + plan.stepSize - 1u + 31u) / 32u;
+    S->rootWinChunks = longK ? 1u : (31u + p->K + plan.stepSize - 1u + 31u) / 32u;
+    const uint32_t winChunks = expand ? S->pktChunks : S->rootWinChunks;
     const int wantPerCU = std::max(1, ix->tune.blocksPerCU);   // default 4 = 4 waves/SIMD, what the kernel's VGPR count allows
     const bool entrySlots = mayJump && !ix->wide && !expand;
     g_ldsPad = (uint32_t)std::max(0, ix->tune.ldsPad);
@@ -1309,6 +1311,10 @@ static int run_expand(gm_index* ix, const SearchSetup& S, SearchArgs A, const gm
         if (ix->pktYCap < needY) { uint4* d = nullptr; if (ix->d_pktY) { hipFree(ix->d_pktY); ix->d_pktY = nullptr; ix->pktYCap = 0; } if (hipMalloc(&d, needY * 16) != hipSuccess) { (void)hipGetLastError(); set_error("no device memory for %llu node packets", (unsigned long long)capY); return GM_ERR_OOM; } GM_HIP(hipMemsetAsync(d, 0, needY * 16, st)); ix->d_pktY = d; ix->pktYCap = needY; }
     }
     A.pktX = ix->d_pktX; A.pktY = ix->d_pktY; A.capX = (uint32_t)capX; A.capY = (uint32_t)capY;
+    if (ix->pktUnits != U) {   // packets of another size lie in the buffers: a slot's stamp word would be somebody's window symbols
+        if (ix->pktUnits) { GM_HIP(hipMemsetAsync(ix->d_pktX, 0, ix->pktXCap * 16, st)); GM_HIP(hipMemsetAsync(ix->d_pktY, 0, ix->pktYCap * 16, st)); }
+        ix->pktUnits = U;
+    }
     A.xctl = reinterpret_cast<ExpandCtl*>(ix->d_xctl);
     ExpandProgress* prog = reinterpret_cast<ExpandProgress*>(ix->d_xprog);
     ExpandProgress* hprog = reinterpret_cast<ExpandProgress*>(ix->h_xprog);
@@ -1321,12 +1327,29 @@ static int run_expand(gm_index* ix, const SearchSetup& S, SearchArgs A, const gm
     const uint64_t smaller = twoPlus ? std::min(capX, capY) : capX;
     blocksA = std::max<uint64_t>(1, std::min<uint64_t>(blocksA, smaller / (4ull * 4ull * XREGION)));
     blocksA = std::min<uint64_t>(blocksA, std::max<uint64_t>(1, (S.totalChunks + 3) / 4));
+    {   // one block of work at its worst (64 rotations per item) must fit a quarter of either buffer beside the open regions: grow tiny buffers
+        const uint64_t floorCap = 4ull * (uint64_t)S.itemsPerBlock * 64ull + 2ull * blocksA * 4ull * XREGION;
+        if (capX < floorCap || (twoPlus && capY < floorCap)) {
+            capX = std::max<uint64_t>(capX, floorCap); if (twoPlus) capY = std::max<uint64_t>(capY, floorCap);
+            const uint64_t needX = capX * U, needY = capY * U;
+            if (ix->pktXCap < needX) { uint4* d = nullptr; if (ix->d_pktX) { hipFree(ix->d_pktX); ix->d_pktX = nullptr; ix->pktXCap = 0; } if (hipMalloc(&d, needX * 16) != hipSuccess) { (void)hipGetLastError(); set_error("no device memory for %llu node packets", (unsigned long long)capX); return GM_ERR_OOM; } GM_HIP(hipMemsetAsync(d, 0, needX * 16, st)); ix->d_pktX = d; ix->pktXCap = needX; }
+            if (ix->pktYCap < needY) { uint4* d = nullptr; if (ix->d_pktY) { hipFree(ix->d_pktY); ix->d_pktY = nullptr; ix->pktYCap = 0; } if (hipMalloc(&d, needY * 16) != hipSuccess) { (void)hipGetLastError(); set_error("no device memory for %llu node packets", (unsigned long long)capY); return GM_ERR_OOM; } GM_HIP(hipMemsetAsync(d, 0, needY * 16, st)); ix->d_pktY = d; ix->pktYCap = needY; }
+            A.pktX = ix->d_pktX; A.pktY = ix->d_pktY; A.capX = (uint32_t)capX; A.capY = (uint32_t)capY;
+        }
+    }
     const uint64_t slack = blocksA * 4ull * XREGION;
     const uint32_t usableX = (uint32_t)(capX - std::min<uint64_t>(slack, capX / 2)), usableY = (uint32_t)(capY - std::min<uint64_t>(twoPlus ? slack : 0, capY / 2));
+    // A chunk is the unit that is redone when its packets do not fit: whatever a chunk can produce at most (64 rotations per work item) must fit
+    // half a buffer, or a slice could fail on its first chunk for ever.  (Only the tiny buffers of the tests ever shorten a chunk.)
+    const uint64_t usableMin = std::min<uint64_t>(usableX, twoPlus ? usableY : usableX);
+    const uint64_t chunkWorst = (uint64_t)S.itemsPerBlock * 64ull;
+    const uint32_t G = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(S.expandBlocks, (usableMin / 2) / std::max<uint64_t>(chunkWorst, 1)));
+    const uint64_t totalChunks = (S.numBlocksCall + G - 1) / G;
+    A.expandBlocks = G;
     // first slice: a guess at the packets a chunk makes (8 per k-mer); the slices behind it follow what their predecessor measured
-    const uint64_t guess = (uint64_t)S.expandBlocks * S.plan.stepSize * 8ull;
-    const uint32_t firstChunks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(usableX, twoPlus ? usableY : usableX) / std::max<uint64_t>(guess, 1), 0x7FFFFFFFull));
-    hipLaunchKernelGGL(expand_reset_kernel, dim3(1), dim3(1), 0, st, prog, (unsigned long long)S.totalChunks);
+    const uint64_t guess = (uint64_t)G * S.plan.stepSize * 8ull;
+    const uint32_t firstChunks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(usableMin / std::max<uint64_t>(guess, 1), 0x7FFFFFFFull));
+    hipLaunchKernelGGL(expand_reset_kernel, dim3(1), dim3(1), 0, st, prog, (unsigned long long)totalChunks);
     SearchArgs W = A;                                              // the walker's view
     W.workCounter = &A.xctl->walkCounter;
     unsigned long long lastSeen = 0; bool seen = false;
@@ -1342,7 +1365,7 @@ static int run_expand(gm_index* ix, const SearchSetup& S, SearchArgs A, const gm
         if (i >= 2u) {
             GM_HIP(hipEventSynchronize(ix->evX[(i - 2u) & 3u]));
             const unsigned long long c = hprog[(i - 2u) & 3u].committed;
-            if (c >= S.totalChunks) break;
+            if (c >= totalChunks) break;
             if (seen && c == lastSeen) { set_error("the split search made no progress (packet buffers of %llu + %llu packets)", (unsigned long long)capX, (unsigned long long)capY); return GM_ERR_INTERNAL; }
             lastSeen = c; seen = true;
         }
@@ -1481,6 +1504,7 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
         C.steal = C.numRoots < 64ull * 4ull * 1024ull ? 1u : C.steal;
         C.lqCap = 128u;   // leaves are located by the whole wavefront (gm_kernels.h: LeafQueueEnv)
         C.entrySlots = 0u;
+        C.winChunks = S.rootWinChunks;   // (it draws roots and stages their windows at any alignment: a walker's packets start at nibble 0 and need a chunk less)
         C.workCounter = reinterpret_cast<unsigned long long*>(ix->d_small) + 1;   // its own counter: the two kernels run side by side
         C.stack = ix->d_stack + ix->stackCap / 2;                                  // ... and its own half of the spill area (prepare_search)
         const uint64_t useful = (C.numRoots + 255) / 256;

@@ -118,6 +118,7 @@ struct gm_index {
     hipEvent_t evX[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t* d_wmap = nullptr; uint64_t wmapCap = 0;
     uint32_t lastSlices = 0;           // slices of the last call that took the split search (statistics)
+    uint32_t pktUnits = 0;             // 16-byte units per packet of what the buffers hold
     uint32_t* d_patterns = nullptr; uint64_t patternsCap = 0;
     uint4* d_jinfo = nullptr; uint64_t jinfoCap = 0;
     bool nRunsValid = false;

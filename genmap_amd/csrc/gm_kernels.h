@@ -1668,7 +1668,7 @@ __global__ __launch_bounds__(256) void expand_kernel(const SearchArgs A)
     uint32_t rb[3] = {0u, 0u, 0u}, ru[3] = {XREGION, XREGION, XREGION};   // wave-uniform: the wavefront's open region per class, packets used in it
     bool dead = false;                                                      // wave-uniform: a reservation did not fit
 #ifdef GM_COUNTERS
-    uint32_t cJumps = 0, cWords = 0, cDrops = 0, cDrops2 = 0, cSelf = 0, cPackets = 0;
+    uint32_t cJumps = 0, cWords = 0, cDrops = 0, cDrops2 = 0, cPackets = 0;
 #endif
     for (;;) {
         unsigned long long cid = 0ull;
@@ -1739,27 +1739,8 @@ __global__ __launch_bounds__(256) void expand_kernel(const SearchArgs A)
 #endif
                     take = x.take != 0u;
                     h0 = make_uint4(x.flo, x.rlo, x.w, x.meta); cls = expand_class(x.errs);
-                    if (take && A.selfHit && x.w == 1u && ((nss >> 8) & 1u) == 0u && x.errs == 0u && x.rlo != ~0u) {
-                        // Forward strand, no error spent, ONE row: the window's own location (search_body: self hits) -- settled here, no packet.
-                        // (windows holding an N take the ordinary path; the symbols behind the window in its last chunk count too: harmless)
-                        unsigned long long anyN = 0ull;
-                        for (uint32_t j = 0; j < 2u * A.pktChunks; ++j) anyN |= nib64(mem, A.textBegin + win + 16u * j) & 0x4444444444444444ull;
-                        if (anyN == 0ull) {
-                            take = false;
-                            RootT<uint32_t> rt; rt.win = win; rt.n = nss & 0xFFu; rt.strand = 0u; rt.search = (nss >> 9) & 7u;
-                            const uint4 q = jl[20u + rt.search];   // (a regular block: it has jump patterns)
-                            rt.rec.x = q.x; rt.rec.y = q.y; rt.rec.z = q.z; rt.rec.w = q.w;
-                            uint32_t smin, smax;
-                            if (self_hit_kmers(x.meta, rt, A.K, smin, smax)) {   // CountEnv::leaf_range with the difference plane (the host clears selfHit without one)
-                                const uint32_t lo = win + smin, hi = win + smax;
-                                __hip_atomic_fetch_add(&A.diff[lo], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                if (hi + 1u < win + rt.n) __hip_atomic_fetch_add(&A.diff[hi + 1u], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            }
-#ifdef GM_COUNTERS
-                            cSelf++;
-#endif
-                        }
-                    }
+                    // (self hits -- forward strand, no error spent, one row: the window's own location -- stay with the walker: a chunk of phase A that
+                    //  does not fit its buffers is redone by the next slice, and an add into the difference plane cannot be taken back)
                 } else if (pendRoot) {
                     pendRoot = false; take = true; cls = 0u;
                     const uint32_t n = nss & 0xFFu, search = (nss >> 9) & 7u;
@@ -1812,7 +1793,6 @@ __global__ __launch_bounds__(256) void expand_kernel(const SearchArgs A)
 #ifdef GM_COUNTERS
     atomicAdd(&A.counters[38], (unsigned long long)cJumps);
     atomicAdd(&A.counters[41], (unsigned long long)cDrops);
-    atomicAdd(&A.counters[45], (unsigned long long)cSelf);
     atomicAdd(&A.counters[47], (unsigned long long)cWords);
     atomicAdd(&A.counters[48], (unsigned long long)cDrops2);
     atomicAdd(&A.counters[49], (unsigned long long)cPackets);   // detail[47]: node packets written by phase A

@@ -366,16 +366,6 @@ static void search_plan(const MapPlan& plan, const HostIndex<WPP>& ix, Env& env,
                 const XNode x = expand_filter(flo, rlo, w, entry_nb(flo, w), rw, jm0, xr.jn, nbWord[search], E, (uint32_t)g_nbFilter, env.saArr ? verifyT : 0u);
                 if (!x.take) { if (w) g_packets[3]++; continue; }
                 Node nd; nd.flo = x.flo; nd.rlo = x.rlo; nd.w = x.w; nd.meta = x.meta;
-                if (Env::RANGE_ADD && g_selfHit && x.w == 1u && strand == 0u && x.errs == 0u && x.rlo != ~0u) {   // self hits are settled by phase A
-                    uint64_t anyN = 0;
-                    for (uint32_t j = 0; j < 2u * pkt_chunks_for(K, plan.stepSize); ++j) anyN |= nib64(mem, (uint64_t)rt.win + 16u * j) & 0x4444444444444444ull;
-                    if (!anyN) {
-                        uint32_t smin, smax;
-                        if (self_hit_kmers(nd.meta, rt, K, smin, smax)) { if constexpr (Env::RANGE_ADD) env.leaf_range(rt, smin, smax); }
-                        env.selfHits++;
-                        continue;
-                    }
-                }
                 packet(expand_class(x.errs), nd, rt);
             }
         }

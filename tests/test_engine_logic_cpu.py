@@ -203,7 +203,7 @@ def emu_map2(ix, wpp, K, E, first_seq=0, n_seq=None, xo=None, infix=0, revcompl=
 def expand_mode(request):
     """0: a root's jump patterns are consumed by the lane that walks their subtrees (the kernels of rounds 3-5); 1: phase A / phase B of
     round 6 (gm_expand.h): one work item per (root, item), node packets in three lists, every packet walked from its own needle window,
-    self hits settled by phase A, the neighbour filters of one- and two-row table entries on"""
+    the neighbour filters of one- and two-row table entries on"""
     e = emu()
     e.gm_emu_set_expand(request.param)
     yield request.param
@@ -334,7 +334,7 @@ def test_groups_of_jump_patterns_read_through_the_existence_bitmap(K, E, expand_
 def test_phase_a_node_packets_and_neighbour_filters(K, E):
     """gm_expand.h end to end on the CPU: expand_root (J-mer index, neighbours and the two letters behind the J-mer taken from the 4-bit text at
     any alignment, both strands), expand_item / expand_word / expand_next (plain patterns and groups of every layout), expand_filter (one- and
-    two-row entries, rows-only nodes), self hits settled by phase A, the three lists -- equal to the oracle with the filters on, one-row only,
+    two-row entries, rows-only nodes), the three lists -- equal to the oracle with the filters on, one-row only,
     and off; the filters must end nodes and every list must be used."""
     e = emu()
     e.gm_emu_packets.argtypes = [C.c_void_p, C.c_int]
@@ -369,7 +369,7 @@ def test_phase_a_node_packets_and_neighbour_filters(K, E):
                     e.gm_emu_packets(H._ptr(pk), 1)
                     assert pk[0] > 0 and (jump < 16 or K >= 64 or (pk[1] > 0 and (E < 2 or pk[2] > 0))), pk
                     ended[(groups, nbf, T, jump)] = int(pk[3])
-                    assert st[6] > 0                       # self hits (settled by phase A)
+                    assert st[6] > 0                       # self hits (the walker's: a redone chunk of phase A must not add twice)
         assert ended[(0, 1, 1, 16)] > 0 and ended[(0, 0, 1, 16)] == 0 and ended[(0, 1, 1, 16)] >= ended[(0, 2, 1, 16)] > 0, ended
         # slices and a selection go through the same code
         e.gm_emu_set_nb_filter(1)
