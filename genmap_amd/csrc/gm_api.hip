@@ -357,7 +357,7 @@ void gm_index_free(gm_index* ix)
     if (ix->evDone) hipEventDestroy(ix->evDone);
     hipFree(ix->d_shardOut); hipFree(ix->d_patterns); hipFree(ix->d_jinfo); hipFree(ix->d_cblocks);
     if (ix->h_stage) hipHostFree(ix->h_stage);
-    hipFree(ix->d_pktX); hipFree(ix->d_pktY); hipFree(ix->d_xctl); hipFree(ix->d_xprog); hipFree(ix->d_wmap);
+    hipFree(ix->d_pkt); hipFree(ix->d_xctl); hipFree(ix->d_xprog); hipFree(ix->d_wmap);
     if (ix->h_xprog) hipHostFree(ix->h_xprog);
     for (auto& e : ix->evX) if (e) hipEventDestroy(e);
     for (auto& e : ix->evStage) if (e) hipEventDestroy(e);
@@ -1012,7 +1012,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         (ix->tune.expand > 0 || (ix->tune.expand < 0 && S->numRoots >= (1ull << 20)))) {
         wmapHost = make_wmap(plan.nStrands, plan.nSearches, firstItem, nItems);
         S->itemsPerBlock = (uint32_t)wmapHost.size();
-        S->expandBlocks = ix->tune.expandChunk > 0 ? (uint32_t)ix->tune.expandChunk : std::max<uint32_t>(1u, 1024u / std::max<uint32_t>(S->itemsPerBlock, 1u));
+        S->expandBlocks = ix->tune.expandChunk > 0 ? (uint32_t)ix->tune.expandChunk : std::max<uint32_t>(1u, 2048u / std::max<uint32_t>(S->itemsPerBlock, 1u));   // (about 2048 work items: the chunk counter is ONE address, good for ~15 M returning atomics a second -- with 1024 items per chunk it was the limit of phase A; the packets of a chunk are neighbours in the lists, and long runs of neighbours make the walker's pools uneven)
         S->expandBlocks = std::min<uint32_t>(S->expandBlocks, (1u << 22) / std::max<uint32_t>(S->itemsPerBlock, 1u));   // (work items of a chunk are numbered in 32 bits)
         S->totalChunks = (S->numBlocksCall + S->expandBlocks - 1) / S->expandBlocks;
         S->pktChunks = pkt_chunks_for(p->K, plan.stepSize);
@@ -1288,57 +1288,58 @@ static int run_expand(gm_index* ix, const SearchSetup& S, SearchArgs A, const gm
         GM_HIP(hipHostMalloc(&ix->h_xprog, 4 * sizeof(ExpandProgress)));
         for (int i = 0; i < 4; ++i) GM_HIP(hipEventCreateWithFlags(&ix->evX[i], hipEventDisableTiming));
     }
-    // packet buffers: X (patterns without / with one substitution, from its two ends) and Y (two or more); kept between calls, grown on demand
+    // packet buffers: X (patterns without / with one substitution, from its two ends) and Y (two or more) are the two parts of ONE allocation
+    // that is kept between calls and only ever grows
+    const bool twoPlus = p->E >= 2;
+    const uint64_t have = ix->pktCap * 16ull;
     uint64_t budget;
     if (ix->tune.expandMB > 0) budget = (uint64_t)ix->tune.expandMB << 20;
     else {
         size_t freeB = 0, totalB = 0;
         if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) freeB = 0;
-        const uint64_t have = (ix->pktXCap + ix->pktYCap) * 16ull;
-        budget = std::min<uint64_t>((freeB + have) / 3, 12ull << 30);
-        budget = std::max<uint64_t>(budget, have);                 // (never shrink below what is there)
+        budget = std::max<uint64_t>(std::min<uint64_t>((freeB + have) / 3, 12ull << 30), have);   // (never below what is there)
     }
     // what the call can use at all: every (work item, rotation) a packet (64 per item at most), rounded up generously
     const uint64_t worstPackets = std::min<uint64_t>(S.numBlocksCall * (uint64_t)S.itemsPerBlock * 64ull + (1u << 20), 1ull << 31);
-    const bool twoPlus = p->E >= 2;
     uint64_t pkts = std::min<uint64_t>(budget / (16ull * U), worstPackets + (twoPlus ? worstPackets : 0));
-    pkts = std::min<uint64_t>(pkts, (1ull << 31) - 1);
-    uint64_t capY = twoPlus ? pkts * 3 / 5 : 4ull * XREGION, capX = twoPlus ? pkts - capY : pkts;
-    capX = std::max<uint64_t>(capX, 16ull * XREGION); capY = std::max<uint64_t>(capY, 4ull * XREGION);
-    {
-        const uint64_t needX = capX * U, needY = capY * U;
-        if (ix->pktXCap < needX) { uint4* d = nullptr; if (ix->d_pktX) { hipFree(ix->d_pktX); ix->d_pktX = nullptr; ix->pktXCap = 0; } if (hipMalloc(&d, needX * 16) != hipSuccess) { (void)hipGetLastError(); set_error("no device memory for %llu node packets", (unsigned long long)capX); return GM_ERR_OOM; } GM_HIP(hipMemsetAsync(d, 0, needX * 16, st)); ix->d_pktX = d; ix->pktXCap = needX; }
-        if (ix->pktYCap < needY) { uint4* d = nullptr; if (ix->d_pktY) { hipFree(ix->d_pktY); ix->d_pktY = nullptr; ix->pktYCap = 0; } if (hipMalloc(&d, needY * 16) != hipSuccess) { (void)hipGetLastError(); set_error("no device memory for %llu node packets", (unsigned long long)capY); return GM_ERR_OOM; } GM_HIP(hipMemsetAsync(d, 0, needY * 16, st)); ix->d_pktY = d; ix->pktYCap = needY; }
-    }
-    A.pktX = ix->d_pktX; A.pktY = ix->d_pktY; A.capX = (uint32_t)capX; A.capY = (uint32_t)capY;
-    if (ix->pktUnits != U) {   // packets of another size lie in the buffers: a slot's stamp word would be somebody's window symbols
-        if (ix->pktUnits) { GM_HIP(hipMemsetAsync(ix->d_pktX, 0, ix->pktXCap * 16, st)); GM_HIP(hipMemsetAsync(ix->d_pktY, 0, ix->pktYCap * 16, st)); }
-        ix->pktUnits = U;
-    }
-    A.xctl = reinterpret_cast<ExpandCtl*>(ix->d_xctl);
-    ExpandProgress* prog = reinterpret_cast<ExpandProgress*>(ix->d_xprog);
-    ExpandProgress* hprog = reinterpret_cast<ExpandProgress*>(ix->h_xprog);
     // phase A: as many wavefronts as the device holds, but no more than leave three quarters of a buffer to packets (a wavefront keeps one
     // open region per class)
     int perCU = 0;
     GM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, expand_kernel, 256, 0));
     perCU = std::max(1, std::min(perCU, 8));
-    uint64_t blocksA = (uint64_t)ix->numCU * (uint64_t)perCU;
-    const uint64_t smaller = twoPlus ? std::min(capX, capY) : capX;
-    blocksA = std::max<uint64_t>(1, std::min<uint64_t>(blocksA, smaller / (4ull * 4ull * XREGION)));
-    blocksA = std::min<uint64_t>(blocksA, std::max<uint64_t>(1, (S.totalChunks + 3) / 4));
-    {   // one block of work at its worst (64 rotations per item) must fit a quarter of either buffer beside the open regions: grow tiny buffers
-        const uint64_t floorCap = 4ull * (uint64_t)S.itemsPerBlock * 64ull + 2ull * blocksA * 4ull * XREGION;
-        if (capX < floorCap || (twoPlus && capY < floorCap)) {
-            capX = std::max<uint64_t>(capX, floorCap); if (twoPlus) capY = std::max<uint64_t>(capY, floorCap);
-            const uint64_t needX = capX * U, needY = capY * U;
-            if (ix->pktXCap < needX) { uint4* d = nullptr; if (ix->d_pktX) { hipFree(ix->d_pktX); ix->d_pktX = nullptr; ix->pktXCap = 0; } if (hipMalloc(&d, needX * 16) != hipSuccess) { (void)hipGetLastError(); set_error("no device memory for %llu node packets", (unsigned long long)capX); return GM_ERR_OOM; } GM_HIP(hipMemsetAsync(d, 0, needX * 16, st)); ix->d_pktX = d; ix->pktXCap = needX; }
-            if (ix->pktYCap < needY) { uint4* d = nullptr; if (ix->d_pktY) { hipFree(ix->d_pktY); ix->d_pktY = nullptr; ix->pktYCap = 0; } if (hipMalloc(&d, needY * 16) != hipSuccess) { (void)hipGetLastError(); set_error("no device memory for %llu node packets", (unsigned long long)capY); return GM_ERR_OOM; } GM_HIP(hipMemsetAsync(d, 0, needY * 16, st)); ix->d_pktY = d; ix->pktYCap = needY; }
-            A.pktX = ix->d_pktX; A.pktY = ix->d_pktY; A.capX = (uint32_t)capX; A.capY = (uint32_t)capY;
+    if (ix->tune.expandOcc > 0) perCU = ix->tune.expandOcc;   // (measurement: blocks of phase A per CU, resident or not)
+    uint64_t blocksA = std::min<uint64_t>((uint64_t)ix->numCU * (uint64_t)perCU, std::max<uint64_t>(1, (S.totalChunks + 3) / 4));
+    blocksA = std::max<uint64_t>(1, std::min<uint64_t>(blocksA, (twoPlus ? pkts * 2 / 5 : pkts) / (4ull * 4ull * XREGION)));
+    // one block of work at its worst (64 rotations per item) must fit a quarter of either buffer beside the open regions: tiny budgets are raised
+    const uint64_t floorCap = 4ull * (uint64_t)S.itemsPerBlock * 64ull + 2ull * blocksA * 4ull * XREGION;
+    pkts = std::max<uint64_t>(pkts, twoPlus ? floorCap * 5 / 2 + 16 : floorCap);
+    pkts = std::min<uint64_t>(pkts, (1ull << 31) - 1);
+    if (ix->pktCap < pkts * U) {
+        uint4* d = nullptr;
+        if (hipMalloc(&d, pkts * U * 16) != hipSuccess) {
+            (void)hipGetLastError();
+            if (ix->pktCap / U < (twoPlus ? floorCap * 5 / 2 + 16 : floorCap)) { set_error("no device memory for %llu node packets", (unsigned long long)pkts); return GM_ERR_OOM; }
+            pkts = ix->pktCap / U;       // (what is there will do: more, smaller slices)
+        } else {
+            if (ix->d_pkt) GM_HIP(hipFree(ix->d_pkt));   // (synchronises with the device: nothing reads the old buffer any more)
+            GM_HIP(hipMemsetAsync(d, 0, pkts * U * 16, st));
+            ix->d_pkt = d; ix->pktCap = pkts * U; ix->pktUnits = U;
         }
+    } else if (ix->tune.expandMB <= 0) pkts = ix->pktCap / U;        // (everything that is there; a forced budget -- tests -- uses its share of it)
+    if (ix->pktUnits != U) {   // packets of another size lie in the buffer: a slot's stamp word would be somebody's window symbols
+        GM_HIP(hipMemsetAsync(ix->d_pkt, 0, ix->pktCap * 16, st));
+        ix->pktUnits = U;
     }
+    pkts = std::min<uint64_t>(pkts, (1ull << 31) - 1);
+    uint64_t capY = twoPlus ? pkts * 3 / 5 : 0, capX = pkts - capY;
+    if (!twoPlus) capY = 0;
+    A.pktX = ix->d_pkt; A.pktY = ix->d_pkt + capX * U; A.capX = (uint32_t)capX; A.capY = (uint32_t)std::max<uint64_t>(capY, XREGION);   // (capY is never reached with one substitution at most: no class-2 packet exists)
+    if (!twoPlus) A.pktY = ix->d_pkt;
+    A.xctl = reinterpret_cast<ExpandCtl*>(ix->d_xctl);
+    ExpandProgress* prog = reinterpret_cast<ExpandProgress*>(ix->d_xprog);
+    ExpandProgress* hprog = reinterpret_cast<ExpandProgress*>(ix->h_xprog);
     const uint64_t slack = blocksA * 4ull * XREGION;
-    const uint32_t usableX = (uint32_t)(capX - std::min<uint64_t>(slack, capX / 2)), usableY = (uint32_t)(capY - std::min<uint64_t>(twoPlus ? slack : 0, capY / 2));
+    const uint32_t usableX = (uint32_t)(capX - std::min<uint64_t>(slack, capX / 2)), usableY = twoPlus ? (uint32_t)(capY - std::min<uint64_t>(slack, capY / 2)) : 0xFFFFFFFFu;   // (no packet of the third class exists with one substitution at most)
     // A chunk is the unit that is redone when its packets do not fit: whatever a chunk can produce at most (64 rotations per work item) must fit
     // half a buffer, or a slice could fail on its first chunk for ever.  (Only the tiny buffers of the tests ever shorten a chunk.)
     const uint64_t usableMin = std::min<uint64_t>(usableX, twoPlus ? usableY : usableX);
@@ -2015,7 +2016,7 @@ int gm_index_set_tuning(gm_index* ix, const char* name, int64_t value)
         {"iter_cap", &ix->tune.iterCap, dflt.iterCap, 1, 0x7FFFFFFF}, {"stall_cap", &ix->tune.stallCap, dflt.stallCap, 1, 0x7FFFFFFF},   // bounds of a hung search loop (tests force them)
         {"pat_batch", &ix->tune.patBatch, dflt.patBatch, 1, 64},
         {"expand", &ix->tune.expand, dflt.expand, 0, 1}, {"expand_mb", &ix->tune.expandMB, dflt.expandMB, 1, 1 << 20},   // the split search (gm_expand.h)
-        {"expand_chunk", &ix->tune.expandChunk, dflt.expandChunk, 1, 1 << 16}, {"sat_draw_w", &ix->tune.satDrawW, dflt.satDrawW, 0, 0x7FFFFFFF},
+        {"expand_chunk", &ix->tune.expandChunk, dflt.expandChunk, 1, 1 << 16}, {"expand_occ", &ix->tune.expandOcc, dflt.expandOcc, 1, 64}, {"sat_draw_w", &ix->tune.satDrawW, dflt.satDrawW, 0, 0x7FFFFFFF},
         {"jump_groups", &ix->tune.jumpGroups, dflt.jumpGroups, 0, 1},   // groups of jump patterns behind the existence bitmap: 0 never, 1 wherever possible, -1 where they save table reads
     };
     for (auto& t : tab) if (!strcmp(t.n, name)) {

@@ -144,6 +144,31 @@ GM_HD bool expand_next(XItem& it, uint32_t& rw)
     return true;
 }
 
+// position of the k-th set bit of m (k = 0: the lowest; k < popcount(m)): bisection, no loop over the bits
+GM_HD uint32_t nth_set_bit(unsigned long long m, uint32_t k)
+{
+    uint32_t pos = 0;
+    for (uint32_t w = 32u; w >= 1u; w >>= 1) {
+        const unsigned long long part = (m >> pos) & ((1ull << w) - 1ull);
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t c = (uint32_t)__popcll(part);
+#else
+        const uint32_t c = (uint32_t)__builtin_popcountll(part);
+#endif
+        if (k >= c) { k -= c; pos += w; }
+    }
+    return pos;
+}
+// rotation word number k of an item (expand_kernel deals the rotations of 64 items out to the lanes of the wavefront: lane j takes the j-th)
+GM_HD uint32_t expand_count(const XItem& it) { return it.state == 1u ? 1u : it.state == 3u ?
+#if defined(__HIP_DEVICE_COMPILE__)
+    (uint32_t)__popcll(it.alive)
+#else
+    (uint32_t)__builtin_popcountll(it.alive)
+#endif
+    : 0u; }
+GM_HD uint32_t expand_nth(uint32_t gcur, uint32_t sh, bool plain, unsigned long long alive, uint32_t k) { return plain ? gcur : gcur | nth_set_bit(alive, k) << sh; }
+
 // A table entry {fwd lo, rev lo, width, neighbour word} of the J-mer with rotation word rw applied -> a node at depth J, or nothing.
 // jm0: meta of the node at depth J without errors; h: 4th word of the search's jump record (which neighbours count).
 // (search_body part A of round 5, line by line: the one-row and the two-row neighbour filter)

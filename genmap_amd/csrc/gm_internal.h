@@ -39,6 +39,7 @@ struct Tuning {
     int expand = -1;                   // -1: where it pays (gm_api.hip: prepare_search), 0: never (the one-loop kernel of rounds 3-5), 1: whenever the call has jump patterns
     int expandMB = -1;                 // MiB of packet buffers (-1: a share of the free device memory); tests force small ones: many slices, overflowing chunks
     int expandChunk = -1;              // k-mer blocks per chunk of phase A (-1: about a thousand work items)
+    int expandOcc = -1;                // blocks of phase A per CU (-1: what the occupancy query says, at most 8)
     int satDrawW = -1;                 // the walker drops a drawn node at least this wide when its block's k-mers are all at MAX (-1: 16)
 };
 }  // namespace gm
@@ -113,7 +114,7 @@ struct gm_index {
     gm_map_stats stats{};
     // ---- jump patterns and the correction pass of N-less frequency calls (gm_oss.h, gm_engine.h: Env::NLESS) ----
     // ---- the split search (gm_expand.h): node packets, control blocks, progress readback ----
-    uint4* d_pktX = nullptr; uint4* d_pktY = nullptr; uint64_t pktXCap = 0, pktYCap = 0;   // in uint4 units
+    uint4* d_pkt = nullptr; uint64_t pktCap = 0;   // node packets (X part | Y part), in uint4 units
     void* d_xctl = nullptr; void* d_xprog = nullptr; void* h_xprog = nullptr;              // ExpandCtl, ExpandProgress (gm_kernels.h); 4 page-locked copies
     hipEvent_t evX[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t* d_wmap = nullptr; uint64_t wmapCap = 0;

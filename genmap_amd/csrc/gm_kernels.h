@@ -26,20 +26,27 @@ namespace gm {
 struct ExpandCtl {
     unsigned long long nextChunk;        // work counter of phase A
     unsigned long long tailsX;           // packets reserved in X: class 0 | class 1 << 32
-    unsigned long long walkCounter;      // work counter of the walker (phase B)
+    unsigned long long walkCounter;      // (unused: the walker's counters are the stripes below)
     unsigned long long chunkBegin, chunkEnd;
     uint32_t tailY, failFrom;
     uint32_t valid[3];                   // per class: end of the last reservation that fitted (fit is monotone in the order of the atomics)
     uint32_t stamp;
     uint32_t t[3];                       // what the walker draws: valid[] at the end of phase A
     uint32_t pad;
+    // The walker's work counters.  Packets are drawn in pools of WORK_CHUNK_NODES; pool number c * XSTRIPES + j comes from stripe j's
+    // counter.  One counter would be asked 13 M times a second at K=30 e=2 -- all a single address serves -- and larger pools leave the
+    // wavefronts of a slice finishing far apart (2048 per pool: 137 -> 238 ms); a wavefront starts at its own stripe and moves on to the
+    // next when one has run out, so the stripes also even each other out at the end of a slice.
+    unsigned long long walk[16 * 16];    // stripe j at walk[16 j]: 128 bytes apart
 };
+constexpr uint32_t XSTRIPES = 16;
 struct ExpandProgress {
     unsigned long long committed;        // chunks of the call that are done (searched, or handed to a walker launch queued behind)
     unsigned long long totalChunks;
     uint32_t stampCounter, slices, lastChunks, lastX, lastY, pad;
 };
-constexpr uint32_t XREGION = 256;        // packets per reservation
+constexpr uint32_t XREGION = 1024;       // packets per reservation (a returning device-scope atomic on ONE address: the part serves ~15 M of them per second --
+                                         // measured: phase A with chunks of 4 / 18 / 72 blocks 335 / 132 / 75 ms, profiles/r06 -- so every counter here is drawn from rarely)
 
 struct SearchArgs {
     const uint32_t* blk[2];     // rank blocks: [0] forward BWT (extend left), [1] reverse BWT (extend right)
@@ -275,6 +282,7 @@ constexpr uint32_t STEAL_LEVELS = 16;  // a lane gives away at most this many bo
 // group / a MID group, the current set of live rotations belongs to a MID group; bits 8..11 the two letters behind the J-mer, bit 12: both are letters
 // (JF_* flags of the pattern-fetch state, item_layout, jump_decide: gm_oss.h -- shared with the CPU harness)
 constexpr uint32_t WORK_CHUNK = 256;   // roots taken from the global counter per atomic
+constexpr uint32_t WORK_CHUNK_NODES = 256;    // node packets per pool of the walker of the split search (striped counters: ExpandCtl::walk)
 constexpr uint32_t VERIFY_TMAX = 16;   // widest range resolved by verification
 constexpr uint32_t VERIFY_ROWS = 2;    // rows of one node queued per iteration at most (SearchArgs::verifyRows; the rest waits on the lane's stack)
 
@@ -1094,6 +1102,8 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     // the walker of the split search (Env::NODES): what phase A left for this slice (wave-uniform), and the header of the packet in flight
     uint32_t xt0 = 0, xt1 = 0, xwork = 0, xfail = 0, xstamp = 0;
     uint4 ph0 = make_uint4(0, 0, 0, 0), ph1 = make_uint4(0, 0, 0, 0);
+    uint32_t satA = 0, satB = 0; bool satPend = false;   // the saturation test of a freshly drawn packet: two counters in flight
+    uint32_t xstripe = (blockIdx.x * 4u + (threadIdx.x >> 6)) % XSTRIPES, xtried = 0;   // wave-uniform: the stripe this wavefront draws from, stripes it has found empty
     if constexpr (EnvT::NODES) {
         const ExpandCtl* xc = A.xctl;
         xt0 = xc->t[0]; xt1 = xc->t[1]; xwork = xt0 + xt1 + xc->t[2]; xfail = xc->failFrom; xstamp = xc->stamp;
@@ -1103,6 +1113,12 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
     // gives up, raises the sticky error flag and the host reports GM_ERR_INTERNAL instead of waiting for ever.
     uint32_t itGuard = 0;
     for (;;) {
+        if constexpr (EnvT::NODES) {
+            if (satPend) {   // the packet drawn two iterations ago has taken one step; its block's counters have arrived
+                satPend = false;
+                if (satA >= A.maxVal && satB >= A.maxVal && env.saturated(rt, 0u, rt.n - 1u)) { have = false; env.sp = 0u; env.sbase = 0u; }   // (its stack held this packet's nodes only: a lane draws with an empty stack)
+            }
+        }
 #ifndef GM_POP_LOOP
         if (!have && env.sp > 0) {   // one pop per iteration: a node dropped as saturated costs the lane one idle turn
 #else
@@ -1272,9 +1288,15 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                     rt.rec.x = q.x; rt.rec.y = q.y; rt.rec.z = q.z; rt.rec.w = q.w;
                     env.woff = 0u; env.on_root();
                     have = true; w1run = 0;
-                    // every k-mer of the block at MAX already (the lists come in the order of the patterns' substitutions: by the time a pattern
-                    // with errors is drawn, what the exact pattern of its root has found is in the accumulators): nothing below can change the result
-                    if (nd.w >= A.satDrawW) have = !env.saturated(rt, 0u, rt.n - 1u);
+                    // Every k-mer of the block at MAX already (the lists come in the order of the patterns' substitutions: by the time a pattern
+                    // with errors is drawn, what the exact pattern of its root has found is in the accumulators)?  Then nothing below can change
+                    // the result.  The block's first and last counter are requested here and looked at in the NEXT iteration (the step below waits
+                    // for its rank blocks anyway): a blocking test stalled the wavefront for a memory round trip per drawn packet -- K=30 e=1 2.1x slower.
+                    if (nd.w >= A.satDrawW) {
+                        satA = __hip_atomic_load(&A.acc[rt.win], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        satB = __hip_atomic_load(&A.acc[rt.win + rt.n - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        satPend = true;
+                    }
                 }
             }
         }
@@ -1627,6 +1649,7 @@ __global__ void expand_slice_begin_kernel(ExpandProgress* prog, ExpandCtl* ctl, 
     if (r > maxChunks) r = maxChunks;
     ctl->chunkBegin = begin; ctl->chunkEnd = begin + r < total ? begin + r : total;
     ctl->nextChunk = begin; ctl->tailsX = 0ull; ctl->tailY = 0u; ctl->failFrom = 0xFFFFFFFFu; ctl->walkCounter = 0ull;
+    for (uint32_t j = 0; j < XSTRIPES; ++j) ctl->walk[16u * j] = 0ull;
     ctl->valid[0] = ctl->valid[1] = ctl->valid[2] = 0u; ctl->t[0] = ctl->t[1] = ctl->t[2] = 0u;
     ctl->stamp = ++prog->stampCounter;
 }
@@ -1655,11 +1678,16 @@ __global__ __launch_bounds__(256) void expand_kernel(const SearchArgs A)
         __device__ __forceinline__ void pair(uint64_t i, uint64_t& lo, uint64_t& hi) const { const u64x2 v = *reinterpret_cast<const u64x2*>(t + i); lo = v.x; hi = v.y; }
     } mem{reinterpret_cast<const unsigned long long*>(A.text4)};
     __shared__ uint4 jl[28];
+    __shared__ uint4 cx0s[256], cx1s[256];   // per lane of a batch: {J-mer index, neighbours, meta at depth J, filter mask}, {window origin, root word, the item's own rotations, layout shift | flags}
+    __shared__ uint2 cx2s[256];              // ... the item's surviving rotations
+    __shared__ uint32_t pres[256];           // ... rotations of the lanes before it
     load_jump_records(jl, A);
     if (threadIdx.x < 8u) jl[20u + threadIdx.x] = A.table[(size_t)(A.stepSize - 1u) * 8u + threadIdx.x];
     __syncthreads();
     const LdsTab tab{jl};
     const uint32_t lane = threadIdx.x & 63u;
+    uint4* const cx0 = cx0s + (threadIdx.x & ~63u); uint4* const cx1 = cx1s + (threadIdx.x & ~63u);
+    uint2* const cx2 = cx2s + (threadIdx.x & ~63u); uint32_t* const pre = pres + (threadIdx.x & ~63u);
     ExpandCtl* const ctl = A.xctl;
     const uint32_t U = PKT_HEADER_UNITS + A.pktChunks;
     const uint32_t G = A.expandBlocks, IPB = A.itemsPerBlock;
@@ -1720,32 +1748,58 @@ __global__ __launch_bounds__(256) void expand_kernel(const SearchArgs A)
                     }
                 }
             }
+            // ---- the rotations of the 64 items, dealt out anew: lane j takes the j-th rotation of the batch, so that a turn of the loop reads 64
+            // table entries whatever the items' sizes (an item has 0 .. 64 surviving rotations: with one item per lane a turn lasted as long as a
+            // memory round trip and there were as many turns as the largest item had rotations -- 127 ms of a 283 ms pass, profiles/r06) ----
+            uint32_t cnt = 0;
+            if (pendRoot) cnt = 1u;
+            else if (on && !xr.bad) cnt = expand_count(it);
+            uint32_t incl = cnt;
+#pragma unroll
+            for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)incl, (int)d); if (lane >= d) incl += up; }
+            const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+            if (total == 0u) continue;
+            // the lanes' contexts and the exclusive prefix sums of their counts, in LDS (this wavefront's 64 slots)
+            cx0[lane] = make_uint4(xr.jb, xr.jn, jm0, hword);
+            cx1[lane] = make_uint4(win, nss, it.gcur, it.sh | (pendRoot ? 0x100u : 0u) | (it.state == 1u ? 0x200u : 0u));
+            cx2[lane] = make_uint2((uint32_t)it.alive, (uint32_t)(it.alive >> 32));
+            pre[lane] = incl - cnt;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll 1
-            for (;;) {
-                const bool more = on && !xr.bad && (it.state == 1u || (it.state == 3u && it.alive != 0ull));
-                if (__ballot(more || pendRoot) == 0ull) break;
+            for (uint32_t t0 = 0; t0 < total; t0 += 64u) {
+                const uint32_t g = t0 + lane;
                 bool take = false;
-                uint32_t cls = 0;
+                uint32_t cls = 0, pwin = 0, pnss = 0;
                 uint4 h0 = make_uint4(0, 0, 0, 0);
-                if (more) {
-                    uint32_t rw = 0;
-                    expand_next(it, rw);
-                    const uint4 e = A.jtab[rot_add(xr.jb, rw)];
-                    const XNode x = expand_filter(e.x, e.y, e.z, e.w, rw, jm0, xr.jn, hword, A.E, A.nbFilter, A.verifyT);
+                if (g < total) {
+                    uint32_t src = 0;   // the last lane whose first rotation is <= g (lanes without rotations share their successor's start)
+#pragma unroll
+                    for (uint32_t step = 32u; step >= 1u; step >>= 1) if (pre[src | step] <= g) src |= step;
+                    const uint32_t k = g - pre[src];
+                    const uint4 c0 = cx0[src], c1 = cx1[src];
+                    pwin = c1.x; pnss = c1.y;
+                    if (c1.w & 0x100u) {   // an odd block shape or an N inside the J-mer: the root itself (root_node, gm_engine.h)
+                        take = true; cls = 0u;
+                        const uint32_t n = pnss & 0xFFu, search = (pnss >> 9) & 7u;
+                        const uint32_t a = n - 1u + ((A.table[(size_t)(n - 1u) * 8u + search].y >> 16) & 0xFFu);
+                        h0 = make_uint4(0u, 0u, (uint32_t)A.nRows, meta_pack(a, a, 0u, 0u, M_OSS));
+                    } else {
+                        const uint2 av = cx2[src];
+                        const uint32_t rw = expand_nth(c1.z, c1.w & 31u, (c1.w & 0x200u) != 0u, (unsigned long long)av.y << 32 | av.x, k);   // the k-th surviving rotation of the item
+                        const uint4 e = A.jtab[rot_add(c0.x, rw)];
+                        const XNode x = expand_filter(e.x, e.y, e.z, e.w, rw, c0.z, c0.y, c0.w, A.E, A.nbFilter, A.verifyT);
 #ifdef GM_COUNTERS
-                    cJumps++;
-                    if (!x.take && e.z == 1u) cDrops++;
-                    if (e.z == 2u && (xr.jn & 0x8000u) && A.nbFilter == 1u) cDrops2 += x.take ? (x.rlo == ~0u ? 1u : 0u) : 2u;
+                        cJumps++;
+                        if (!x.take && e.z == 1u) cDrops++;
+                        if (e.z == 2u && (c0.y & 0x8000u) && A.nbFilter == 1u) cDrops2 += x.take ? (x.rlo == ~0u ? 1u : 0u) : 2u;
 #endif
-                    take = x.take != 0u;
-                    h0 = make_uint4(x.flo, x.rlo, x.w, x.meta); cls = expand_class(x.errs);
-                    // (self hits -- forward strand, no error spent, one row: the window's own location -- stay with the walker: a chunk of phase A that
-                    //  does not fit its buffers is redone by the next slice, and an add into the difference plane cannot be taken back)
-                } else if (pendRoot) {
-                    pendRoot = false; take = true; cls = 0u;
-                    const uint32_t n = nss & 0xFFu, search = (nss >> 9) & 7u;
-                    const uint32_t a = n - 1u + ((A.table[(size_t)(n - 1u) * 8u + search].y >> 16) & 0xFFu);   // root_node (gm_engine.h)
-                    h0 = make_uint4(0u, 0u, (uint32_t)A.nRows, meta_pack(a, a, 0u, 0u, M_OSS));
+                        take = x.take != 0u;
+                        h0 = make_uint4(x.flo, x.rlo, x.w, x.meta); cls = expand_class(x.errs);
+                        // (self hits -- forward strand, no error spent, one row: the window's own location -- stay with the walker: a chunk of phase A
+                        //  that does not fit its buffers is redone by the next slice, and an add into the difference plane cannot be taken back)
+                    }
                 }
                 // ---- append: every class in turn, all lanes in step ----
 #pragma unroll
@@ -1753,14 +1807,14 @@ __global__ __launch_bounds__(256) void expand_kernel(const SearchArgs A)
                     const bool mine = take && cls == c;
                     const unsigned long long m = __ballot(mine);
                     if (m == 0ull) continue;
-                    const uint32_t cnt = (uint32_t)__popcll(m), room = XREGION - ru[c];
+                    const uint32_t cntc = (uint32_t)__popcll(m), room = XREGION - ru[c];
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                     uint32_t nbase = 0xFFFFFFFFu;
-                    if (cnt > room) {   // a new region for this class: ONE atomic per XREGION packets
+                    if (cntc > room) {   // a new region for this class: ONE atomic per XREGION packets
                         if (lane == 0u) {
                             if (c == 2u) {
-                                const uint32_t b = atomicAdd(&ctl->tailY, XREGION);
-                                if (b <= A.capY - XREGION) { nbase = b; atomicMax(&ctl->valid[2], b + XREGION); }
+                                const uint32_t b2 = atomicAdd(&ctl->tailY, XREGION);
+                                if (b2 <= A.capY - XREGION) { nbase = b2; atomicMax(&ctl->valid[2], b2 + XREGION); }
                             } else {
                                 const unsigned long long old = atomicAdd(&ctl->tailsX, c == 0u ? (unsigned long long)XREGION : (unsigned long long)XREGION << 32);
                                 const uint32_t b0 = (uint32_t)old, b1 = (uint32_t)(old >> 32);
@@ -1774,19 +1828,20 @@ __global__ __launch_bounds__(256) void expand_kernel(const SearchArgs A)
                         const uint32_t slot = rank < room ? rb[c] + ru[c] + rank : nbase + (rank - room);
                         uint4* pk = (c == 2u ? A.pktY : A.pktX) + (size_t)(c == 1u ? A.capX - 1u - slot : slot) * U;
                         pk[0] = h0;
-                        pk[1] = make_uint4(win, nss, (uint32_t)cid, stamp);
+                        pk[1] = make_uint4(pwin, pnss, (uint32_t)cid, stamp);
                         for (uint32_t j = 0; j < A.pktChunks; ++j) {
-                            const unsigned long long w0 = nib64(mem, A.textBegin + win + 32u * j), w1 = nib64(mem, A.textBegin + win + 32u * j + 16u);
+                            const unsigned long long w0 = nib64(mem, A.textBegin + pwin + 32u * j), w1 = nib64(mem, A.textBegin + pwin + 32u * j + 16u);
                             pk[2u + j] = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
                         }
 #ifdef GM_COUNTERS
                         cPackets++;
 #endif
                     }
-                    if (cnt > room) { rb[c] = nbase; ru[c] = cnt - room; } else ru[c] += cnt;
+                    if (cntc > room) { rb[c] = nbase; ru[c] = cntc - room; } else ru[c] += cntc;
                 }
                 if (dead) break;
             }
+            __builtin_amdgcn_wave_barrier();   // (the next batch overwrites the contexts)
         }
         if (dead) { if (lane == 0u) atomicMin(&ctl->failFrom, (uint32_t)cid); break; }   // this chunk (and every later one) is redone by the next slice
     }

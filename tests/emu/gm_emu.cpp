@@ -358,8 +358,11 @@ static void search_plan(const MapPlan& plan, const HostIndex<WPP>& ix, Env& env,
             }
             const uint32_t off = rt.n - 1u;
             const uint32_t jm0 = meta_pack((js.meta0 & 0x1FFu) + off, ((js.meta0 >> 9) & 0x1FFu) + off, js.meta0 >> 18, 0u, M_OSS);
-            uint32_t rw;
-            while (expand_next(it, rw)) {
+            const XItem it0 = it;
+            for (uint32_t kk = 0, nrot = expand_count(it0); kk < nrot; ++kk) {
+                // the device deals the rotations of 64 items out to its lanes (expand_nth: the k-th surviving rotation); the item's own iterator must agree
+                const uint32_t rw = expand_nth(it0.gcur, it0.sh, it0.state == 1u, it0.alive, kk);
+                { uint32_t rw2 = 0; if (!expand_next(it, rw2) || rw2 != rw) g_hangs += 1000000; }
                 uint32_t flo, rlo, w;
                 table_entry<WPP>(ix, rot_add(xr.jb, rw), J, flo, rlo, w);
                 if (nPatterns) ++*nPatterns;

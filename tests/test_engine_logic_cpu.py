@@ -378,6 +378,8 @@ def test_phase_a_node_packets_and_neighbour_filters(K, E):
         iv = [(40, 900), (2400, 2600), (4100, 4500)]
         out3, _ = emu_map2(ix, 1, K, E, value_bits=16, verify_t=1, jump=15, intervals=iv)
         assert np.array_equal(out3, ix.mappability(K, E, value_bits=16, intervals=iv, threads=4))
+        e.gm_emu_hangs.restype = C.c_uint64
+        assert e.gm_emu_hangs(1) == 0      # expand_nth (the device's way to a rotation) agreed with the item's own iterator everywhere, every word address was right
     finally:
         e.gm_emu_set_expand(0); e.gm_emu_set_jump_groups(0); e.gm_emu_set_nb_filter(1)
 
