@@ -658,6 +658,12 @@ def main():
         # (a root that jumps reads one 16-byte table entry per pattern instead of the single q-mer entry: counted as jump_lookups)
         # ... and one 8-byte bitmap word per group of patterns: jump_words)
         alg = bb * sp["rank_lines"] + 16 * (d.get("jump_lookups", 0) or sp["roots"]) + 8 * d.get("jump_words", 0) + n + n + ver
+        # the split search (round 6): every node packet is written once by phase A and read once by the walker
+        step = rec["K"] - g.tuned_infix_length(rec["K"], rec["E"]) + 1
+        pkt_bytes = 16 * (2 + (rec["K"] + step - 1 + 31) // 32)
+        packets = d.get("packets", 0)
+        alg_strict = alg
+        alg += 2 * pkt_bytes * packets
         # N > 1: per GPU -- a rank's share of the bytes over the slowest rank's kernel time, against one GPU's peak
         ach = alg / world / (rec["kernel_ms"] * 1e-3) / 1e9
         # random requests the kernel issues (rank blocks, table entries, records) against the measured ceiling of the memory system
@@ -672,7 +678,8 @@ def main():
                 # counters tally 64 B per request at the fabric side of the L2, whatever the request's width); null when not collected
                 "traffic": tsum, "traffic_fetch_bytes": tr.get("FETCH_SIZE"), "traffic_write_bytes": tr.get("WRITE_SIZE"),
                 "traffic_over_algorithmic": (tsum / alg) if tsum else None,
-                "per_gpu": True, "kernel": "search_kernel", "kernel_ms": rec["kernel_ms"], "algorithmic_bytes": alg, "rank_lines": sp["rank_lines"],
+                "per_gpu": True, "kernel": "search_kernel" if not packets else "search phase of one pass: expand_kernel + search_kernel<CountEnv<..,2>> (walker) launches of its slices", "kernel_ms": rec["kernel_ms"], "algorithmic_bytes": alg, "rank_lines": sp["rank_lines"],
+                "node_packets": packets, "packet_bytes": pkt_bytes, "slices": d.get("slices", 0), "algorithmic_bytes_without_packets": alg_strict,
                 "roots": sp["roots"], "node_steps": sp["node_steps"], "node_steps_per_kmer": sp["node_steps"] / rec["num_kmers"],
                 "verify_items": d["verify_items"], "verify_chunks": d["verify_chunks"], "jump_lookups": d.get("jump_lookups", 0), "jump_words": d.get("jump_words", 0),
                 "lanes_with_node_per_iteration": d["active_lane_sum"] / max(1, d["wave_iterations"])}
@@ -711,13 +718,22 @@ def main():
                    "--workload", args.workload, "--scale", str(args.scale), "--sampling", str(args.sampling), "--reps", "1", "--cfg"] + [f"{K},{E},1.0" for K, E in cfgs] + ["--", ""]
             try:
                 subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900, env=dict(os.environ, TMPDIR="/tmp"), cwd=str(ROOT))
-                acc = {}
+                # the search phase of one pass = every search_kernel / expand_kernel dispatch (the split search of round 6 takes several per
+                # pass) up to the pass's finalize kernel; the correction pass (ScatterEnv) is not part of it
+                rows = []
                 for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
                     for r in csv.DictReader(open(f)):
-                        if "search_kernel" in r["Kernel_Name"] and "ScatterEnv" not in r["Kernel_Name"] and r["Counter_Name"] == counter:
-                            acc[int(r["Dispatch_Id"])] = acc.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
-                vals = [acc[k] for k in sorted(acc)]
-                for i, ke in enumerate(cfgs):   # two dispatches per configuration (a warm-up and one more): the second
+                        if r["Counter_Name"] == counter or "finalize" in r["Kernel_Name"]:
+                            rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"], float(r["Counter_Value"]) if r["Counter_Name"] == counter else 0.0))
+                rows.sort()
+                vals, cur, seen_fin = [], 0.0, set()
+                for did, name, v in rows:
+                    if "finalize" in name:
+                        if did not in seen_fin:
+                            seen_fin.add(did); vals.append(cur); cur = 0.0
+                    elif ("search_kernel" in name or "expand_kernel" in name) and "ScatterEnv" not in name:
+                        cur += v
+                for i, ke in enumerate(cfgs):   # two passes per configuration (a warm-up and one more): the second
                     if 2 * i + 1 < len(vals):
                         res.setdefault(ke, {})[counter] = vals[2 * i + 1] * 1024.0   # the counter is reported in KB
             except Exception as e:

@@ -360,6 +360,11 @@ void gm_index_free(gm_index* ix)
     hipFree(ix->d_pkt); hipFree(ix->d_xctl); hipFree(ix->d_xprog); hipFree(ix->d_wmap);
     if (ix->h_xprog) hipHostFree(ix->h_xprog);
     for (auto& e : ix->evX) if (e) hipEventDestroy(e);
+    if (ix->stXA) hipStreamDestroy(ix->stXA);
+    for (auto& q : ix->stXB) if (q) hipStreamDestroy(q);
+    for (auto& e : ix->evXA) if (e) hipEventDestroy(e);
+    for (auto& e : ix->evXB) if (e) hipEventDestroy(e);
+    if (ix->evXGo) hipEventDestroy(ix->evXGo);
     for (auto& e : ix->evStage) if (e) hipEventDestroy(e);
     if (ix->stCorr) hipStreamDestroy(ix->stCorr);
     if (ix->evCorrGo) hipEventDestroy(ix->evCorrGo);
@@ -828,7 +833,7 @@ struct SearchSetup {
     uint64_t posBase = 0, posEnd = 0;   // slice positions covered by the selected blocks: [posBase, posEnd)
     bool jump = false;                  // the call runs the N-less kernel (with jump patterns where they apply) + the correction pass
     // the split search (gm_expand.h): phase A enumerates the jump patterns of the call's blocks into node packets, the walker draws packets
-    bool expand = false;
+    bool expand = false, overlap = false;
     uint32_t itemsPerBlock = 0, expandBlocks = 0, pktChunks = 0;
     uint32_t rootWinChunks = 0;         // LDS chunks per lane of a kernel that stages the windows of ROOTS (any alignment): the correction pass beside a walker
     uint64_t numBlocksCall = 0, totalChunks = 0;
@@ -1009,10 +1014,10 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     S->expand = false;
     S->numBlocksCall = rpb ? S->numRoots / rpb : 0;
     if (jumpJ >= 1 && !ix->wide && !longK && S->numBlocksCall > 0 && patHost.size() < (1u << 24) &&
-        (ix->tune.expand > 0 || (ix->tune.expand < 0 && S->numRoots >= (1ull << 20)))) {
+        (ix->tune.expand > 0 || (ix->tune.expand < 0 && S->numRoots >= (1ull << 20) && p->K < 64u))) {   // (K=100 e=1 has 0.16 table reads per k-mer: nothing to split off -- its walker measured 150 ms against the 120 ms of the one-loop kernel on 30 % of 3.09 Gbp)
         wmapHost = make_wmap(plan.nStrands, plan.nSearches, firstItem, nItems);
         S->itemsPerBlock = (uint32_t)wmapHost.size();
-        S->expandBlocks = ix->tune.expandChunk > 0 ? (uint32_t)ix->tune.expandChunk : std::max<uint32_t>(1u, 2048u / std::max<uint32_t>(S->itemsPerBlock, 1u));   // (about 2048 work items: the chunk counter is ONE address, good for ~15 M returning atomics a second -- with 1024 items per chunk it was the limit of phase A; the packets of a chunk are neighbours in the lists, and long runs of neighbours make the walker's pools uneven)
+        S->expandBlocks = ix->tune.expandChunk > 0 ? (uint32_t)ix->tune.expandChunk : std::max<uint32_t>(1u, 8192u / std::max<uint32_t>(S->itemsPerBlock, 1u));   // (about 8192 work items: the chunk counter is ONE address, good for ~15 M returning atomics a second -- with 1024 items per chunk it was the limit of phase A; the packets of a chunk are neighbours in the lists, and long runs of neighbours make the walker's pools uneven)
         S->expandBlocks = std::min<uint32_t>(S->expandBlocks, (1u << 22) / std::max<uint32_t>(S->itemsPerBlock, 1u));   // (work items of a chunk are numbered in 32 bits)
         S->totalChunks = (S->numBlocksCall + S->expandBlocks - 1) / S->expandBlocks;
         S->pktChunks = pkt_chunks_for(p->K, plan.stepSize);
@@ -1053,7 +1058,10 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     // (long k-mers read their needle from the text; the walker of the split search stages the window of its packet, which starts at nibble 0)
     S->rootWinChunks = longK ? 1u : (31u + p->K + plan.stepSize - 1u + 31u) / 32u;
     const uint32_t winChunks = expand ? S->pktChunks : S->rootWinChunks;
-    const int wantPerCU = std::max(1, ix->tune.blocksPerCU);   // default 4 = 4 waves/SIMD, what the kernel's VGPR count allows
+    // (the split search runs phase A of the next slice BESIDE the walker: three walker blocks per CU leave the fourth slot -- registers and LDS -- to a block of phase A)
+    const bool overlap = expand && ix->tune.expandOverlap > 0;   // (off by default: phase A is not light enough on the vector ALU yet -- 3.09 Gbp K=30 e=2 236 ms side by side against 215 one after the other, profiles/r06)
+    S->overlap = overlap;
+    const int wantPerCU = std::max(1, overlap ? std::min(ix->tune.blocksPerCU, 3) : ix->tune.blocksPerCU);   // default 4 = 4 waves/SIMD, what the kernel's VGPR count allows
     const bool entrySlots = mayJump && !ix->wide && !expand;
     g_ldsPad = (uint32_t)std::max(0, ix->tune.ldsPad);
     auto lds_bytes_for = [&](uint32_t d) { return (size_t)g_ldsPad + (size_t)(4u * vqCap * nu + 4u * 64u * (d * nu + winChunks)) * 16u + 4u * 80u * 4u + 448u + (entrySlots ? 4096u : 0u) + (lqCap ? 4u * (lqCap * 16u + 80u * 4u) : 0u); };   // == search_lds_bytes
@@ -1236,7 +1244,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     for (uint32_t k = 0; k < 8u; ++k) { A.layShift[k] = layShift[k]; A.layPlane0[k] = layPlane0[k]; A.layPlane1[k] = layPlane1[k]; }
     A.tableL = longK ? ix->d_tableL : nullptr;
     A.pktChunks = S->pktChunks; A.wmap = ix->d_wmap; A.itemsPerBlock = S->itemsPerBlock; A.expandBlocks = S->expandBlocks; A.numBlocksCall = S->numBlocksCall;
-    A.satDrawW = (uint32_t)(ix->tune.satDrawW >= 0 ? ix->tune.satDrawW : 16);
+    A.satDrawW = (uint32_t)(ix->tune.satDrawW >= 0 ? ix->tune.satDrawW : 1);   // (3.09 Gbp K=30 e=2: 1 -> 267 ms, 4 -> 269, 16 -> 285, never -> 326 with the test's two counters requested at the draw and looked at an iteration later)
     if (longK) { A.lqCap = 0u; A.entrySlots = 0u; A.selfHit = 0u; A.spillDepth = depth; A.steal = ix->tune.steal >= 0 ? (uint32_t)std::min(ix->tune.steal, 2) : 2u; }   // (2: lanes share before every root draw, 3.09 Gbp K=300 e=1 +19 %, K=1000 e=1 +14 %, e=0 +4 % over sharing at the end only; profiles/r05/longk_scale.txt)
     A.sliceBegin = text_begin; A.sliceLen = text_len; A.ownBegin = 0; A.ownEnd = text_len; A.ownChunkLen = 0; A.selBlocks = nullptr; A.nSelBlocks = 0;
     *Aout = A;
@@ -1282,7 +1290,14 @@ static int run_expand(gm_index* ix, const SearchSetup& S, SearchArgs A, const gm
 {
     const uint32_t U = PKT_HEADER_UNITS + S.pktChunks;            // 16-byte units per packet
     if (!ix->d_xctl) {
-        GM_HIP(hipMalloc(&ix->d_xctl, sizeof(ExpandCtl)));
+        GM_HIP(hipMalloc(&ix->d_xctl, 2 * sizeof(ExpandCtl)));
+        GM_HIP(hipStreamCreateWithFlags(&ix->stXA, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            GM_HIP(hipStreamCreateWithFlags(&ix->stXB[i], hipStreamNonBlocking));
+            GM_HIP(hipEventCreateWithFlags(&ix->evXA[i], hipEventDisableTiming));
+            GM_HIP(hipEventCreateWithFlags(&ix->evXB[i], hipEventDisableTiming));
+        }
+        GM_HIP(hipEventCreateWithFlags(&ix->evXGo, hipEventDisableTiming));
         GM_HIP(hipMalloc(&ix->d_xprog, sizeof(ExpandProgress)));
         GM_HIP(hipMemset(ix->d_xprog, 0, sizeof(ExpandProgress)));
         GM_HIP(hipHostMalloc(&ix->h_xprog, 4 * sizeof(ExpandProgress)));
@@ -1307,9 +1322,10 @@ static int run_expand(gm_index* ix, const SearchSetup& S, SearchArgs A, const gm
     int perCU = 0;
     GM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, expand_kernel, 256, 0));
     perCU = std::max(1, std::min(perCU, 8));
+    if (S.overlap) perCU = 1;                                  // beside the walker: ONE block per CU takes the slot the walker's three blocks leave
     if (ix->tune.expandOcc > 0) perCU = ix->tune.expandOcc;   // (measurement: blocks of phase A per CU, resident or not)
     uint64_t blocksA = std::min<uint64_t>((uint64_t)ix->numCU * (uint64_t)perCU, std::max<uint64_t>(1, (S.totalChunks + 3) / 4));
-    blocksA = std::max<uint64_t>(1, std::min<uint64_t>(blocksA, (twoPlus ? pkts * 2 / 5 : pkts) / (4ull * 4ull * XREGION)));
+    blocksA = std::max<uint64_t>(1, std::min<uint64_t>(blocksA, (twoPlus ? pkts * 2 / 5 : pkts) / (S.overlap ? 2u : 1u) / (4ull * 4ull * XREGION)));
     // one block of work at its worst (64 rotations per item) must fit a quarter of either buffer beside the open regions: tiny budgets are raised
     const uint64_t floorCap = 4ull * (uint64_t)S.itemsPerBlock * 64ull + 2ull * blocksA * 4ull * XREGION;
     pkts = std::max<uint64_t>(pkts, twoPlus ? floorCap * 5 / 2 + 16 : floorCap);
@@ -1331,10 +1347,17 @@ static int run_expand(gm_index* ix, const SearchSetup& S, SearchArgs A, const gm
         ix->pktUnits = U;
     }
     pkts = std::min<uint64_t>(pkts, (1ull << 31) - 1);
-    uint64_t capY = twoPlus ? pkts * 3 / 5 : 0, capX = pkts - capY;
-    if (!twoPlus) capY = 0;
-    A.pktX = ix->d_pkt; A.pktY = ix->d_pkt + capX * U; A.capX = (uint32_t)capX; A.capY = (uint32_t)std::max<uint64_t>(capY, XREGION);   // (capY is never reached with one substitution at most: no class-2 packet exists)
-    if (!twoPlus) A.pktY = ix->d_pkt;
+    // overlap: two sets of buffers -- phase A fills one while the walker empties the other
+    const bool overlap = S.overlap && pkts / 2 >= (twoPlus ? floorCap * 5 / 2 + 16 : floorCap);
+    const uint64_t setPkts = overlap ? pkts / 2 : pkts;
+    uint64_t capY = twoPlus ? setPkts * 3 / 5 : 0, capX = setPkts - capY;
+    uint4* const setBase[2] = {ix->d_pkt, ix->d_pkt + (overlap ? setPkts * U : 0)};
+    auto use_set = [&](SearchArgs& a, uint32_t q) {
+        a.pktX = setBase[q]; a.pktY = twoPlus ? setBase[q] + capX * U : setBase[q];
+        a.capX = (uint32_t)capX; a.capY = (uint32_t)std::max<uint64_t>(capY, XREGION);   // (capY is never reached with one substitution at most: no class-2 packet exists)
+        a.xctl = reinterpret_cast<ExpandCtl*>(ix->d_xctl) + q;
+    };
+    use_set(A, 0);
     A.xctl = reinterpret_cast<ExpandCtl*>(ix->d_xctl);
     ExpandProgress* prog = reinterpret_cast<ExpandProgress*>(ix->d_xprog);
     ExpandProgress* hprog = reinterpret_cast<ExpandProgress*>(ix->h_xprog);
@@ -1351,18 +1374,31 @@ static int run_expand(gm_index* ix, const SearchSetup& S, SearchArgs A, const gm
     const uint64_t guess = (uint64_t)G * S.plan.stepSize * 8ull;
     const uint32_t firstChunks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(usableMin / std::max<uint64_t>(guess, 1), 0x7FFFFFFFull));
     hipLaunchKernelGGL(expand_reset_kernel, dim3(1), dim3(1), 0, st, prog, (unsigned long long)totalChunks);
-    SearchArgs W = A;                                              // the walker's view
-    W.workCounter = &A.xctl->walkCounter;
     unsigned long long lastSeen = 0; bool seen = false;
     uint32_t i = 0;
+    // Overlap: phase A of every slice runs in slice order on a stream of its own; the walkers of even and odd slices have a stream each (the
+    // tail of one walker -- wavefronts that have run out of packets -- is filled by the head of the next); phase A of slice i waits for the
+    // walker of slice i - 2, which read the buffers it fills.  Without overlap everything is queued on the call's stream.
+    hipStream_t sa = overlap ? ix->stXA : st;
+    if (overlap) {
+        GM_HIP(hipEventRecord(ix->evXGo, st));                       // accumulators cleared, counters zeroed, buffers zeroed
+        GM_HIP(hipStreamWaitEvent(ix->stXA, ix->evXGo, 0));
+        for (int q = 0; q < 2; ++q) GM_HIP(hipStreamWaitEvent(ix->stXB[q], ix->evXGo, 0));
+    }
     for (;; ++i) {
-        hipLaunchKernelGGL(expand_slice_begin_kernel, dim3(1), dim3(1), 0, st, prog, A.xctl, usableX, usableY, firstChunks, 0x7FFFFFFFu);
-        hipLaunchKernelGGL(expand_kernel, dim3((unsigned)blocksA), dim3(256), 0, st, A);
-        hipLaunchKernelGGL(expand_slice_commit_kernel, dim3(1), dim3(1), 0, st, prog, A.xctl, A.errorFlag);
+        const uint32_t q = overlap ? (i & 1u) : 0u;
+        use_set(A, q);
+        hipStream_t sb = overlap ? ix->stXB[q] : st;
+        if (overlap && i >= 2u) GM_HIP(hipStreamWaitEvent(sa, ix->evXB[q], 0));   // the walker of slice i - 2 has left these buffers
+        hipLaunchKernelGGL(expand_slice_begin_kernel, dim3(1), dim3(1), 0, sa, prog, A.xctl, usableX, usableY, firstChunks, 0x7FFFFFFFu);
+        hipLaunchKernelGGL(expand_kernel, dim3((unsigned)blocksA), dim3(256), 0, sa, A);
+        hipLaunchKernelGGL(expand_slice_commit_kernel, dim3(1), dim3(1), 0, sa, prog, A.xctl, A.errorFlag);
         GM_HIP(hipGetLastError());
-        GM_HIP(hipMemcpyAsync(&hprog[i & 3u], prog, sizeof(ExpandProgress), hipMemcpyDeviceToHost, st));
-        GM_HIP(hipEventRecord(ix->evX[i & 3u], st));
-        int rc = launch_search(ix, LEAF_COUNT_NODES, W, S.blocks, st); if (rc) return rc;
+        GM_HIP(hipMemcpyAsync(&hprog[i & 3u], prog, sizeof(ExpandProgress), hipMemcpyDeviceToHost, sa));
+        GM_HIP(hipEventRecord(ix->evX[i & 3u], sa));
+        if (overlap) { GM_HIP(hipEventRecord(ix->evXA[q], sa)); GM_HIP(hipStreamWaitEvent(sb, ix->evXA[q], 0)); }
+        int rc = launch_search(ix, LEAF_COUNT_NODES, A, S.blocks, sb); if (rc) return rc;
+        if (overlap) GM_HIP(hipEventRecord(ix->evXB[q], sb));
         if (i >= 2u) {
             GM_HIP(hipEventSynchronize(ix->evX[(i - 2u) & 3u]));
             const unsigned long long c = hprog[(i - 2u) & 3u].committed;
@@ -1370,6 +1406,10 @@ static int run_expand(gm_index* ix, const SearchSetup& S, SearchArgs A, const gm
             if (seen && c == lastSeen) { set_error("the split search made no progress (packet buffers of %llu + %llu packets)", (unsigned long long)capX, (unsigned long long)capY); return GM_ERR_INTERNAL; }
             lastSeen = c; seen = true;
         }
+    }
+    if (overlap) {   // the call's stream goes on when both walkers and phase A have ended
+        GM_HIP(hipStreamWaitEvent(st, ix->evXB[0], 0)); GM_HIP(hipStreamWaitEvent(st, ix->evXB[1], 0));
+        GM_HIP(hipEventRecord(ix->evXA[0], sa)); GM_HIP(hipStreamWaitEvent(st, ix->evXA[0], 0));
     }
     ix->lastSlices = i + 1u;
     return GM_OK;
@@ -2016,7 +2056,7 @@ int gm_index_set_tuning(gm_index* ix, const char* name, int64_t value)
         {"iter_cap", &ix->tune.iterCap, dflt.iterCap, 1, 0x7FFFFFFF}, {"stall_cap", &ix->tune.stallCap, dflt.stallCap, 1, 0x7FFFFFFF},   // bounds of a hung search loop (tests force them)
         {"pat_batch", &ix->tune.patBatch, dflt.patBatch, 1, 64},
         {"expand", &ix->tune.expand, dflt.expand, 0, 1}, {"expand_mb", &ix->tune.expandMB, dflt.expandMB, 1, 1 << 20},   // the split search (gm_expand.h)
-        {"expand_chunk", &ix->tune.expandChunk, dflt.expandChunk, 1, 1 << 16}, {"expand_occ", &ix->tune.expandOcc, dflt.expandOcc, 1, 64}, {"sat_draw_w", &ix->tune.satDrawW, dflt.satDrawW, 0, 0x7FFFFFFF},
+        {"expand_chunk", &ix->tune.expandChunk, dflt.expandChunk, 1, 1 << 16}, {"expand_occ", &ix->tune.expandOcc, dflt.expandOcc, 1, 64}, {"expand_overlap", &ix->tune.expandOverlap, dflt.expandOverlap, 0, 1}, {"sat_draw_w", &ix->tune.satDrawW, dflt.satDrawW, 0, 0x7FFFFFFF},
         {"jump_groups", &ix->tune.jumpGroups, dflt.jumpGroups, 0, 1},   // groups of jump patterns behind the existence bitmap: 0 never, 1 wherever possible, -1 where they save table reads
     };
     for (auto& t : tab) if (!strcmp(t.n, name)) {

@@ -39,8 +39,9 @@ struct Tuning {
     int expand = -1;                   // -1: where it pays (gm_api.hip: prepare_search), 0: never (the one-loop kernel of rounds 3-5), 1: whenever the call has jump patterns
     int expandMB = -1;                 // MiB of packet buffers (-1: a share of the free device memory); tests force small ones: many slices, overflowing chunks
     int expandChunk = -1;              // k-mer blocks per chunk of phase A (-1: about a thousand work items)
+    int expandOverlap = -1;            // 1: phase A of slice i + 1 runs beside the walker of slice i (three walker blocks and one block of phase A per CU); 0 / -1: one after the other
     int expandOcc = -1;                // blocks of phase A per CU (-1: what the occupancy query says, at most 8)
-    int satDrawW = -1;                 // the walker drops a drawn node at least this wide when its block's k-mers are all at MAX (-1: 16)
+    int satDrawW = -1;                 // the walker drops a drawn node at least this wide when its block's k-mers are all at MAX (-1: 1 = every packet)
 };
 }  // namespace gm
 
@@ -117,6 +118,8 @@ struct gm_index {
     uint4* d_pkt = nullptr; uint64_t pktCap = 0;   // node packets (X part | Y part), in uint4 units
     void* d_xctl = nullptr; void* d_xprog = nullptr; void* h_xprog = nullptr;              // ExpandCtl, ExpandProgress (gm_kernels.h); 4 page-locked copies
     hipEvent_t evX[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t stXA = nullptr, stXB[2] = {nullptr, nullptr};   // phase A in slice order | the walkers of even / odd slices
+    hipEvent_t evXA[2] = {nullptr, nullptr}, evXB[2] = {nullptr, nullptr}, evXGo = nullptr;
     uint32_t* d_wmap = nullptr; uint64_t wmapCap = 0;
     uint32_t lastSlices = 0;           // slices of the last call that took the split search (statistics)
     uint32_t pktUnits = 0;             // 16-byte units per packet of what the buffers hold
