@@ -1230,7 +1230,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     // the wavefront is idle gains 1.5 % (3.09 Gbp) to 5 % (249 Mbp) (profiles/r02/sweep_steal_e2.txt, sweep_chr1_steal_*.txt)
     uint32_t stealDefault = 0u;
     if ((p->E <= 1 && p->K < 64 && ix->nRows >= (1ull << 30)) || S->numRoots < 64ull * 4ull * 1024ull) stealDefault = 1u;
-    else if (p->E >= 2) stealDefault = p->K < 64 ? 16u : (p->E >= 3 ? 4u : 8u);   // K=100 e=2: 8 -> +5.7 %, 16 -> 0 (sweep_steal_longk.txt); K=101 e=3 / e=4: 4 -> -2 / -7 % over 8 (r04)
+    else if (p->E >= 2) stealDefault = p->K < 64 ? (expand ? 8u : 16u) : (p->E >= 3 ? 4u : 8u);   // (the walker of the split search: 8 -> -3.3 % over 16, 4 the same; profiles/r06)   // K=100 e=2: 8 -> +5.7 %, 16 -> 0 (sweep_steal_longk.txt); K=101 e=3 / e=4: 4 -> -2 / -7 % over 8 (r04)
     // e=1 at K >= 64: sharing used to lose 5..9 % (r02); with verified runs added in two atomics the balance turned: an exchange when a
     // quarter of the wavefront is idle gains 2-6 % on 3.09 Gbp (profiles/r04/sweep_k100_knobs.txt, sweep_verify_t_ext.txt)
     // (round 5, with four blocks per CU again: an exchange at half a wavefront idle, -3.4 % over a quarter)
@@ -1312,7 +1312,9 @@ static int run_expand(gm_index* ix, const SearchSetup& S, SearchArgs A, const gm
     else {
         size_t freeB = 0, totalB = 0;
         if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) freeB = 0;
-        budget = std::max<uint64_t>(std::min<uint64_t>((freeB + have) / 3, 12ull << 30), have);   // (never below what is there)
+        // (a third of what is free, 32 GiB at most: 3.09 Gbp K=30 e=2 on 10 % of the text 1056 / 651 / 577 / 576 ms with 6 / 12 / 24 / 40 GiB -- a slice ends
+        //  with the wavefronts waiting for its heaviest packets, and the longer the lists the more of a root's exact hits are counted before its patterns with errors are drawn)
+        budget = std::max<uint64_t>(std::min<uint64_t>((freeB + have) / 3, 32ull << 30), have);   // (never below what is there)
     }
     // what the call can use at all: every (work item, rotation) a packet (64 per item at most), rounded up generously
     const uint64_t worstPackets = std::min<uint64_t>(S.numBlocksCall * (uint64_t)S.itemsPerBlock * 64ull + (1u << 20), 1ull << 31);

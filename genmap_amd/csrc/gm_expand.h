@@ -89,20 +89,24 @@ GM_HD XRoot expand_root(const Mem& mem, uint64_t g, uint32_t W, uint32_t strand,
     const uint64_t up = nib64(mem, g + ni + J);
     const uint32_t d = ni < NB_SYMS ? ni : NB_SYMS;
     const uint64_t low = nib64(mem, g + ni - d);      // symbol ni - 1 - i sits in nibble d - 1 - i
-    // needle(a0 + J + i): forward strand the i-th symbol above, reverse strand the complement of the i-th symbol below; needle(a0 - 1 - i) the other way round
-    auto above = [&](uint32_t i) { return (uint32_t)(up >> (4u * i)) & 15u; };
-    auto below = [&](uint32_t i) { return i < d ? (uint32_t)(low >> (4u * (d - 1u - i))) & 15u : (uint32_t)SYM_N; };
-    auto right = [&](uint32_t i) { return strand ? complement(below(i)) : above(i); };
-    auto left = [&](uint32_t i) { return strand ? complement(above(i)) : below(i); };
+    // needle(a0 + J + i): forward strand the i-th symbol above, reverse strand the complement of the i-th symbol below; needle(a0 - 1 - i) the
+    // other way round.  Six symbols per side at once (no loop over the neighbours: phase A is paid per (root, item)):
+    //   ab: nibble i = the i-th symbol above; be: nibble i = the i-th symbol below (N where the window has none)
+    const uint32_t ab = (uint32_t)up & 0xFFFFFFu;
+    const uint32_t be = (d ? (uint32_t)(nib_reverse16(low) >> (4u * (16u - d))) : 0u) | (0x444444u << (4u * d) & 0xFFFFFFu);
+    const uint32_t rt6 = strand ? (uint32_t)nib_complement(be) & 0xFFFFFFu : ab, lf6 = strand ? (uint32_t)nib_complement(ab) & 0xFFFFFFu : be;
+    auto pack2 = [](uint32_t x) {   // six nibbles (letters) -> six 2-bit groups
+        x &= 0x333333u; x = (x | x >> 2) & 0x0F0F0Fu;
+        return (x & 0xFu) | ((x >> 8) & 0xFu) << 4 | ((x >> 16) & 0xFu) << 8;
+    };
     if (filter) {
-        uint32_t notLetter = 0u, jn = 0u;
         const uint32_t nr = (nbWord >> 12) & 7u, nl = (nbWord >> 28) & 7u;
-        for (uint32_t i = 0; i < nr; ++i) { const uint32_t c = right(i); notLetter |= c >> 2; jn |= (c & 3u) << (2u * i); }
-        for (uint32_t i = 0; i < nl; ++i) { const uint32_t c = left(i); notLetter |= c >> 2; jn |= (c & 3u) << (16u + 2u * i); }
-        r.jn = notLetter ? 0u : (jn | 0x8000u);   // a needle N mismatches everything: such roots take no shortcut
+        const uint32_t mr = (1u << (4u * nr)) - 1u, ml = (1u << (4u * nl)) - 1u;
+        const uint32_t notLetter = ((rt6 & mr) | (lf6 & ml)) & 0x444444u;
+        r.jn = notLetter ? 0u : (pack2(rt6 & mr) | pack2(lf6 & ml) << 16 | 0x8000u);   // a needle N mismatches everything: such roots take no shortcut
     }
     if (wantExt) {
-        const uint32_t e0 = right(0u), e1 = right(1u);
+        const uint32_t e0 = rt6 & 15u, e1 = (rt6 >> 4) & 15u;
         if ((e0 | e1) < SYM_N) r.ext = JF_EXTOK | (e0 << 2 | e1) << JF_EXT_SHIFT;
     }
     return r;
@@ -147,17 +151,15 @@ GM_HD bool expand_next(XItem& it, uint32_t& rw)
 // position of the k-th set bit of m (k = 0: the lowest; k < popcount(m)): bisection, no loop over the bits
 GM_HD uint32_t nth_set_bit(unsigned long long m, uint32_t k)
 {
-    uint32_t pos = 0;
-    for (uint32_t w = 32u; w >= 1u; w >>= 1) {
-        const unsigned long long part = (m >> pos) & ((1ull << w) - 1ull);
-#if defined(__HIP_DEVICE_COMPILE__)
-        const uint32_t c = (uint32_t)__popcll(part);
-#else
-        const uint32_t c = (uint32_t)__builtin_popcountll(part);
-#endif
-        if (k >= c) { k -= c; pos += w; }
+    const uint32_t lo = (uint32_t)m, cl = popc32(lo);
+    uint32_t x = lo, pos = 0;
+    if (k >= cl) { k -= cl; x = (uint32_t)(m >> 32); pos = 32u; }
+    uint32_t off = 0;
+    for (uint32_t w = 16u; w >= 1u; w >>= 1) {
+        const uint32_t c = popc32((x >> off) & ((1u << w) - 1u));
+        if (k >= c) { k -= c; off += w; }
     }
-    return pos;
+    return pos + off;
 }
 // rotation word number k of an item (expand_kernel deals the rotations of 64 items out to the lanes of the wavefront: lane j takes the j-th)
 GM_HD uint32_t expand_count(const XItem& it) { return it.state == 1u ? 1u : it.state == 3u ?
