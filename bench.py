@@ -62,6 +62,26 @@ def cpu_model():
     return "unknown"
 
 
+def physical_cores():
+    """physical cores of the host (sockets x cores: distinct (physical id, core id) pairs of /proc/cpuinfo); os.cpu_count() counts hardware threads"""
+    try:
+        seen, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            seen.add((phys, core))
+        return len(seen) or (os.cpu_count() or 1)
+    except OSError:
+        return os.cpu_count() or 1
+
+
 class CpuBaseline:
     """The oracle (a port of the reference algorithm, kind="port") on this box's host cores, on a bounded sample of the SAME positions the
     GPU rate covers: seeded random intervals of 1,000 positions spread over every sequence of the text (repeat families, unique
@@ -72,6 +92,7 @@ class CpuBaseline:
     and first touched by the threads that use them."""
 
     INTERVAL = 1000
+    TARGET_S = 8.0     # length of the all-thread timed run (the one-thread run: half of it); --cpu-seconds
 
     def __init__(self, codes, lens, bwt, threads, seq_file_id=None, sa=None):
         sys.path.insert(0, str(ROOT / "tests"))
@@ -156,16 +177,16 @@ class CpuBaseline:
                 if t_sum >= target or per_file * self.INTERVAL >= max(tl for _, _, tl in slices):
                     return per_file, npos, t_sum
                 per_file = int(max(per_file * 2, per_file * (target * 1.3) / max(t_sum, 1e-3)))
-        m, npos, dt = timed(self.threads, 8.0, 50)
-        m1, npos1, dt1 = timed(1, 4.0, max(1, m // max(8, self.threads // 2)))
-        return {"value": npos / dt, "unit": "k-mers/s", "cores": self.threads, "kind": "port", "build": self.build, "cpu_model": self.model,
+        m, npos, dt = timed(self.threads, self.TARGET_S, 50)
+        m1, npos1, dt1 = timed(1, self.TARGET_S / 2, max(1, m // max(8, self.threads // 2)))
+        return {"value": npos / dt, "unit": "k-mers/s", "cores": physical_cores(), "threads": self.threads, "kind": "port", "build": self.build, "cpu_model": self.model,
                 "threads_1": {"value": npos1 / dt1, "unit": "k-mers/s", "sample": f"{m1} intervals per file: {npos1} positions, {dt1:.1f} s"},
                 "sample": f"{npos} k-mer positions in {m} seeded random intervals of {self.INTERVAL} per FASTA file ({len(slices)} files) of the same index, K={K} E={E}, --exclude-pseudo, both strands, {dt:.1f} s"}
 
     def run(self, K, E, first_guess, **kw):
-        m, npos, dt = self._timed(K, E, self.threads, 8.0, max(1, first_guess // self.INTERVAL), **kw)
-        m1, npos1, dt1 = self._timed(K, E, 1, 4.0, max(1, m // max(8, self.threads // 2)), **kw)
-        return {"value": npos / dt, "unit": "k-mers/s", "cores": self.threads, "kind": "port", "build": self.build, "cpu_model": self.model,
+        m, npos, dt = self._timed(K, E, self.threads, self.TARGET_S, max(1, first_guess // self.INTERVAL), **kw)
+        m1, npos1, dt1 = self._timed(K, E, 1, self.TARGET_S / 2, max(1, m // max(8, self.threads // 2)), **kw)
+        return {"value": npos / dt, "unit": "k-mers/s", "cores": physical_cores(), "threads": self.threads, "kind": "port", "build": self.build, "cpu_model": self.model,
                 "threads_1": {"value": npos1 / dt1, "unit": "k-mers/s", "sample": f"the first {m1} of the same intervals: {npos1} positions, {dt1:.1f} s"},
                 "sample": f"{npos} k-mer positions in {m} seeded random intervals of {self.INTERVAL} spread over all {len(self.lens)} sequences of the same index, K={K} E={E}, both strands, {dt:.1f} s (output vector cleared outside the timed call)"}
 
@@ -215,6 +236,9 @@ def main():
     ap.add_argument("--trace", type=float, default=0.0, help="print stage markers from every rank and, after this many seconds, every thread's Python stack (diagnosis of a stalled multi-rank run)")
     ap.add_argument("--allow-mixed-features", action="store_true", help="N > 1: time the run even if the ranks' index replicas differ (records, table length)")
     ap.add_argument("--no-preflight", action="store_true", help="N > 1: skip the verified (100,1) step through both transports that precedes every timing")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="length of the all-thread run of cpu_baseline (the one-thread run takes half of it)")
+    ap.add_argument("--extra-configs", default="chr1,bacteria5", help="default workload at N = 1 only: BASELINE configs measured on an index of their own by a child process each "
+                    "(chr1: C2, K=30 e=0 on the chr1-like text; bacteria5: C5) and reported as sub-records; '' = none")
     ap.add_argument("--no-traffic", action="store_true", help="skip roofline.traffic (two extra processes under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE after the timed part, N = 1 only)")
     ap.add_argument("--protocol", default="", choices=["", "reference"], help="reference: the reference's own benchmark protocol (benchmarks/bench.sh:35-43: (5,0), (6,0), (101,0..4)) "
                     "on the same index, one pass each -- tools/protocol_reference.py; E = 4 takes minutes, never part of the default line")
@@ -230,6 +254,7 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(args.trace, repeat=True, file=sys.stderr)
     c5 = args.workload == "bacteria5" and not args.fasta
+    CpuBaseline.TARGET_S = max(0.5, args.cpu_seconds)
     args.K = args.K or (24 if c5 else 30)
     args.E = args.E if args.E >= 0 else (1 if c5 else 2)
 
@@ -857,6 +882,29 @@ def main():
             if not args.no_cpu_baseline:
                 r["cpu_baseline"] = cpu_rec(rec)
             result["sub"].append(r)
+    # ---- the other BASELINE configurations, each on an index of its own (a child process of this program after the main index is gone):
+    # C2 = chr1-like 249 Mbp at K=30 e=0, C5 = five bacteria, K=24 e=1 --exclude-pseudo.  Three timed steps, roofline from the twin's counters and
+    # a short cpu_baseline each; no counter-traffic passes (they are the minutes of this program). ----
+    if world == 1 and args.workload == "grch38" and not args.fasta and args.scale == 1.0 and args.extra_configs:
+        import subprocess
+        cpu = None   # (the oracle index of the 3.09 Gbp text: tens of GB of host memory)
+        torch.cuda.empty_cache()
+        for wlname in [w for w in args.extra_configs.split(",") if w]:
+            cmd = [sys.executable, str(ROOT / "bench.py"), "--workload", wlname, "--steps", "3", "--warmup", "1", "--sub", "", "--no-traffic", "--no-host-rate",
+                   "--cpu-seconds", "3", "--extra-configs", ""] + (["--K", "30", "--E", "0"] if wlname == "chr1" else ["--no-csv"])
+            if args.no_cpu_baseline:
+                cmd.append("--no-cpu-baseline")
+            t0 = time.time()
+            try:
+                p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, cwd=str(ROOT))
+                rec = json.loads(p.stdout.decode().strip().splitlines()[-1])
+                r = {"workload": rec["config"]["workload"], "K": rec["config"]["K"], "E": rec["config"]["E"], "value": rec["value"], "unit": rec["unit"], "steps": rec["steps"],
+                     "warmup": rec["warmup"], "ms_per_step": rec["ms_per_step"], "roofline": rec.get("roofline"), "cpu_baseline": rec.get("cpu_baseline"),
+                     "config": rec["config"], "baseline_config": "C2" if wlname == "chr1" else "C5", "own_index": True}
+                result.setdefault("sub", []).append(r)
+                log(f"extra config {wlname}: {rec['value']:.4g} {rec['unit']}, {rec['ms_per_step']:.2f} ms/step ({time.time() - t0:.0f} s)")
+            except Exception as e:
+                log(f"extra config {wlname} failed: {e}")
     print(json.dumps(result), flush=True)
 
 

@@ -1319,6 +1319,9 @@ static int run_expand(gm_index* ix, const SearchSetup& S, SearchArgs A, const gm
     // what the call can use at all: every (work item, rotation) a packet (64 per item at most), rounded up generously
     const uint64_t worstPackets = std::min<uint64_t>(S.numBlocksCall * (uint64_t)S.itemsPerBlock * 64ull + (1u << 20), 1ull << 31);
     uint64_t pkts = std::min<uint64_t>(budget / (16ull * U), worstPackets + (twoPlus ? worstPackets : 0));
+    // (a call over a small share of the text -- one of eight ranks on one device, a range of a sweep -- does not take gigabytes it cannot fill: eight packets per k-mer is
+    //  twice what a genome makes at K=30 e=2; a repeat-rich share just takes more slices)
+    if (ix->tune.expandMB <= 0) pkts = std::min<uint64_t>(pkts, S.kmers * 8ull + (1ull << 22));
     // phase A: as many wavefronts as the device holds, but no more than leave three quarters of a buffer to packets (a wavefront keeps one
     // open region per class)
     int perCU = 0;
