@@ -552,8 +552,7 @@ template <typename T> static int grow(T** p, uint64_t* cap, uint64_t need)
 enum LeafMode { LEAF_COUNT = 0, LEAF_FILESET = 1, LEAF_OCC_COUNT = 2, LEAF_OCC_EMIT = 3, LEAF_STORE = 4, LEAF_STORE8 = 5, LEAF_COUNT_JUMP = 6, LEAF_SCATTER = 7, LEAF_COUNT_NODES = 8 };
 
 // nu = 16-byte units per stored node / queue entry: 1, or 2 with 64-bit rows (gm_kernels.h: NodeIO)
-static uint32_t g_ldsPad = 0;   // (measurement: bytes of LDS requested on top of what a block uses -- where is the occupancy cliff?  knob "lds_pad")
-static inline size_t search_lds_bytes(const SearchArgs& A, uint32_t nu) { return (size_t)g_ldsPad + (size_t)(4u * A.vqCap * nu + 4u * 64u * (A.ldsDepth * nu + A.winChunks)) * 16u + 4u * 80u * 4u + 448u + (A.entrySlots ? 4096u : 0u) + (A.lqCap ? 4u * (A.lqCap * 16u + 80u * 4u) : 0u); }
+static inline size_t search_lds_bytes(const SearchArgs& A, uint32_t nu) { return (size_t)A.ldsPad + (size_t)(4u * A.vqCap * nu + 4u * 64u * (A.ldsDepth * nu + A.winChunks)) * 16u + 4u * 80u * 4u + 448u + (A.entrySlots ? 4096u : 0u) + (A.lqCap ? 4u * (A.lqCap * 16u + 80u * 4u) : 0u); }
 
 template <int WPP, class EnvT>
 static int launch_one(const SearchArgs& A, unsigned blocks, hipStream_t st)
@@ -834,6 +833,7 @@ struct SearchSetup {
     bool jump = false;                  // the call runs the N-less kernel (with jump patterns where they apply) + the correction pass
     // the split search (gm_expand.h): phase A enumerates the jump patterns of the call's blocks into node packets, the walker draws packets
     bool expand = false, overlap = false;
+    uint32_t exactItem = 0, rootsPerBlock = 0;   // two passes of phase A: the first takes one item per root (gm_expand.h: expand_strip_exact)
     uint32_t itemsPerBlock = 0, expandBlocks = 0, pktChunks = 0;
     uint32_t rootWinChunks = 0;         // LDS chunks per lane of a kernel that stages the windows of ROOTS (any alignment): the correction pass beside a walker
     uint64_t numBlocksCall = 0, totalChunks = 0;
@@ -931,6 +931,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     uint64_t jbitsWords = 0; std::vector<uint4> jinfo2Host(8, make_uint4(0, 0, 0, 0));
     const uint4* jtab = nullptr;
     uint32_t firstItem[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nItems[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool hasExact[8] = {false, false, false, false, false, false, false, false};   // the search's patterns include the one without a substitution
     std::vector<uint32_t> wmapHost;
     S->jump = mayJump;
     if (S->jump) {
@@ -1000,6 +1001,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
                 }
                 jumpAPacked[s2 >> 2] |= js[s2].regionA << (8u * (s2 & 3u));
                 firstItem[s2] = (uint32_t)patHost.size(); nItems[s2] = (uint32_t)items[s2].items.size();
+                for (uint32_t d : js[s2].pat) hasExact[s2] = hasExact[s2] || (d & 7u) == 0u;
                 patHost.insert(patHost.end(), items[s2].items.begin(), items[s2].items.end());
             }
             const void *p0 = ix->d_patterns, *j0 = ix->d_jinfo;
@@ -1017,6 +1019,13 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         (ix->tune.expand > 0 || (ix->tune.expand < 0 && S->numRoots >= (1ull << 20) && p->K < 64u))) {   // (K=100 e=1 has 0.16 table reads per k-mer: nothing to split off -- its walker measured 150 ms against the 120 ms of the one-loop kernel on 30 % of 3.09 Gbp)
         wmapHost = make_wmap(plan.nStrands, plan.nSearches, firstItem, nItems);
         S->itemsPerBlock = (uint32_t)wmapHost.size();
+        // two passes: the work items of the first -- one per root, the pattern without a substitution: a plain item (rotation word 0) behind the
+        // items of every search, so that no layout claims it (gm_oss.h: item_layout) -- follow the work map of the second
+        S->exactItem = (uint32_t)patHost.size();
+        patHost.push_back(0u);
+        for (uint32_t st2 = 0; st2 < plan.nStrands; ++st2) for (uint32_t s2 = 0; s2 < plan.nSearches; ++s2) wmapHost.push_back(wmap_pack(s2, st2, S->exactItem) | (hasExact[s2] ? 0u : WMAP_ROOT_ONLY));
+        S->rootsPerBlock = plan.nStrands * plan.nSearches;
+        { const void* p0 = ix->d_patterns; rc = grow(&ix->d_patterns, &ix->patternsCap, (uint64_t)patHost.size()); if (rc) return rc; if (p0 != ix->d_patterns) ix->sigValid = false; }
         S->expandBlocks = ix->tune.expandChunk > 0 ? (uint32_t)ix->tune.expandChunk : std::max<uint32_t>(1u, 8192u / std::max<uint32_t>(S->itemsPerBlock, 1u));   // (about 8192 work items: the chunk counter is ONE address, good for ~15 M returning atomics a second -- with 1024 items per chunk it was the limit of phase A; the packets of a chunk are neighbours in the lists, and long runs of neighbours make the walker's pools uneven)
         S->expandBlocks = std::min<uint32_t>(S->expandBlocks, (1u << 22) / std::max<uint32_t>(S->itemsPerBlock, 1u));   // (work items of a chunk are numbered in 32 bits)
         S->totalChunks = (S->numBlocksCall + S->expandBlocks - 1) / S->expandBlocks;
@@ -1063,8 +1072,8 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     S->overlap = overlap;
     const int wantPerCU = std::max(1, overlap ? std::min(ix->tune.blocksPerCU, 3) : ix->tune.blocksPerCU);   // default 4 = 4 waves/SIMD, what the kernel's VGPR count allows
     const bool entrySlots = mayJump && !ix->wide && !expand;
-    g_ldsPad = (uint32_t)std::max(0, ix->tune.ldsPad);
-    auto lds_bytes_for = [&](uint32_t d) { return (size_t)g_ldsPad + (size_t)(4u * vqCap * nu + 4u * 64u * (d * nu + winChunks)) * 16u + 4u * 80u * 4u + 448u + (entrySlots ? 4096u : 0u) + (lqCap ? 4u * (lqCap * 16u + 80u * 4u) : 0u); };   // == search_lds_bytes
+    const uint32_t ldsPad = (uint32_t)std::max(0, ix->tune.ldsPad);   // (measurement: where is the occupancy cliff?)
+    auto lds_bytes_for = [&](uint32_t d) { return (size_t)ldsPad + (size_t)(4u * vqCap * nu + 4u * 64u * (d * nu + winChunks)) * 16u + 4u * 80u * 4u + 448u + (entrySlots ? 4096u : 0u) + (lqCap ? 4u * (lqCap * 16u + 80u * 4u) : 0u); };   // == search_lds_bytes
     // Blocks per CU that REALLY become resident: the occupancy query says four blocks of up to 40,960 B fit the 160 KB of a CU, the device
     // runs three of them beyond ~38.6 KB per block (measured with padded launches, 3.09 Gbp: K=30 e=2 244 ms at 36,544 and 37,568 B per
     // block, 250 at 38,592, 279 at 39,616 and 40,640 = the time of three blocks per CU; K=100 e=1 192 / 193 / 220 ms at 36,544 / 38,592 /
@@ -1244,6 +1253,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     for (uint32_t k = 0; k < 8u; ++k) { A.layShift[k] = layShift[k]; A.layPlane0[k] = layPlane0[k]; A.layPlane1[k] = layPlane1[k]; }
     A.tableL = longK ? ix->d_tableL : nullptr;
     A.pktChunks = S->pktChunks; A.wmap = ix->d_wmap; A.itemsPerBlock = S->itemsPerBlock; A.expandBlocks = S->expandBlocks; A.numBlocksCall = S->numBlocksCall;
+    A.ldsPad = ldsPad;
     A.satDrawW = (uint32_t)(ix->tune.satDrawW >= 0 ? ix->tune.satDrawW : 1);   // (3.09 Gbp K=30 e=2: 1 -> 267 ms, 4 -> 269, 16 -> 285, never -> 326 with the test's two counters requested at the draw and looked at an iteration later)
     if (longK) { A.lqCap = 0u; A.entrySlots = 0u; A.selfHit = 0u; A.spillDepth = depth; A.steal = ix->tune.steal >= 0 ? (uint32_t)std::min(ix->tune.steal, 2) : 2u; }   // (2: lanes share before every root draw, 3.09 Gbp K=300 e=1 +19 %, K=1000 e=1 +14 %, e=0 +4 % over sharing at the end only; profiles/r05/longk_scale.txt)
     A.sliceBegin = text_begin; A.sliceLen = text_len; A.ownBegin = 0; A.ownEnd = text_len; A.ownChunkLen = 0; A.selBlocks = nullptr; A.nSelBlocks = 0;
@@ -1368,15 +1378,17 @@ static int run_expand(gm_index* ix, const SearchSetup& S, SearchArgs A, const gm
     ExpandProgress* hprog = reinterpret_cast<ExpandProgress*>(ix->h_xprog);
     const uint64_t slack = blocksA * 4ull * XREGION;
     const uint32_t usableX = (uint32_t)(capX - std::min<uint64_t>(slack, capX / 2)), usableY = twoPlus ? (uint32_t)(capY - std::min<uint64_t>(slack, capY / 2)) : 0xFFFFFFFFu;   // (no packet of the third class exists with one substitution at most)
+    uint32_t slicesTotal = 0;
+    auto run_pass = [&](uint32_t mode, uint32_t ipb, const uint32_t* wmapPtr, uint32_t wantBlocks) -> int {
     // A chunk is the unit that is redone when its packets do not fit: whatever a chunk can produce at most (64 rotations per work item) must fit
     // half a buffer, or a slice could fail on its first chunk for ever.  (Only the tiny buffers of the tests ever shorten a chunk.)
     const uint64_t usableMin = std::min<uint64_t>(usableX, twoPlus ? usableY : usableX);
-    const uint64_t chunkWorst = (uint64_t)S.itemsPerBlock * 64ull;
-    const uint32_t G = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(S.expandBlocks, (usableMin / 2) / std::max<uint64_t>(chunkWorst, 1)));
+    const uint64_t chunkWorst = (uint64_t)ipb * 64ull;
+    const uint32_t G = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(wantBlocks, (usableMin / 2) / std::max<uint64_t>(chunkWorst, 1)));
     const uint64_t totalChunks = (S.numBlocksCall + G - 1) / G;
-    A.expandBlocks = G;
+    A.expandBlocks = G; A.itemsPerBlock = ipb; A.wmap = wmapPtr; A.xmode = mode;
     // first slice: a guess at the packets a chunk makes (8 per k-mer); the slices behind it follow what their predecessor measured
-    const uint64_t guess = (uint64_t)G * S.plan.stepSize * 8ull;
+    const uint64_t guess = (uint64_t)G * S.plan.stepSize * (mode == 1u ? 2ull : 8ull);
     const uint32_t firstChunks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(usableMin / std::max<uint64_t>(guess, 1), 0x7FFFFFFFull));
     hipLaunchKernelGGL(expand_reset_kernel, dim3(1), dim3(1), 0, st, prog, (unsigned long long)totalChunks);
     unsigned long long lastSeen = 0; bool seen = false;
@@ -1416,7 +1428,18 @@ static int run_expand(gm_index* ix, const SearchSetup& S, SearchArgs A, const gm
         GM_HIP(hipStreamWaitEvent(st, ix->evXB[0], 0)); GM_HIP(hipStreamWaitEvent(st, ix->evXB[1], 0));
         GM_HIP(hipEventRecord(ix->evXA[0], sa)); GM_HIP(hipStreamWaitEvent(st, ix->evXA[0], 0));
     }
-    ix->lastSlices = i + 1u;
+    slicesTotal += i + 1u;
+    return GM_OK;
+    };
+    // One pass over every pattern, or two: the patterns without a substitution first (a work item per root), then the rest for the blocks
+    // that are not at MAX yet (gm_expand.h: expand_strip_exact).  The second order costs an easy text a few per cent (more launches) and spares a
+    // repeat-rich one most of phase A (profiles/r06).
+    const bool twoPass = ix->tune.expandTwoPass != 0 && A.maxVal != 0xFFFFFFFFu;
+    if (twoPass) {
+        int rc = run_pass(1u, S.rootsPerBlock, ix->d_wmap + S.itemsPerBlock, std::max<uint32_t>(1u, 8192u / std::max<uint32_t>(S.rootsPerBlock, 1u))); if (rc) return rc;
+        rc = run_pass(2u, S.itemsPerBlock, ix->d_wmap, S.expandBlocks); if (rc) return rc;
+    } else { int rc = run_pass(0u, S.itemsPerBlock, ix->d_wmap, S.expandBlocks); if (rc) return rc; }
+    ix->lastSlices = slicesTotal;
     return GM_OK;
 }
 
@@ -1430,6 +1453,7 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
                     const uint64_t* whole = nullptr, int firstOfWhole = -1)
 {
     if (!d_out) { set_error("null output"); return GM_ERR_BAD_ARG; }
+    if (ix && !whole) ix->piece.active = false;   // (any call that is not a piece of a share ends the share a caller was delivering: gm_map_device)
     SearchSetup S; SearchArgs A;
     int rc = prepare_search(ix, text_begin, text_len, first_seq, n_seq, p, intervals, n_intervals, st, &S, &A, /*wantJump=*/p->exclude_pseudo == 0, /*leaf queue*/p->exclude_pseudo ? 128u : 0u);
     if (rc) return rc;
@@ -1620,6 +1644,7 @@ static int locate_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uin
 {
     hipStream_t st = nullptr;
     SearchSetup S; SearchArgs A;
+    if (ix) ix->piece.active = false;
     int rc = prepare_search(ix, text_begin, text_len, first_seq, n_seq, p, intervals, n_intervals, st, &S, &A, false, 128u);
     if (rc) return rc;
     if (!ix->d_sa && !ix->d_saMark) { set_error("csv output needs an index with suffix array samples (sampling >= 1)"); return GM_ERR_NEED_LOCATE; }
@@ -1716,8 +1741,22 @@ int gm_map_device(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t
     if (p && (p->flags & GM_MAP_FLAG_PIECE)) {   // one launch of a share the caller delivers in several calls (include/genmap_amd.h)
         if (n_intervals > 0 || p->kmer_begin < p->whole_begin || p->kmer_end > p->whole_end) { set_error("GM_MAP_FLAG_PIECE: a piece lies inside its share, and a selection is not delivered in pieces"); return GM_ERR_BAD_ARG; }
         const uint64_t whole[2] = {p->whole_begin, p->whole_end};
-        return map_impl(ix, text_begin, text_len, first_seq, n_seq, p, intervals, n_intervals, seq_file_id, out_device, (hipStream_t)stream, nullptr, whole, p->kmer_begin == p->whole_begin ? 1 : 0);
+        // The pieces of a share arrive in order and nothing else runs on the index between them: the first clears the accumulators and starts the
+        // share's one correction pass, the later ones rely on both.  The index remembers the share it is in the middle of.
+        const bool first = p->kmer_begin == p->whole_begin;
+        gm_index::PieceState& ps = ix->piece;
+        if (!first && !(ps.active && ps.wholeBegin == p->whole_begin && ps.wholeEnd == p->whole_end && ps.K == p->K && ps.E == p->E && ps.textBegin == text_begin && ps.textLen == text_len &&
+                        ps.chunkIndex == p->chunk_index && ps.chunkStride == p->chunk_stride && ps.next == p->kmer_begin)) {
+            set_error("GM_MAP_FLAG_PIECE: this piece does not continue the share the index is in the middle of (pieces come in order, first piece first, and no other call in between)");
+            return GM_ERR_BAD_ARG;
+        }
+        ps.active = false;
+        const int rc = map_impl(ix, text_begin, text_len, first_seq, n_seq, p, intervals, n_intervals, seq_file_id, out_device, (hipStream_t)stream, nullptr, whole, first ? 1 : 0);
+        if (rc == GM_OK && p->kmer_end < p->whole_end)
+            ps = gm_index::PieceState{true, p->whole_begin, p->whole_end, p->kmer_end, text_begin, text_len, p->K, p->E, p->chunk_index, p->chunk_stride};
+        return rc;
     }
+    if (ix) ix->piece.active = false;
     return map_impl(ix, text_begin, text_len, first_seq, n_seq, p, intervals, n_intervals, seq_file_id, out_device, (hipStream_t)stream);
 }
 
@@ -1854,6 +1893,7 @@ int gm_map_shard(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t 
     if (p->value_bits != 8 && p->value_bits != 16) return GM_ERR_BAD_VALUE_BITS;
     if (p->K < 1 || p->K > MAX_K_LONG) return GM_ERR_BAD_K;
     GM_HIP(hipSetDevice(ix->device));
+    ix->piece.active = false;   // (its own pieces go through map_impl directly)
     const size_t eb = p->value_bits / 8;
     if (!ix->stCompute) {
         GM_HIP(hipStreamCreateWithFlags(&ix->stCompute, hipStreamNonBlocking));
@@ -2061,7 +2101,7 @@ int gm_index_set_tuning(gm_index* ix, const char* name, int64_t value)
         {"iter_cap", &ix->tune.iterCap, dflt.iterCap, 1, 0x7FFFFFFF}, {"stall_cap", &ix->tune.stallCap, dflt.stallCap, 1, 0x7FFFFFFF},   // bounds of a hung search loop (tests force them)
         {"pat_batch", &ix->tune.patBatch, dflt.patBatch, 1, 64},
         {"expand", &ix->tune.expand, dflt.expand, 0, 1}, {"expand_mb", &ix->tune.expandMB, dflt.expandMB, 1, 1 << 20},   // the split search (gm_expand.h)
-        {"expand_chunk", &ix->tune.expandChunk, dflt.expandChunk, 1, 1 << 16}, {"expand_occ", &ix->tune.expandOcc, dflt.expandOcc, 1, 64}, {"expand_overlap", &ix->tune.expandOverlap, dflt.expandOverlap, 0, 1}, {"sat_draw_w", &ix->tune.satDrawW, dflt.satDrawW, 0, 0x7FFFFFFF},
+        {"expand_chunk", &ix->tune.expandChunk, dflt.expandChunk, 1, 1 << 16}, {"expand_occ", &ix->tune.expandOcc, dflt.expandOcc, 1, 64}, {"expand_overlap", &ix->tune.expandOverlap, dflt.expandOverlap, 0, 1}, {"expand_two_pass", &ix->tune.expandTwoPass, dflt.expandTwoPass, 0, 1}, {"sat_draw_w", &ix->tune.satDrawW, dflt.satDrawW, 0, 0x7FFFFFFF},
         {"jump_groups", &ix->tune.jumpGroups, dflt.jumpGroups, 0, 1},   // groups of jump patterns behind the existence bitmap: 0 never, 1 wherever possible, -1 where they save table reads
     };
     for (auto& t : tab) if (!strcmp(t.n, name)) {

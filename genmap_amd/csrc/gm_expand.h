@@ -35,6 +35,8 @@ GM_HD uint32_t pkt_root_word(uint32_t n, uint32_t strand, uint32_t search) { ret
 
 // work item q of a k-mer block -> {search | strand << 3 | item number among the call's items << 8}
 GM_HD uint32_t wmap_pack(uint32_t search, uint32_t strand, uint32_t jp) { return search | strand << 3 | jp << 8; }
+constexpr uint32_t WMAP_ROOT_ONLY = 16u;   // first pass of two: the search has no pattern without a substitution (a lower bound inside its first J characters): its work
+                                           // item only speaks for the roots that walk the tree from its root
 
 // 16 symbols of the 4-bit text starting at symbol p (any alignment).  Mem::pair(i, lo, hi): 64-bit words i and i + 1 of the packed text.
 template <class Mem> GM_HD uint64_t nib64(const Mem& mem, uint64_t p)
@@ -146,6 +148,17 @@ GM_HD bool expand_next(XItem& it, uint32_t& rw)
     rw = it.gcur | ctz64(it.alive) << it.sh;
     it.alive &= it.alive - 1ull;
     return true;
+}
+
+// Two passes (gm_api.hip: run_expand): the patterns WITHOUT a substitution of every root first -- a work item per root, the J-mer's own
+// table entry -- and their packets walked; then everything else, for the blocks whose k-mers are not all at MAX already.  On a genome the
+// k-mers inside young repeat families have thousands of exact copies: what the first pass counts for them ends the second pass before
+// it reads a single bitmap word.  This takes the pattern without a substitution out of an item of the second pass.
+GM_HD void expand_strip_exact(XItem& it)
+{
+    if (it.gcur != 0u) return;                       // some character outside the group is substituted
+    if (it.state == 1u) it.state = 0u;               // the plain pattern without a substitution
+    else if (it.state == 3u) it.alive &= ~1ull;      // rotation 0 of the group's own three characters
 }
 
 // position of the k-th set bit of m (k = 0: the lowest; k < popcount(m)): bisection, no loop over the bits

@@ -40,6 +40,7 @@ struct Tuning {
     int expandMB = -1;                 // MiB of packet buffers (-1: a share of the free device memory); tests force small ones: many slices, overflowing chunks
     int expandChunk = -1;              // k-mer blocks per chunk of phase A (-1: about a thousand work items)
     int expandOverlap = -1;            // 1: phase A of slice i + 1 runs beside the walker of slice i (three walker blocks and one block of phase A per CU); 0 / -1: one after the other
+    int expandTwoPass = -1;            // 1 / -1: the patterns without a substitution of every root first, then the rest for blocks not at MAX yet; 0: one pass
     int expandOcc = -1;                // blocks of phase A per CU (-1: what the occupancy query says, at most 8)
     int satDrawW = -1;                 // the walker drops a drawn node at least this wide when its block's k-mers are all at MAX (-1: 1 = every packet)
 };
@@ -130,6 +131,9 @@ struct gm_index {
     uint2* d_cblocks = nullptr; uint64_t cblocksCap = 0;   // block list of the text windows that hold N, for (corrK, corrE, corrInfix)
     uint64_t nCBlocks = 0; uint32_t corrK = 0, corrE = 0, corrInfix = 0; bool corrValid = false;
     bool corrTimed = false;    // ev[1], ev[2] bracket the correction pass of the last call
+    // the share a caller is delivering piece by piece through gm_map_device (GM_MAP_FLAG_PIECE): what the next piece must continue
+    struct PieceState { bool active; uint64_t wholeBegin, wholeEnd, next, textBegin, textLen; uint32_t K, E, chunkIndex, chunkStride; };
+    PieceState piece{false, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t pieceIndex = 0;   // gm_map_shard delivers a call in several launches: launch number inside the call (statistics accumulate)
     uint32_t statPieces = 0;   // launches the statistics of the last call cover
     int buildRounds[2] = {0, 0};

@@ -154,10 +154,12 @@ struct SearchArgs {
     uint32_t capX, capY;            // packets the buffers hold
     uint32_t pktChunks;             // 16-byte chunks of needle window per packet
     ExpandCtl* xctl;
+    uint32_t xmode;                 // phase A: 0 every pattern of every root (one pass), 1 the patterns without a substitution (a work item per root), 2 the rest, for blocks not at MAX yet
     const uint32_t* wmap;           // work item of a block -> search | strand << 3 | item << 8 (gm_expand.h: make_wmap)
     uint32_t itemsPerBlock;         // work items per k-mer block
     uint32_t expandBlocks;          // k-mer blocks per chunk of phase A
     uint64_t numBlocksCall;         // k-mer blocks of the call (numRoots / rootsPerBlock)
+    uint32_t ldsPad;                // measurement: bytes of LDS requested on top of what a block uses (knob "lds_pad"; travels with the call: two host threads may drive two indexes)
     uint32_t satDrawW;              // walker: a drawn node at least this wide is dropped when all k-mers of its block are at MAX already
 };
 
@@ -1729,12 +1731,20 @@ __global__ __launch_bounds__(256) void expand_kernel(const SearchArgs A)
                 nss = pkt_root_word(n, strand, search);
                 const uint4 fji = jl[search];   // {first item | items << 16, meta at depth J relative to n - 1, first item, neighbour-filter mask}
                 hword = fji.w;
-                if (n == A.stepSize) {
+                // (pass 2 of two: a block whose k-mers the first pass has all brought to MAX needs nothing more -- min(total, MAX), src/algo.hpp:36,48,191)
+                bool blockDone = false;
+                if (A.xmode == 2u) {
+                    blockDone = true;
+                    for (uint32_t i = 0; i < n && blockDone; ++i) blockDone = A.acc[win + i] >= A.maxVal;
+                }
+                if (n == A.stepSize && !blockDone) {
                     const uint32_t a0 = n - 1u + (((search < 4u ? A.jumpAPacked[0] : A.jumpAPacked[1]) >> (8u * (search & 3u))) & 0xFFu);
                     xr = expand_root(mem, A.textBegin + win, A.K + n - 1u, strand, a0, A.jumpJ, fji.w, (jl[12u + search].w & 0xFFu) != 0u);
                 }
-                if (xr.bad) pendRoot = jp == (fji.x & 0xFFFFu);   // an odd block shape or an N inside the J-mer: the root walks the tree from its root
-                else {
+                // an odd block shape or an N inside the J-mer: the root walks the tree from its root (said by its first item's lane; with two passes: by the first)
+                if (blockDone) xr.bad = 1u;
+                else if (xr.bad) pendRoot = A.xmode == 1u ? true : A.xmode == 2u ? false : jp == (fji.x & 0xFFFFu);
+                if (!xr.bad) {
                     jm0 = meta_pack((fji.y & 0x1FFu) + n - 1u, ((fji.y >> 9) & 0x1FFu) + n - 1u, fji.y >> 18, 0u, M_OSS);
                     jd = A.patterns[jp];
                     const uint4 lim = jl[12u + search];
@@ -1746,6 +1756,8 @@ __global__ __launch_bounds__(256) void expand_kernel(const SearchArgs A)
                         cWords++;
 #endif
                     }
+                    if (A.xmode == 2u) expand_strip_exact(it);   // (the first pass has taken the pattern without a substitution)
+                    if (wm & WMAP_ROOT_ONLY) it.state = 0u;      // (first pass: this search has no such pattern)
                 }
             }
             // ---- the rotations of the 64 items, dealt out anew: lane j takes the j-th rotation of the batch, so that a turn of the loop reads 64

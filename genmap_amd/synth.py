@@ -99,6 +99,71 @@ def make_sequence(length, seed, dna5=True, n_frac=0.07, short_copies_per_mbp=400
     return text
 
 
+def _plant_shared_family(text, cons_seed, seed, fam_id, unit_len, copies, div_lo, div_hi):
+    """like _plant_family, but the consensus comes from `cons_seed` (one family for the whole genome: copies on every sequence)
+    and every other copy is planted reverse-complemented"""
+    n = len(text)
+    if n <= unit_len + 1 or copies <= 0:
+        return
+    cons = random_bases(cons_seed, 1000 + fam_id, 0, unit_len)
+    pos = (_hash_range(seed, 2000 + fam_id, 0, copies) % np.uint64(n - unit_len)).astype(np.int64)
+    hh = _hash_range(seed, 3000 + fam_id, 0, copies)
+    divs = div_lo + (div_hi - div_lo) * ((hh >> np.uint64(11)).astype(np.float64) / float(1 << 53))
+    flip = (hh & np.uint64(1)).astype(bool)
+    B = max(1, (1 << 24) // unit_len)
+    for s in range(0, copies, B):
+        p = pos[s:s + B]
+        k = len(p)
+        h = _hash_range(seed, 4000 + fam_id, s * unit_len, k * unit_len).reshape(k, unit_len)
+        u = (h >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+        mut = u < divs[s:s + k, None]
+        sub = ((h & np.uint64(3)) % np.uint64(3) + np.uint64(1)).astype(np.uint8)
+        block = np.where(mut, (cons[None, :] + sub) & 3, cons[None, :]).astype(np.uint8)
+        f = flip[s:s + k]
+        block[f] = (3 - block[f])[:, ::-1]
+        idx = p[:, None] + np.arange(unit_len, dtype=np.int64)[None, :]
+        text[idx.reshape(-1)] = block.reshape(-1)
+
+
+def make_sequence_hard(length, seed, satellite=0, dna5=True, n_frac=0.07):
+    """A chromosome of the HARD variant of S3 ("grch38h"): what S3 lacks against a real genome.  The repeat families are shared by ALL
+    sequences (one consensus per family for the whole text), half of their copies lie on the reverse strand, a young SINE-like subfamily
+    (1-3 % from its consensus, ~3 % of the text) puts thousands of copies within two substitutions of one another at K = 30, and
+    `satellite` > 0 plants an array of that many bases of a 171-bp monomer (1-2 % between monomers), as at a centromere."""
+    text = np.empty(length, dtype=np.uint8)
+    CH = 1 << 24
+    for s in range(0, length, CH):
+        m = min(CH, length - s)
+        text[s:s + m] = random_bases(seed, 1, s, m)
+    mbp = length / 1e6
+    G = 424242   # the genome-wide consensus seed
+    _plant_shared_family(text, G, seed, 1, 300, int(400 * mbp), 0.10, 0.15)        # old SINE-like, as S3 but genome-wide and on both strands
+    _plant_shared_family(text, G, seed, 2, 6000, int(20 * mbp), 0.03, 0.07)        # LINE-like
+    _plant_shared_family(text, G, seed, 4, 300, int(0.03 * length / 300), 0.01, 0.03)   # young SINE-like subfamily: ~3 % of the text
+    _plant_family(text, seed, 3, 1300, int(8 * mbp), 0.0, 0.01)                    # recent segmental copies (per sequence)
+    _plant_tandem(text, seed, 0.02)
+    if satellite > 0 and length > 4 * satellite:
+        mono = random_bases(G, 9001, 0, 171)
+        start = int(length * 0.40)
+        arr = np.resize(mono, satellite).copy()
+        h = _hash_range(seed, 9002, 0, satellite)
+        mut = ((h >> np.uint64(11)).astype(np.float64) / float(1 << 53)) < 0.015
+        arr[mut] = (arr[mut] + ((h[mut] & np.uint64(3)) % np.uint64(3) + np.uint64(1)).astype(np.uint8)) & 3
+        text[start:start + satellite] = arr
+    if dna5 and length >= 1000:
+        end = max(1, min(10000, length // 200))
+        text[:end] = 4
+        text[length - end:] = 4
+        big = int(length * n_frac) - 2 * end
+        if big > 0:
+            start = int(length * 0.49)
+            text[start:start + big] = 4
+        k = max(1, int(mbp))
+        iso = (_hash_range(seed, 7000, 0, k) % np.uint64(length)).astype(np.int64)
+        text[iso] = 4
+    return text
+
+
 # GRCh38 primary assembly chromosome lengths (chr1..22, X, Y)
 GRCH38_LENGTHS = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717,
                   133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285,
@@ -118,6 +183,10 @@ def workload(name, scale=1.0):
         lens = [max(1000, int(x * scale)) for x in GRCH38_LENGTHS]
         parts = [make_sequence(ln, seed=300 + i) for i, ln in enumerate(lens)]
         return np.concatenate(parts), lens, f"S3 grch38-like {sum(lens)} bp in {len(lens)} sequences Dna5"
+    if name == "grch38h":    # the hard variant of S3 (round 6): genome-wide families on both strands, a young subfamily, two satellite arrays
+        lens = [max(1000, int(x * scale)) for x in GRCH38_LENGTHS]
+        parts = [make_sequence_hard(ln, seed=300 + i, satellite=int(scale * (2_000_000 if i == 0 else 1_200_000 if i == 8 else 0))) for i, ln in enumerate(lens)]
+        return np.concatenate(parts), lens, f"S3h grch38-like (genome-wide families on both strands, young subfamily, satellites) {sum(lens)} bp in {len(lens)} sequences Dna5"
     raise ValueError(name)
 
 

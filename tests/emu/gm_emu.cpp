@@ -318,7 +318,7 @@ static void search_plan(const MapPlan& plan, const HostIndex<WPP>& ix, Env& env,
         };
         struct Pkt { Node nd; uint32_t win, nss; std::vector<uint64_t> w; };
         std::vector<Pkt> lists[3];
-        const uint32_t ipb = (uint32_t)wmap.size();
+
         const uint64_t nBlocks = plan.useList ? plan.blocks.size() : plan.numBlocks;
         auto packet = [&](uint32_t cls, const Node& nd, const Root& rt) {
             Pkt p; p.nd = nd; p.win = rt.win; p.nss = pkt_root_word(rt.n, rt.strand, rt.search);
@@ -326,8 +326,21 @@ static void search_plan(const MapPlan& plan, const HostIndex<WPP>& ix, Env& env,
             for (uint32_t j = 0; j < words; ++j) p.w.push_back(nib64(mem, (uint64_t)rt.win + 16u * j));
             lists[cls].push_back(p); g_packets[cls]++;
         };
-        for (uint64_t b = 0; b < nBlocks; ++b) for (uint32_t q = 0; q < ipb; ++q) {
-            const uint32_t wm = wmap[q], search = wm & 7u, strand = (wm >> 3) & 1u, jp = wm >> 8;
+        // mode 0: every pattern of every root in one pass; 1: the patterns without a substitution, a work item per root (the J-mer's own table
+        // entry); 2: everything else (gm_expand.h: expand_strip_exact).  g_expand == 2 runs 1 and 2 one after the other, like gm_api.hip: run_expand.
+        const uint32_t exactItem = (uint32_t)pat.size();
+        pat.push_back(0u);
+        std::vector<uint32_t> wmap1;
+        for (uint32_t st = 0; st < plan.nStrands; ++st) for (uint32_t s2 = 0; s2 < plan.nSearches; ++s2) {
+            bool hasExact = false;
+            for (uint32_t d : jumps[s2].pat) hasExact = hasExact || (d & 7u) == 0u;
+            wmap1.push_back(wmap_pack(s2, st, exactItem) | (hasExact ? 0u : WMAP_ROOT_ONLY));
+        }
+        auto phaseA = [&](uint32_t mode) {
+        const std::vector<uint32_t>& wm_ = mode == 1u ? wmap1 : wmap;
+        const uint32_t ipbm = (uint32_t)wm_.size();
+        for (uint64_t b = 0; b < nBlocks; ++b) for (uint32_t q = 0; q < ipbm; ++q) {
+            const uint32_t wm = wm_[q], search = wm & 7u, strand = (wm >> 3) & 1u, jp = wm >> 8;
             Root rt;
             if (plan.useList) { rt.win = (uint32_t)MapPlan::block_pos(plan.blocks[b]); rt.n = MapPlan::block_n(plan.blocks[b]); }
             else { rt.win = (uint32_t)(b * plan.stepSize); rt.n = (uint32_t)std::min<uint64_t>(plan.stepSize, plan.numKmers - rt.win); }
@@ -336,8 +349,8 @@ static void search_plan(const MapPlan& plan, const HostIndex<WPP>& ix, Env& env,
             const uint32_t W = K + rt.n - 1u;
             XRoot xr; xr.jb = xr.jn = xr.ext = 0u; xr.bad = 1u;
             if (rt.n == plan.stepSize) xr = expand_root(mem, rt.win, W, strand, rt.n - 1u + js.regionA, J, nbWord[search], items[search].ext);
-            if (xr.bad) {   // an odd block shape, or an N inside the J-mer: the root walks the tree from its root (its first item's lane says so)
-                if (jp == first[search]) packet(0u, root_node(rt, (uint32_t)rows), rt);
+            if (xr.bad) {   // an odd block shape, or an N inside the J-mer: the root walks the tree from its root (its first item's lane says so; with two passes the first)
+                if (mode == 1u || (mode == 0u && jp == first[search])) packet(0u, root_node(rt, (uint32_t)rows), rt);
                 continue;
             }
             const uint32_t jd = pat[jp];
@@ -356,6 +369,8 @@ static void search_plan(const MapPlan& plan, const HostIndex<WPP>& ix, Env& env,
                 }
                 expand_word(it, word, jd, xr, tab);
             }
+            if (mode == 2u) expand_strip_exact(it);
+            if (wm & WMAP_ROOT_ONLY) it.state = 0u;
             const uint32_t off = rt.n - 1u;
             const uint32_t jm0 = meta_pack((js.meta0 & 0x1FFu) + off, ((js.meta0 >> 9) & 0x1FFu) + off, js.meta0 >> 18, 0u, M_OSS);
             const XItem it0 = it;
@@ -363,6 +378,8 @@ static void search_plan(const MapPlan& plan, const HostIndex<WPP>& ix, Env& env,
                 // the device deals the rotations of 64 items out to its lanes (expand_nth: the k-th surviving rotation); the item's own iterator must agree
                 const uint32_t rw = expand_nth(it0.gcur, it0.sh, it0.state == 1u, it0.alive, kk);
                 { uint32_t rw2 = 0; if (!expand_next(it, rw2) || rw2 != rw) g_hangs += 1000000; }
+                if (mode == 1u && rw != 0u) g_hangs += 1000000;
+                if (mode == 2u && rw == 0u) g_hangs += 1000000;
                 uint32_t flo, rlo, w;
                 table_entry<WPP>(ix, rot_add(xr.jb, rw), J, flo, rlo, w);
                 if (nPatterns) ++*nPatterns;
@@ -372,12 +389,20 @@ static void search_plan(const MapPlan& plan, const HostIndex<WPP>& ix, Env& env,
                 packet(expand_class(x.errs), nd, rt);
             }
         }
-        for (uint32_t cls = 0; cls < 3u; ++cls) for (const Pkt& p : lists[cls]) {
-            Root rt; rt.win = p.win; rt.n = p.nss & 0xFFu; rt.strand = (p.nss >> 8) & 1u; rt.search = (p.nss >> 9) & 7u;
-            rt.rec = plan.table[(size_t)(rt.n - 1) * 8 + rt.search];
-            env.pwin = p.w.data();
-            walk(p.nd, rt);
+        };
+        auto walkLists = [&]() {
+        for (uint32_t cls = 0; cls < 3u; ++cls) {
+            for (const Pkt& p : lists[cls]) {
+                Root rt; rt.win = p.win; rt.n = p.nss & 0xFFu; rt.strand = (p.nss >> 8) & 1u; rt.search = (p.nss >> 9) & 7u;
+                rt.rec = plan.table[(size_t)(rt.n - 1) * 8 + rt.search];
+                env.pwin = p.w.data();
+                walk(p.nd, rt);
+            }
+            lists[cls].clear();
         }
+        };
+        if (g_expand >= 2) { phaseA(1u); walkLists(); phaseA(2u); walkLists(); }
+        else { phaseA(0u); walkLists(); }
         env.pwin = nullptr;
         return;
     }

@@ -199,11 +199,12 @@ def emu_map2(ix, wpp, K, E, first_seq=0, n_seq=None, xo=None, infix=0, revcompl=
     return out, stats
 
 
-@pytest.fixture(params=[0, 1], ids=["one_loop", "split"])
+@pytest.fixture(params=[0, 1, 2], ids=["one_loop", "split", "split_two_passes"])
 def expand_mode(request):
     """0: a root's jump patterns are consumed by the lane that walks their subtrees (the kernels of rounds 3-5); 1: phase A / phase B of
     round 6 (gm_expand.h): one work item per (root, item), node packets in three lists, every packet walked from its own needle window,
-    the neighbour filters of one- and two-row table entries on"""
+    the neighbour filters of one- and two-row table entries on; 2: the same in two passes -- the patterns without a substitution of every
+    root first (a work item per root), then everything else (gm_expand.h: expand_strip_exact)"""
     e = emu()
     e.gm_emu_set_expand(request.param)
     yield request.param
@@ -357,10 +358,10 @@ def test_phase_a_node_packets_and_neighbour_filters(K, E):
     pk = np.zeros(4, dtype=np.uint64)
     ended = {}
     try:
-        e.gm_emu_set_expand(1)
-        for groups in (0, 2):
+        for groups, xmode in ((0, 1), (2, 1), (2, 2), (0, 2)):
+            e.gm_emu_set_expand(xmode)
             e.gm_emu_set_jump_groups(groups)
-            for nbf in (1, 2, 0):
+            for nbf in ((1, 2, 0) if xmode == 1 else (1,)):
                 e.gm_emu_set_nb_filter(nbf)
                 for T, jump in ((1, 16), (4, 9), (0, 12)):
                     e.gm_emu_packets(H._ptr(pk), 1)
@@ -368,9 +369,9 @@ def test_phase_a_node_packets_and_neighbour_filters(K, E):
                     assert np.array_equal(out, exp), (K, E, groups, nbf, T, jump, np.flatnonzero(out != exp)[:10])
                     e.gm_emu_packets(H._ptr(pk), 1)
                     assert pk[0] > 0 and (jump < 16 or K >= 64 or (pk[1] > 0 and (E < 2 or pk[2] > 0))), pk
-                    ended[(groups, nbf, T, jump)] = int(pk[3])
+                    ended[(groups, nbf, T, jump, xmode)] = int(pk[3])
                     assert st[6] > 0                       # self hits (the walker's: a redone chunk of phase A must not add twice)
-        assert ended[(0, 1, 1, 16)] > 0 and ended[(0, 0, 1, 16)] == 0 and ended[(0, 1, 1, 16)] >= ended[(0, 2, 1, 16)] > 0, ended
+        assert ended[(0, 1, 1, 16, 1)] > 0 and ended[(0, 0, 1, 16, 1)] == 0 and ended[(0, 1, 1, 16, 1)] >= ended[(0, 2, 1, 16, 1)] > 0 and ended[(0, 1, 1, 16, 2)] == ended[(0, 1, 1, 16, 1)], ended
         # slices and a selection go through the same code
         e.gm_emu_set_nb_filter(1)
         out2, _ = emu_map2(ix, 1, K, E, first_seq=0, n_seq=2, value_bits=16, verify_t=1, jump=15)

@@ -272,13 +272,14 @@ def test_gpu_split_search_phase_a_and_walker(K, E):
             slices_seen = set()
             for mb, chunk, T, coop, ctx, steal, flt, grp, satw in ((-1, -1, -1, -1, 1, -1, 1, -1, -1), (1, 1, 1, 1, 1, 0, 2, 1, 0), (2, 7, 4, 0, 0, 1, 0, 0, 1 << 20),
                                                                     (1, -1, 0, 1, 1, 16, 1, 1, -1), (3, 50, -1, -1, 1, -1, 1, -1, 4)):
-                ix.set_tuning(expand=1, expand_mb=mb, expand_chunk=chunk, verify_t=T, coop=coop, use_ctx=ctx, steal=steal, jump_filter=flt, jump_groups=grp, sat_draw_w=satw)
+                ix.set_tuning(expand=1, expand_mb=mb, expand_chunk=chunk, verify_t=T, coop=coop, use_ctx=ctx, steal=steal, jump_filter=flt, jump_groups=grp, sat_draw_w=satw,
+                              expand_two_pass=(-1, 0, 1, 0, 1)[(mb + chunk) % 5])   # one pass over every pattern / the patterns without a substitution first, then the rest
                 for bits in (8, 16):
                     out = ix.map(K, E, value_bits=bits)
                     assert np.array_equal(out, exp[bits]), (K, E, bb, bits, mb, chunk, T, coop, ctx, steal, flt, grp, satw, np.flatnonzero(out != exp[bits])[:10])
                     slices_seen.add(ix.last_stats()["detail"]["slices"])
             assert min(slices_seen) >= 1 and max(slices_seen) > 3, slices_seen     # the small buffers forced many slices
-            ix.set_tuning(expand=0, expand_mb=-1, expand_chunk=-1, verify_t=-1, coop=-1, use_ctx=1, steal=-1, jump_filter=1, jump_groups=-1, sat_draw_w=-1)
+            ix.set_tuning(expand=0, expand_mb=-1, expand_chunk=-1, verify_t=-1, coop=-1, use_ctx=1, steal=-1, jump_filter=1, jump_groups=-1, sat_draw_w=-1, expand_two_pass=-1)
             assert np.array_equal(ix.map(K, E, value_bits=8), exp[8]) and ix.last_stats()["detail"]["slices"] == 0
             # shares of one vector: k-mer ranges, interleaved chunks, a selection -- each through the split search with small buffers
             ix.set_tuning(expand=1, expand_mb=2)
@@ -503,6 +504,18 @@ def test_gpu_one_correction_pass_per_call_beside_the_main_search():
                 assert ix.last_stats()["detail"]["correction_us"] > 0
                 acc |= buf
             assert np.array_equal(acc[:n].cpu().numpy(), exp), (K, E, "pieces of a share")
+            # a piece that does not continue the share the index is in the middle of is refused: a later piece without its first,
+            # a piece out of order, a piece after another call on the index
+            buf = torch.zeros(plan.padded_len(n), dtype=torch.uint8, device="cuda:0")
+            st0 = torch.cuda.current_stream().cuda_stream
+            for bad in ("no first piece", "out of order", "another call in between"):
+                if bad != "no first piece":
+                    ix.map_device(buf.data_ptr(), K, E, value_bits=8, kmer_range=pieces[0], chunks=plan.chunk_arg(0), piece_of=share, stream=st0)
+                if bad == "another call in between":
+                    ix.map(K, 0, value_bits=8)
+                with pytest.raises(g.GenmapError):
+                    ix.map_device(buf.data_ptr(), K, E, value_bits=8, kmer_range=pieces[2 if bad == "out of order" else 1], chunks=plan.chunk_arg(0), piece_of=share, stream=st0)
+                torch.cuda.synchronize(); ix.sync()
             ix.set_tuning(jump=0)
             assert np.array_equal(ix.map(K, E, value_bits=8), exp), (K, E, "plain walk")
             ix.set_tuning(jump=-1)
