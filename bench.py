@@ -232,6 +232,7 @@ def main():
     ap.add_argument("--no-host-rate", action="store_true", help="skip value_host (its gm_map call launches the search kernel in four pieces: keeps a rocprofv3 kernel trace of the timed launches clean)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true")
+    ap.add_argument("--c5-per-file", action="store_true", help="bacteria5 at N = 1: one launch per FASTA file (round 5) instead of one for all of them")
     ap.add_argument("--no-csv", action="store_true", help="bacteria5: skip the csv location lists (gm_locate), time the --exclude-pseudo frequencies only")
     ap.add_argument("--trace", type=float, default=0.0, help="print stage markers from every rank and, after this many seconds, every thread's Python stack (diagnosis of a stalled multi-rank run)")
     ap.add_argument("--allow-mixed-features", action="store_true", help="N > 1: time the run even if the ranks' index replicas differ (records, table length)")
@@ -513,9 +514,15 @@ def main():
         for _, recs in files5:
             tl = sum(len(c) for _, c in recs)
             slices.append((first, len(recs), tl)); first += len(recs)
+        # N = 1: the five files in ONE launch of the persistent kernel (what gm_map_files does: a value depends on the k-mer and on the whole index, not on
+        # the file it is computed with; positions across a file boundary cross a sequence boundary and are zeroed by resetLimits) -- the five launches
+        # of 6.4 ms filled and drained 256 CUs for 4 Mbp each (profiles/r05).  N > 1 keeps a share per file and rank.
+        files = list(slices)
+        if world == 1 and not args.c5_per_file:
+            slices = [(0, first, sum(tl for _, _, tl in files))]
         infix = args.infix or g.tuned_infix_length(K, E, locating=True)   # --exclude-pseudo and csv locate: the library's block shape for those calls
         step_size = K - infix + 1
-        total_kmers = sum(tl - K + 1 for _, _, tl in slices)
+        total_kmers = sum(tl - K + 1 for _, _, tl in files)
         bufs = []
         for _, _, tl in slices:
             rg = shard_ranges(tl - K + 1, step_size, world)

@@ -54,7 +54,7 @@ MAP_FLAG_RANGE = 1
 MAP_FLAG_PIECE = 2    # GM_MAP_FLAG_PIECE: the call is one launch of the share (whole_begin, whole_end)
 WIDE_ROWS = 0x10000   # GM_BLOCK_WIDE_ROWS: OR into block_bytes to force 64-bit rows
 
-EXPORTS = ["gm_device_alloc", "gm_device_free", "gm_ipc_export", "gm_ipc_open", "gm_ipc_close", "gm_push_pieces", "gm_map_shard", "gm_host_pin", "gm_host_unpin", "gm_index_set_tuning", "gm_index_sync", "gm_map_kernel_times", "gm_map_runs", "gm_runs_free", "gm_tuned_infix_length", "gm_tuned_infix_length_locating", "gm_index_export_sa", "gm_locate", "gm_locations_free", "gm_status_string", "gm_last_error", "gm_device_count", "gm_index_build", "gm_index_import", "gm_index_import_sampled", "gm_index_export_sa_sampled",
+EXPORTS = ["gm_map_files", "gm_device_alloc", "gm_device_free", "gm_ipc_export", "gm_ipc_open", "gm_ipc_close", "gm_push_pieces", "gm_map_shard", "gm_host_pin", "gm_host_unpin", "gm_index_set_tuning", "gm_index_sync", "gm_map_kernel_times", "gm_map_runs", "gm_runs_free", "gm_tuned_infix_length", "gm_tuned_infix_length_locating", "gm_index_export_sa", "gm_locate", "gm_locations_free", "gm_status_string", "gm_last_error", "gm_device_count", "gm_index_build", "gm_index_import", "gm_index_import_sampled", "gm_index_export_sa_sampled",
            "gm_index_export_bwt", "gm_index_get_info", "gm_index_free", "gm_map", "gm_map_device",
            "gm_last_map_stats", "gm_default_infix_length"]
 
@@ -102,6 +102,8 @@ def load_library(profiling=False):
     lib.gm_index_free.argtypes = [vp]
     lib.gm_map.restype = C.c_int
     lib.gm_map.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(MapParams), vp, C.c_uint64, vp, vp]
+    lib.gm_map_files.restype = C.c_int
+    lib.gm_map_files.argtypes = [vp, C.c_uint32, vp, vp, C.POINTER(MapParams), vp, vp]
     lib.gm_map_shard.restype = C.c_int
     lib.gm_map_shard.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(MapParams), vp, C.c_uint64, vp, vp]
     lib.gm_host_pin.restype = C.c_int
@@ -358,6 +360,18 @@ class Index:
         sf = None if seq_file_id is None else np.ascontiguousarray(seq_file_id, dtype=np.uint32)
         _check(self._lib, self._lib.gm_map(self._h, tb, tl, first_seq, n_seq, C.byref(p), _ptr(iv), 0 if iv is None else len(iv) // 2, _ptr(sf), _ptr(out)))
         return out
+
+    def map_files(self, files, K, E, overlap=None, infix=0, revcompl=True, value_bits=16, exclude_pseudo=False, seq_file_id=None):
+        """gm_map_files: the reference's loop over the FASTA files of an index (src/mappability.hpp:289-365) as one call; files = [(first_seq, n_seq), ..]
+        consecutive and ascending; returns one host array per file."""
+        p = self._params(K, E, overlap, infix, revcompl, value_bits, exclude_pseudo, None, None)
+        fs = np.ascontiguousarray([f for f, _ in files], dtype=np.uint32)
+        ns = np.ascontiguousarray([n for _, n in files], dtype=np.uint32)
+        outs = [np.zeros(self._slice(f, n)[2], dtype=np.uint8 if value_bits == 8 else np.uint16) for f, n in files]
+        ptrs = (C.c_void_p * len(outs))(*[o.ctypes.data for o in outs])
+        sf = None if seq_file_id is None else np.ascontiguousarray(seq_file_id, dtype=np.uint32)
+        _check(self._lib, self._lib.gm_map_files(self._h, len(files), _ptr(fs), _ptr(ns), C.byref(p), _ptr(sf), ptrs))
+        return outs
 
     def map_shard(self, out, K, E, first_seq=0, n_seq=None, overlap=None, infix=0, revcompl=True, value_bits=16,
                   exclude_pseudo=False, intervals=None, seq_file_id=None, kmer_range=None, chunks=None):

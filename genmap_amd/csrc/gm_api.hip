@@ -1783,6 +1783,37 @@ int gm_map(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32_t first_
     return rc;
 }
 
+int gm_map_files(gm_index* ix, uint32_t n_files, const uint32_t* file_first_seq, const uint32_t* file_n_seq, const gm_map_params* p,
+                 const uint32_t* seq_file_id, void* const* out_host)
+{
+    if (!ix || !p || !file_first_seq || !file_n_seq || !out_host || n_files == 0) { set_error("null argument"); return GM_ERR_BAD_ARG; }
+    if (p->value_bits != 8 && p->value_bits != 16) return GM_ERR_BAD_VALUE_BITS;
+    if ((p->flags & (GM_MAP_FLAG_RANGE | GM_MAP_FLAG_PIECE)) || p->kmer_begin != 0 || p->kmer_end != 0 || (p->chunk_blocks > 0 && p->chunk_stride > 1)) {
+        set_error("gm_map_files takes whole files (no k-mer range, no interleaved chunks)"); return GM_ERR_BAD_ARG;
+    }
+    for (uint32_t f = 0; f < n_files; ++f) {
+        if (file_n_seq[f] == 0 || (uint64_t)file_first_seq[f] + file_n_seq[f] > ix->nSeq || (f > 0 && file_first_seq[f] != file_first_seq[f - 1] + file_n_seq[f - 1])) {
+            set_error("gm_map_files: the files are consecutive runs of the index's sequences, in ascending order"); return GM_ERR_BAD_ARG;
+        }
+        if (!out_host[f]) { set_error("null output"); return GM_ERR_BAD_ARG; }
+    }
+    GM_HIP(hipSetDevice(ix->device));
+    const uint32_t s0 = file_first_seq[0], s1 = file_first_seq[n_files - 1] + file_n_seq[n_files - 1];
+    const uint64_t tb = ix->cum[s0], tl = ix->cum[s1] - tb;
+    const size_t eb = p->value_bits / 8;
+    void* d_out = nullptr;
+    GM_HIP(hipMalloc(&d_out, tl * eb + 16));
+    int rc = map_impl(ix, tb, tl, s0, s1 - s0, p, nullptr, 0, seq_file_id, d_out, nullptr);   // ONE launch over the k-mers of every file
+    for (uint32_t f = 0; f < n_files && !rc; ++f) {
+        const uint64_t b = ix->cum[file_first_seq[f]] - tb, n = ix->cum[file_first_seq[f] + file_n_seq[f]] - ix->cum[file_first_seq[f]];
+        hipError_t e = hipMemcpy(out_host[f], (const uint8_t*)d_out + b * eb, n * eb, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { set_error("copy back failed: %s", hipGetErrorString(e)); rc = GM_ERR_HIP; }
+    }
+    if (!rc) rc = check_device_error(ix);
+    hipFree(d_out);
+    return rc;
+}
+
 int gm_host_pin(void* host, uint64_t bytes)
 {
     if (!host) return GM_ERR_BAD_ARG;

@@ -164,6 +164,16 @@ int gm_map_device(gm_index *idx, uint64_t text_begin, uint64_t text_len, uint32_
                   const gm_map_params *params, const uint64_t *intervals, uint64_t n_intervals,
                   const uint32_t *seq_file_id, void *out_device, void *stream);
 
+/* The per-FASTA-file loop of the reference (src/mappability.hpp:289-365: one computeMappability per file of the index) as ONE call:
+ * n_files files, file i made of the sequences [file_first_seq[i], file_first_seq[i] + file_n_seq[i]), consecutive and in ascending order;
+ * out_host[i]: the values of file i (its text length, value_bits wide).  The files' k-mers are searched in one launch of the persistent
+ * kernel -- a value depends on the k-mer at its position and on the whole index, not on the file it is computed with, and the positions that
+ * cross a sequence (hence a file) boundary are zeroed by resetLimits either way -- instead of filling and draining the device once per
+ * file (config C5: five launches of 6.4 ms for 4 Mbp each).  No selection (intervals) and no shard arguments; gm_map per file is the
+ * general form. */
+int gm_map_files(gm_index *idx, uint32_t n_files, const uint32_t *file_first_seq, const uint32_t *file_n_seq,
+                 const gm_map_params *params, const uint32_t *seq_file_id, void *const *out_host);
+
 /* One device's share of a computeMappability call whose result is assembled in HOST memory by several devices (the
  * `genmap map -D 0,1,..` path: one index replica and one host thread per GPU).  Computes the interleaved chunks selected by
  * params->chunk_blocks / chunk_index / chunk_stride (all of the k-mer range when chunk_stride <= 1) and copies exactly

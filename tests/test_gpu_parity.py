@@ -1245,6 +1245,35 @@ def test_gpu_ecoli_like_full_size_vs_oracle():
     ix.close()
 
 
+def test_gpu_map_files_is_the_per_file_loop_in_one_launch():
+    """gm_map_files (the loop of src/mappability.hpp:289-365 as one call) against gm_map per file: frequencies and --exclude-pseudo, both widths,
+    K below and above 64, files of one and of several sequences, a run of files in the middle of the index; bad file lists are refused."""
+    g = _gm()
+    rng = np.random.default_rng(515)
+    lens = [9000, 31, 4000, 7000, 2500, 2500, 40, 12000]
+    codes = _repeat_text(rng, sum(lens), True)
+    codes[9100:9400] = codes[100:400]; codes[16000:16300] = codes[100:400]
+    files = [(0, 2), (2, 1), (3, 3), (6, 2)]
+    fid = np.array([f for f, (_, n) in enumerate(files) for _ in range(n)], dtype=np.uint32)
+    ix = g.Index.build(codes, lens, sampling=1)
+    try:
+        for K, E in ((24, 1), (30, 2), (100, 1), (30, 0)):
+            for ep in (False, True):
+                for bits in (8, 16):
+                    want = [ix.map(K, E, first_seq=f, n_seq=n, value_bits=bits, exclude_pseudo=ep, seq_file_id=fid) for f, n in files]
+                    got = ix.map_files(files, K, E, value_bits=bits, exclude_pseudo=ep, seq_file_id=fid)
+                    for a, b, fl in zip(got, want, files):
+                        assert np.array_equal(a, b), (K, E, ep, bits, fl, np.flatnonzero(a != b)[:10])
+                    got = ix.map_files(files[1:3], K, E, value_bits=bits, exclude_pseudo=ep, seq_file_id=fid)
+                    assert all(np.array_equal(a, b) for a, b in zip(got, want[1:3])), (K, E, ep, bits, "middle files")
+        with pytest.raises(g.GenmapError):
+            ix.map_files([(0, 2), (3, 3)], 24, 1)          # a gap
+        with pytest.raises(g.GenmapError):
+            ix.map_files([(2, 1), (0, 2)], 24, 1)          # not ascending
+    finally:
+        ix.close()
+
+
 def test_gpu_five_bacteria_full_size_exclude_pseudo_vs_oracle():
     """BASELINE config C5 at its real size (S5: five related genomes, ~21 Mbp in 10 sequences): K=24 e=1 --exclude-pseudo.
     The oracle adopts the GPU-built BWTs and suffix array (checked against each other first: check_sa_against_bwt) and
@@ -1261,9 +1290,12 @@ def test_gpu_five_bacteria_full_size_exclude_pseudo_vs_oracle():
     ora = H.OracleIndex(gen.codes, gen.seq_len, keep_sa=False, bwt=(bf, br), sa=sa)
     K, E, T = 24, 1, os.cpu_count() or 8
     nfiles = len(files)
-    for name, first, nseq, tb, tl in gen.file_slices():
+    # the batched entry (round 6): the five files in ONE launch -- every file's vector must be the one its own gm_map call gives
+    batched = ix.map_files([(first, nseq) for _, first, nseq, _, _ in gen.file_slices()], K, E, value_bits=16, exclude_pseudo=True, seq_file_id=gen.seq_file)
+    for q, (name, first, nseq, tb, tl) in enumerate(gen.file_slices()):
         out = ix.map(K, E, first_seq=first, n_seq=nseq, value_bits=16, exclude_pseudo=True, seq_file_id=gen.seq_file)
         assert out.max() <= nfiles
+        assert np.array_equal(batched[q], out), (name, "gm_map_files")
         iv = [(0, 4000), (tl // 3 - 2000, tl // 3 + 2000), (tl * 20 // 21 - 3000, tl * 20 // 21 + 3000), (tl - 5000, tl - K + 1)]   # start, N patch, island edge, end
         iv = [(max(0, a), min(tl - K + 1, b)) for a, b in iv]
         want, _, locs = ora.mappability(K, E, first_seq=first, n_seq=nseq, text_begin=tb, text_len=tl, value_bits=16, directory=True,

@@ -31,7 +31,7 @@ for cfg, setting in [(c, s2) for c in a.cfg for s2 in a.settings]:
     st = ix.last_stats()
     nk = st["kmers"]
     d = st["detail"]
-    print(json.dumps({"workload": desc, "K": K, "E": E, "settings": setting, "kmers": nk, "jump_lookups_per_kmer": d.get("jump_lookups", 0) / nk, "jump_words_per_kmer": d.get("jump_words", 0) / nk, "jump_filtered_per_kmer": d.get("jump_filtered", 0) / nk, "correction_us": d.get("correction_us", 0), "steps_per_kmer": st["node_steps"] / nk, "lines_per_kmer": st["rank_lines"] / nk,
+    print(json.dumps({"workload": desc, "K": K, "E": E, "settings": setting, "kmers": nk, "jump_lookups_per_kmer": d.get("jump_lookups", 0) / nk, "jump_words_per_kmer": d.get("jump_words", 0) / nk, "jump_filtered_per_kmer": d.get("jump_filtered", 0) / nk, "packets_per_kmer": d.get("packets", 0) / nk, "slices": d.get("slices", 0), "correction_us": d.get("correction_us", 0), "steps_per_kmer": st["node_steps"] / nk, "lines_per_kmer": st["rank_lines"] / nk,
                       "oss_frac": d["steps_oss"] / st["node_steps"], "ext_w1_frac": d["ext_w1"] / st["node_steps"], "ext_w2_4_frac": d["ext_w2_4"] / st["node_steps"],
                       "oss_w1_frac": d["oss_w1"] / st["node_steps"], "pushes_per_step": d["pushes"] / st["node_steps"], "verify_items_per_kmer": d["verify_items"] / nk, "verify_items_oss_frac": d["verify_items_oss"] / max(1, d["verify_items"]), "chunks_per_item": d["verify_chunks"] / max(1, d["verify_items"]), "lanes_active_per_iteration": d["active_lane_sum"] / max(1, d["wave_iterations"]), "wave_iterations": d["wave_iterations"], "cyc_fetch_frac": d["cyc_fetch"] / max(1, d["cyc_fetch"] + d["cyc_verify"] + d["cyc_step"]), "cyc_verify_frac": d["cyc_verify"] / max(1, d["cyc_fetch"] + d["cyc_verify"] + d["cyc_step"]), "cyc_step_frac": d["cyc_step"] / max(1, d["cyc_fetch"] + d["cyc_verify"] + d["cyc_step"]), "cyc_per_iter": (d["cyc_fetch"] + d["cyc_verify"] + d["cyc_step"]) / max(1, d["wave_iterations"]), "verify_rounds": d["verify_rounds"], "fetch_parts_pop_share_st32_st1": [round(d[k] / max(1, d["cyc_fetch"] + d["cyc_verify"] + d["cyc_step"]), 3) for k in ("cyc_pop", "cyc_share", "cyc_stage32", "cyc_stage1")], "stolen_per_kmer": d["stolen"] / nk, "search_ms_instrumented": st["search_ms"],
                       # how often a wavefront executes a region, per loop iteration (x the region's instruction count = its share of the work)
