@@ -1387,6 +1387,7 @@ static int run_expand(gm_index* ix, const SearchSetup& S, SearchArgs A, const gm
     const uint32_t G = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(wantBlocks, (usableMin / 2) / std::max<uint64_t>(chunkWorst, 1)));
     const uint64_t totalChunks = (S.numBlocksCall + G - 1) / G;
     A.expandBlocks = G; A.itemsPerBlock = ipb; A.wmap = wmapPtr; A.xmode = mode;
+    A.wmapRoots = ix->d_wmap + S.itemsPerBlock; A.rootsPerBlockA = S.rootsPerBlock; A.xshare = ix->tune.expandShare > 0 ? 1u : 0u;   // (off until measured)
     // first slice: a guess at the packets a chunk makes (8 per k-mer); the slices behind it follow what their predecessor measured
     const uint64_t guess = (uint64_t)G * S.plan.stepSize * (mode == 1u ? 2ull : 8ull);
     const uint32_t firstChunks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(usableMin / std::max<uint64_t>(guess, 1), 0x7FFFFFFFull));
@@ -2132,7 +2133,7 @@ int gm_index_set_tuning(gm_index* ix, const char* name, int64_t value)
         {"iter_cap", &ix->tune.iterCap, dflt.iterCap, 1, 0x7FFFFFFF}, {"stall_cap", &ix->tune.stallCap, dflt.stallCap, 1, 0x7FFFFFFF},   // bounds of a hung search loop (tests force them)
         {"pat_batch", &ix->tune.patBatch, dflt.patBatch, 1, 64},
         {"expand", &ix->tune.expand, dflt.expand, 0, 1}, {"expand_mb", &ix->tune.expandMB, dflt.expandMB, 1, 1 << 20},   // the split search (gm_expand.h)
-        {"expand_chunk", &ix->tune.expandChunk, dflt.expandChunk, 1, 1 << 16}, {"expand_occ", &ix->tune.expandOcc, dflt.expandOcc, 1, 64}, {"expand_overlap", &ix->tune.expandOverlap, dflt.expandOverlap, 0, 1}, {"expand_two_pass", &ix->tune.expandTwoPass, dflt.expandTwoPass, 0, 1}, {"sat_draw_w", &ix->tune.satDrawW, dflt.satDrawW, 0, 0x7FFFFFFF},
+        {"expand_chunk", &ix->tune.expandChunk, dflt.expandChunk, 1, 1 << 16}, {"expand_occ", &ix->tune.expandOcc, dflt.expandOcc, 1, 64}, {"expand_overlap", &ix->tune.expandOverlap, dflt.expandOverlap, 0, 1}, {"expand_two_pass", &ix->tune.expandTwoPass, dflt.expandTwoPass, 0, 1}, {"expand_share", &ix->tune.expandShare, dflt.expandShare, 0, 1}, {"sat_draw_w", &ix->tune.satDrawW, dflt.satDrawW, 0, 0x7FFFFFFF},
         {"jump_groups", &ix->tune.jumpGroups, dflt.jumpGroups, 0, 1},   // groups of jump patterns behind the existence bitmap: 0 never, 1 wherever possible, -1 where they save table reads
     };
     for (auto& t : tab) if (!strcmp(t.n, name)) {

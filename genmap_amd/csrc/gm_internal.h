@@ -41,6 +41,7 @@ struct Tuning {
     int expandChunk = -1;              // k-mer blocks per chunk of phase A (-1: about a thousand work items)
     int expandOverlap = -1;            // 1: phase A of slice i + 1 runs beside the walker of slice i (three walker blocks and one block of phase A per CU); 0 / -1: one after the other
     int expandTwoPass = -1;            // 1 / -1: the patterns without a substitution of every root first, then the rest for blocks not at MAX yet; 0: one pass
+    int expandShare = -1;              // 1 / -1: phase A computes a root's context once (a lane per root of a group of blocks, LDS), 0: every item computes it
     int expandOcc = -1;                // blocks of phase A per CU (-1: what the occupancy query says, at most 8)
     int satDrawW = -1;                 // the walker drops a drawn node at least this wide when its block's k-mers are all at MAX (-1: 1 = every packet)
 };

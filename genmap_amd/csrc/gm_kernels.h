@@ -154,6 +154,9 @@ struct SearchArgs {
     uint32_t capX, capY;            // packets the buffers hold
     uint32_t pktChunks;             // 16-byte chunks of needle window per packet
     ExpandCtl* xctl;
+    const uint32_t* wmapRoots;      // phase A: (strand, search) of root q of a block (the work map of the first of two passes)
+    uint32_t rootsPerBlockA;        // strands x searches
+    uint32_t xshare;                // 1: the root contexts of a group of blocks are computed once, by a lane per ROOT, and read by the roots' items from LDS
     uint32_t xmode;                 // phase A: 0 every pattern of every root (one pass), 1 the patterns without a substitution (a work item per root), 2 the rest, for blocks not at MAX yet
     const uint32_t* wmap;           // work item of a block -> search | strand << 3 | item << 8 (gm_expand.h: make_wmap)
     uint32_t itemsPerBlock;         // work items per k-mer block
@@ -1683,6 +1686,11 @@ __global__ __launch_bounds__(256) void expand_kernel(const SearchArgs A)
     __shared__ uint4 cx0s[256], cx1s[256];   // per lane of a batch: {J-mer index, neighbours, meta at depth J, filter mask}, {window origin, root word, the item's own rotations, layout shift | flags}
     __shared__ uint2 cx2s[256];              // ... the item's surviving rotations
     __shared__ uint32_t pres[256];           // ... rotations of the lanes before it
+    // root contexts of a group of blocks (A.xshare): a root's J-mer, neighbours and window are the same for every one of its ~9 items -- one lane per ROOT
+    // computes them for the 10 blocks (K=30 e=2: 60 roots) whose ~560 items the next nine turns of the wavefront work through
+    __shared__ uint4 rc0s[256];              // {J-mer index, neighbours, the two letters behind, window origin}
+    __shared__ uint32_t rc1s[256];           // n | bad << 8 | block at MAX << 9
+    __shared__ uint4 wwins[4 * 16 * 3];      // the packet window (from nibble 0) of every block of the group, up to three chunks
     load_jump_records(jl, A);
     if (threadIdx.x < 8u) jl[20u + threadIdx.x] = A.table[(size_t)(A.stepSize - 1u) * 8u + threadIdx.x];
     __syncthreads();
@@ -1690,6 +1698,9 @@ __global__ __launch_bounds__(256) void expand_kernel(const SearchArgs A)
     const uint32_t lane = threadIdx.x & 63u;
     uint4* const cx0 = cx0s + (threadIdx.x & ~63u); uint4* const cx1 = cx1s + (threadIdx.x & ~63u);
     uint2* const cx2 = cx2s + (threadIdx.x & ~63u); uint32_t* const pre = pres + (threadIdx.x & ~63u);
+    uint4* const rc0 = rc0s + (threadIdx.x & ~63u); uint32_t* const rc1 = rc1s + (threadIdx.x & ~63u); uint4* const wwin = wwins + (threadIdx.x >> 6) * 48u;
+    const uint32_t RPB = A.rootsPerBlockA;
+    const uint32_t NB = (A.xshare && RPB >= 1u && RPB <= 64u && A.pktChunks <= 3u) ? (64u / RPB < 16u ? 64u / RPB : 16u) : 0u;   // blocks per group (0: every item computes its root's context itself)
     ExpandCtl* const ctl = A.xctl;
     const uint32_t U = PKT_HEADER_UNITS + A.pktChunks;
     const uint32_t G = A.expandBlocks, IPB = A.itemsPerBlock;
@@ -1707,40 +1718,73 @@ __global__ __launch_bounds__(256) void expand_kernel(const SearchArgs A)
         if (cid >= chunkEnd || cid >= (unsigned long long)__hip_atomic_load(&ctl->failFrom, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
         const unsigned long long blk0 = cid * G;
         const uint32_t nblk = A.numBlocksCall - blk0 < G ? (uint32_t)(A.numBlocksCall - blk0) : G;
-        const uint32_t nwork = nblk * IPB;
+        // a root's context: the block's window origin and length, "at MAX already" (second pass), J-mer / neighbours / letters behind (expand_root)
+        auto root_context = [&](uint32_t blockInChunk, uint32_t search, uint32_t strand, uint32_t& win, uint32_t& n, bool& blockDone) -> XRoot {
+            XRoot xr; xr.jb = xr.jn = xr.ext = 0u; xr.bad = 1u;
+            unsigned long long gb = blk0 + blockInChunk;        // ordinal of the block among this call's blocks (gm_stage1.inc)
+            if (A.chunkBlocks) {
+                const uint32_t qq = (uint32_t)gb / A.chunkBlocks;
+                gb = (unsigned long long)(qq * A.chunkStride + A.chunkIndex) * A.chunkBlocks + ((uint32_t)gb - qq * A.chunkBlocks);
+            }
+            gb += A.blockBegin;
+            if (A.blockList) { const uint2 e = A.blockList[gb]; win = e.x; n = e.y & 0xFFu; }   // (32-bit rows: slice positions fit 32 bits)
+            else { win = (uint32_t)gb * A.stepSize; const uint32_t left = (uint32_t)A.numKmers - win; n = left < A.stepSize ? left : A.stepSize; }
+            // (pass 2 of two: a block whose k-mers the first pass has all brought to MAX needs nothing more -- min(total, MAX), src/algo.hpp:36,48,191)
+            blockDone = false;
+            if (A.xmode == 2u) {
+                blockDone = true;
+                for (uint32_t i = 0; i < n && blockDone; ++i) blockDone = A.acc[win + i] >= A.maxVal;
+            }
+            if (n == A.stepSize && !blockDone) {
+                const uint32_t a0 = n - 1u + (((search < 4u ? A.jumpAPacked[0] : A.jumpAPacked[1]) >> (8u * (search & 3u))) & 0xFFu);
+                xr = expand_root(mem, A.textBegin + win, A.K + n - 1u, strand, a0, A.jumpJ, jl[search].w, (jl[12u + search].w & 0xFFu) != 0u);
+            }
+            return xr;
+        };
+#pragma unroll 1
+        for (uint32_t g0 = 0; g0 < nblk && !dead; g0 += (NB ? NB : nblk)) {
+        const uint32_t nbg = NB ? (nblk - g0 < NB ? nblk - g0 : NB) : nblk;
+        if (NB) {   // ---- one lane per ROOT of the group ----
+            uint4 c0 = make_uint4(0, 0, 0, 0); uint32_t c1 = 0x100u;
+            if (lane < nbg * RPB) {
+                const uint32_t bi = lane / RPB, rq = lane - bi * RPB;
+                const uint32_t wm1 = A.wmapRoots[rq];
+                uint32_t win, n; bool blockDone;
+                const XRoot xr = root_context(g0 + bi, wm1 & 7u, (wm1 >> 3) & 1u, win, n, blockDone);
+                c0 = make_uint4(xr.jb, xr.jn, xr.ext, win); c1 = n | (xr.bad ? 0x100u : 0u) | (blockDone ? 0x200u : 0u);
+                if (rq == 0u && !blockDone)   // the block's packet window: what every packet of its roots carries
+                    for (uint32_t j = 0; j < A.pktChunks; ++j) {
+                        const unsigned long long w0 = nib64(mem, A.textBegin + win + 32u * j), w1 = nib64(mem, A.textBegin + win + 32u * j + 16u);
+                        wwin[bi * 3u + j] = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
+                    }
+            }
+            rc0[lane] = c0; rc1[lane] = c1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        const uint32_t nwork = nbg * IPB;
 #pragma unroll 1
         for (uint32_t base = 0; base < nwork && !dead; base += 64u) {
             const uint32_t l = base + lane;
             const bool on = l < nwork;
             XRoot xr; xr.jb = xr.jn = xr.ext = 0u; xr.bad = 1u;
             XItem it; it.alive = 0ull; it.gcur = it.sh = it.state = it.widx = it.wsel = 0u;
-            uint32_t win = 0, nss = 0, jm0 = 0, hword = 0, jd = 0;
+            uint32_t win = 0, nss = 0, jm0 = 0, hword = 0, jd = 0, big = 0;
             bool pendRoot = false;
             if (on) {
                 const uint32_t bi = l / IPB, q = l - bi * IPB;
                 const uint32_t wm = A.wmap[q], search = wm & 7u, strand = (wm >> 3) & 1u, jp = wm >> 8;
-                unsigned long long gb = blk0 + bi;        // ordinal of the block among this call's blocks (gm_stage1.inc)
-                if (A.chunkBlocks) {
-                    const uint32_t qq = (uint32_t)gb / A.chunkBlocks;
-                    gb = (unsigned long long)(qq * A.chunkStride + A.chunkIndex) * A.chunkBlocks + ((uint32_t)gb - qq * A.chunkBlocks);
-                }
-                gb += A.blockBegin;
-                uint32_t n;
-                if (A.blockList) { const uint2 e = A.blockList[gb]; win = e.x; n = e.y & 0xFFu; }   // (32-bit rows: slice positions fit 32 bits)
-                else { win = (uint32_t)gb * A.stepSize; const uint32_t left = (uint32_t)A.numKmers - win; n = left < A.stepSize ? left : A.stepSize; }
+                uint32_t n; bool blockDone;
+                if (NB) {
+                    const uint32_t ri = bi * RPB + strand * A.nSearches + search;
+                    const uint4 c0 = rc0[ri]; const uint32_t c1 = rc1[ri];
+                    xr.jb = c0.x; xr.jn = c0.y; xr.ext = c0.z; win = c0.w; n = c1 & 0xFFu; xr.bad = (c1 >> 8) & 1u; blockDone = ((c1 >> 9) & 1u) != 0u;
+                    big = bi;
+                } else xr = root_context(g0 + bi, search, strand, win, n, blockDone);
                 nss = pkt_root_word(n, strand, search);
                 const uint4 fji = jl[search];   // {first item | items << 16, meta at depth J relative to n - 1, first item, neighbour-filter mask}
                 hword = fji.w;
-                // (pass 2 of two: a block whose k-mers the first pass has all brought to MAX needs nothing more -- min(total, MAX), src/algo.hpp:36,48,191)
-                bool blockDone = false;
-                if (A.xmode == 2u) {
-                    blockDone = true;
-                    for (uint32_t i = 0; i < n && blockDone; ++i) blockDone = A.acc[win + i] >= A.maxVal;
-                }
-                if (n == A.stepSize && !blockDone) {
-                    const uint32_t a0 = n - 1u + (((search < 4u ? A.jumpAPacked[0] : A.jumpAPacked[1]) >> (8u * (search & 3u))) & 0xFFu);
-                    xr = expand_root(mem, A.textBegin + win, A.K + n - 1u, strand, a0, A.jumpJ, fji.w, (jl[12u + search].w & 0xFFu) != 0u);
-                }
                 // an odd block shape or an N inside the J-mer: the root walks the tree from its root (said by its first item's lane; with two passes: by the first)
                 if (blockDone) xr.bad = 1u;
                 else if (xr.bad) pendRoot = A.xmode == 1u ? true : A.xmode == 2u ? false : jp == (fji.x & 0xFFFFu);
@@ -1773,7 +1817,7 @@ __global__ __launch_bounds__(256) void expand_kernel(const SearchArgs A)
             if (total == 0u) continue;
             // the lanes' contexts and the exclusive prefix sums of their counts, in LDS (this wavefront's 64 slots)
             cx0[lane] = make_uint4(xr.jb, xr.jn, jm0, hword);
-            cx1[lane] = make_uint4(win, nss, it.gcur, it.sh | (pendRoot ? 0x100u : 0u) | (it.state == 1u ? 0x200u : 0u));
+            cx1[lane] = make_uint4(win, nss, it.gcur, it.sh | (pendRoot ? 0x100u : 0u) | (it.state == 1u ? 0x200u : 0u) | big << 16);
             cx2[lane] = make_uint2((uint32_t)it.alive, (uint32_t)(it.alive >> 32));
             pre[lane] = incl - cnt;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1783,7 +1827,7 @@ __global__ __launch_bounds__(256) void expand_kernel(const SearchArgs A)
             for (uint32_t t0 = 0; t0 < total; t0 += 64u) {
                 const uint32_t g = t0 + lane;
                 bool take = false;
-                uint32_t cls = 0, pwin = 0, pnss = 0;
+                uint32_t cls = 0, pwin = 0, pnss = 0, pbi = 0;
                 uint4 h0 = make_uint4(0, 0, 0, 0);
                 if (g < total) {
                     uint32_t src = 0;   // the last lane whose first rotation is <= g (lanes without rotations share their successor's start)
@@ -1791,7 +1835,7 @@ __global__ __launch_bounds__(256) void expand_kernel(const SearchArgs A)
                     for (uint32_t step = 32u; step >= 1u; step >>= 1) if (pre[src | step] <= g) src |= step;
                     const uint32_t k = g - pre[src];
                     const uint4 c0 = cx0[src], c1 = cx1[src];
-                    pwin = c1.x; pnss = c1.y;
+                    pwin = c1.x; pnss = c1.y; pbi = c1.w >> 16;
                     if (c1.w & 0x100u) {   // an odd block shape or an N inside the J-mer: the root itself (root_node, gm_engine.h)
                         take = true; cls = 0u;
                         const uint32_t n = pnss & 0xFFu, search = (pnss >> 9) & 7u;
@@ -1841,7 +1885,8 @@ __global__ __launch_bounds__(256) void expand_kernel(const SearchArgs A)
                         uint4* pk = (c == 2u ? A.pktY : A.pktX) + (size_t)(c == 1u ? A.capX - 1u - slot : slot) * U;
                         pk[0] = h0;
                         pk[1] = make_uint4(pwin, pnss, (uint32_t)cid, stamp);
-                        for (uint32_t j = 0; j < A.pktChunks; ++j) {
+                        if (NB) for (uint32_t j = 0; j < A.pktChunks; ++j) pk[2u + j] = wwin[pbi * 3u + j];   // (the group's windows are in LDS)
+                        else for (uint32_t j = 0; j < A.pktChunks; ++j) {
                             const unsigned long long w0 = nib64(mem, A.textBegin + pwin + 32u * j), w1 = nib64(mem, A.textBegin + pwin + 32u * j + 16u);
                             pk[2u + j] = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
                         }
@@ -1854,6 +1899,8 @@ __global__ __launch_bounds__(256) void expand_kernel(const SearchArgs A)
                 if (dead) break;
             }
             __builtin_amdgcn_wave_barrier();   // (the next batch overwrites the contexts)
+        }
+        __builtin_amdgcn_wave_barrier();   // (the next group overwrites the root contexts)
         }
         if (dead) { if (lane == 0u) atomicMin(&ctl->failFrom, (uint32_t)cid); break; }   // this chunk (and every later one) is redone by the next slice
     }
