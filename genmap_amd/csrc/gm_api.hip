@@ -1387,7 +1387,7 @@ static int run_expand(gm_index* ix, const SearchSetup& S, SearchArgs A, const gm
     const uint32_t G = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(wantBlocks, (usableMin / 2) / std::max<uint64_t>(chunkWorst, 1)));
     const uint64_t totalChunks = (S.numBlocksCall + G - 1) / G;
     A.expandBlocks = G; A.itemsPerBlock = ipb; A.wmap = wmapPtr; A.xmode = mode;
-    A.wmapRoots = ix->d_wmap + S.itemsPerBlock; A.rootsPerBlockA = S.rootsPerBlock; A.xshare = ix->tune.expandShare > 0 ? 1u : 0u;   // (off until measured)
+    A.wmapRoots = ix->d_wmap + S.itemsPerBlock; A.rootsPerBlockA = S.rootsPerBlock; A.xshare = ix->tune.expandShare != 0 ? 1u : 0u;   // (3.09 Gbp, 10 % / 30 % of the k-mers: K=30 e=2 540 -> 527 ms, e=1 323 -> 320: phase A is bound by its fetches, not by its instructions)
     // first slice: a guess at the packets a chunk makes (8 per k-mer); the slices behind it follow what their predecessor measured
     const uint64_t guess = (uint64_t)G * S.plan.stepSize * (mode == 1u ? 2ull : 8ull);
     const uint32_t firstChunks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(usableMin / std::max<uint64_t>(guess, 1), 0x7FFFFFFFull));

@@ -273,13 +273,14 @@ def test_gpu_split_search_phase_a_and_walker(K, E):
             for mb, chunk, T, coop, ctx, steal, flt, grp, satw in ((-1, -1, -1, -1, 1, -1, 1, -1, -1), (1, 1, 1, 1, 1, 0, 2, 1, 0), (2, 7, 4, 0, 0, 1, 0, 0, 1 << 20),
                                                                     (1, -1, 0, 1, 1, 16, 1, 1, -1), (3, 50, -1, -1, 1, -1, 1, -1, 4)):
                 ix.set_tuning(expand=1, expand_mb=mb, expand_chunk=chunk, verify_t=T, coop=coop, use_ctx=ctx, steal=steal, jump_filter=flt, jump_groups=grp, sat_draw_w=satw,
-                              expand_two_pass=(-1, 0, 1, 0, 1)[(mb + chunk) % 5])   # one pass over every pattern / the patterns without a substitution first, then the rest
+                              expand_two_pass=(-1, 0, 1, 0, 1)[(mb + chunk) % 5],   # one pass over every pattern / the patterns without a substitution first, then the rest
+                              expand_share=(-1, 0, 1)[(mb + chunk) % 3])             # a root's context computed once per root (LDS) / by every one of its items
                 for bits in (8, 16):
                     out = ix.map(K, E, value_bits=bits)
                     assert np.array_equal(out, exp[bits]), (K, E, bb, bits, mb, chunk, T, coop, ctx, steal, flt, grp, satw, np.flatnonzero(out != exp[bits])[:10])
                     slices_seen.add(ix.last_stats()["detail"]["slices"])
             assert min(slices_seen) >= 1 and max(slices_seen) > 3, slices_seen     # the small buffers forced many slices
-            ix.set_tuning(expand=0, expand_mb=-1, expand_chunk=-1, verify_t=-1, coop=-1, use_ctx=1, steal=-1, jump_filter=1, jump_groups=-1, sat_draw_w=-1, expand_two_pass=-1)
+            ix.set_tuning(expand=0, expand_mb=-1, expand_chunk=-1, verify_t=-1, coop=-1, use_ctx=1, steal=-1, jump_filter=1, jump_groups=-1, sat_draw_w=-1, expand_two_pass=-1, expand_share=-1)
             assert np.array_equal(ix.map(K, E, value_bits=8), exp[8]) and ix.last_stats()["detail"]["slices"] == 0
             # shares of one vector: k-mer ranges, interleaved chunks, a selection -- each through the split search with small buffers
             ix.set_tuning(expand=1, expand_mb=2)
