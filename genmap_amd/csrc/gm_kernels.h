@@ -6,6 +6,12 @@
 //                        a ballot/mbcnt rank -- the "warp-ballot work queue" of the search tree.  Lanes keep
 //                        their pending nodes in a lane-private LIFO in HBM/L2 (16-byte nodes, one
 //                        global_store_dwordx4 / global_load_dwordx4 each).
+//                        With Env::NODES (round 6) the same loop is the WALKER of the split search: lanes draw node packets
+//                        that phase A wrote (one round trip each: header into registers, needle window by LDS DMA).
+//   expand_kernel        phase A of the split search (gm_expand.h): one lane per (k-mer block, strand, search, item) turns the
+//                        jump patterns of a root into node packets -- bitmap word, table entries dealt out to all lanes of the
+//                        wavefront, neighbour filters -- in three lists by the pattern's substitutions; expand_slice_begin /
+//                        _commit_kernel cut a call into slices that fit the packet buffers (decided on the device).
 //   finalize_kernel      acc (u32, saturating-safe) -> c[] as uint8/uint16:  min(total, MAX)
 //                        (std::min(count + hits, max_val), /root/reference/src/algo.hpp:36,48,191)
 //   reset_limits_kernel  resetLimits, /root/reference/src/algo.hpp:10-22
@@ -26,7 +32,7 @@ namespace gm {
 struct ExpandCtl {
     unsigned long long nextChunk;        // work counter of phase A
     unsigned long long tailsX;           // packets reserved in X: class 0 | class 1 << 32
-    unsigned long long walkCounter;      // (unused: the walker's counters are the stripes below)
+    unsigned long long reserved0;        // (the walker's counters are the stripes below)
     unsigned long long chunkBegin, chunkEnd;
     uint32_t tailY, failFrom;
     uint32_t valid[3];                   // per class: end of the last reservation that fitted (fit is monotone in the order of the atomics)
@@ -1653,7 +1659,7 @@ __global__ void expand_slice_begin_kernel(ExpandProgress* prog, ExpandCtl* ctl, 
     if (r < 1ull) r = 1ull;
     if (r > maxChunks) r = maxChunks;
     ctl->chunkBegin = begin; ctl->chunkEnd = begin + r < total ? begin + r : total;
-    ctl->nextChunk = begin; ctl->tailsX = 0ull; ctl->tailY = 0u; ctl->failFrom = 0xFFFFFFFFu; ctl->walkCounter = 0ull;
+    ctl->nextChunk = begin; ctl->tailsX = 0ull; ctl->tailY = 0u; ctl->failFrom = 0xFFFFFFFFu; ctl->reserved0 = 0ull;
     for (uint32_t j = 0; j < XSTRIPES; ++j) ctl->walk[16u * j] = 0ull;
     ctl->valid[0] = ctl->valid[1] = ctl->valid[2] = 0u; ctl->t[0] = ctl->t[1] = ctl->t[2] = 0u;
     ctl->stamp = ++prog->stampCounter;
