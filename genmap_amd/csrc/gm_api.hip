@@ -92,6 +92,35 @@ __global__ __launch_bounds__(256) void pack_text4_kernel(const uint8_t* __restri
     }
 }
 
+// 2-bit packed copy of the text for needle windows (SearchArgs::win2): chunk c holds symbols [64c, 64c + 64), symbol i at bits 2 (i & 63) of the chunk, an N as A;
+// flags[b] bit j: chunk 8b + j holds an N (16 bits: a window's chunks are one aligned load whatever chunk it starts in).  One thread per flag entry.
+__global__ __launch_bounds__(256) void pack_text2_kernel(const uint4* __restrict__ text4, uint64_t nChunks4, uint4* __restrict__ text2, uint64_t nChunks2, uint16_t* __restrict__ flags, uint64_t nFlags)
+{
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nFlags; b += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t f = 0;
+        for (uint32_t j = 0; j < 16; ++j) {
+            const uint64_t c = 8 * b + j;
+            uint32_t o[4], anyN = 0;
+            for (uint32_t h = 0; h < 2; ++h) {
+                const uint4 v = 2 * c + h < nChunks4 ? text4[2 * c + h] : make_uint4(0u, 0u, 0u, 0u);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                anyN |= (v.x | v.y | v.z | v.w) & 0x44444444u;
+                for (uint32_t k = 0; k < 2; ++k) {
+                    unsigned long long t = ((unsigned long long)w[2 * k + 1] << 32 | w[2 * k]) & 0x3333333333333333ull;
+                    t = (t | (t >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+                    t = (t | (t >> 4)) & 0x00FF00FF00FF00FFull;
+                    t = (t | (t >> 8)) & 0x0000FFFF0000FFFFull;
+                    t = (t | (t >> 16)) & 0x00000000FFFFFFFFull;
+                    o[2 * h + k] = (uint32_t)t;
+                }
+            }
+            if (j < 8 && c < nChunks2) text2[c] = make_uint4(o[0], o[1], o[2], o[3]);
+            f |= (anyN ? 1u : 0u) << j;
+        }
+        flags[b] = (uint16_t)f;
+    }
+}
+
 // sentinel text: sequence s occupies [cum[s] + s, cum[s+1] + s), its sentinel follows
 __global__ __launch_bounds__(256) void sentinel_text_kernel(const uint8_t* __restrict__ codes, const uint64_t* __restrict__ cum, uint32_t nSeq, uint64_t textLen,
                                                             uint8_t* __restrict__ out)
@@ -345,7 +374,7 @@ void gm_index_free(gm_index* ix)
 {
     if (!ix) return;
     hipSetDevice(ix->device);
-    hipFree(ix->d_blk[0]); hipFree(ix->d_blk[1]); hipFree(ix->d_textAlloc); hipFree(ix->d_text4); hipFree(ix->d_cum); hipFree(ix->d_sa); hipFree(ix->d_textSAlloc); hipFree(ix->d_C); hipFree(ix->d_ctx);
+    hipFree(ix->d_blk[0]); hipFree(ix->d_blk[1]); hipFree(ix->d_textAlloc); hipFree(ix->d_text4); hipFree(ix->d_text2); hipFree(ix->d_nflag); hipFree(ix->d_cum); hipFree(ix->d_sa); hipFree(ix->d_textSAlloc); hipFree(ix->d_C); hipFree(ix->d_ctx);
     hipFree(ix->d_saMark); hipFree(ix->d_saSamples);
     for (auto& kv : ix->qtables) hipFree(kv.second);
     for (auto& kv : ix->jbits) hipFree(kv.second);
@@ -641,6 +670,18 @@ template <int WPP> static int occupancy_blocks(int* out, size_t ldsBytes)
 static int check_device_error(gm_index* ix);
 
 // table of all q-mers for this index (cached)
+// the 2-bit text and its N flags (pack_text2_kernel), made by the first call that stages windows from them
+static int ensure_text2(gm_index* ix, hipStream_t st)
+{
+    if (ix->d_text2) return GM_OK;
+    const uint64_t nChunks4 = ix->textLen / 32 + 20, nChunks2 = ix->textLen / 64 + 24, nFlags = nChunks2 / 8 + 2;   // (padding as behind the 4-bit text: a window may be staged past the end)
+    if (hipMalloc(&ix->d_text2, nChunks2 * 16) != hipSuccess) { ix->d_text2 = nullptr; (void)hipGetLastError(); return GM_ERR_HIP; }
+    if (hipMalloc(&ix->d_nflag, nFlags * 2) != hipSuccess) { hipFree(ix->d_text2); ix->d_text2 = nullptr; ix->d_nflag = nullptr; (void)hipGetLastError(); return GM_ERR_HIP; }
+    hipLaunchKernelGGL(pack_text2_kernel, dim3(grid_for(nFlags)), dim3(256), 0, st, ix->d_text4, nChunks4, ix->d_text2, nChunks2, ix->d_nflag, nFlags);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+}
+
 static int get_qtable(gm_index* ix, uint32_t* qio, const uint4** out)
 {
     uint32_t q = *qio;
@@ -1066,7 +1107,14 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
     uint32_t vqCap = verifyT ? vq_cap(verifyRows) : 1u;
     // (long k-mers read their needle from the text; the walker of the split search stages the window of its packet, which starts at nibble 0)
     S->rootWinChunks = longK ? 1u : (31u + p->K + plan.stepSize - 1u + 31u) / 32u;
-    const uint32_t winChunks = expand ? S->pktChunks : S->rootWinChunks;
+    // windows at 2 bits per symbol: where the chunks they save give LDS stack levels back (K=100 e=1: five chunks -> three, no stack level in LDS -> two);
+    // the correction pass, the walker of the split search and long k-mers keep theirs.  3.09 Gbp, kernel time with them against without
+    // (profiles/r06/dev/win2_sweep.txt): K=100 e=1 353 / 366 ms, e=0 31.2 / 32.9, K=64 e=1 585 / 596, K=150 e=1 326 / 348, K=250 e=1 (half the k-mers)
+    // 206 / 244, K=101 e=4 (0.4 %) 645-672 / 690-716; K=101 e=2 and e=3 the same.  Short windows (K < 64) save a chunk at most and were not measured.
+    const uint32_t win2Chunks = (63u + p->K + plan.stepSize - 1u + 63u) / 64u;
+    bool win2 = !expand && !longK && (ix->tune.win2 > 0 || (ix->tune.win2 < 0 && p->K >= 64u && S->rootWinChunks > win2Chunks));
+    if (win2 && ensure_text2(ix, st) != GM_OK) { if (ix->tune.win2 > 0) { set_error("no device memory for the 2-bit text"); return GM_ERR_HIP; } win2 = false; }   // (no memory for it: the 4-bit windows)
+    const uint32_t winChunks = expand ? S->pktChunks : win2 ? win2Chunks : S->rootWinChunks;
     // (the split search runs phase A of the next slice BESIDE the walker: three walker blocks per CU leave the fourth slot -- registers and LDS -- to a block of phase A)
     const bool overlap = expand && ix->tune.expandOverlap > 0;   // (off by default: phase A is not light enough on the vector ALU yet -- 3.09 Gbp K=30 e=2 236 ms side by side against 215 one after the other, profiles/r06)
     S->overlap = overlap;
@@ -1188,7 +1236,7 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
         ix->lastQ = std::max(qA, qB) | jumpJ << 8;
     }
     A.entrySlots = entrySlots ? 1u : 0u;
-    A.text4 = ix->d_text4; A.textBegin = text_begin; A.vqCap = vqCap; A.verifyRows = verifyRows ? verifyRows : 1u; A.ldsDepth = ldsDepth; A.winChunks = winChunks; A.lqCap = lqCap;
+    A.text4 = ix->d_text4; A.text2 = win2 ? ix->d_text2 : nullptr; A.nflag = win2 ? reinterpret_cast<const uint8_t*>(ix->d_nflag) : nullptr; A.win2 = win2 ? 1u : 0u; A.textBegin = text_begin; A.vqCap = vqCap; A.verifyRows = verifyRows ? verifyRows : 1u; A.ldsDepth = ldsDepth; A.winChunks = winChunks; A.lqCap = lqCap;
     A.workCounter = reinterpret_cast<unsigned long long*>(ix->d_small);
     A.errorFlag = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ix->d_small) + SMALL_ERR_OFF);
     // (a wavefront without a node for seconds on end is spinning: a root has a few hundred patterns at most.  iter_cap bounds ALL iterations: tests)
@@ -1575,7 +1623,7 @@ static int map_impl(gm_index* ix, uint64_t text_begin, uint64_t text_len, uint32
         C.steal = C.numRoots < 64ull * 4ull * 1024ull ? 1u : C.steal;
         C.lqCap = 128u;   // leaves are located by the whole wavefront (gm_kernels.h: LeafQueueEnv)
         C.entrySlots = 0u;
-        C.winChunks = S.rootWinChunks;   // (it draws roots and stages their windows at any alignment: a walker's packets start at nibble 0 and need a chunk less)
+        C.win2 = 0u; C.winChunks = S.rootWinChunks;   // (it draws roots and stages their windows at any alignment: a walker's packets start at nibble 0 and need a chunk less)
         C.workCounter = reinterpret_cast<unsigned long long*>(ix->d_small) + 1;   // its own counter: the two kernels run side by side
         C.stack = ix->d_stack + ix->stackCap / 2;                                  // ... and its own half of the spill area (prepare_search)
         const uint64_t useful = (C.numRoots + 255) / 256;
@@ -2134,6 +2182,7 @@ int gm_index_set_tuning(gm_index* ix, const char* name, int64_t value)
         {"pat_batch", &ix->tune.patBatch, dflt.patBatch, 1, 64},
         {"expand", &ix->tune.expand, dflt.expand, 0, 1}, {"expand_mb", &ix->tune.expandMB, dflt.expandMB, 1, 1 << 20},   // the split search (gm_expand.h)
         {"expand_chunk", &ix->tune.expandChunk, dflt.expandChunk, 1, 1 << 16}, {"expand_occ", &ix->tune.expandOcc, dflt.expandOcc, 1, 64}, {"expand_overlap", &ix->tune.expandOverlap, dflt.expandOverlap, 0, 1}, {"expand_two_pass", &ix->tune.expandTwoPass, dflt.expandTwoPass, 0, 1}, {"expand_share", &ix->tune.expandShare, dflt.expandShare, 0, 1}, {"sat_draw_w", &ix->tune.satDrawW, dflt.satDrawW, 0, 0x7FFFFFFF},
+        {"win2", &ix->tune.win2, dflt.win2, 0, 1},   // needle windows at 2 bits per symbol
         {"jump_groups", &ix->tune.jumpGroups, dflt.jumpGroups, 0, 1},   // groups of jump patterns behind the existence bitmap: 0 never, 1 wherever possible, -1 where they save table reads
     };
     for (auto& t : tab) if (!strcmp(t.n, name)) {

@@ -43,6 +43,7 @@ struct Tuning {
     int expandTwoPass = -1;            // 1 / -1: the patterns without a substitution of every root first, then the rest for blocks not at MAX yet; 0: one pass
     int expandShare = -1;              // 1 / -1: phase A computes a root's context once (a lane per root of a group of blocks, LDS), 0: every item computes it
     int expandOcc = -1;                // blocks of phase A per CU (-1: what the occupancy query says, at most 8)
+    int win2 = -1;                     // needle windows at 2 bits per symbol: 1 always, 0 never, -1 where they give LDS stack levels back (long windows)
     int satDrawW = -1;                 // the walker drops a drawn node at least this wide when its block's k-mers are all at MAX (-1: 1 = every packet)
 };
 }  // namespace gm
@@ -59,6 +60,8 @@ struct gm_index {
     uint8_t* d_text = nullptr;        // sentinel-free codes, one byte each (= d_textAlloc + 16: readers may touch a few bytes around)
     uint8_t* d_textAlloc = nullptr; uint8_t* d_textSAlloc = nullptr;
     uint4* d_text4 = nullptr;         // the text at 4 bits per symbol: needle windows are staged into LDS from it
+    uint4* d_text2 = nullptr;         // ... at 2 bits per symbol (an N stored as A), made by the first call that stages windows from it (ensure_text2)
+    uint16_t* d_nflag = nullptr;      // entry b: bit j = chunk 8b + j of d_text2 (64 symbols) holds an N
     std::vector<uint64_t> cum;        // nSeq + 1
     uint64_t* d_cum = nullptr;
     void* d_sa = nullptr;             // forward suffix array, uint32_t or (wide) uint64_t per row (kept when sampling == 1): locate = one HBM read

@@ -116,6 +116,9 @@ struct SearchArgs {
     uint32_t selfHit;               // 1: a single error-free row on the forward strand is the window's own location -- no lookup at all
     // ---- LDS staging (per wavefront): verification queue | top of the lane stacks | packed needle windows ----
     const uint4* text4;             // whole text, 4 bits per symbol (32 symbols per 16-byte chunk), sentinel-free
+    const uint4* text2;             // win2: the text at 2 bits per symbol (64 symbols per chunk; an N is stored as A) ...
+    const uint8_t* nflag;           // ... and one bit per chunk of it: the chunk holds an N (roots whose window touches such a chunk read their needle from text4: text_char)
+    uint32_t win2;                  // 1: roots stage their needle windows from text2 (long windows: two chunks less per lane, the LDS of two stack levels)
     uint64_t textBegin;             // slice offset inside the text (symbols)
     uint32_t vqCap;                 // queue entries per wavefront
     uint32_t verifyRows;            // rows of one node queued per iteration (1 or 2)
@@ -507,9 +510,21 @@ template <int WPP> struct EnvBase {
     __device__ __forceinline__ uint32_t text_char(const Root& rt, uint32_t pos) const
     {
         const uint32_t W = K + rt.n - 1u;
-        const uint32_t nib = woff + (rt.strand ? (W - 1u - pos) : pos);
-        const uint32_t b = lwin[(nib >> 5) * 1024u + ((nib & 31u) >> 1)];   // chunk stride = 64 lanes x 16 bytes
-        const uint32_t c = (b >> ((nib & 1u) * 4u)) & 15u;
+        const uint32_t p = rt.strand ? (W - 1u - pos) : pos;
+        uint32_t c;
+        if (A.win2) {   // (wave-uniform) windows at 2 bits per symbol; bit 7 of woff: the window touches a chunk with an N -- the 4-bit text in HBM knows where
+            if (woff & 128u) {
+                const uint64_t g = A.textBegin + (uint64_t)rt.win + p;
+                c = (reinterpret_cast<const uint8_t*>(A.text4)[g >> 1] >> (((uint32_t)g & 1u) * 4u)) & 15u;
+            } else {
+                const uint32_t s2 = (woff & 63u) + p;
+                c = (lwin[(s2 >> 6) * 1024u + ((s2 & 63u) >> 2)] >> ((s2 & 3u) * 2u)) & 3u;
+            }
+        } else {
+            const uint32_t nib = woff + p;
+            const uint32_t b = lwin[(nib >> 5) * 1024u + ((nib & 31u) >> 1)];   // chunk stride = 64 lanes x 16 bytes
+            c = (b >> ((nib & 1u) * 4u)) & 15u;
+        }
         return rt.strand ? complement(c) : c;
     }
     __device__ __forceinline__ void push(const Node& nd)
@@ -1314,6 +1329,11 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
         // stage 2: window chunks and record have arrived -> stage the window in LDS, look the first q characters up
         if (!EnvT::NODES && fs == 1u) {
             env.note_wave(4);
+            if (A.win2) {   // does the window touch a chunk of the 2-bit text that holds an N?  (bit 7 of the window offset: text_char)
+                const uint64_t ch = (A.textBegin + (uint64_t)frt.win) >> 6;
+                const uint32_t nch2 = (env.woff + A.K + frt.n - 1u + 63u) >> 6;
+                if ((ftNb >> ((uint32_t)ch & 7u)) & ((1u << nch2) - 1u)) env.woff |= 128u;
+            }
             if constexpr (!EnvT::LEGACY_LOOP) {   // the OSS record of the root's search: from LDS for the regular block shape, from the table for the odd ones (ends of the text / of an interval)
                 uint4 q;
                 if (frt.n == A.stepSize) q = jl[20u + frt.search]; else q = A.table[(size_t)(frt.n - 1u) * 8u + frt.search];
@@ -1324,6 +1344,23 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                 // 16 symbols starting at the lowest text position of the q-mer, 4 bits each: from the window this lane staged in
                 // LDS in stage 1 (the asynchronous global -> LDS loads are awaited explicitly: nothing else orders them)
                 __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+                uint32_t bad, lo2;
+                if (A.win2) {
+                    // 2 bits per symbol: the q-mer's 32 bits straight from the window; an N (stored as A) shows in the 4-bit text only -- rare roots, the slow path of text_char
+                    const uint32_t p0 = frt.strand ? (A.K + frt.n - 1u) - fa0 - fql : fa0, ni = (env.woff & 63u) + p0;
+                    const uint8_t* wc = reinterpret_cast<const uint8_t*>(wbase + lane) + (ni >> 6) * 1024u;   // chunk stride: 64 lanes x 16 bytes
+                    const uint4 c0 = *reinterpret_cast<const uint4*>(wc);
+                    const uint32_t c1 = *reinterpret_cast<const uint32_t*>(wc + 1024u);
+                    const uint32_t wi = (ni & 63u) >> 4, sh = (ni & 15u) * 2u;
+                    const uint32_t vl = wi == 0u ? c0.x : wi == 1u ? c0.y : wi == 2u ? c0.z : c0.w, vh = wi == 0u ? c0.y : wi == 1u ? c0.z : wi == 2u ? c0.w : c1;
+                    const uint32_t v = sh ? (vl >> sh) | (vh << (32u - sh)) : vl;
+                    lo2 = fql >= 16u ? v : (v & ((1u << (2u * fql)) - 1u));
+                    bad = 0u;
+                    if (env.woff & 128u) {
+                        const uint64_t g0 = A.textBegin + (uint64_t)frt.win + p0;
+                        for (uint32_t i = 0; i < fql; ++i) bad |= (reinterpret_cast<const uint8_t*>(A.text4)[(g0 + i) >> 1] >> ((((uint32_t)g0 + i) & 1u) * 4u)) & 4u;
+                    }
+                } else {
                 const uint32_t ni = env.woff + (frt.strand ? (A.K + frt.n - 1u) - fa0 - fql : fa0);
                 const uint8_t* wc = reinterpret_cast<const uint8_t*>(wbase + lane) + (ni >> 5) * 1024u;   // chunk stride: 64 lanes x 16 bytes
                 const uint4 c0 = *reinterpret_cast<const uint4*>(wc);
@@ -1335,13 +1372,14 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
                 // the table index without a loop over the symbols: nibbles -> 2-bit symbols (symbol i at bits 2i); a code above 3
                 // (N) anywhere in the q-mer makes the root empty
                 const unsigned long long qmask = fql >= 16u ? ~0ull : ((1ull << (4u * fql)) - 1ull);
-                const uint32_t bad = (v & qmask & 0xCCCCCCCCCCCCCCCCull) != 0ull ? 1u : 0u;
+                bad = (v & qmask & 0xCCCCCCCCCCCCCCCCull) != 0ull ? 1u : 0u;
                 unsigned long long t = v & qmask & 0x3333333333333333ull;
                 t = (t | (t >> 2)) & 0x0F0F0F0F0F0F0F0Full;
                 t = (t | (t >> 4)) & 0x00FF00FF00FF00FFull;
                 t = (t | (t >> 8)) & 0x0000FFFF0000FFFFull;
                 t = (t | (t >> 16)) & 0x00000000FFFFFFFFull;
-                const uint32_t lo2 = (uint32_t)t;                                   // sum of c_i << 2i
+                lo2 = (uint32_t)t;                                   // sum of c_i << 2i
+                }
                 const uint32_t m2 = fql >= 16u ? 0xFFFFFFFFu : ((1u << (2u * fql)) - 1u);
                 // reverse strand: needle(a0 + q-1-i) = 3 - c_i, i.e. the complement of every 2-bit group, same order
                 // forward strand: symbol i is needle(a0 + i), most significant first: reverse the order of the groups
@@ -1393,8 +1431,8 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
             // node.  (k-mers that cross a sequence end are zeroed by resetLimits whatever is added here; a window with an N anywhere
             // takes the ordinary path, which knows which k-mers the N spoils.)
             if (A.selfHit && have && nd.w == 1u && rt.strand == 0u && (EnvT::EXACT_ONLY || (meta_errs(nd.meta) == 0u && nd.rlo != ~(row_t)0))) {   // (not the left-over rows of a wider node; e = 0 has neither errors nor such nodes)
-                const uint32_t W = A.K + rt.n - 1u, nch = (env.woff + W + 31u) >> 5;
-                uint32_t anyN = 0;
+                const uint32_t W = A.K + rt.n - 1u, nch = A.win2 ? 0u : (env.woff + W + 31u) >> 5;
+                uint32_t anyN = A.win2 ? (env.woff & 128u) : 0u;   // (2-bit windows: the chunk flags of stage 2)
                 for (uint32_t c = 0; c < nch; ++c) {
                     const uint4 v = *reinterpret_cast<const uint4*>(env.lwin + c * 1024u);
                     anyN |= (v.x | v.y | v.z | v.w) & 0x44444444u;   // (nibbles of the neighbouring text in the first / last chunk count too: harmless)

@@ -285,7 +285,10 @@ int gm_index_sync(gm_index *idx);
  * patterns (16: the 69 GB table of all 16-mers, the default beyond 2^30 rows), jump_filter = 0 switches the neighbour test of one- and
  * two-row table entries off (2: one-row entries only), jump_groups = 0 / 1 forbids / forces the groups of jump patterns behind the
  * bitmaps (default: where they are expected to save table reads), range_add = 0 adds verified runs k-mer by k-mer instead of through the
- * difference plane, verify_t_ext = widest node verified in the extension phase.  Results never depend on these.
+ * difference plane, verify_t_ext = widest node verified in the extension phase; expand = 0 / 1 forbids / forces the split search (phase A writes
+ * node packets, a walker draws them: gm_expand.h; default: frequency calls with errors at K < 64 over 2^20 roots or more), expand_mb = its packet
+ * buffers in MiB, expand_two_pass / expand_share / expand_chunk / sat_draw_w = its schedule; win2 = 0 / 1 forbids / forces needle windows staged
+ * from a 2-bit copy of the text (default: K >= 64 where that saves LDS).  Results never depend on these.
  * Two TEST-ONLY knobs do change the output: no_saturate = 1 counts without the min(total, MAX) clamp and stores the low bits,
  * no_store = 1 only switches e = 0 from plain stores to the atomic accumulators (same result).
  * value -1 restores the library default of any knob except part_bias; values outside a knob's range are GM_ERR_BAD_ARG.

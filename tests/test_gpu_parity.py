@@ -840,25 +840,27 @@ def _torch_small_k_counts(codes_np, K, max_val, device, lens, chunk=1 << 28):
     import torch
     assert K <= 12
     mtot = len(codes_np) - K + 1
-    hist = torch.zeros(4 ** K, dtype=torch.int64, device=device)
-    keys = []
-    for a in range(0, mtot, chunk):
+    def keys_of(a):                          # (computed twice rather than kept: 9 bytes a position are 28 GB at 3.09 Gbp, beside an index with its tables)
         c, isn, nN, inside, n, m = _window_masks(codes_np, lens, K, device, a, min(mtot, a + chunk))
         valid = (nN == 0) & inside
         c2 = torch.where(isn, torch.zeros_like(c), c).to(torch.int32)
+        del c, isn, nN, inside
         fwd = torch.zeros(m, dtype=torch.int32, device=device); rc = torch.zeros(m, dtype=torch.int32, device=device)
         for i in range(K):
             fwd.mul_(4).add_(c2[i:i + m]); rc.mul_(4).add_(3 - c2[K - 1 - i:K - 1 - i + m])
+        return fwd, rc, valid
+    hist = torch.zeros(4 ** K, dtype=torch.int64, device=device)
+    for a in range(0, mtot, chunk):
+        fwd, rc, valid = keys_of(a)
         hist += torch.bincount(fwd[valid].to(torch.int64), minlength=4 ** K)
-        keys.append((fwd.cpu(), rc.cpu(), valid.cpu()))
-        del c, isn, nN, inside, c2, fwd, rc, valid
-    out = np.zeros(len(codes_np), dtype=np.int64)
-    a = 0
-    for fwd, rc, valid in keys:
-        f, r, v = fwd.to(device).to(torch.int64), rc.to(device).to(torch.int64), valid.to(device)
-        tot = torch.where(v, hist[f] + hist[r], torch.zeros_like(f)).clamp_(max=max_val)
+        del fwd, rc, valid
+    out = np.zeros(len(codes_np), dtype=np.uint16 if max_val <= 65535 else np.int64)
+    hist = hist.clamp_(max=max_val).to(torch.int32)
+    for a in range(0, mtot, chunk):
+        fwd, rc, valid = keys_of(a)
+        tot = torch.where(valid, hist[fwd.to(torch.int64)] + hist[rc.to(torch.int64)], torch.zeros_like(fwd)).clamp_(max=max_val)
         out[a:a + tot.numel()] = tot.cpu().numpy()
-        a += tot.numel()
+        del fwd, rc, valid, tot
     return out
 
 
@@ -1090,6 +1092,69 @@ def _interval_set(lens, K, n_per=3000):
     return [(max(0, a), min(n - K + 1, b)) for a, b in iv]
 
 
+@pytest.mark.parametrize("K,E", [(100, 1), (64, 1), (100, 0), (150, 2), (250, 1), (101, 3), (30, 2), (30, 0), (24, 1), (9, 1)])
+def test_gpu_needle_windows_at_two_bits_per_symbol(K, E):
+    """Long windows stage their needle from a 2-bit copy of the text (two LDS chunks less per lane at K=100: room for two stack levels); a
+    window that touches a 64-symbol chunk with an N reads its letters from the 4-bit text instead (text_char).  Forced on every kernel
+    (win2 = 1: plain walk, jump patterns, exact-only, the locating policies) on a text with single Ns at every chunk alignment, N runs
+    across chunk borders, Ns in the first and last window of a sequence; against the oracle and against the 4-bit windows."""
+    g = _gm()
+    rng = np.random.default_rng(K * 7 + E + 2606)
+    lens = [60000, K, 700, K - 1, 30000, 65, 64, 63, 129]
+    codes = _repeat_text(rng, sum(lens), True)
+    for q in range(64):                                     # a lone N at every offset inside a chunk, far enough apart that windows around them hold one N
+        codes[3000 + q * 400 + q] = 4
+    for q, L in enumerate((1, 2, 3, 63, 64, 65, 127, 128, 130)):
+        codes[40000 + q * 900 - L // 2: 40000 + q * 900 - L // 2 + L] = 4
+    codes[0] = 4; codes[59999] = 4; codes[60000] = 4        # the ends of a sequence
+    ora = H.OracleIndex(codes, lens, keep_sa=True)
+    exp = ora.mappability(K, E, value_bits=16, threads=8)
+    dflt = dict(win2=-1, jump=-1, steal=-1, coop=-1, verify_t=-1, self_hit=-1, expand=-1, lds_stack=-1)
+    for bb in (32, 64, WIDE):
+        ix = g.Index.build(codes, lens, block_bytes=bb, sampling=1)
+        try:
+            for tune in (dict(win2=1, expand=0), dict(win2=1, expand=0, jump=0), dict(win2=1, expand=0, steal=2, coop=1, verify_t=0), dict(win2=1, expand=0, self_hit=0, lds_stack=1), dict(win2=0, expand=0)):
+                ix.set_tuning(**{**dflt, **tune})
+                out = ix.map(K, E, value_bits=16)
+                assert np.array_equal(out, exp), (K, E, bb, tune, np.flatnonzero(out != exp)[:10])
+            ix.set_tuning(**dflt)
+            assert np.array_equal(ix.map(K, E, value_bits=8), np.minimum(exp, 255).astype(np.uint8))      # the default choice
+            # a k-mer range and intervals whose ends fall inside chunks
+            ix.set_tuning(**{**dflt, "win2": 1, "expand": 0})
+            n = len(codes)
+            host = np.zeros(n, dtype=np.uint16)
+            cut = [0, 777, 51001, n]
+            for r in range(3):
+                ix.map_shard(host, K, E, value_bits=16, kmer_range=(cut[r], cut[r + 1]))
+            assert np.array_equal(host, exp), (K, E, bb, "k-mer ranges")
+            iv = [(5, 69), (3001, 3002), (39990, 41111), (59900, 60100)]
+            assert np.array_equal(ix.map(K, E, value_bits=16, intervals=iv), ora.mappability(K, E, value_bits=16, intervals=iv, threads=8)), (K, E, bb, "selection")
+        finally:
+            ix.close()
+    if (K, E) in ((100, 1), (30, 2), (24, 1)):             # the locating policies: --exclude-pseudo and csv
+        ix = g.Index.build(codes, lens, sampling=1)
+        ix.set_tuning(win2=1, expand=0)
+        try:
+            fid = np.asarray([0, 0, 0, 0, 1, 1, 1, 1, 1], dtype=np.uint16)
+            want = ora.mappability(K, E, value_bits=16, directory=True, exclude_pseudo=True, seq_file_id=fid, threads=8)
+            out = ix.map(K, E, value_bits=16, exclude_pseudo=True, seq_file_id=fid)
+            assert np.array_equal(out, want), np.flatnonzero(out != want)[:10]
+        finally:
+            ix.close()
+
+
+def _laps(name):
+    """GM_TEST_LAPS=1: the wall-clock of a long test's parts on stderr (where the suite's minutes go)"""
+    import sys, time
+    t = [time.time()]
+    def lap(what):
+        now = time.time()
+        if os.environ.get("GM_TEST_LAPS"):
+            print(f"[laps] {name}: {what}: {now - t[0]:.1f} s", file=sys.stderr, flush=True)
+        t[0] = now
+    return lap
+
+
 def test_gpu_full_size_grch38_e0_everywhere_e1_e2_k100_on_intervals():
     """BASELINE configs C3 and C4 on their own text (S3: 24 sequences, 3,088,269,832 bp): K=30 e=0 at every position against
     the index-free sort-and-count restatement; K=30 e=2 (C3), K=100 e=1 (C4) and K=30 e=1 against the CPU oracle (which
@@ -1098,12 +1163,15 @@ def test_gpu_full_size_grch38_e0_everywhere_e1_e2_k100_on_intervals():
     import torch
     g = _gm()
     from genmap_amd import synth
+    lap = _laps("full-size grch38")
     scale = float(os.environ.get("GM_GRCH38_SCALE", "1.0"))
     codes, lens, _ = synth.workload("grch38", scale)
     n = len(codes)
     exp = _torch_exact_counts(codes, 30, 255, "cuda:0", lens=lens).astype(np.uint8)   # before the index exists: both need > 100 GB
     torch.cuda.empty_cache()
+    lap("text + sort-and-count")
     ix = g.Index.build(codes, lens, sampling=1)
+    lap("index build")
     # the exported index itself, before the oracle adopts it: symbol histograms of both BWTs, and the suffix array against the forward
     # BWT (permutation, preceding symbols, LF-walk consistency) -- on the device, 3.09 G rows are minutes of numpy
     bf, br = ix.export_bwt()
@@ -1113,12 +1181,14 @@ def test_gpu_full_size_grch38_e0_everywhere_e1_e2_k100_on_intervals():
     H.check_sa_against_bwt_device(codes, lens, bf, sa, "cuda:0")
     del sa
     torch.cuda.empty_cache()
+    lap("export + SA checks")
     out0 = ix.map(30, 0, value_bits=8)
     assert np.array_equal(out0, exp)
     del exp
     ora = H.OracleIndex(codes, lens, keep_sa=False, bwt=(bf, br))
     del bf, br
-    iv = _interval_set(lens, 100, n_per=50000)   # ~400 k positions: seconds for the oracle on the GPU box's host cores
+    lap("oracle adopts the BWTs")
+    iv = _interval_set(lens, 100, n_per=35000)   # ~280 k positions: seconds for the oracle on the GPU box's host cores
     sel = np.zeros(n, bool)
     for a, b in iv:
         sel[a:b] = True
@@ -1129,6 +1199,7 @@ def test_gpu_full_size_grch38_e0_everywhere_e1_e2_k100_on_intervals():
         assert (got[~sel] == 0).all()
         if (K, E) == (30, 2):
             assert (np.minimum(got[sel], 255) >= out0[sel]).all()      # monotone in e
+    lap("edge intervals, four settings")
     # ... and, for the metric's own settings, 2 million positions in 2,112 seeded random intervals spread over all 24 sequences (88 per sequence,
     # 950 positions each: whole k-mer blocks of either shape and their ragged ends) against the oracle: config C3 (K=30, e=2) and C4 (K=100, e=1).
     # (the hand-picked intervals above aim at the edges; these sample the bulk: repeat families, unique sequence, both strands)
@@ -1155,6 +1226,7 @@ def test_gpu_full_size_grch38_e0_everywhere_e1_e2_k100_on_intervals():
         assert np.array_equal(got, want), (K, E, "random intervals", np.flatnonzero(got != want)[:10])
         assert (got[~rsel] == 0).all()
     del rsel
+    lap("2 M random positions (30,2) (100,1)")
     # "the same result under every schedule" (tests/tests.sh:47-60) at the metric's own size: the default schedule (jumps of 16 characters,
     # neighbour filter, N-less pass + correction pass, verification records, self hits, difference plane) against the plain tree walk
     # with N children (none of those) -- K=30 e=1 at EVERY position, e=2 on 5 % of the k-mer blocks across a sequence boundary
@@ -1175,6 +1247,7 @@ def test_gpu_full_size_grch38_e0_everywhere_e1_e2_k100_on_intervals():
     assert np.array_equal(d2, p2), np.flatnonzero(d2 != p2)[:10]
     assert (d2[r2[0] + 6:r2[1] - 6] >= d1[r2[0] + 6:r2[1] - 6]).all()
     del d2, p2
+    lap("default against plain walk (30,1) (30,2)")
     # ... and config C4's (K=100, e=1) at EVERY position: groups behind the bitmaps / difference plane / two-row verification against the plain walk
     # (round 6: the two further 5 % shares of e=2 made room for the reference's own benchmark list, below)
     a = ix.map(100, 1, value_bits=8)
@@ -1183,6 +1256,7 @@ def test_gpu_full_size_grch38_e0_everywhere_e1_e2_k100_on_intervals():
     ix.set_tuning(**dflt)
     assert np.array_equal(a, b), np.flatnonzero(a != b)[:10]
     del a, b
+    lap("default against plain walk (100,1)")
     # ---- the reference's own benchmark list at the metric's size (benchmarks/bench.sh:35-43: K = 5, 6 at e = 0, K = 101 at e = 0 .. 4; the
     # deep-stack, many-verification regime of E = 3, 4 was timed in round 5 and checked on 90-kbp texts only: tests/tests.cpp:212-260) ----
     # (101,2) on the 2 M random positions, (101,3) on ~100 k and (101,4) on ~20 k of them, all 24 sequences, against the oracle
@@ -1192,6 +1266,7 @@ def test_gpu_full_size_grch38_e0_everywhere_e1_e2_k100_on_intervals():
         want = ora.mappability(K, E, value_bits=16, threads=os.cpu_count() or 8, intervals=rv)
         assert np.array_equal(got, want), (K, E, "reference benchmark list", np.flatnonzero(got != want)[:10])
         assert got.any()
+    lap("K=101 e=2,3,4,0 against the oracle")
     # (101,3): the default schedule against the plain tree walk on 1 % of the k-mer blocks across a sequence boundary
     r3 = (max(0, mid - int(0.005 * n)), min(n - 100, mid + int(0.005 * n)))
     a = ix.map(101, 3, value_bits=8, kmer_range=r3)
@@ -1200,13 +1275,15 @@ def test_gpu_full_size_grch38_e0_everywhere_e1_e2_k100_on_intervals():
     ix.set_tuning(**dflt)
     assert np.array_equal(a, b), ("K=101 e=3 default vs plain walk", np.flatnonzero(a != b)[:10])
     del a, b, ora
+    lap("(101,3) default against plain walk")
     # K = 5 and 6 at e = 0, every position, against a histogram of the text's 5- / 6-mers (every one of them occurs millions of times: the
     # count IS the rank difference, nearly everything saturates -- what remains to be right are the windows with N and the sequence ends)
     for K in (5, 6):
         got = ix.map(K, 0, value_bits=16)
-        want = _torch_small_k_counts(codes, K, 65535, "cuda:0", lens).astype(np.uint16)
+        want = _torch_small_k_counts(codes, K, 65535, "cuda:0", lens).astype(np.uint16, copy=False)
         assert np.array_equal(got, want), (K, 0, np.flatnonzero(got != want)[:10])
         assert (got == 0).any() and (got == 65535).any()
+    lap("K=5,6")
     ix.close()
 
 

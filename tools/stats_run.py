@@ -16,7 +16,7 @@ a = ap.parse_args()
 codes, lens, desc = synth.workload(a.workload, a.scale)
 ix = g.Index.build(codes, lens, sampling=1, profiling=True)
 out = torch.zeros(len(codes) + 16, dtype=torch.uint8, device="cuda:0")
-DEFAULTS = dict(verify_t=-1, lds_stack=-1, blocks_per_cu=4, qtable=-1, sat_min_w=256, fetch_batch=-1, probation=-1, verify_cost=3, skip_dup=-1, coop=-1, use_ctx=1, steal=-1, part_bias=0, oss_weights=-1, jump=-1, self_hit=1, jump_filter=1, range_add=1, verify_t_ext=-1, jump_groups=-1, expand=-1, expand_mb=-1, expand_chunk=-1, sat_draw_w=-1, expand_occ=-1, expand_overlap=-1, expand_two_pass=-1, expand_share=-1)
+DEFAULTS = dict(verify_t=-1, lds_stack=-1, blocks_per_cu=4, qtable=-1, sat_min_w=256, fetch_batch=-1, probation=-1, verify_cost=3, skip_dup=-1, coop=-1, use_ctx=1, steal=-1, part_bias=0, oss_weights=-1, jump=-1, self_hit=1, jump_filter=1, range_add=1, verify_t_ext=-1, jump_groups=-1, expand=-1, expand_mb=-1, expand_chunk=-1, sat_draw_w=-1, expand_occ=-1, expand_overlap=-1, expand_two_pass=-1, expand_share=-1, win2=-1)
 for cfg, setting in [(c, s2) for c in a.cfg for s2 in a.settings]:
     K, E = map(int, cfg.split(","))
     knobs = dict(DEFAULTS)

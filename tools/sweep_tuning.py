@@ -9,7 +9,7 @@ import torch
 import genmap_amd as g
 from genmap_amd import synth
 
-DEFAULTS = dict(verify_t=-1, lds_stack=-1, blocks_per_cu=4, qtable=-1, sat_min_w=256, fetch_batch=-1, probation=-1, verify_cost=3, no_store=0, no_saturate=0, skip_dup=-1, coop=-1, use_ctx=1, steal=-1, part_bias=0, oss_weights=-1, child_tables=-1, jump=-1, self_hit=1, jump_filter=1, range_add=1, verify_t_ext=-1, jump_groups=-1, iter_cap=-1, stall_cap=-1, fast_verify=-1, no_wrap=-1, jump_layouts=-1, lds_pad=0, pat_batch=-1, expand=-1, expand_mb=-1, expand_chunk=-1, sat_draw_w=-1, expand_occ=-1, expand_overlap=-1, expand_two_pass=-1, expand_share=-1)
+DEFAULTS = dict(verify_t=-1, lds_stack=-1, blocks_per_cu=4, qtable=-1, sat_min_w=256, fetch_batch=-1, probation=-1, verify_cost=3, no_store=0, no_saturate=0, skip_dup=-1, coop=-1, use_ctx=1, steal=-1, part_bias=0, oss_weights=-1, child_tables=-1, jump=-1, self_hit=1, jump_filter=1, range_add=1, verify_t_ext=-1, jump_groups=-1, iter_cap=-1, stall_cap=-1, fast_verify=-1, no_wrap=-1, jump_layouts=-1, lds_pad=0, pat_batch=-1, expand=-1, expand_mb=-1, expand_chunk=-1, sat_draw_w=-1, expand_occ=-1, expand_overlap=-1, expand_two_pass=-1, expand_share=-1, win2=-1)
 ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="chr1"); ap.add_argument("--scale", type=float, default=1.0)
 ap.add_argument("--cfg", nargs="+", default=["30,2,1.0"])
