@@ -507,12 +507,13 @@ template <int WPP> struct EnvBase {
         if (lo | hi) { steps += 1; lines += 1 + (bl != bh); }
 #endif
     }
-    __device__ __forceinline__ uint32_t text_char(const Root& rt, uint32_t pos) const
+    // (the walker of the split search never stages 2-bit windows: CountEnv<WPP, 2> instantiates this with WIN2_POSSIBLE = false and keeps the loop it was tuned with)
+    template <bool WIN2_POSSIBLE = true> __device__ __forceinline__ uint32_t text_char_impl(const Root& rt, uint32_t pos) const
     {
         const uint32_t W = K + rt.n - 1u;
         const uint32_t p = rt.strand ? (W - 1u - pos) : pos;
         uint32_t c;
-        if (A.win2) {   // (wave-uniform) windows at 2 bits per symbol; bit 7 of woff: the window touches a chunk with an N -- the 4-bit text in HBM knows where
+        if (WIN2_POSSIBLE && A.win2) {   // (wave-uniform) windows at 2 bits per symbol; bit 7 of woff: the window touches a chunk with an N -- the 4-bit text in HBM knows where
             if (woff & 128u) {
                 const uint64_t g = A.textBegin + (uint64_t)rt.win + p;
                 c = (reinterpret_cast<const uint8_t*>(A.text4)[g >> 1] >> (((uint32_t)g & 1u) * 4u)) & 15u;
@@ -527,6 +528,7 @@ template <int WPP> struct EnvBase {
         }
         return rt.strand ? complement(c) : c;
     }
+    __device__ __forceinline__ uint32_t text_char(const Root& rt, uint32_t pos) const { return text_char_impl<true>(rt, pos); }
     __device__ __forceinline__ void push(const Node& nd)
     {
         const uint32_t lv = sbase + sp;
@@ -682,6 +684,7 @@ template <int WPP, int MODE = 0> struct CountEnv : EnvBase<WPP> {
     uint32_t leafSum = 0;
     uint32_t rootHits = 0;   // hits this lane has added for its current root (gates the saturation check)
     __device__ __forceinline__ CountEnv(const SearchArgs& a, uint4* s, uint32_t k) : EnvBase<WPP>(a, s, k) {}
+    __device__ __forceinline__ uint32_t text_char(const Root& rt, uint32_t pos) const { return this->template text_char_impl<MODE != 2>(rt, pos); }
     __device__ __forceinline__ void on_root() { rootHits = 0; }
     __device__ __forceinline__ uint32_t root_hits() const { return rootHits; }
     __device__ __forceinline__ void set_root_hits(uint32_t v) { rootHits = v; }
@@ -1431,8 +1434,9 @@ __device__ __forceinline__ void search_body(const SearchArgs& A)
             // node.  (k-mers that cross a sequence end are zeroed by resetLimits whatever is added here; a window with an N anywhere
             // takes the ordinary path, which knows which k-mers the N spoils.)
             if (A.selfHit && have && nd.w == 1u && rt.strand == 0u && (EnvT::EXACT_ONLY || (meta_errs(nd.meta) == 0u && nd.rlo != ~(row_t)0))) {   // (not the left-over rows of a wider node; e = 0 has neither errors nor such nodes)
-                const uint32_t W = A.K + rt.n - 1u, nch = A.win2 ? 0u : (env.woff + W + 31u) >> 5;
-                uint32_t anyN = A.win2 ? (env.woff & 128u) : 0u;   // (2-bit windows: the chunk flags of stage 2)
+                const bool w2 = !EnvT::NODES && A.win2;
+                const uint32_t W = A.K + rt.n - 1u, nch = w2 ? 0u : (env.woff + W + 31u) >> 5;
+                uint32_t anyN = w2 ? (env.woff & 128u) : 0u;   // (2-bit windows: the chunk flags of stage 2)
                 for (uint32_t c = 0; c < nch; ++c) {
                     const uint4 v = *reinterpret_cast<const uint4*>(env.lwin + c * 1024u);
                     anyN |= (v.x | v.y | v.z | v.w) & 0x44444444u;   // (nibbles of the neighbouring text in the first / last chunk count too: harmless)
