@@ -241,6 +241,7 @@ def main():
     ap.add_argument("--extra-configs", default="chr1,bacteria5", help="default workload at N = 1 only: BASELINE configs measured on an index of their own by a child process each "
                     "(chr1: C2, K=30 e=0 on the chr1-like text; bacteria5: C5) and reported as sub-records; '' = none")
     ap.add_argument("--no-traffic", action="store_true", help="skip roofline.traffic (two extra processes under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE after the timed part, N = 1 only)")
+    ap.add_argument("--tune", default="", help="experiments: scheduling knobs 'name=value,...' set on the index before anything is timed (gm_index_set_tuning; results never depend on them); recorded in config.tune")
     ap.add_argument("--protocol", default="", choices=["", "reference"], help="reference: the reference's own benchmark protocol (benchmarks/bench.sh:35-43: (5,0), (6,0), (101,0..4)) "
                     "on the same index, one pass each -- tools/protocol_reference.py; E = 4 takes minutes, never part of the default line")
     args = ap.parse_args()
@@ -309,6 +310,8 @@ def main():
     else:
         ix = g.Index.build(codes, lens, sampling=args.sampling, block_bytes=args.block_bytes, device=local_rank)
     t_build = time.time() - t0
+    if args.tune:
+        ix.set_tuning(**{kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tune.split(",") if kv})
     info = ix.info()
     log(f"index built on the GPU in {t_build:.1f} s: {info['n_rows']} rows, {info['block_bytes']}-B blocks, {info['device_bytes'] / 2**30:.2f} GiB")
 
@@ -864,6 +867,8 @@ def main():
         "config": {"workload": wl(head), "K": head["K"], "E": head["E"], "text_len": n, "block_bytes": info["block_bytes"],
                    "parallelism": parallelism, "index_build_s": round(t_build, 2), "index_device_gib": round(info["device_bytes"] / 2**30, 2)},
     }
+    if args.tune:
+        result["config"]["tune"] = args.tune
     if world > 1:
         result["rccl_ranks"] = rccl_ranks   # dist.get_world_size() of the nccl (= RCCL) process group the gathers ran on (0: another backend)
         result["backend"] = args.backend
