@@ -1226,6 +1226,10 @@ static int prepare_search(gm_index* ix, uint64_t text_begin, uint64_t text_len, 
             // (long k-mers, gm_longk.h: the first block of the REGULAR shape bounds the prefix; shorter blocks at the end of the text have longer infixes)
             const uint32_t bl0 = longK ? oss_bl(plan.tableL[(size_t)(plan.stepSize - 1) * 8 + s], 0) : oss_bl(r, 0);
             uint32_t q = std::min(qmax, bl0 > 0 ? bl0 - 1u : 0u);
+            if (longK) for (uint32_t n2 = 1; n2 <= plan.stepSize; ++n2) {   // ... and no shape's first block may be shorter than the prefix + 1 (never seen: checked, not assumed)
+                const uint32_t b2 = oss_bl(plan.tableL[(size_t)(n2 - 1) * 8 + s], 0);
+                q = std::min(q, b2 > 0 ? b2 - 1u : 0u);
+            }
             if (q == 0) continue;
             if (qA == 0 || qA == q) { if (qA == 0) { rc = get_qtable(ix, &q, &A.qtabA); if (rc) return rc; qA = q; } }
             else if (qB == 0 || qB == q) { if (qB == 0) { rc = get_qtable(ix, &q, &A.qtabB); if (rc) return rc; qB = q; } A.qselMask |= 1u << s; }

@@ -791,6 +791,7 @@ template <int WPP, class Derived> struct LeafQueueEnv : EnvBase<WPP> {
     // called by one lane (any control flow): returns false when the queue is full -- the caller then walks the leaf itself
     __device__ __forceinline__ bool enqueue(row_t flo, uint32_t w, uint64_t target)
     {
+        if (A.lqCap == 0u) return false;   // (gm_longk.h: no queue at all -- no counter to bump either)
         const uint32_t slot = atomicAdd(&lqCtl[0], 1u);
         if (slot >= A.lqCap) return false;
         lq[slot] = make_uint4((uint32_t)flo, w, (uint32_t)target, (uint32_t)(target >> 32) | (uint32_t)((uint64_t)flo >> 32) << 24);

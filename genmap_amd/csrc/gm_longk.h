@@ -49,12 +49,19 @@ __global__ __launch_bounds__(256) void longk_kernel(const SearchArgs A)
     LN nd; nd.flo = nd.rlo = nd.w = 0; nd.ab = nd.tem = 0;
     Root rt; rt.win = 0; rt.n = 1; rt.strand = 0; rt.search = 0; rt.rec = OssRecord{0, 0, 0, 0};
     uint32_t W = K;
-    uint32_t guard = 0;
+    uint32_t guard = 0, stall = 0;
+    bool did = false;   // this lane handled a node in the last iteration
     auto push = [&](const LN& x) {
         if (sbase + sp < A.stackDepth) { stk[(size_t)(sbase + sp) * nth] = x; ++sp; }
         else atomicOr(A.errorFlag, 1u);   // never expected: stack_bound(E, stepSize) + STEAL_LEVELS
     };
     for (;;) {
+        // a hung loop ends as an error here too (search_body: stall_cap): consecutive iterations in which no lane of the wavefront handled a node
+        if (A.guardKeep == 0u) {
+            stall = __ballot(did) != 0ull ? 0u : stall + 1u;
+            if (stall > A.guardCap) { atomicOr(A.errorFlag, 2u); break; }
+        }
+        did = false;
         // ---- work sharing inside the wavefront (the scheme of gm_kernels.h: search_body) once the roots have run out: a lane with nothing
         // left takes the BOTTOM entry (the oldest, i.e. largest pending subtree) of a lane that holds a node and a stack.  One lane walks
         // its root's whole subtree with a dependent memory round trip per step: a root inside a repeat family (thousands of near-identical
@@ -151,6 +158,7 @@ __global__ __launch_bounds__(256) void longk_kernel(const SearchArgs A)
             if (!have) continue;   // (nothing left for this lane, or a root that ended at its table entry)
         }
         if (++guard > A.guardCap && A.guardKeep != 0u) { atomicOr(A.errorFlag, 2u); break; }   // (iter_cap: tests force the bound)
+        did = true;
         // one node: settled against the text when it is narrow, else split / stepped (gm_longk_step.h: the same code the CPU harness runs)
         long_node(nd, have, rt, *rec, K, E, (R)A.verifyT, (R)A.satMinW, env,
                   [&](uint32_t pos) { const uint32_t c = A.text[(size_t)rt.win + (rt.strand ? W - 1u - pos : pos)]; return rt.strand ? complement(c) : c; }, push);

@@ -355,6 +355,9 @@ def test_gpu_long_kmers_beyond_255(bb):
         with pytest.raises(g.GenmapError) as ei:
             ix.map(32769, 0, value_bits=8)
         assert ei.value.status == -6                                                               # GM_ERR_BAD_K
+        ix.set_tuning(stall_cap=1 << 12)                                                           # the idle bound (iterations of a wavefront without a node) never fires on a healthy run
+        assert np.array_equal(ix.map(300, 1, value_bits=8), np.minimum(ora.mappability(300, 1, value_bits=16, threads=8), 255).astype(np.uint8))
+        ix.set_tuning(stall_cap=-1)
         ix.set_tuning(iter_cap=3)                                                                  # the hang guard covers this kernel too
         with pytest.raises(g.GenmapError) as ei:
             ix.map(300, 1, value_bits=8)
