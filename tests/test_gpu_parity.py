@@ -1178,8 +1178,13 @@ def test_gpu_full_size_grch38_e0_everywhere_e1_e2_k100_on_intervals():
     # the exported index itself, before the oracle adopts it: symbol histograms of both BWTs, and the suffix array against the forward
     # BWT (permutation, preceding symbols, LF-walk consistency) -- on the device, 3.09 G rows are minutes of numpy
     bf, br = ix.export_bwt()
-    hist = np.bincount(codes, minlength=6); hist[5] = len(lens)
-    assert np.array_equal(np.bincount(bf, minlength=6), hist) and np.array_equal(np.bincount(br, minlength=6), hist)
+    def dev_hist(a):   # (on the device: three numpy histograms of 3.09 G symbols were 15 s of this test)
+        h = torch.zeros(6, dtype=torch.int64, device="cuda:0")
+        for i in range(0, len(a), 1 << 28):
+            h += torch.bincount(torch.from_numpy(a[i:i + (1 << 28)]).to("cuda:0").to(torch.int32), minlength=6)[:6]
+        return h.cpu().numpy()
+    hist = dev_hist(codes).astype(np.int64); hist[5] = len(lens)
+    assert np.array_equal(dev_hist(bf), hist) and np.array_equal(dev_hist(br), hist)
     sa = ix.export_sa()
     H.check_sa_against_bwt_device(codes, lens, bf, sa, "cuda:0")
     del sa
@@ -1192,14 +1197,12 @@ def test_gpu_full_size_grch38_e0_everywhere_e1_e2_k100_on_intervals():
     del bf, br
     lap("oracle adopts the BWTs")
     iv = _interval_set(lens, 100, n_per=35000)   # ~280 k positions: seconds for the oracle on the GPU box's host cores
-    sel = np.zeros(n, bool)
-    for a, b in iv:
-        sel[a:b] = True
+    sel = np.unique(np.concatenate([np.arange(a, b) for a, b in iv]))  # (positions, not a 3 GB mask: nothing outside them may be set)
     for K, E, bits in ((30, 2, 16), (100, 1, 16), (30, 1, 8), (30, 0, 16)):
         got = ix.map(K, E, value_bits=bits, intervals=iv)
         want = ora.mappability(K, E, value_bits=bits, threads=os.cpu_count() or 8, intervals=iv)
         assert np.array_equal(got, want), (K, E)
-        assert (got[~sel] == 0).all()
+        assert np.count_nonzero(got) == np.count_nonzero(got[sel])
         if (K, E) == (30, 2):
             assert (np.minimum(got[sel], 255) >= out0[sel]).all()      # monotone in e
     lap("edge intervals, four settings")
@@ -1218,16 +1221,14 @@ def test_gpu_full_size_grch38_e0_everywhere_e1_e2_k100_on_intervals():
             b = min(a + 950, int(cumv[q + 1]))
             if b > a:
                 riv.append((a, b))
-    rsel = np.zeros(n, bool)
-    for a, b in riv:
-        rsel[a:b] = True
-    assert rsel.sum() >= 1_900_000 * min(1.0, scale) or scale < 1.0
+    rsel = np.unique(np.concatenate([np.arange(a, b) for a, b in riv]))
+    assert len(rsel) >= 1_900_000 * min(1.0, scale) or scale < 1.0
     for K, E in ((30, 2), (100, 1)):
         rv = [(a, min(b, n - K + 1)) for a, b in riv if a < n - K + 1]
         got = ix.map(K, E, value_bits=8, intervals=rv)
         want = ora.mappability(K, E, value_bits=8, threads=os.cpu_count() or 8, intervals=rv)
         assert np.array_equal(got, want), (K, E, "random intervals", np.flatnonzero(got != want)[:10])
-        assert (got[~rsel] == 0).all()
+        assert np.count_nonzero(got) == np.count_nonzero(got[rsel])
     del rsel
     lap("2 M random positions (30,2) (100,1)")
     # "the same result under every schedule" (tests/tests.sh:47-60) at the metric's own size: the default schedule (jumps of 16 characters,
