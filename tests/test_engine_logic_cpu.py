@@ -317,7 +317,7 @@ def test_groups_of_jump_patterns_read_through_the_existence_bitmap(K, E, expand_
     exp = ix.mappability(K, E, value_bits=16, threads=4)
     e = emu()
     try:
-        for T, jump in ((0, 16), (1, 15), (4, 9), (1, 5)):
+        for T, jump in (((0, 16), (1, 15), (4, 9), (1, 5)) if E < 4 else ((0, 16), (4, 9))):   # (four errors: a minute per mode with all four -- the jump lengths of the device and a short one)
             e.gm_emu_set_jump_groups(0)
             plain, st0 = emu_map2(ix, 1, K, E, value_bits=16, verify_t=T, jump=jump)
             e.gm_emu_set_jump_groups(1)
