@@ -74,7 +74,7 @@ def test_bench_reports_physical_cores_not_hardware_threads():
         elif line.startswith("core id"):
             core = line.split(":")[1].strip()
         elif not line.strip():
-            if core is not None:
+            if phys is not None and core is not None:
                 ids.add((phys, core))
             phys = core = None
     if ids:
