@@ -79,3 +79,44 @@ def test_bench_reports_physical_cores_not_hardware_threads():
             phys = core = None
     if ids:
         assert c == len(ids)
+
+
+def _kmer_keys(codes, K):
+    """2-bit packed K-mers (K <= 31) of an N-free stretch model: windows with an N are dropped"""
+    import numpy as np
+    c = codes.astype(np.uint64)
+    n = len(c) - K + 1
+    key = np.zeros(n, dtype=np.uint64)
+    bad = np.zeros(n, dtype=bool)
+    for i in range(K):
+        key = (key << np.uint64(2)) | (c[i:i + n] & np.uint64(3))
+        bad |= codes[i:i + n] > 3
+    return key[~bad]
+
+
+def test_hard_workload_shares_its_families_between_sequences_and_strands():
+    """synth.workload("grch38h"): the same 24 lengths as S3, but the repeat families are common to ALL sequences and half of
+    the copies are reverse-complemented -- S3 seeds every sequence by itself and plants forward copies only.  Checked where it shows: 24-mers that
+    two different sequences have in common, on either strand."""
+    import numpy as np
+    sys.path.insert(0, str(ROOT))
+    from genmap_amd import synth
+    K = 24
+    easy, lens_e, _ = synth.workload("grch38", 0.001)
+    hard, lens_h, desc = synth.workload("grch38h", 0.001)
+    assert lens_e == lens_h and len(lens_h) == 24 and "S3h" in desc
+    again, _, _ = synth.workload("grch38h", 0.001)
+    assert np.array_equal(hard, again)                                   # deterministic
+    assert (hard <= 4).all() and (hard == 4).any()
+
+    def shared(text, lens, rc):
+        cum = np.concatenate([[0], np.cumsum(lens)])
+        a = text[cum[0]:cum[1]]
+        b = text[cum[1]:cum[2]]
+        if rc:
+            b = np.where(b[::-1] < 4, 3 - b[::-1], 4).astype(np.uint8)
+        return len(np.intersect1d(_kmer_keys(a, K), _kmer_keys(b, K)))
+    fwd_e, rc_e = shared(easy, lens_e, False), shared(easy, lens_e, True)
+    fwd_h, rc_h = shared(hard, lens_h, False), shared(hard, lens_h, True)
+    assert fwd_h > 20 * max(fwd_e, 1) and rc_h > 20 * max(rc_e, 1), (fwd_e, rc_e, fwd_h, rc_h)
+    assert rc_h > fwd_h // 10 and fwd_h > rc_h // 10                     # both orientations, neither a rarity
